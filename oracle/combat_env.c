@@ -1,0 +1,589 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY (see combat_env.h). "R/" = /root/reference/envs/JSBSim/ */
+#include "combat_env.h"
+#include "geodesy.h"
+#include <math.h>
+#include <string.h>
+
+#define FT2M 0.3048
+#define RAD2DEG (180.0 / M_PI)
+
+static double clampd(double lo, double v, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static double norm3(const double v[3]) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+static double sign0(double v) { return (v > 0) - (v < 0); }
+
+int or_env_obs_dim(int task) {
+  switch (task) {
+    case OR_TASK_HEADING: return 12;
+    case OR_TASK_SINGLECOMBAT: return 15;
+    default: return 21;
+  }
+}
+int or_env_act_dim(int task) { return task == OR_TASK_SHOOT_MISSILE ? 5 : 4; }
+
+void or_env_default_config(OrEnvConfig* c, int task) {
+  memset(c, 0, sizeof *c);
+  c->task = task;
+  c->sim_freq = 60;
+  c->agent_interaction_steps = 6;
+  c->center_lon = 120.0; c->center_lat = 60.0; c->center_alt = 0.0;
+  c->altitude_limit = 2500; c->acc_limit_x = c->acc_limit_y = c->acc_limit_z = 10.0;
+  c->posture_scale = 15.0; c->posture_potential = 1;   /* R/configs/scenario1 YAMLs */
+  c->altitude_scale = 1.0; c->event_scale = 1.0; c->event_potential = 1;
+  c->heading_scale = 1.0; c->missile_posture_scale = 30.0; c->shoot_penalty_scale = 1.0;
+  c->alt_safe = 4.0; c->alt_danger = 3.5; c->alt_kv = 0.2;
+  c->max_attack_angle = 45; c->max_attack_distance = 14000; c->min_attack_interval = 25;
+  for (int i = 0; i < OR_MAX_AC; i++) f16_default_init(&c->init[i]);
+  if (task == OR_TASK_HEADING) {
+    /* R/configs/singlecontrol/heading.yaml */
+    c->n_aircraft = 1; c->n_ego = 1; c->max_steps = 10000;
+    c->posture_scale = 1.0; c->posture_potential = 0; c->event_potential = 0;
+    c->max_heading_increment = 180; c->max_altitude_increment = 7000; c->max_velocities_u_increment = 100; c->check_interval = 30;
+  } else {
+    /* aircraft block of R/configs/scenario1/WVR_selfplay.yaml:15-40 */
+    c->n_aircraft = 2; c->n_ego = 1; c->max_steps = 9000;
+    c->init[1].lon_deg = 120.5; c->init[1].lat_geod_deg = 60.1; c->init[1].psi_deg = 180.0;
+    c->num_missiles[0] = c->num_missiles[1] = 2;
+  }
+}
+
+/* ------------------------------------------------------------------ numpy PCG64 + Generator.uniform */
+void or_env_seed_pcg64(OrEnv* e, uint64_t shi, uint64_t slo, uint64_t ihi, uint64_t ilo) {
+  e->rng_state = ((unsigned __int128)shi << 64) | slo;
+  e->rng_inc = ((unsigned __int128)ihi << 64) | ilo;
+}
+static uint64_t pcg64_next(OrEnv* e) {
+  const unsigned __int128 mult = ((unsigned __int128)0x2360ED051FC65DA4ULL << 64) | 0x4385DF649FCCF645ULL;
+  e->rng_state = e->rng_state * mult + e->rng_inc;
+  uint64_t hi = (uint64_t)(e->rng_state >> 64), lo = (uint64_t)e->rng_state;
+  uint64_t x = hi ^ lo;
+  unsigned rot = (unsigned)(hi >> 58);
+  return (x >> rot) | (x << ((-rot) & 63));
+}
+double or_env_uniform(OrEnv* e, double lo, double hi) {
+  double u = (double)(pcg64_next(e) >> 11) * (1.0 / 9007199254740992.0);
+  return lo + (hi - lo) * u;
+}
+
+/* ------------------------------------------------------------------ utils.py:58-103 */
+void or_get_AO_TA_R(const double ego[6], const double enm[6], int two_d, double out[4]) {
+  double ev, nv, R, pe, pn;
+  double dx = enm[0] - ego[0], dy = enm[1] - ego[1], dz = enm[2] - ego[2];
+  if (two_d) {
+    ev = sqrt(ego[3] * ego[3] + ego[4] * ego[4]);
+    nv = sqrt(enm[3] * enm[3] + enm[4] * enm[4]);
+    R = sqrt(dx * dx + dy * dy);
+    pe = dx * ego[3] + dy * ego[4];
+    pn = dx * enm[3] + dy * enm[4];
+  } else {
+    ev = norm3(ego + 3);
+    nv = norm3(enm + 3);
+    R = sqrt(dx * dx + dy * dy + dz * dz);
+    pe = dx * ego[3] + dy * ego[4] + dz * ego[5];
+    pn = dx * enm[3] + dy * enm[4] + dz * enm[5];
+  }
+  out[0] = acos(clampd(-1, pe / (R * ev + 1e-8), 1));
+  out[1] = acos(clampd(-1, pn / (R * nv + 1e-8), 1));
+  out[2] = R;
+  out[3] = sign0(ego[3] * dy - ego[4] * dx);
+}
+
+/* posture_reward.py:58-75, versions v2 / v3 (the only ones the YAMLs select) */
+double or_posture_reward(double AO, double TA, double R) {
+  double orn = 1 / (50 * AO / M_PI + 2) + 1.0 / 2 + fmin(atanh(1. - fmax(2 * TA / M_PI, 1e-4)) / (2 * M_PI), 0.) + 0.5;
+  double rng = 1 * (R < 5) + (R >= 5) * clampd(0, -0.032 * R * R + 0.284 * R + 0.38, 1) + clampd(0, exp(-0.16 * R), 0.2);
+  return orn * rng;
+}
+/* altitude_reward.py:20-40 */
+double or_altitude_reward(double z, double vz, double safe, double danger, double kv) {
+  double Pv = 0., PH = 0.;
+  if (z <= safe) Pv = -clampd(0., vz / kv * (safe - z) / safe, 1.);
+  if (z <= danger) PH = clampd(0., z / danger, 1.) - 1. - 1.;
+  return Pv + PH;
+}
+
+/* ------------------------------------------------------------------ MissileSimulator, simulatior.py:393-608 */
+void or_missile_init(OrMissile* m, int model, double dt) {
+  memset(m, 0, sizeof *m);
+  m->status = OR_MSL_INACTIVE;
+  m->parent = m->target = -1;
+  m->g = 9.81; m->dm = 6; m->v_min = 150;
+  if (model == 0) { /* AIM-9L defaults :421-433 */
+    m->t_max = 60; m->t_thrust = 3; m->Isp = 120; m->Length = 2.87; m->Diameter = 0.127; m->cD = 0.4; m->m0 = 84;
+    m->K = 3; m->nyz_max = 30; m->Rc = 300;
+  } else { /* the set both AIM_9M and AIM_120B carry :659-672, :696-709 */
+    m->t_max = 27.22; m->t_thrust = 1.4; m->Isp = 1837; m->Length = 3.66; m->Diameter = 0.18; m->cD = 0.02; m->m0 = 152;
+    m->K = 5; m->nyz_max = 50; m->Rc = 5;
+  }
+  m->recede_max = (int)(5 / dt);
+}
+void or_missile_launch(OrMissile* m, const double geodetic[3], const double position[3], const double velocity[3], const double rpy[3]) {
+  memcpy(m->geodetic, geodetic, sizeof m->geodetic);
+  memcpy(m->position, position, sizeof m->position);
+  memcpy(m->velocity, velocity, sizeof m->velocity);
+  m->posture[0] = 0; m->posture[1] = rpy[1]; m->posture[2] = rpy[2];
+  m->t = 0; m->m = m->m0; m->dtheta = m->dphi = 0;
+  m->status = OR_MSL_LAUNCHED;
+  m->dist_prev = INFINITY;
+  m->recede_count = 0; m->recede_len = 0;
+}
+int or_missile_run(OrMissile* m, const double tp[3], const double tv[3], int target_alive, double dt, double lon0, double lat0, double alt0) {
+  m->t += dt;
+  /* _guidance :556-576 */
+  double xm = m->position[0], ym = m->position[1], zm = m->position[2];
+  double dxm = m->velocity[0], dym = m->velocity[1], dzm = m->velocity[2];
+  double vm = norm3(m->velocity);
+  double theta_m = asin(dzm / vm);
+  double xt = tp[0], yt = tp[1], zt = tp[2], dxt = tv[0], dyt = tv[1], dzt = tv[2];
+  double Rxy = sqrt((xm - xt) * (xm - xt) + (ym - yt) * (ym - yt));
+  double Rxyz = sqrt((xm - xt) * (xm - xt) + (ym - yt) * (ym - yt) + (zt - zm) * (zt - zm));
+  double dbeta = ((dyt - dym) * (xt - xm) - (dxt - dxm) * (yt - ym)) / (Rxy * Rxy);
+  double deps = ((dzt - dzm) * (Rxy * Rxy) - (zt - zm) * ((xt - xm) * (dxt - dxm) + (yt - ym) * (dyt - dym))) / (Rxyz * Rxyz * Rxy);
+  double K = fmax(m->K * (m->t_max - m->t) / m->t_max, 0);
+  double ny = clampd(-m->nyz_max, K * vm / m->g * cos(theta_m) * dbeta, m->nyz_max);
+  double nz = clampd(-m->nyz_max, K * vm / m->g * deps + cos(theta_m), m->nyz_max);
+  double distance = Rxyz;
+  /* run :520-533 */
+  int inc = distance > m->dist_prev;
+  if (m->recede_len < m->recede_max) m->recede_len++;
+  m->recede_count = inc ? m->recede_count + 1 : 0; /* sum(deque) >= maxlen <=> the last maxlen samples were all True */
+  m->dist_prev = distance;
+  if (distance < m->Rc && target_alive && m->status != OR_MSL_MISS) {
+    m->status = OR_MSL_HIT;
+  } else if (m->t > m->t_max || norm3(m->velocity) < m->v_min || m->recede_count >= m->recede_max || !target_alive) {
+    m->status = OR_MSL_MISS;
+  } else {
+    /* _state_trans :578-608 */
+    for (int i = 0; i < 3; i++) m->position[i] += dt * m->velocity[i];
+    or_neu2lla(m->position[0], m->position[1], m->position[2], lon0, lat0, alt0, m->geodetic);
+    double v = norm3(m->velocity);
+    double theta = m->posture[1], phi = m->posture[2];
+    double Isp = (m->t < m->t_thrust) ? m->Isp : 0;
+    double T = m->g * Isp * m->dm;
+    double S = M_PI * (m->Diameter / 2) * (m->Diameter / 2) + hypot(sin(m->dtheta), sin(m->dphi)) * m->Diameter * m->Length;
+    double rho = 1.225 * exp(-m->geodetic[2] / 9300);
+    double D = 0.5 * m->cD * S * rho * v * v;
+    double nx = (T - D) / (m->m * m->g);
+    double dv = m->g * (nx - sin(theta));
+    m->dphi = m->g / v * (ny / cos(theta));
+    m->dtheta = m->g / v * (nz - cos(theta));
+    v += dt * dv; phi += dt * m->dphi; theta += dt * m->dtheta;
+    m->velocity[0] = v * cos(theta) * cos(phi);
+    m->velocity[1] = v * cos(theta) * sin(phi);
+    m->velocity[2] = v * sin(theta);
+    m->posture[0] = 0; m->posture[1] = theta; m->posture[2] = phi;
+    if (m->t < m->t_thrust) m->m = m->m - dt * m->dm;
+  }
+  return m->status;
+}
+
+/* ------------------------------------------------------------------ AircraftSimulator wrapper */
+static double in_range_deg(double a) { /* utils.py:106-111, Python % semantics */
+  a = fmod(a, 360.0);
+  if (a < 0) a += 360.0;
+  if (a > 180) a -= 360;
+  return a;
+}
+static double h_sl_m(const OrAircraft* a) { return clampd(-500, a->fdm.h_sl * FT2M, 26000); }        /* catalog.py:292-296 */
+static double mps(double fps) { return clampd(-700, fps * FT2M, 700); }                                /* catalog.py:298-338 */
+static double vc_mps(const OrAircraft* a) { return clampd(0, a->fdm.vc_fps * FT2M, 1400); }
+
+static void update_properties(const OrEnv* e, OrAircraft* a) { /* simulatior.py:238-258 */
+  a->geodetic[0] = a->fdm.lon * RAD2DEG;
+  a->geodetic[1] = a->fdm.lat_geod * RAD2DEG;
+  a->geodetic[2] = h_sl_m(a);
+  or_lla2neu(a->geodetic[0], a->geodetic[1], a->geodetic[2], e->cfg.center_lon, e->cfg.center_lat, e->cfg.center_alt, a->position);
+  a->posture[0] = a->fdm.phi; a->posture[1] = a->fdm.tht; a->posture[2] = a->fdm.psi;
+  a->velocity[0] = mps(a->fdm.vel_ned[0]); a->velocity[1] = mps(a->fdm.vel_ned[1]); a->velocity[2] = mps(a->fdm.vel_ned[2]);
+}
+static void aircraft_reload(const OrEnv* e, OrAircraft* a, const F16Init* ic, int num_missiles) { /* simulatior.py:152-190 */
+  int team = a->team;
+  memset(a, 0, sizeof *a);
+  a->team = team;
+  a->bloods = 100; a->status = OR_ALIVE;
+  a->remaining_missiles = num_missiles;
+  a->last_missile = -1;
+  f16_reset(&a->fdm, ic);
+  update_properties(e, a);
+}
+static void aircraft_run(const OrEnv* e, OrAircraft* a) { /* simulatior.py:210-229 */
+  if (a->status != OR_ALIVE) return;
+  if (a->bloods <= 0) a->status = OR_SHOTDOWN;
+  f16_tick(&a->fdm, 1.0 / e->cfg.sim_freq);
+  update_properties(e, a);
+}
+static int extreme_state(const OrAircraft* a) { /* catalog.py:386-416 */
+  const F16State* s = &a->fdm;
+  int ev = norm3(s->v_eci) >= 1e10;
+  int er = norm3(s->pqr) >= 1000;
+  int ea = s->h_sl >= 1e10;
+  double mx = fmax(fabs(s->npilot[0]), fmax(fabs(s->npilot[1]), fabs(s->npilot[2])));
+  int eacc = mx > 1e1;
+  return ea || er || ev || eacc;
+}
+
+void or_env_init(OrEnv* e, const OrEnvConfig* c) {
+  memset(e, 0, sizeof *e);
+  e->cfg = *c;
+  e->obs_dim = or_env_obs_dim(c->task);
+  e->act_dim = or_env_act_dim(c->task);
+  for (int i = 0; i < c->n_aircraft; i++) e->ac[i].team = (i < c->n_ego) ? 0 : 1;
+  e->mp_prev_missile = -1;
+}
+
+/* first alive missile aimed at aircraft i, in launch order (simulatior.py:321-325) */
+static int missile_warning(const OrEnv* e, int i) {
+  for (int k = 0; k < e->n_msl; k++)
+    if (e->msl[k].target == i && e->msl[k].status == OR_MSL_LAUNCHED) return k;
+  return -1;
+}
+static int first_enemy(const OrEnv* e, int i) {
+  for (int k = 0; k < e->cfg.n_aircraft; k++) if (e->ac[k].team != e->ac[i].team) return k;
+  return -1;
+}
+
+/* ------------------------------------------------------------------ observations */
+static void obs_heading(const OrEnv* e, int i, double* o) { /* heading_task.py:67-100 */
+  const OrAircraft* a = &e->ac[i];
+  double d_alt = clampd(-40000, (a->target_altitude_ft - a->fdm.h_sl) * FT2M, 40000);
+  double d_hdg = clampd(-180, in_range_deg(a->target_heading_deg - a->fdm.psi * RAD2DEG), 180);
+  double d_vel = clampd(-1400, a->target_velocities_u_mps - mps(a->fdm.uvw[0]), 1400);
+  o[0] = d_alt / 1000; o[1] = d_hdg / 180 * M_PI; o[2] = d_vel / 340; o[3] = h_sl_m(a) / 5000;
+  o[4] = sin(a->fdm.phi); o[5] = cos(a->fdm.phi); o[6] = sin(a->fdm.tht); o[7] = cos(a->fdm.tht);
+  o[8] = mps(a->fdm.uvw[0]) / 340; o[9] = mps(a->fdm.uvw[1]) / 340; o[10] = mps(a->fdm.uvw[2]) / 340; o[11] = vc_mps(a) / 340;
+  for (int k = 0; k < 12; k++) o[k] = clampd(-10, o[k], 10);
+}
+static void feature6(const OrAircraft* a, double f[6]) {
+  f[0] = a->position[0]; f[1] = a->position[1]; f[2] = a->position[2];
+  f[3] = a->velocity[0]; f[4] = a->velocity[1]; f[5] = a->velocity[2];
+}
+static void obs_combat(const OrEnv* e, int i, double* o) { /* singlecombat_task.py:88-139, singlecombat_with_missile_task.py:31-99 */
+  const OrAircraft* a = &e->ac[i];
+  const OrAircraft* en = &e->ac[first_enemy(e, i)];
+  int dim = e->obs_dim;
+  for (int k = 0; k < dim; k++) o[k] = 0;
+  double ef[6], nf[6], r[4];
+  feature6(a, ef); feature6(en, nf);
+  o[0] = h_sl_m(a) / 5000;
+  o[1] = sin(a->fdm.phi); o[2] = cos(a->fdm.phi); o[3] = sin(a->fdm.tht); o[4] = cos(a->fdm.tht);
+  o[5] = mps(a->fdm.uvw[0]) / 340; o[6] = mps(a->fdm.uvw[1]) / 340; o[7] = mps(a->fdm.uvw[2]) / 340; o[8] = vc_mps(a) / 340;
+  or_get_AO_TA_R(ef, nf, e->cfg.task == OR_TASK_SINGLECOMBAT, r);
+  o[9] = (mps(en->fdm.uvw[0]) - mps(a->fdm.uvw[0])) / 340;
+  o[10] = (h_sl_m(en) - h_sl_m(a)) / 1000;
+  o[11] = r[0]; o[12] = r[1]; o[13] = r[2] / 10000; o[14] = r[3];
+  if (e->cfg.task == OR_TASK_SINGLECOMBAT) {
+    for (int k = 0; k < 15; k++) o[k] = clampd(-10, o[k], 10);
+    return;
+  }
+  int mk = missile_warning(e, i);
+  if (mk >= 0) {
+    const OrMissile* m = &e->msl[mk];
+    double mf[6] = {m->position[0], m->position[1], m->position[2], m->velocity[0], m->velocity[1], m->velocity[2]};
+    or_get_AO_TA_R(ef, mf, 0, r);
+    o[15] = (norm3(m->velocity) - mps(a->fdm.uvw[0])) / 340;
+    o[16] = (mf[2] - h_sl_m(a)) / 1000;
+    o[17] = r[0]; o[18] = r[1]; o[19] = r[2] / 10000; o[20] = r[3];
+  }
+}
+static void get_obs(const OrEnv* e, double* obs) {
+  for (int i = 0; i < e->cfg.n_aircraft; i++) {
+    if (e->cfg.task == OR_TASK_HEADING) obs_heading(e, i, obs + i * e->obs_dim);
+    else obs_combat(e, i, obs + i * e->obs_dim);
+  }
+}
+
+/* ------------------------------------------------------------------ rewards */
+static double process(double r, double scale, int potential, double* pre) { /* reward_function_base.py:48-63 */
+  r *= scale;
+  if (potential) { double out = r - *pre; *pre = r; return out; }
+  return r;
+}
+static double rw_posture(OrEnv* e, int i) { /* posture_reward.py:26-49 */
+  double ef[6], nf[6], r[4], sum = 0;
+  feature6(&e->ac[i], ef);
+  for (int k = 0; k < e->cfg.n_aircraft; k++) {
+    if (e->ac[k].team == e->ac[i].team) continue;
+    feature6(&e->ac[k], nf);
+    or_get_AO_TA_R(ef, nf, 0, r);
+    sum += or_posture_reward(r[0], r[1], r[2] / 1000);
+  }
+  return process(sum, e->cfg.posture_scale, e->cfg.posture_potential, &e->ac[i].pre_posture);
+}
+static double rw_altitude(OrEnv* e, int i) {
+  const OrAircraft* a = &e->ac[i];
+  double v = or_altitude_reward(a->position[2] / 1000, a->velocity[2] / 340, e->cfg.alt_safe, e->cfg.alt_danger, e->cfg.alt_kv);
+  return process(v, e->cfg.altitude_scale, e->cfg.altitude_potential, &e->ac[i].pre_altitude);
+}
+static double rw_event(OrEnv* e, int i) { /* event_driven_reward.py:15-34 */
+  double r = 0;
+  if (e->ac[i].status == OR_SHOTDOWN) r -= 200; else if (e->ac[i].status == OR_CRASH) r -= 200;
+  for (int k = 0; k < e->n_msl; k++) if (e->msl[k].parent == i && e->msl[k].status == OR_MSL_HIT) r += 200;
+  return process(r, e->cfg.event_scale, e->cfg.event_potential, &e->ac[i].pre_event);
+}
+static double rw_shoot_penalty(OrEnv* e, int i) { /* shoot_penalty_reward.py:13-32 */
+  double r = 0;
+  if (e->ac[i].remaining_missiles == e->ac[i].pre_remaining_missiles - 1) r -= 30;
+  e->ac[i].pre_remaining_missiles = e->ac[i].remaining_missiles;
+  return process(r, e->cfg.shoot_penalty_scale, e->cfg.shoot_penalty_potential, &e->ac[i].pre_shoot);
+}
+static double rw_missile_posture(OrEnv* e, int i) { /* missile_posture_reward.py:18-46 */
+  double reward = 0;
+  int mk = missile_warning(e, i);
+  if (mk >= 0) {
+    const double* mv = e->msl[mk].velocity;
+    const double* av = e->ac[i].velocity;
+    if (e->mp_prev_missile < 0) e->mp_prev_missile = mk; /* previous_missile_v aliases that missile's live _velocity array */
+    double v_dec = (norm3(e->msl[e->mp_prev_missile].velocity) - norm3(mv)) / 340 * e->cfg.missile_posture_scale;
+    double angle = (mv[0] * av[0] + mv[1] * av[1] + mv[2] * av[2]) / (norm3(mv) * norm3(av));
+    if (angle < 0) reward = angle / (fmax(v_dec, 0) + 1);
+    else reward = angle * fmax(v_dec, 0);
+  } else {
+    e->mp_prev_missile = -1;
+  }
+  return reward;
+}
+static double rw_heading(OrEnv* e, int i) { /* heading_reward.py:18-71 */
+  OrAircraft* a = &e->ac[i];
+  double p = a->fdm.pqr[0], q = a->fdm.pqr[1];
+  double roll_rate_r = 0, pitch_rate_r = 0;
+  if (e->current_step > 1) { roll_rate_r = -fabs(p - a->last_roll_rate); pitch_rate_r = -fabs(q - a->last_pitch_rate); }
+  double d_hdg = clampd(-180, in_range_deg(a->target_heading_deg - a->fdm.psi * RAD2DEG), 180);
+  double d_alt = clampd(-40000, (a->target_altitude_ft - a->fdm.h_sl) * FT2M, 40000);
+  double d_vel = clampd(-1400, a->target_velocities_u_mps - mps(a->fdm.uvw[0]), 1400);
+  double hr = exp(-pow(d_hdg / 5.0, 2)), ar = exp(-pow(d_alt / 15.24, 2));
+  double rr = exp(-pow(a->fdm.phi / 0.35, 2)), sr = exp(-pow(d_vel / 24, 2));
+  double reward = pow(hr * ar * rr * sr, 1.0 / 4);
+  if (e->current_step > 1) reward += roll_rate_r + pitch_rate_r;
+  a->last_roll_rate = p; a->last_pitch_rate = q;
+  return process(reward, e->cfg.heading_scale, e->cfg.heading_potential, &a->pre_heading);
+}
+static double task_reward_terms(OrEnv* e, int i) {
+  switch (e->cfg.task) {
+    case OR_TASK_HEADING: { double r = rw_heading(e, i); return r + rw_altitude(e, i); }
+    case OR_TASK_SINGLECOMBAT: { double r = rw_altitude(e, i); r += rw_posture(e, i); return r + rw_event(e, i); }
+    case OR_TASK_DODGE_MISSILE: { double r = rw_posture(e, i); r += rw_missile_posture(e, i); r += rw_altitude(e, i); return r + rw_event(e, i); }
+    default: { double r = rw_posture(e, i); r += rw_altitude(e, i); r += rw_event(e, i); return r + rw_shoot_penalty(e, i); }
+  }
+}
+static double get_reward(OrEnv* e, int i) { /* singlecombat_task.py:190-195; heading task uses BaseTask.get_reward */
+  if (e->cfg.task == OR_TASK_HEADING) return task_reward_terms(e, i);
+  if (e->ac[i].die_flag) return 0.0;
+  e->ac[i].die_flag = e->ac[i].status != OR_ALIVE;
+  return task_reward_terms(e, i);
+}
+static void reward_reset(OrEnv* e) { /* reward_function_base.py:20-32 — each potential term seeds pre_rewards via get_reward */
+  for (int i = 0; i < e->cfg.n_aircraft; i++) {
+    OrAircraft* a = &e->ac[i];
+    a->pre_posture = a->pre_altitude = a->pre_event = a->pre_heading = a->pre_shoot = 0;
+    a->pre_remaining_missiles = e->cfg.num_missiles[i];
+  }
+  e->mp_prev_missile = -1;
+  int t = e->cfg.task;
+  /* reset order = reward_functions list order of the task */
+  if (t == OR_TASK_HEADING) {
+    if (e->cfg.heading_potential) for (int i = 0; i < e->cfg.n_aircraft; i++) rw_heading(e, i);
+    if (e->cfg.altitude_potential) for (int i = 0; i < e->cfg.n_aircraft; i++) rw_altitude(e, i);
+    return;
+  }
+  if (e->cfg.altitude_potential) for (int i = 0; i < e->cfg.n_aircraft; i++) rw_altitude(e, i);
+  if (e->cfg.posture_potential) for (int i = 0; i < e->cfg.n_aircraft; i++) rw_posture(e, i);
+  if (e->cfg.event_potential) for (int i = 0; i < e->cfg.n_aircraft; i++) rw_event(e, i);
+  if (t == OR_TASK_SHOOT_MISSILE && e->cfg.shoot_penalty_potential) for (int i = 0; i < e->cfg.n_aircraft; i++) rw_shoot_penalty(e, i);
+}
+
+/* ------------------------------------------------------------------ terminations (first that fires wins, task_base.py:88-112) */
+static int t_low_altitude(OrEnv* e, int i, int* code) { /* low_altitude.py:15-34 */
+  if (h_sl_m(&e->ac[i]) <= e->cfg.altitude_limit) { e->ac[i].status = OR_CRASH; *code = OR_DONE_LOW_ALTITUDE; return 1; }
+  return 0;
+}
+static int t_extreme(OrEnv* e, int i, int* code) { /* extreme_state.py:14-33 */
+  if (extreme_state(&e->ac[i])) { e->ac[i].status = OR_CRASH; *code = OR_DONE_EXTREME_STATE; return 1; }
+  return 0;
+}
+static int t_overload(OrEnv* e, int i, int* code) { /* overload.py:18-46 */
+  const F16State* s = &e->ac[i].fdm;
+  if (s->sim_time > 10 && (fabs(s->npilot[0]) > e->cfg.acc_limit_x || fabs(s->npilot[1]) > e->cfg.acc_limit_y || fabs(s->npilot[2] + 1) > e->cfg.acc_limit_z)) {
+    e->ac[i].status = OR_CRASH; *code = OR_DONE_OVERLOAD; return 1;
+  }
+  return 0;
+}
+static int t_safe_return(OrEnv* e, int i, int* code) { /* safe_return.py:15-50 */
+  if (e->ac[i].status == OR_SHOTDOWN) { *code = OR_DONE_SHOTDOWN; return 1; }
+  if (e->ac[i].status == OR_CRASH) { *code = OR_DONE_CRASHED; return 1; }
+  int enemies_dead = 1, no_missile = 1;
+  for (int k = 0; k < e->cfg.n_aircraft; k++) if (e->ac[k].team != e->ac[i].team && e->ac[k].status == OR_ALIVE) enemies_dead = 0;
+  for (int k = 0; k < e->n_msl; k++) if (e->msl[k].target == i && e->msl[k].status == OR_MSL_LAUNCHED) no_missile = 0;
+  if (enemies_dead && no_missile) { *code = OR_DONE_MISSION_COMPLETE; return 1; }
+  return 0;
+}
+static int t_timeout(OrEnv* e, int i, int* code) { /* timeout.py:14-32 */
+  (void)i;
+  if (e->current_step >= e->cfg.max_steps) { *code = OR_DONE_TIMEOUT; return 1; }
+  return 0;
+}
+static int t_unreach_heading(OrEnv* e, int i, int* code) { /* unreach_heading.py:22-65 */
+  static const double inc_size[15] = {0.2, 0.4, 0.6, 0.8, 1.0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+  OrAircraft* a = &e->ac[i];
+  int done = 0;
+  double check_time = a->heading_check_time;
+  if (a->fdm.sim_time >= check_time) {
+    double d_hdg = clampd(-180, in_range_deg(a->target_heading_deg - a->fdm.psi * RAD2DEG), 180);
+    if (fabs(d_hdg) > 10) done = 1;
+    else {
+      double delta = inc_size[e->heading_turn_counts];
+      double dh = or_env_uniform(e, -delta, delta) * e->cfg.max_heading_increment;
+      double da = or_env_uniform(e, -delta, delta) * e->cfg.max_altitude_increment;
+      double dv = or_env_uniform(e, -delta, delta) * e->cfg.max_velocities_u_increment;
+      double nh = fmod(a->target_heading_deg + dh + 360, 360);
+      if (nh < 0) nh += 360;
+      a->target_heading_deg = clampd(0, nh, 360);
+      a->target_altitude_ft = clampd(-1400, a->target_altitude_ft + da, 85000);
+      a->target_velocities_u_mps = clampd(-700, a->target_velocities_u_mps + dv, 700);
+      a->heading_check_time = clampd(0, check_time + e->cfg.check_interval, 1000000);
+      e->heading_turn_counts += 1;
+    }
+  }
+  if (done) *code = OR_DONE_UNREACH_HEADING;
+  return done;
+}
+static int get_termination(OrEnv* e, int i, int* code) {
+  if (e->cfg.task == OR_TASK_HEADING) /* heading_task.py:20-26 */
+    return t_unreach_heading(e, i, code) || t_extreme(e, i, code) || t_overload(e, i, code) || t_low_altitude(e, i, code) || t_timeout(e, i, code);
+  /* singlecombat_task.py:34-40 */
+  return t_low_altitude(e, i, code) || t_extreme(e, i, code) || t_overload(e, i, code) || t_safe_return(e, i, code) || t_timeout(e, i, code);
+}
+
+/* ------------------------------------------------------------------ task.step */
+static int new_missile(OrEnv* e, int parent, int target, int model) {
+  if (e->n_msl >= OR_MAX_MSL) return -1;
+  int k = e->n_msl++;
+  OrMissile* m = &e->msl[k];
+  or_missile_init(m, model, 1.0 / e->cfg.sim_freq);
+  m->parent = parent; m->target = target;
+  or_missile_launch(m, e->ac[parent].geodetic, e->ac[parent].position, e->ac[parent].velocity, e->ac[parent].posture);
+  return k;
+}
+static void task_step(OrEnv* e) {
+  int t = e->cfg.task;
+  if (t == OR_TASK_HEADING) return;
+  if (e->cfg.use_artillery) { /* singlecombat_task.py:162-188 */
+    for (int i = 0; i < e->cfg.n_aircraft; i++) {
+      double ef[6], nf[6], r[4];
+      feature6(&e->ac[i], ef);
+      for (int k = 0; k < e->cfg.n_aircraft; k++) {
+        if (e->ac[k].team == e->ac[i].team || e->ac[k].status != OR_ALIVE) continue;
+        feature6(&e->ac[k], nf);
+        or_get_AO_TA_R(ef, nf, 0, r);
+        double AO = r[0], Rk = r[2] / 1000, of = 0, df = 0;
+        if (AO >= 0 && AO <= 0.5236) of = 1 - AO / 0.5236; else if (AO >= -0.5236 && AO <= 0) of = 1 + AO / 0.5236;
+        if (Rk <= 1) df = 1; else if (Rk > 1 && Rk <= 3) df = (3 - Rk) / 2.;
+        e->ac[k].bloods -= of * df;
+      }
+    }
+  }
+  if (t == OR_TASK_DODGE_MISSILE) { /* singlecombat_with_missile_task.py:108-124 */
+    for (int i = 0; i < e->cfg.n_aircraft; i++) {
+      OrAircraft* a = &e->ac[i];
+      int en = first_enemy(e, i);
+      double tg[3] = {e->ac[en].position[0] - a->position[0], e->ac[en].position[1] - a->position[1], e->ac[en].position[2] - a->position[2]};
+      double dist = norm3(tg);
+      double dot = tg[0] * a->velocity[0] + tg[1] * a->velocity[1] + tg[2] * a->velocity[2];
+      double ang = RAD2DEG * acos(clampd(-1, dot / (dist * norm3(a->velocity) + 1e-8), 1));
+      int maxlen = a->lock_n;
+      a->lock_window[a->lock_pos % maxlen] = ang < e->cfg.max_attack_angle;
+      a->lock_pos++;
+      int filled = a->lock_pos < maxlen ? a->lock_pos : maxlen, sum = 0;
+      for (int k = 0; k < filled; k++) sum += a->lock_window[k];
+      int interval = e->current_step - a->last_shoot_time;
+      int shoot = a->status == OR_ALIVE && sum >= maxlen && dist <= e->cfg.max_attack_distance && a->remaining_missiles > 0 && interval >= e->cfg.min_attack_interval;
+      if (shoot) {
+        new_missile(e, i, en, 0);
+        a->remaining_missiles -= 1;
+        a->last_shoot_time = e->current_step;
+      }
+    }
+  } else if (t == OR_TASK_SHOOT_MISSILE) { /* :194-204 */
+    for (int i = 0; i < e->cfg.n_aircraft; i++) {
+      OrAircraft* a = &e->ac[i];
+      int shoot = a->status == OR_ALIVE && a->shoot_action && a->remaining_missiles > 0;
+      int prev_done = a->last_missile < 0 || e->msl[a->last_missile].status == OR_MSL_HIT || e->msl[a->last_missile].status == OR_MSL_MISS;
+      if (shoot && prev_done) {
+        a->last_missile = new_missile(e, i, first_enemy(e, i), 0);
+        a->remaining_missiles -= 1;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ reset / step */
+void or_env_reset(OrEnv* e, double* obs) {
+  const OrEnvConfig* c = &e->cfg;
+  e->current_step = 0;
+  e->n_msl = 0;
+  if (c->task == OR_TASK_HEADING) { /* singlecontrol_env.py:24-49 */
+    double hdg = or_env_uniform(e, 0., 180.), alt = or_env_uniform(e, 14000., 30000.), u = or_env_uniform(e, 400., 1200.);
+    F16Init ic = c->init[0];
+    ic.psi_deg = clampd(0, hdg, 360); ic.h_sl_ft = clampd(-1400, alt, 85000); ic.u_fps = u;
+    aircraft_reload(e, &e->ac[0], &ic, 0);
+    e->ac[0].target_heading_deg = clampd(0, hdg, 360);
+    e->ac[0].target_altitude_ft = clampd(-1400, alt, 85000);
+    e->ac[0].target_velocities_u_mps = clampd(-700, u * 0.3048, 700);
+    e->ac[0].heading_check_time = 0;
+    e->heading_turn_counts = 0;
+  } else {
+    for (int i = 0; i < c->n_aircraft; i++) aircraft_reload(e, &e->ac[i], &c->init[i], c->num_missiles[i]);
+  }
+  /* task.reset */
+  for (int i = 0; i < c->n_aircraft; i++) {
+    OrAircraft* a = &e->ac[i];
+    a->die_flag = 0;
+    a->last_shoot_time = -c->min_attack_interval;
+    a->lock_n = (int)(1 / ((double)c->agent_interaction_steps / c->sim_freq));
+    if (a->lock_n > 16) a->lock_n = 16;
+    a->lock_pos = 0;
+    a->shoot_action = 0;
+    a->last_missile = -1;
+  }
+  reward_reset(e);
+  get_obs(e, obs);
+}
+
+static void decode_action(const OrEnv* e, int i, const double* act, double out[4]) {
+  (void)i;
+  if (e->cfg.task == OR_TASK_HEADING) { /* heading_task.py:102-110 */
+    out[0] = act[0] * 2. / (41 - 1.) - 1.; out[1] = act[1] * 2. / (41 - 1.) - 1.; out[2] = act[2] * 2. / (41 - 1.) - 1.;
+    out[3] = act[3] * 0.5 / (30 - 1.) + 0.4;
+  } else { /* singlecombat_task.py:141-153 */
+    out[0] = act[0] / 20 - 1.; out[1] = act[1] / 20 - 1.; out[2] = act[2] / 20 - 1.; out[3] = act[3] / 58 + 0.4;
+  }
+}
+
+void or_env_step(OrEnv* e, const double* actions, double* obs, double* rew, uint8_t* done, int32_t* info) {
+  const OrEnvConfig* c = &e->cfg;
+  e->current_step += 1;
+  int code = OR_DONE_NONE;
+  for (int i = 0; i < c->n_aircraft; i++) {
+    const double* act = actions + i * e->act_dim;
+    double u[4];
+    if (c->task == OR_TASK_SHOOT_MISSILE) e->ac[i].shoot_action = act[4] != 0; /* :182-184 */
+    decode_action(e, i, act, u);
+    f16_set_controls(&e->ac[i].fdm, u[0], u[1], u[2], u[3]);
+  }
+  double dt = 1.0 / c->sim_freq;
+  for (int s = 0; s < c->agent_interaction_steps; s++) { /* env_base.py:139-154 */
+    for (int i = 0; i < c->n_aircraft; i++) aircraft_run(e, &e->ac[i]);
+    for (int k = 0; k < e->n_msl; k++) {
+      OrMissile* m = &e->msl[k];
+      /* MissileSimulator.run is called for every entry, whatever its status (simulatior.py:520-533) */
+      OrAircraft* tg = &e->ac[m->target];
+      int st = or_missile_run(m, tg->position, tg->velocity, tg->status == OR_ALIVE, dt, c->center_lon, c->center_lat, c->center_alt);
+      if (st == OR_MSL_HIT && tg->status == OR_ALIVE) tg->status = OR_SHOTDOWN;
+    }
+  }
+  task_step(e);
+  get_obs(e, obs);
+  for (int i = 0; i < c->n_aircraft; i++) done[i] = (uint8_t)get_termination(e, i, &code);
+  for (int i = 0; i < c->n_aircraft; i++) rew[i] = get_reward(e, i);
+  int all = 1;
+  for (int i = 0; i < c->n_aircraft; i++) all = all && done[i];
+  if (info) { info[0] = e->current_step; info[1] = code; info[2] = e->heading_turn_counts; info[3] = all; }
+}

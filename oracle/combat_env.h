@@ -1,0 +1,129 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU (plain C, float64) restatement of the reference's per-env step orchestration:
+ *   envs/JSBSim/envs/env_base.py:98-173 (reset/step), envs/JSBSim/core/simulatior.py (aircraft wrapper,
+ *   MissileSimulator), envs/JSBSim/tasks/{heading_task,singlecombat_task,singlecombat_with_missile_task}.py,
+ *   envs/JSBSim/reward_functions/, envs/JSBSim/termination_conditions/, envs/JSBSim/utils/utils.py.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it; the product never does.
+ * The Python parts restated here are pinned by tests/golden/ vectors generated from the reference's own
+ * Python (see tests/golden/make_golden.py); the FDM underneath is "parity unpinned" (see f16_fdm.h).
+ */
+#ifndef ORACLE_COMBAT_ENV_H
+#define ORACLE_COMBAT_ENV_H
+#include <stdint.h>
+#include "f16_fdm.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OR_MAX_AC 8
+#define OR_MAX_MSL 64
+
+enum { OR_TASK_HEADING = 0, OR_TASK_SINGLECOMBAT = 1, OR_TASK_DODGE_MISSILE = 2, OR_TASK_SHOOT_MISSILE = 3 };
+enum { OR_ALIVE = 0, OR_CRASH = 1, OR_SHOTDOWN = 2 };
+enum { OR_MSL_INACTIVE = -1, OR_MSL_LAUNCHED = 0, OR_MSL_HIT = 1, OR_MSL_MISS = 2 };
+/* done reason codes written to info (first condition that fired for the LAST agent evaluated, like info['done_condition']) */
+enum { OR_DONE_NONE = 0, OR_DONE_LOW_ALTITUDE = 1, OR_DONE_EXTREME_STATE = 2, OR_DONE_OVERLOAD = 3, OR_DONE_SHOTDOWN = 4,
+       OR_DONE_CRASHED = 5, OR_DONE_MISSION_COMPLETE = 6, OR_DONE_TIMEOUT = 7, OR_DONE_UNREACH_HEADING = 8 };
+
+typedef struct {
+  int task;
+  int n_aircraft;                  /* aircraft in the env; first n_ego are team A (ego), the rest team B */
+  int n_ego;
+  int sim_freq;                    /* 60 */
+  int agent_interaction_steps;     /* 6 */
+  int max_steps;
+  double center_lon, center_lat, center_alt;
+  double altitude_limit;           /* m */
+  double acc_limit_x, acc_limit_y, acc_limit_z;
+  F16Init init[OR_MAX_AC];
+  int num_missiles[OR_MAX_AC];
+  /* rewards (reward_function_base.py:14-15): scale / potential per term */
+  double posture_scale; int posture_potential;
+  double altitude_scale; int altitude_potential;
+  double event_scale; int event_potential;
+  double heading_scale; int heading_potential;
+  double missile_posture_scale;
+  double shoot_penalty_scale; int shoot_penalty_potential;
+  double alt_safe, alt_danger, alt_kv;       /* AltitudeReward */
+  /* rule-based launch (singlecombat_with_missile_task.py:19-21) */
+  double max_attack_angle, max_attack_distance; int min_attack_interval;
+  /* heading task (unreach_heading.py:27-31) */
+  double max_heading_increment, max_altitude_increment, max_velocities_u_increment, check_interval;
+  int use_artillery;
+} OrEnvConfig;
+
+typedef struct {
+  F16State fdm;
+  int status;
+  double bloods;
+  double geodetic[3];   /* lon deg, lat deg, alt m (clipped) */
+  double position[3];   /* N, E, U m */
+  double posture[3];    /* roll, pitch, yaw rad */
+  double velocity[3];   /* vN, vE, vDOWN m/s (clipped) */
+  int team;
+  /* task bookkeeping */
+  int die_flag;
+  int remaining_missiles;
+  int last_shoot_time;
+  int lock_window[16]; int lock_n, lock_pos;   /* deque(maxlen=int(1/time_interval)) */
+  int shoot_action;
+  int last_missile;     /* index of agent_last_shot_missile, -1 = none */
+  /* heading task extras */
+  double target_heading_deg, target_altitude_ft, target_velocities_u_mps, heading_check_time;
+  double last_roll_rate, last_pitch_rate;
+  /* reward memory */
+  double pre_posture, pre_altitude, pre_event, pre_heading, pre_shoot;
+  int pre_remaining_missiles;
+} OrAircraft;
+
+typedef struct {
+  int status;
+  int parent, target;
+  double geodetic[3], position[3], velocity[3], posture[3];
+  double t, m, dtheta, dphi, dist_prev;
+  int recede_count;     /* consecutive "distance increased" samples (deque of maxlen int(5/dt)) */
+  int recede_len, recede_max;
+  /* parameters (simulatior.py:421-433) */
+  double g, t_max, t_thrust, Isp, Length, Diameter, cD, m0, dm, K, nyz_max, Rc, v_min;
+} OrMissile;
+
+typedef struct {
+  OrEnvConfig cfg;
+  OrAircraft ac[OR_MAX_AC];
+  OrMissile msl[OR_MAX_MSL];
+  int n_msl;
+  int current_step;
+  int heading_turn_counts;
+  /* MissilePostureReward shared memory: index of the missile whose velocity array was aliased, -1 = None */
+  int mp_prev_missile;
+  /* numpy Generator(PCG64) state mirror for env.np_random */
+  unsigned __int128 rng_state, rng_inc;
+  int obs_dim, act_dim;
+} OrEnv;
+
+int or_env_obs_dim(int task);
+int or_env_act_dim(int task);
+void or_env_default_config(OrEnvConfig* c, int task);
+void or_env_init(OrEnv* e, const OrEnvConfig* c);
+/* seed with the raw PCG64 state/inc as numpy reports them (np.random.PCG64(seed).state['state']) */
+void or_env_seed_pcg64(OrEnv* e, uint64_t state_hi, uint64_t state_lo, uint64_t inc_hi, uint64_t inc_lo);
+double or_env_uniform(OrEnv* e, double lo, double hi);
+void or_env_reset(OrEnv* e, double* obs /* [n_aircraft][obs_dim] */);
+void or_env_step(OrEnv* e, const double* actions /* [n_aircraft][act_dim] */, double* obs, double* rew, uint8_t* done,
+                 int32_t* info /* [4]: current_step, done_code, heading_turn_counts, all_done */);
+
+/* exposed pieces for golden-vector tests */
+void or_get_AO_TA_R(const double ego[6], const double enm[6], int two_d, double out[4]);
+double or_posture_reward(double AO, double TA, double R_km);
+double or_altitude_reward(double ego_z_km, double ego_vz_mh, double safe, double danger, double kv);
+void or_missile_init(OrMissile* m, int model /*0 AIM-9L, 1 AIM-120B parameter set*/, double dt);
+void or_missile_launch(OrMissile* m, const double geodetic[3], const double position[3], const double velocity[3], const double rpy[3]);
+/* one MissileSimulator.run(); returns new status; target_alive in/out semantics as the reference (HIT => caller shoots down target) */
+int or_missile_run(OrMissile* m, const double tgt_pos[3], const double tgt_vel[3], int target_alive, double dt,
+                   double lon0, double lat0, double alt0);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
