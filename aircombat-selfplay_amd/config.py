@@ -1,0 +1,114 @@
+"""Scenario YAML -> ac_config_t.
+
+Mirrors ``parse_config`` (reference envs/JSBSim/utils/utils.py:7-23) and the ``getattr(config, f'{Class}_{param}', default)``
+convention of the reward / termination classes (reward_function_base.py:14-15, altitude_reward.py:14-16, low_altitude.py:13,
+overload.py:18-20, timeout.py:16), for the tasks the HIP path implements.
+"""
+import yaml
+
+from .capi import (AcConfig, AC_MAX_AGENTS, AC_TASK_HEADING, AC_TASK_SINGLECOMBAT, AC_TASK_DODGE_MISSILE,
+                   AC_TASK_SHOOT_MISSILE)
+
+TASK_IDS = {
+    "heading": AC_TASK_HEADING,
+    "singlecombat": AC_TASK_SINGLECOMBAT,            # SingleCombatTask (1v1, no weapons)
+    "singlecombat_dodge_missile": AC_TASK_DODGE_MISSILE,
+    "singlecombat_shoot": AC_TASK_SHOOT_MISSILE,     # SingleCombatShootMissileTask
+}
+
+# defaults of AircraftSimulator.clear_defalut_condition (simulatior.py:192-208)
+_IC_DEFAULT = dict(lon_deg=120.0, lat_geod_deg=60.0, h_sl_ft=20000.0, psi_deg=0.0, u_fps=800.0, v_fps=0.0, w_fps=0.0,
+                   p_rad_sec=0.0, q_rad_sec=0.0, r_rad_sec=0.0)
+_IC_KEYS = dict(ic_long_gc_deg="lon_deg", ic_lat_geod_deg="lat_geod_deg", ic_h_sl_ft="h_sl_ft", ic_psi_true_deg="psi_deg",
+                ic_u_fps="u_fps", ic_v_fps="v_fps", ic_w_fps="w_fps", ic_p_rad_sec="p_rad_sec", ic_q_rad_sec="q_rad_sec",
+                ic_r_rad_sec="r_rad_sec")
+
+
+def _clip(v, lo, hi):
+    return min(max(v, lo), hi)
+
+
+def config_from_dict(data, task=None):
+    """Build an AcConfig from a parsed scenario dict; ``task`` overrides the YAML's task name with one of TASK_IDS."""
+    cfg = AcConfig()
+    name = task or data.get("task")
+    if name not in TASK_IDS:
+        raise NotImplementedError(f"Unknown taskname: {name} (available: {sorted(TASK_IDS)})")
+    cfg.task = TASK_IDS[name]
+    acs = data["aircraft_configs"]
+    uids = list(acs.keys())
+    if len(uids) > AC_MAX_AGENTS:
+        raise ValueError("too many aircraft")
+    team0 = uids[0][0]
+    ego = [u for u in uids if u[0] == team0]
+    enm = [u for u in uids if u[0] != team0]
+    if uids != ego + enm:
+        raise ValueError("aircraft_configs must list the ego team first (BaseEnv._pack order)")
+    cfg.n_agents = len(uids)
+    cfg.n_ego = len(ego)
+    cfg.sim_freq = int(data.get("sim_freq", 60))
+    cfg.agent_interaction_steps = int(data.get("agent_interaction_steps", 12))   # env_base.py:27
+    cfg.max_steps = int(data.get("max_steps", 100))                              # env_base.py:25
+    lon, lat, alt = data.get("battle_field_center", (120.0, 60.0, 0.0))
+    cfg.center_lon, cfg.center_lat, cfg.center_alt = float(lon), float(lat), float(alt)
+    cfg.altitude_limit = float(data.get("altitude_limit", 2500))
+    cfg.acc_limit_x = float(data.get("acceleration_limit_x", 10.0))
+    cfg.acc_limit_y = float(data.get("acceleration_limit_y", 10.0))
+    cfg.acc_limit_z = float(data.get("acceleration_limit_z", 10.0))
+    for i, uid in enumerate(uids):
+        ic = dict(_IC_DEFAULT)
+        for k, v in (acs[uid].get("init_state") or {}).items():
+            if k in _IC_KEYS:
+                ic[_IC_KEYS[k]] = float(v)
+        # catalogue bounds applied by set_property_value (catalog.py:237,247)
+        ic["h_sl_ft"] = _clip(ic["h_sl_ft"], -1400, 85000)
+        ic["psi_deg"] = _clip(ic["psi_deg"], 0, 360)
+        for k, v in ic.items():
+            setattr(cfg.init[i], k, v)
+        cfg.num_missiles[i] = int(acs[uid].get("missile", 0))
+    g = data.get
+    cfg.posture_scale = float(g("PostureReward_scale", 1.0)); cfg.posture_potential = int(bool(g("PostureReward_potential", False)))
+    cfg.altitude_scale = float(g("AltitudeReward_scale", 1.0)); cfg.altitude_potential = int(bool(g("AltitudeReward_potential", False)))
+    cfg.event_scale = float(g("EventDrivenReward_scale", 1.0)); cfg.event_potential = int(bool(g("EventDrivenReward_potential", False)))
+    cfg.missile_posture_scale = float(g("MissilePostureReward_scale", 1.0))
+    cfg.shoot_penalty_scale = float(g("ShootPenaltyReward_scale", 1.0)); cfg.shoot_penalty_potential = int(bool(g("ShootPenaltyReward_potential", False)))
+    for ver, want in (("PostureReward_orientation_version", "v2"), ("PostureReward_range_version", "v3")):
+        if g(ver, want) != want:
+            raise NotImplementedError(f"{ver}={g(ver)}: only {want} (the one every shipped YAML selects) is implemented")
+    cfg.alt_safe = float(g("AltitudeReward_safe_altitude", 4.0))
+    cfg.alt_danger = float(g("AltitudeReward_danger_altitude", 3.5))
+    cfg.alt_kv = float(g("AltitudeReward_Kv", 0.2))
+    cfg.max_attack_angle = float(g("max_attack_angle", 180))
+    cfg.max_attack_distance = float(g("max_attack_distance", float("inf")))
+    cfg.min_attack_interval = int(g("min_attack_interval", 125))
+    cfg.use_artillery = int(bool(g("use_artillery", False)))
+    return cfg
+
+
+def config_from_yaml(path, task=None):
+    with open(path, "r", encoding="utf-8") as f:
+        data = yaml.load(f, Loader=yaml.FullLoader)
+    return config_from_dict(data, task=task)
+
+
+def default_config(task="singlecombat"):
+    """The 1v1 block of reference configs/scenario1/WVR_selfplay.yaml (BASELINE configs C2 / C3)."""
+    data = {
+        "task": task, "sim_freq": 60, "agent_interaction_steps": 6, "max_steps": 9000, "altitude_limit": 2500,
+        "acceleration_limit_x": 10.0, "acceleration_limit_y": 10.0, "acceleration_limit_z": 10.0,
+        "aircraft_configs": {
+            "A0100": {"color": "Blue", "model": "f16", "missile": 2,
+                      "init_state": {"ic_long_gc_deg": 120.0, "ic_lat_geod_deg": 60.0, "ic_h_sl_ft": 20000,
+                                     "ic_psi_true_deg": 0, "ic_u_fps": 800.0}},
+            "B0100": {"color": "Red", "model": "f16", "missile": 2,
+                      "init_state": {"ic_h_sl_ft": 20000, "ic_lat_geod_deg": 60.1, "ic_long_gc_deg": 120.5,
+                                     "ic_psi_true_deg": 180.0, "ic_u_fps": 800.0}},
+        },
+        "max_attack_angle": 45, "max_attack_distance": 14000, "min_attack_interval": 25,
+        "battle_field_center": [120.0, 60.0, 0.0],
+        "MissilePostureReward_scale": 30, "PostureReward_scale": 15.0, "PostureReward_potential": True,
+        "PostureReward_orientation_version": "v2", "PostureReward_range_version": "v3",
+        "AltitudeReward_safe_altitude": 4.0, "AltitudeReward_danger_altitude": 3.5, "AltitudeReward_Kv": 0.2,
+        "EventDrivenReward_scale": 1, "EventDrivenReward_potential": True,
+    }
+    return config_from_dict(data)

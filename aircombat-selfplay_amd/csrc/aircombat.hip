@@ -1,0 +1,981 @@
+// libaircombat_hip.so — MI355X (gfx950) vectorised air-combat step() behind the C ABI of include/aircombat.h.
+//
+// One kernel launch advances every aircraft of every env by one env step (6 FDM ticks), runs the missile
+// engine, builds observations, rewards and terminations, and resets finished episodes — the work the reference
+// spreads over SubprocVecEnv workers (envs/env_wrappers.py:182-320), BaseEnv.step (envs/JSBSim/envs/env_base.py:115-173),
+// AircraftSimulator/MissileSimulator (envs/JSBSim/core/simulatior.py) and the task/reward/termination classes.
+//
+// Layout in HBM: struct-of-arrays, lane-major. Field f of aircraft n lives at F[f*N + n] (N = E*A), so the 64
+// lanes of a wavefront read 256 contiguous bytes per field (one coalesced request). The A aircraft of one env
+// occupy adjacent lanes (A in {1,2,4,8} divides 64), so all pairwise combat geometry is exchanged with
+// __shfl inside the wavefront; no LDS or global traffic is needed for it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <cmath>
+#include "../../include/aircombat.h"
+#include "f16_device.hpp"
+
+using f16::State;
+using f16::Derived;
+using f16::Tab;
+using f16::clampf;
+
+// ------------------------------------------------------------------------------------------------ state layout
+#define AC_F_FIELDS(X)                                                                                           \
+  X(vx) X(vy) X(vz) X(q0) X(q1) X(q2) X(q3) X(wp) X(wq) X(wr) X(hv1x) X(hv1y) X(hv1z) X(hv2x) X(hv2y) X(hv2z)   \
+  X(ha1x) X(ha1y) X(ha1z) X(wdx) X(wdy) X(wdz) X(aix) X(aiy) X(aiz) X(bax) X(bay) X(baz) X(da) X(de) X(dr)       \
+  X(thr) X(pin_r) X(pin_p) X(pin_y) X(pi_r) X(pi_p) X(pi_y) X(tef) X(ail) X(elev) X(sbdeg) X(alpha) X(mach)      \
+  X(vckts) X(vg) X(ap) X(aq) X(ar) X(npx) X(npy) X(npz) X(n1) X(n2) X(n2norm) X(ff) X(tank0) X(tank1)
+#define AC_TF_FIELDS(X) X(bloods) X(pre_posture) X(pre_altitude) X(pre_event) X(pre_shoot)
+#define AC_TI_FIELDS(X)                                                                                  \
+  X(status) X(die_flag) X(remaining) X(pre_remaining) X(shoot_action) X(last_missile) X(last_shoot_time) \
+  X(lock_bits) X(lock_pos) X(cur_step)
+
+enum {
+#define X(n) FF_##n,
+  AC_F_FIELDS(X) AC_TF_FIELDS(X)
+#undef X
+  NF
+};
+enum {
+  FI_eng, FI_ticks,
+#define X(n) FI_##n,
+  AC_TI_FIELDS(X)
+#undef X
+  NI
+};
+enum { ND = 3 };
+// missile slot fields
+enum { MF_px, MF_py, MF_pz, MF_vx, MF_vy, MF_vz, MF_theta, MF_psi, MF_t, MF_m, MF_dth, MF_dph, MF_dprev, NMF };
+enum { MI_status, MI_recede, MI_order, NMI };
+enum { MSL_INACTIVE = -1, MSL_LAUNCHED = 0, MSL_HIT = 1, MSL_MISS = 2 };
+
+static const char* kStateNames[AC_STATE_LEN] = {
+    "rx", "ry", "rz",
+#define X(n) #n,
+    AC_F_FIELDS(X) AC_TF_FIELDS(X) "eng", "ticks", AC_TI_FIELDS(X)
+#undef X
+};
+
+struct Task {  // per-aircraft task bookkeeping
+#define X(n) float n;
+  AC_TF_FIELDS(X)
+#undef X
+#define X(n) int n;
+  AC_TI_FIELDS(X)
+#undef X
+};
+
+struct Msl {
+  float px, py, pz, vx, vy, vz, theta, psi, t, m, dth, dph, dprev;
+  int status, recede, order;
+};
+
+// Device-side scenario constants (passed by value to the kernels).
+struct DevCfg {
+  int task, A, n_ego, substeps, max_steps, obs_dim, act_dim, msl_slots;
+  int N;                      // aircraft lanes = E*A
+  float altitude_limit, acc_x, acc_y, acc_z;
+  float posture_scale, altitude_scale, event_scale, missile_posture_scale, shoot_penalty_scale;
+  int posture_pot, altitude_pot, event_pot, shoot_pot;
+  float alt_safe, alt_danger, alt_kv;
+  float max_attack_angle, max_attack_distance;
+  int min_attack_interval, use_artillery, lock_len;
+  int num_missiles[AC_MAX_AGENTS];
+  // battle-field origin for pymap3d-style geodetic <-> NED (metres, WGS84)
+  double P0x, P0y, P0z, sLat0, cLat0, sLon0, cLon0;
+};
+
+struct DevPtrs {
+  float* F; int* I; double* D;           // live state, SoA [field][N]
+  float* MF; int* MI;                    // missiles, SoA [slot][field][N]
+  const float* tF; const int* tI; const double* tD;  // reset template, [field][A]
+  const float* tab;                      // F16_TAB as fp32 in HBM (staged to LDS per workgroup)
+  const float* actions;                  // [N][act_dim]
+  float* obs; float* rew; uint8_t* done; int* info;
+};
+
+// ------------------------------------------------------------------------------------------------ device helpers
+__device__ __forceinline__ void load_state(const float* F, const int* I, const double* D, int N, int n, State& s, Task& t) {
+#define X(f) s.f = F[FF_##f * N + n];
+  AC_F_FIELDS(X)
+#undef X
+#define X(f) t.f = F[FF_##f * N + n];
+  AC_TF_FIELDS(X)
+#undef X
+  s.eng = I[FI_eng * N + n]; s.ticks = I[FI_ticks * N + n];
+#define X(f) t.f = I[FI_##f * N + n];
+  AC_TI_FIELDS(X)
+#undef X
+  s.rx = D[0 * N + n]; s.ry = D[1 * N + n]; s.rz = D[2 * N + n];
+}
+__device__ __forceinline__ void store_state(float* F, int* I, double* D, int N, int n, const State& s, const Task& t) {
+#define X(f) F[FF_##f * N + n] = s.f;
+  AC_F_FIELDS(X)
+#undef X
+#define X(f) F[FF_##f * N + n] = t.f;
+  AC_TF_FIELDS(X)
+#undef X
+  I[FI_eng * N + n] = s.eng; I[FI_ticks * N + n] = s.ticks;
+#define X(f) I[FI_##f * N + n] = t.f;
+  AC_TI_FIELDS(X)
+#undef X
+  D[0 * N + n] = s.rx; D[1 * N + n] = s.ry; D[2 * N + n] = s.rz;
+}
+__device__ __forceinline__ void load_msl(const float* MF, const int* MI, int N, int n, int slot, Msl& m) {
+  const float* f = MF + (size_t)slot * NMF * N;
+  const int* i = MI + (size_t)slot * NMI * N;
+  m.px = f[MF_px * N + n]; m.py = f[MF_py * N + n]; m.pz = f[MF_pz * N + n];
+  m.vx = f[MF_vx * N + n]; m.vy = f[MF_vy * N + n]; m.vz = f[MF_vz * N + n];
+  m.theta = f[MF_theta * N + n]; m.psi = f[MF_psi * N + n]; m.t = f[MF_t * N + n]; m.m = f[MF_m * N + n];
+  m.dth = f[MF_dth * N + n]; m.dph = f[MF_dph * N + n]; m.dprev = f[MF_dprev * N + n];
+  m.status = i[MI_status * N + n]; m.recede = i[MI_recede * N + n]; m.order = i[MI_order * N + n];
+}
+__device__ __forceinline__ void store_msl(float* MF, int* MI, int N, int n, int slot, const Msl& m) {
+  float* f = MF + (size_t)slot * NMF * N;
+  int* i = MI + (size_t)slot * NMI * N;
+  f[MF_px * N + n] = m.px; f[MF_py * N + n] = m.py; f[MF_pz * N + n] = m.pz;
+  f[MF_vx * N + n] = m.vx; f[MF_vy * N + n] = m.vy; f[MF_vz * N + n] = m.vz;
+  f[MF_theta * N + n] = m.theta; f[MF_psi * N + n] = m.psi; f[MF_t * N + n] = m.t; f[MF_m * N + n] = m.m;
+  f[MF_dth * N + n] = m.dth; f[MF_dph * N + n] = m.dph; f[MF_dprev * N + n] = m.dprev;
+  i[MI_status * N + n] = m.status; i[MI_recede * N + n] = m.recede; i[MI_order * N + n] = m.order;
+}
+
+// What the Python wrapper caches after every JSBSim run (simulatior.py:238-258) plus the clipped unit
+// conversions of the catalogue (catalog.py:292-338).
+struct Props {
+  float n, e, u;            // NEU position about the battle-field centre [m]
+  float vn, ve, vd;         // m/s, clipped to +-700
+  float alt_m;              // clipped to [-500, 26000]
+  float ub, vb, wb, vc;     // body velocities and calibrated airspeed [m/s], clipped
+  float sphi, cphi, stht, ctht;
+  float m11, m12;           // for the heading angle
+};
+__device__ __forceinline__ float mps(float fps) { return clampf(-700.0f, fps * f16::kFt2M, 700.0f); }
+
+__device__ __forceinline__ void make_props(const State& s, const Derived& d, const DevCfg& c, Props& p) {
+  p.alt_m = clampf(-500.0f, d.h_sl_ft * f16::kFt2M, 26000.0f);
+  p.vn = mps(d.vn); p.ve = mps(d.ve); p.vd = mps(d.vd);
+  p.ub = mps(d.u); p.vb = mps(d.v); p.wb = mps(d.w);
+  p.vc = clampf(0.0f, s.vckts * f16::kKts2Fps * f16::kFt2M, 1400.0f);
+  // LLA2NEU(lon, lat_geod, h_sl_m): the reference feeds the sea-level altitude to pymap3d.geodetic2ned as if it
+  // were ellipsoidal height (simulatior.py:240-245, utils.py:30-41). fp64: differences of 6.4e6 m ECEF coordinates.
+  const double a = 6378137.0, b = 6356752.314245179;  // pymap3d WGS84: a, a*(1-1/298.257223563)
+  double sl = d.sLat64, cl = d.cLat64, so = d.sLon64, co = d.cLon64;
+  double Nn = a * a / sqrt(a * a * cl * cl + b * b * sl * sl);
+  double h = (double)p.alt_m;
+  double x = (Nn + h) * cl * co, y = (Nn + h) * cl * so, z = (Nn * (b / a) * (b / a) + h) * sl;
+  double dx = x - c.P0x, dy = y - c.P0y, dz = z - c.P0z;
+  double t = c.cLon0 * dx + c.sLon0 * dy;
+  p.e = (float)(-c.sLon0 * dx + c.cLon0 * dy);
+  p.u = (float)(c.cLat0 * t + c.sLat0 * dz);
+  p.n = (float)(-c.sLat0 * t + c.cLat0 * dz);
+  // Euler sines/cosines from Tl2b = Ti2b * Ti2l^T  (only the five entries GetEuler reads)
+  const float* T = d.T;
+  float m13 = T[0] * d.d_eci[0] + T[1] * d.d_eci[1] + T[2] * d.d_eci[2];
+  float m23 = T[3] * d.d_eci[0] + T[4] * d.d_eci[1] + T[5] * d.d_eci[2];
+  float m33 = T[6] * d.d_eci[0] + T[7] * d.d_eci[1] + T[8] * d.d_eci[2];
+  p.m11 = T[0] * d.n_eci[0] + T[1] * d.n_eci[1] + T[2] * d.n_eci[2];
+  p.m12 = T[0] * d.e_eci[0] + T[1] * d.e_eci[1] + T[2] * d.e_eci[2];
+  p.stht = clampf(-1.0f, -m13, 1.0f);
+  float ct = sqrtf(fmaxf(0.0f, 1.0f - p.stht * p.stht));
+  p.ctht = ct;
+  float ic = (ct > 1e-12f) ? 1.0f / sqrtf(m23 * m23 + m33 * m33) : 0.0f;
+  p.sphi = (ct > 1e-12f) ? m23 * ic : 0.0f;
+  p.cphi = (ct > 1e-12f) ? m33 * ic : 1.0f;
+}
+
+// utils.py:58-103. v = (vN, vE, vDOWN) against an (N, E, UP) position, exactly as the reference mixes them.
+struct Geo { float AO, TA, R, side; };
+template <bool TWO_D>
+__device__ __forceinline__ Geo ao_ta_r(float ex, float ey, float ez, float evx, float evy, float evz,
+                                       float nx, float ny, float nz, float nvx, float nvy, float nvz) {
+  float dx = nx - ex, dy = ny - ey, dz = nz - ez;
+  float ev, nv, R, pe, pn;
+  if (TWO_D) {
+    ev = sqrtf(evx * evx + evy * evy); nv = sqrtf(nvx * nvx + nvy * nvy); R = sqrtf(dx * dx + dy * dy);
+    pe = dx * evx + dy * evy; pn = dx * nvx + dy * nvy;
+  } else {
+    ev = sqrtf(evx * evx + evy * evy + evz * evz); nv = sqrtf(nvx * nvx + nvy * nvy + nvz * nvz);
+    R = sqrtf(dx * dx + dy * dy + dz * dz);
+    pe = dx * evx + dy * evy + dz * evz; pn = dx * nvx + dy * nvy + dz * nvz;
+  }
+  Geo g;
+  g.AO = acosf(clampf(-1.0f, pe / (R * ev + 1e-8f), 1.0f));
+  g.TA = acosf(clampf(-1.0f, pn / (R * nv + 1e-8f), 1.0f));
+  g.R = R;
+  float cr = evx * dy - evy * dx;
+  g.side = (cr > 0.0f) ? 1.0f : ((cr < 0.0f) ? -1.0f : 0.0f);
+  return g;
+}
+// posture_reward.py:58-75 (orientation v2, range v3)
+__device__ __forceinline__ float posture_fn(float AO, float TA, float Rkm) {
+  float x = 1.0f - fmaxf(2.0f * TA / f16::kPi, 1e-4f);
+  float orn = 1.0f / (50.0f * AO / f16::kPi + 2.0f) + 0.5f + fminf(atanhf(x) / (2.0f * f16::kPi), 0.0f) + 0.5f;
+  float rng = (Rkm < 5.0f ? 1.0f : 0.0f) + (Rkm >= 5.0f ? clampf(0.0f, -0.032f * Rkm * Rkm + 0.284f * Rkm + 0.38f, 1.0f) : 0.0f) +
+              clampf(0.0f, __expf(-0.16f * Rkm), 0.2f);
+  return orn * rng;
+}
+// altitude_reward.py:20-40
+__device__ __forceinline__ float altitude_fn(float z_km, float vz_mh, const DevCfg& c) {
+  float Pv = 0.0f, PH = 0.0f;
+  if (z_km <= c.alt_safe) Pv = -clampf(0.0f, vz_mh / c.alt_kv * (c.alt_safe - z_km) / c.alt_safe, 1.0f);
+  if (z_km <= c.alt_danger) PH = clampf(0.0f, z_km / c.alt_danger, 1.0f) - 2.0f;
+  return Pv + PH;
+}
+__device__ __forceinline__ float potential(float r, float scale, int pot, float& pre) {
+  r *= scale;
+  if (pot) { float o = r - pre; pre = r; return o; }
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------ missile engine
+struct MslParam { float g, t_max, t_thrust, Isp, Length, Diameter, cD, m0, dm, K, nyz_max, Rc, v_min; int recede_max; };
+__device__ __forceinline__ MslParam aim9l() {  // simulatior.py:421-433
+  return MslParam{9.81f, 60.0f, 3.0f, 120.0f, 2.87f, 0.127f, 0.4f, 84.0f, 6.0f, 3.0f, 30.0f, 300.0f, 150.0f, 300};
+}
+// geodetic height of an NEU point (utils.py:44-55 -> pymap3d.ned2geodetic): ENU -> ECEF offset in fp64, then the
+// closed-form height of Fukushima's reduction (sub-millimetre, like pymap3d's You-2000 form)
+__device__ __forceinline__ float neu_height(float n, float e, float u, const DevCfg& c) {
+  double t = c.cLat0 * (double)u - c.sLat0 * (double)n;
+  double dz = c.sLat0 * (double)u + c.cLat0 * (double)n;
+  double dx = c.cLon0 * t - c.sLon0 * (double)e;
+  double dy = c.sLon0 * t + c.cLon0 * (double)e;
+  double X = c.P0x + dx, Y = c.P0y + dy, Z = c.P0z + dz;
+  const double a = 6378137.0, b = 6356752.314245179, ec = b / a, ec2 = ec * ec, cc0 = a * (1.0 - ec2);
+  double rxy = sqrt(X * X + Y * Y);
+  double s0 = fabs(Z), zc = ec * s0, c0 = ec * rxy, c02 = c0 * c0, s02 = s0 * s0, a02 = c02 + s02;
+  double a0 = sqrt(a02), a03 = a02 * a0;
+  double s1 = zc * a03 + cc0 * s02 * s0, c1 = rxy * a03 - cc0 * c02 * c0, cs = cc0 * c0 * s0;
+  double b0 = 1.5 * cs * ((rxy * s0 - zc * c0) * a0 - cs);
+  s1 = s1 * a03 - b0 * s0;
+  double cc = ec * (c1 * a03 - b0 * c0);
+  double s12 = s1 * s1, cc2 = cc * cc, norm = sqrt(s12 + cc2);
+  return (float)((rxy * cc + s0 * s1 - a * sqrt(ec2 * s12 + cc2)) / norm);
+}
+// MissileSimulator.run (simulatior.py:520-533) with _guidance (:556-576) and _state_trans (:578-608).
+__device__ __forceinline__ void missile_run(Msl& m, const MslParam& P, float tx, float ty, float tz, float tvx, float tvy, float tvz,
+                                            bool target_alive, const DevCfg& c) {
+  const float dt = 1.0f / 60.0f;
+  m.t += dt;
+  float vm = sqrtf(m.vx * m.vx + m.vy * m.vy + m.vz * m.vz);
+  float cth = sqrtf(fmaxf(0.0f, 1.0f - (m.vz / vm) * (m.vz / vm)));  // cos(asin(dz/v))
+  float ddx = tx - m.px, ddy = ty - m.py, ddz = tz - m.pz;
+  float Rxy2 = ddx * ddx + ddy * ddy, Rxy = sqrtf(Rxy2);
+  float R2 = Rxy2 + ddz * ddz, Rxyz = sqrtf(R2);
+  float dbeta = ((tvy - m.vy) * ddx - (tvx - m.vx) * ddy) / Rxy2;
+  float deps = ((tvz - m.vz) * Rxy2 - ddz * (ddx * (tvx - m.vx) + ddy * (tvy - m.vy))) / (R2 * Rxy);
+  float K = fmaxf(P.K * (P.t_max - m.t) / P.t_max, 0.0f);
+  float ny = clampf(-P.nyz_max, K * vm / P.g * cth * dbeta, P.nyz_max);
+  float nz = clampf(-P.nyz_max, K * vm / P.g * deps + cth, P.nyz_max);
+  m.recede = (Rxyz > m.dprev) ? m.recede + 1 : 0;
+  m.dprev = Rxyz;
+  if (Rxyz < P.Rc && target_alive && m.status != MSL_MISS) {
+    m.status = MSL_HIT;
+  } else if (m.t > P.t_max || vm < P.v_min || m.recede >= P.recede_max || !target_alive) {
+    m.status = MSL_MISS;
+  } else {
+    m.px += dt * m.vx; m.py += dt * m.vy; m.pz += dt * m.vz;
+    float alt = neu_height(m.px, m.py, m.pz, c);
+    float Isp = (m.t < P.t_thrust) ? P.Isp : 0.0f;
+    float Tt = P.g * Isp * P.dm;
+    float sd = __sinf(m.dth), sp = __sinf(m.dph);
+    float S = f16::kPi * 0.25f * P.Diameter * P.Diameter + sqrtf(sd * sd + sp * sp) * P.Diameter * P.Length;
+    float rho = 1.225f * __expf(-alt / 9300.0f);
+    float D = 0.5f * P.cD * S * rho * vm * vm;
+    float nx = (Tt - D) / (m.m * P.g);
+    float st, ct; sincosf(m.theta, &st, &ct);
+    float dv = P.g * (nx - st);
+    m.dph = P.g / vm * (ny / ct);
+    m.dth = P.g / vm * (nz - ct);
+    float v = vm + dt * dv;
+    m.psi += dt * m.dph; m.theta += dt * m.dth;
+    float s2, c2, s3, c3; sincosf(m.theta, &s2, &c2); sincosf(m.psi, &s3, &c3);
+    m.vx = v * c2 * c3; m.vy = v * c2 * s3; m.vz = v * s2;
+    if (m.t < P.t_thrust) m.m -= dt * P.dm;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ 1v1 observation
+// singlecombat_task.py:88-139 (15 values, 2-D AO/TA, clipped to +-10) and
+// singlecombat_with_missile_task.py:31-99 (21 values, 3-D AO/TA, unclipped, missile-warning block).
+struct Enemy { float n, e, u, vn, ve, vd, ub, alt; };
+__device__ __forceinline__ Enemy exchange_1v1(const Props& pr) {
+  Enemy E;
+  E.n = __shfl_xor(pr.n, 1); E.e = __shfl_xor(pr.e, 1); E.u = __shfl_xor(pr.u, 1);
+  E.vn = __shfl_xor(pr.vn, 1); E.ve = __shfl_xor(pr.ve, 1); E.vd = __shfl_xor(pr.vd, 1);
+  E.ub = __shfl_xor(pr.ub, 1); E.alt = __shfl_xor(pr.alt_m, 1);
+  return E;
+}
+struct Incoming { bool any; float px, py, pz, vx, vy, vz; };
+template <int TASK>
+__device__ __forceinline__ void observe_1v1(const Props& pr, const Enemy& E, const Incoming& in, float* ob) {
+  ob[0] = pr.alt_m / 5000.0f;
+  ob[1] = pr.sphi; ob[2] = pr.cphi; ob[3] = pr.stht; ob[4] = pr.ctht;
+  ob[5] = pr.ub / 340.0f; ob[6] = pr.vb / 340.0f; ob[7] = pr.wb / 340.0f; ob[8] = pr.vc / 340.0f;
+  Geo g = (TASK == AC_TASK_SINGLECOMBAT)
+              ? ao_ta_r<true>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd)
+              : ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd);
+  ob[9] = (E.ub - pr.ub) / 340.0f;
+  ob[10] = (E.alt - pr.alt_m) / 1000.0f;
+  ob[11] = g.AO; ob[12] = g.TA; ob[13] = g.R / 10000.0f; ob[14] = g.side;
+  if (TASK == AC_TASK_SINGLECOMBAT) {
+#pragma unroll
+    for (int k = 0; k < 15; ++k) ob[k] = clampf(-10.0f, ob[k], 10.0f);
+  } else {
+#pragma unroll
+    for (int k = 15; k < 21; ++k) ob[k] = 0.0f;
+    if (in.any) {
+      Geo gm = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, in.px, in.py, in.pz, in.vx, in.vy, in.vz);
+      ob[15] = (sqrtf(in.vx * in.vx + in.vy * in.vy + in.vz * in.vz) - pr.ub) / 340.0f;
+      ob[16] = (in.pz - pr.alt_m) / 1000.0f;
+      ob[17] = gm.AO; ob[18] = gm.TA; ob[19] = gm.R / 10000.0f; ob[20] = gm.side;
+    }
+  }
+}
+// PostureReward / AltitudeReward raw values for this lane (posture_reward.py:26-49, altitude_reward.py:20-40)
+__device__ __forceinline__ float posture_raw(const Props& pr, const Enemy& E) {
+  Geo g = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd);
+  return posture_fn(g.AO, g.TA, g.R * 0.001f);
+}
+__device__ __forceinline__ float altitude_raw(const Props& pr, const DevCfg& c) {
+  return altitude_fn(pr.u * 0.001f, pr.vd / 340.0f, c);
+}
+
+template <int TASK>
+struct TaskTraits {
+  static constexpr bool HAS_MSL = (TASK == AC_TASK_SHOOT_MISSILE);
+  static constexpr int MSLOTS = HAS_MSL ? AC_MAX_MISSILES_PER_AGENT : 1;
+  static constexpr int OBS = (TASK == AC_TASK_SINGLECOMBAT) ? 15 : 21;
+};
+
+// ------------------------------------------------------------------------------------------------ the step kernel
+// One lane per aircraft, the two aircraft of a 1v1 env in lanes (2k, 2k+1).
+template <int TASK>
+__global__ __launch_bounds__(64) void step_kernel_1v1(DevPtrs P, DevCfg c) {
+  using TT = TaskTraits<TASK>;
+  constexpr bool HAS_MSL = TT::HAS_MSL;
+  constexpr int MSLOTS = TT::MSLOTS;
+  constexpr int OBS = TT::OBS;
+  __shared__ float lds_tab[F16_TAB_LEN];
+  for (int i = threadIdx.x; i < F16_TAB_LEN; i += blockDim.x) lds_tab[i] = P.tab[i];
+  __syncthreads();
+  const Tab T{lds_tab};
+  const int N = c.N;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = n < N;           // N is even, so both lanes of a pair are live or not together
+  const int nn = live ? n : (N - 2 + (n & 1));  // tail lanes shadow the last env and never store
+  const int slot = nn & 1;
+
+  State s; Task t; Derived d; Props pr;
+  load_state(P.F, P.I, P.D, N, nn, s, t);
+  Msl ms[MSLOTS];
+  int nslots = 0;
+  if (HAS_MSL) {
+    nslots = min(c.num_missiles[slot], MSLOTS);
+#pragma unroll
+    for (int k = 0; k < MSLOTS; ++k) {
+      if (k < nslots) load_msl(P.MF, P.MI, N, nn, k, ms[k]);
+      else { ms[k] = Msl{}; ms[k].status = MSL_INACTIVE; }
+    }
+  }
+
+  // ---- apply actions (normalize_action, singlecombat_task.py:141-153; property bounds catalog.py:189-197)
+  const float* act = P.actions + (size_t)nn * c.act_dim;
+  t.cur_step += 1;
+  s.da = clampf(-1.0f, act[0] / 20.0f - 1.0f, 1.0f);
+  s.de = clampf(-1.0f, act[1] / 20.0f - 1.0f, 1.0f);
+  s.dr = clampf(-1.0f, act[2] / 20.0f - 1.0f, 1.0f);
+  s.thr = clampf(0.0f, act[3] / 58.0f + 0.4f, 0.9f);
+  if (TASK == AC_TASK_SHOOT_MISSILE) t.shoot_action = (act[4] != 0.0f) ? 1 : 0;  // singlecombat_with_missile_task.py:182-184
+
+  // ---- substeps (env_base.py:139-154): every aircraft, then every missile against this substep's aircraft poses
+  const MslParam MP = aim9l();
+  bool have_pose = false;
+  for (int sub = 0; sub < c.substeps; ++sub) {
+    if (t.status == AC_ALIVE) {
+      if (t.bloods <= 0.0f) t.status = AC_SHOTDOWN;  // simulatior.py:220-222: this tick still integrates
+      f16::tick<false>(s, d, T);
+      have_pose = true;
+    }
+    if (HAS_MSL) {
+      if (!have_pose) { f16::locate(s, d); f16::body_frame(s, d); have_pose = true; }  // frozen pose of a dead aircraft
+      make_props(s, d, c, pr);
+      float tx = __shfl_xor(pr.n, 1), ty = __shfl_xor(pr.e, 1), tz = __shfl_xor(pr.u, 1);
+      float tvx = __shfl_xor(pr.vn, 1), tvy = __shfl_xor(pr.ve, 1), tvz = __shfl_xor(pr.vd, 1);
+      bool talive = __shfl_xor(t.status, 1) == AC_ALIVE;
+      bool hit_now = false;
+#pragma unroll
+      for (int k = 0; k < MSLOTS; ++k) {
+        if (k < nslots && ms[k].status != MSL_INACTIVE) {  // run() is called on finished missiles too (env_base.py:142-143)
+          missile_run(ms[k], MP, tx, ty, tz, tvx, tvy, tvz, talive, c);
+          if (ms[k].status == MSL_HIT && talive) { hit_now = true; talive = false; }  // target.shotdown() (:527)
+        }
+      }
+      if (__shfl_xor((int)hit_now, 1) && t.status == AC_ALIVE) t.status = AC_SHOTDOWN;
+    }
+  }
+  if (!have_pose) { f16::locate(s, d); f16::body_frame(s, d); }
+  if (!HAS_MSL || c.substeps == 0) make_props(s, d, c, pr);
+  Enemy E = exchange_1v1(pr);
+
+  // ---- task.step
+  if (c.use_artillery) {  // singlecombat_task.py:162-188: every shooter drains the blood of each ALIVE enemy
+    Geo g = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd);
+    bool ealive = __shfl_xor(t.status, 1) == AC_ALIVE;
+    float of = (g.AO <= 0.5236f) ? 1.0f - g.AO / 0.5236f : 0.0f;
+    float Rk = g.R * 0.001f;
+    float df = (Rk <= 1.0f) ? 1.0f : ((Rk <= 3.0f) ? (3.0f - Rk) * 0.5f : 0.0f);
+    float dmg = ealive ? of * df : 0.0f;
+    t.bloods -= __shfl_xor(dmg, 1);
+  }
+  if (HAS_MSL) {  // singlecombat_with_missile_task.py:194-204: learned shoot bit, previous missile must be done
+    bool prev_done = t.last_missile < 0;
+#pragma unroll
+    for (int k = 0; k < MSLOTS; ++k)
+      if (k == t.last_missile) prev_done = (ms[k].status == MSL_HIT || ms[k].status == MSL_MISS);
+    bool launch = t.status == AC_ALIVE && t.shoot_action && t.remaining > 0 && prev_done;
+    int k = nslots - t.remaining;  // slots are consumed in launch order
+    if (launch && k >= 0 && k < nslots) {
+      // MissileSimulator.launch (simulatior.py:497-514): parent's cached NEU position, (vN, vE, vDOWN), pitch, yaw
+      float tht = asinf(pr.stht);
+      float psi = atan2f(pr.m12, pr.m11);
+      if (psi < 0.0f) psi += 2.0f * f16::kPi;
+#pragma unroll
+      for (int q = 0; q < MSLOTS; ++q)
+        if (q == k) {
+          ms[q].px = pr.n; ms[q].py = pr.e; ms[q].pz = pr.u; ms[q].vx = pr.vn; ms[q].vy = pr.ve; ms[q].vz = pr.vd;
+          ms[q].theta = tht; ms[q].psi = psi; ms[q].t = 0.0f; ms[q].m = MP.m0; ms[q].dth = 0.0f; ms[q].dph = 0.0f;
+          ms[q].dprev = INFINITY; ms[q].recede = 0; ms[q].status = MSL_LAUNCHED; ms[q].order = t.cur_step;
+        }
+      t.last_missile = k;
+      t.remaining -= 1;
+    }
+  }
+
+  // ---- my first alive incoming missile (check_missile_warning, simulatior.py:321-325) is the enemy's live one
+  Incoming inc{false, 0, 0, 0, 0, 0, 0};
+  int my_hits = 0;
+  if (HAS_MSL) {
+    int best = 0x7fffffff, mine = -1;
+#pragma unroll
+    for (int k = 0; k < MSLOTS; ++k) {
+      if (k < nslots && ms[k].status == MSL_LAUNCHED && ms[k].order < best) { best = ms[k].order; mine = k; }
+      if (k < nslots && ms[k].status == MSL_HIT) my_hits += 1;
+    }
+    float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+#pragma unroll
+    for (int k = 0; k < MSLOTS; ++k)
+      if (k == mine) { a0 = ms[k].px; a1 = ms[k].py; a2 = ms[k].pz; a3 = ms[k].vx; a4 = ms[k].vy; a5 = ms[k].vz; }
+    inc.any = __shfl_xor((int)(mine >= 0), 1);
+    inc.px = __shfl_xor(a0, 1); inc.py = __shfl_xor(a1, 1); inc.pz = __shfl_xor(a2, 1);
+    inc.vx = __shfl_xor(a3, 1); inc.vy = __shfl_xor(a4, 1); inc.vz = __shfl_xor(a5, 1);
+  }
+  float ob[OBS];
+  observe_1v1<TASK>(pr, E, inc, ob);
+
+  // ---- terminations (singlecombat_task.py:34-40; first condition that fires wins, task_base.py:88-112).
+  // Agents are evaluated in order (env_base.py:159-166): agent 0's SafeReturn sees agent 1's status from before agent 1's
+  // own checks, agent 1 sees agent 0's status after them.
+  const int status_pre = t.status;
+  int code = AC_DONE_NONE;
+  bool done = false;
+  {
+    float np_max = fmaxf(fabsf(s.npx), fmaxf(fabsf(s.npy), fabsf(s.npz)));
+    float pqr = sqrtf(d.p * d.p + d.q * d.q + d.r * d.r);
+    bool extreme = (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);  // catalog.py:386-416
+    bool overload = ((float)s.ticks * (1.0f / 60.0f) > 10.0f) &&
+                    (fabsf(s.npx) > c.acc_x || fabsf(s.npy) > c.acc_y || fabsf(s.npz + 1.0f) > c.acc_z);  // overload.py:38-46
+    if (pr.alt_m <= c.altitude_limit) { t.status = AC_CRASH; code = AC_DONE_LOW_ALTITUDE; done = true; }
+    else if (extreme) { t.status = AC_CRASH; code = AC_DONE_EXTREME_STATE; done = true; }
+    else if (overload) { t.status = AC_CRASH; code = AC_DONE_OVERLOAD; done = true; }
+  }
+  {
+    int other_pre = __shfl_xor(status_pre, 1), other_post = __shfl_xor(t.status, 1);
+    int enemy_status = (slot == 0) ? other_pre : other_post;
+    if (!done) {  // safe_return.py:15-50, timeout.py:14-32
+      if (t.status == AC_SHOTDOWN) { code = AC_DONE_SHOTDOWN; done = true; }
+      else if (t.status == AC_CRASH) { code = AC_DONE_CRASHED; done = true; }
+      else if (enemy_status != AC_ALIVE && !inc.any) { code = AC_DONE_MISSION_COMPLETE; done = true; }
+      else if (t.cur_step >= c.max_steps) { code = AC_DONE_TIMEOUT; done = true; }
+    }
+  }
+
+  // ---- rewards (after every termination ran, env_base.py:168-171; die-flag latch singlecombat_task.py:190-195)
+  float reward = 0.0f;
+  if (!t.die_flag) {
+    t.die_flag = (t.status != AC_ALIVE) ? 1 : 0;
+    float r_alt = potential(altitude_raw(pr, c), c.altitude_scale, c.altitude_pot, t.pre_altitude);
+    float r_pos = potential(posture_raw(pr, E), c.posture_scale, c.posture_pot, t.pre_posture);
+    float ev = ((t.status != AC_ALIVE) ? -200.0f : 0.0f) + 200.0f * (float)my_hits;  // event_driven_reward.py:15-34
+    float r_ev = potential(ev, c.event_scale, c.event_pot, t.pre_event);
+    reward = r_alt + r_pos + r_ev;
+    if (TASK == AC_TASK_SHOOT_MISSILE) {  // shoot_penalty_reward.py:13-32
+      float sp = (t.remaining == t.pre_remaining - 1) ? -30.0f : 0.0f;
+      t.pre_remaining = t.remaining;
+      reward += potential(sp, c.shoot_penalty_scale, c.shoot_pot, t.pre_shoot);
+    }
+  }
+
+  // ---- episode end: every agent done => the env is reset and its observation replaced (env_wrappers.py:191-204)
+  bool all_done = done && (bool)__shfl_xor((int)done, 1);
+  int other_code = __shfl_xor(code, 1);
+  int step_out = t.cur_step;
+  if (all_done) {
+    load_state(P.tF, P.tI, P.tD, 2, slot, s, t);
+#pragma unroll
+    for (int k = 0; k < MSLOTS; ++k) { ms[k] = Msl{}; ms[k].status = MSL_INACTIVE; }
+    const float* tobs = (const float*)(P.tF + (size_t)NF * 2) + slot * OBS;  // template observation follows the template fields
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) ob[k] = tobs[k];
+  }
+  if (live) {
+    store_state(P.F, P.I, P.D, N, n, s, t);
+    if (HAS_MSL) {
+#pragma unroll
+      for (int k = 0; k < MSLOTS; ++k) if (k < nslots) store_msl(P.MF, P.MI, N, n, k, ms[k]);
+    }
+    float* o = P.obs + (size_t)n * OBS;
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) o[k] = ob[k];
+    P.rew[n] = reward;
+    P.done[n] = done ? 1 : 0;
+    if (slot == 0) {
+      int* inf = P.info + (size_t)(n >> 1) * 4;
+      inf[0] = step_out;
+      inf[1] = other_code ? other_code : code;  // info['done_condition'] keeps the last agent's message
+      inf[2] = 0;
+      inf[3] = all_done ? 1 : 0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ initial conditions
+// AircraftSimulator.reload (simulatior.py:152-190) for the scenario's A aircraft, run once per ac_create:
+// FGInitialCondition setters -> FGPropagate::SetInitialState -> RunIC (two suspended executive passes,
+// InitializeDerivatives) -> engine InitRunning -> GetSteadyState. Output: the reset template
+// (state, task bookkeeping with the potential-reward seeds of reward_function_base.py:20-32, and the reset observation).
+struct InitArgs { ac_init_state_t ic[AC_MAX_AGENTS]; };
+
+__device__ double geod_alt_from_asl(double geod_lat, double alt) {  // FGInitialCondition.cpp:749-823 (setgeod branch)
+  const double a = f16::kA, b = f16::kB, e2 = 1.0 - b * b / (a * a);
+  double cg = cos(geod_lat), sg = sin(geod_lat), Nn = a / sqrt(1 - e2 * sg * sg);
+  double n = e2, prev_n = 1.0;
+  int iter = 0;
+  if (cg > fabs(sg)) {
+    double tg = sg / cg, x0 = Nn * e2 * cg, x = 0.0;
+    while (fabs(n - prev_n) > 1E-15 && iter < 10) {
+      double tl = (1 - n) * tg, c2 = 1. / (1. + tl * tl), slr = b / sqrt(1. - e2 * c2), R = slr + alt;
+      x = R * sqrt(c2); prev_n = n; n = x0 / x; iter++;
+    }
+    return x / cg - Nn;
+  }
+  double ctg = cg / sg, z0 = Nn * e2 * sg, z = 0.0;
+  while (fabs(n - prev_n) > 1E-15 && iter < 10) {
+    double ctl = ctg / (1 - n), s2 = 1. / (1. + ctl * ctl), c2 = 1. - s2, slr = b / sqrt(1. - e2 * c2), R = slr + alt;
+    z = R * (ctl >= 0 ? 1.0 : -1.0) * sqrt(s2); prev_n = n; n = z0 / (z0 + z); iter++;
+  }
+  return z / sg - Nn * (1 - e2);
+}
+
+__device__ void initial_state(const ac_init_state_t& ic, const Tab& T, State& s, Derived& d) {
+  s = State{};
+  const double D2R = 3.14159265358979323846 / 180.0;
+  double lon = ic.lon_deg * D2R, lat = ic.lat_geod_deg * D2R, psi = ic.psi_deg * D2R;
+  double hg = geod_alt_from_asl(lat, ic.h_sl_ft);
+  const double ee = 1.0 - (f16::kB / f16::kA) * (f16::kB / f16::kA);
+  double sl = sin(lat), cl = cos(lat), so = sin(lon), co = cos(lon);
+  double RN = f16::kA / sqrt(1.0 - ee * sl * sl);
+  s.rx = (RN + hg) * cl * co; s.ry = (RN + hg) * cl * so; s.rz = ((1 - ee) * RN + hg) * sl;  // epa = 0: ECI == ECEF
+  // qAttitudeECI = Ti2l.GetQuaternion() * qAttitudeLocal (FGPropagate.cpp:166-167); Ti2l = Tec2l at epa = 0 and the
+  // local attitude is a pure yaw (phi = theta = 0). Built the same way so the quaternion's sign matches as well.
+  double Tl[9] = {-co * sl, -so * sl, cl, -so, co, 0.0, -co * cl, -so * cl, -sl};  // Tec2l rows N, E, D
+  double tr[4] = {1.0 + Tl[0] + Tl[4] + Tl[8], 1.0 + Tl[0] - Tl[4] - Tl[8], 1.0 - Tl[0] + Tl[4] - Tl[8], 1.0 - Tl[0] - Tl[4] + Tl[8]};
+  int idx = 0;
+  for (int i = 1; i < 4; ++i) if (tr[i] > tr[idx]) idx = i;
+  double a4[4];
+  double m12 = Tl[1], m21 = Tl[3], m13 = Tl[2], m31 = Tl[6], m23 = Tl[5], m32 = Tl[7];
+  if (idx == 0) { a4[0] = 0.5 * sqrt(tr[0]); a4[1] = 0.25 * (m23 - m32) / a4[0]; a4[2] = 0.25 * (m31 - m13) / a4[0]; a4[3] = 0.25 * (m12 - m21) / a4[0]; }
+  else if (idx == 1) { a4[1] = 0.5 * sqrt(tr[1]); a4[0] = 0.25 * (m23 - m32) / a4[1]; a4[2] = 0.25 * (m12 + m21) / a4[1]; a4[3] = 0.25 * (m31 + m13) / a4[1]; }
+  else if (idx == 2) { a4[2] = 0.5 * sqrt(tr[2]); a4[0] = 0.25 * (m31 - m13) / a4[2]; a4[1] = 0.25 * (m12 + m21) / a4[2]; a4[3] = 0.25 * (m23 + m32) / a4[2]; }
+  else { a4[3] = 0.5 * sqrt(tr[3]); a4[0] = 0.25 * (m12 - m21) / a4[3]; a4[1] = 0.25 * (m13 + m31) / a4[3]; a4[2] = 0.25 * (m23 + m32) / a4[3]; }
+  double b0 = cos(0.5 * psi), b3 = sin(0.5 * psi);  // yaw-only local quaternion (b1 = b2 = 0)
+  double q[4] = {a4[0] * b0 - a4[3] * b3, a4[1] * b0 + a4[2] * b3, a4[2] * b0 - a4[1] * b3, a4[0] * b3 + a4[3] * b0};
+  double qn = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; ++i) q[i] *= qn;
+  s.q0 = (float)q[0]; s.q1 = (float)q[1]; s.q2 = (float)q[2]; s.q3 = (float)q[3];
+  double Tb[9] = {q[0] * q[0] + q[1] * q[1] - q[2] * q[2] - q[3] * q[3], 2.0 * (q[1] * q[2] + q[0] * q[3]), 2.0 * (q[1] * q[3] - q[0] * q[2]),
+                  2.0 * (q[1] * q[2] - q[0] * q[3]), q[0] * q[0] - q[1] * q[1] + q[2] * q[2] - q[3] * q[3], 2.0 * (q[2] * q[3] + q[0] * q[1]),
+                  2.0 * (q[1] * q[3] + q[0] * q[2]), 2.0 * (q[2] * q[3] - q[0] * q[1]), q[0] * q[0] - q[1] * q[1] - q[2] * q[2] + q[3] * q[3]};
+  // inertial rates and velocity: PQRi = PQR + Ti2b*Omega; v_eci = Tb2i*UVW + Omega x r
+  s.wp = (float)(ic.p_rad_sec + f16::kOmega * Tb[2]); s.wq = (float)(ic.q_rad_sec + f16::kOmega * Tb[5]); s.wr = (float)(ic.r_rad_sec + f16::kOmega * Tb[8]);
+  double vix = Tb[0] * ic.u_fps + Tb[3] * ic.v_fps + Tb[6] * ic.w_fps;
+  double viy = Tb[1] * ic.u_fps + Tb[4] * ic.v_fps + Tb[7] * ic.w_fps;
+  double viz = Tb[2] * ic.u_fps + Tb[5] * ic.v_fps + Tb[8] * ic.w_fps;
+  s.vx = (float)(vix - f16::kOmega * s.ry); s.vy = (float)(viy + f16::kOmega * s.rx); s.vz = (float)viz;
+  s.tank0 = (float)F16_TANK0_CONTENTS; s.tank1 = (float)F16_TANK1_CONTENTS;
+  s.eng = f16::PH_OFF | f16::ENG_CUTOFF;  // FGTurbine::ResetToIC
+  // RunIC: Initialize() and RunIC() each run the executive once with dT = 0
+  f16::tick<true, true>(s, d, T);
+  f16::tick<true>(s, d, T);
+  // InitializeDerivatives: every history slot holds the current derivative
+  s.hv1x = s.hv2x = s.vx; s.hv1y = s.hv2y = s.vy; s.hv1z = s.hv2z = s.vz;
+  s.ha1x = s.aix; s.ha1y = s.aiy; s.ha1z = s.aiz;
+  // engine.init_running(): N1/N2 to idle at throttle 0, phase Run; get_steady_state(): fuel flow settles
+  // (Seek at 500 pph per 0.5 s iteration for >= 121 iterations reaches its clamp) on max(thrust*tsfc, idle flow)
+  s.n2 = (float)F16_ENG_IDLEN2; s.n1 = (float)F16_ENG_IDLEN1; s.n2norm = 0.0f;
+  s.eng = f16::PH_RUN | f16::ENG_RUNNING;
+  {
+    f16::Atmos A = f16::atmosphere(d.h_sl_ft);
+    int im, jh, ii; float fm, fh, fi;
+    f16::bracket<T_ENG_MILTHRUST_NC>(T, T_ENG_MILTHRUST_OFF + T_ENG_MILTHRUST_NR, d.h_sl_ft, jh, fh);
+    f16::bracket<T_ENG_IDLETHRUST_NR>(T, T_ENG_IDLETHRUST_OFF, s.mach, ii, fi);
+    (void)im; (void)fm;
+    float idle = (float)F16_ENG_MILTHRUST * f16::tab2i<T_ENG_IDLETHRUST_NR, T_ENG_IDLETHRUST_NC>(T, T_ENG_IDLETHRUST_OFF, ii, fi, jh, fh);
+    float tsfc = (float)F16_ENG_TSFC * sqrtf(A.T * (1.0f / 389.7f)) * (0.84f + 1.0f);
+    float target = idle * tsfc;            // thrust at N2norm = 0 is the idle thrust
+    float ff = (target > 0.0f) ? target : 0.0f;  // Seek from 0 never goes below 0 here: a negative target is approached from above only
+    s.ff = fmaxf(ff, 757.648518f);
+  }
+}
+
+template <int TASK>
+__global__ void init_kernel_1v1(InitArgs ia, DevCfg c, const float* tab, float* tF, int* tI, double* tD) {
+  using TT = TaskTraits<TASK>;
+  constexpr int OBS = TT::OBS;
+  __shared__ float lds_tab[F16_TAB_LEN];
+  for (int i = threadIdx.x; i < F16_TAB_LEN; i += blockDim.x) lds_tab[i] = tab[i];
+  __syncthreads();
+  const Tab T{lds_tab};
+  const int slot = threadIdx.x & 1;
+  State s; Derived d; Task t{}; Props pr;
+  initial_state(ia.ic[slot], T, s, d);
+  t.bloods = 100.0f; t.status = AC_ALIVE;
+  t.remaining = c.num_missiles[slot]; t.pre_remaining = c.num_missiles[slot];
+  t.last_missile = -1; t.last_shoot_time = -c.min_attack_interval;
+  make_props(s, d, c, pr);
+  Enemy E = exchange_1v1(pr);
+  Incoming inc{false, 0, 0, 0, 0, 0, 0};
+  float ob[OBS];
+  observe_1v1<TASK>(pr, E, inc, ob);
+  // potential-based terms are seeded with their value at reset (reward_function_base.py:28-31)
+  if (c.altitude_pot) t.pre_altitude = altitude_raw(pr, c) * c.altitude_scale;
+  if (c.posture_pot) t.pre_posture = posture_raw(pr, E) * c.posture_scale;
+  if (threadIdx.x < 2) {
+    store_state(tF, tI, tD, 2, slot, s, t);
+    float* tobs = tF + (size_t)NF * 2 + slot * OBS;
+    for (int k = 0; k < OBS; ++k) tobs[k] = ob[k];
+  }
+}
+
+// reset(): every env takes the template (SubprocVecEnv.reset -> env.reset(), env_base.py:98-113)
+template <int OBS>
+__global__ void reset_all_kernel(DevPtrs P, DevCfg c) {
+  const int N = c.N;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int slot = n % c.A;
+  State s; Task t;
+  load_state(P.tF, P.tI, P.tD, c.A, slot, s, t);
+  store_state(P.F, P.I, P.D, N, n, s, t);
+  for (int k = 0; k < c.msl_slots; ++k) {
+    Msl m{}; m.status = MSL_INACTIVE;
+    store_msl(P.MF, P.MI, N, n, k, m);
+  }
+  const float* tobs = P.tF + (size_t)NF * c.A + slot * OBS;
+  for (int k = 0; k < OBS; ++k) P.obs[(size_t)n * OBS + k] = tobs[k];
+  P.rew[n] = 0.0f; P.done[n] = 0;
+  if (slot == 0) { int* inf = P.info + (size_t)(n / c.A) * 4; inf[0] = 0; inf[1] = 0; inf[2] = 0; inf[3] = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------ host side (C ABI)
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return -1; }
+#define HIP_OK(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) return fail(std::string(#call) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+struct ac_env {
+  ac_config_t cfg;
+  DevCfg dc;
+  DevPtrs dp;
+  int E, A, N, obs_dim, act_dim, device;
+  hipStream_t stream;
+  float* d_actions;
+  float* d_tab;
+  float* d_tF; int* d_tI; double* d_tD;
+  hipEvent_t ev0, ev1;
+  bool timing;
+};
+
+static void geodetic2ecef_m(double lat_deg, double lon_deg, double alt, double* x, double* y, double* z) {
+  const double a = 6378137.0, b = 6356752.314245179, D2R = M_PI / 180.0;  // pymap3d WGS84
+  double lat = lat_deg * D2R, lon = lon_deg * D2R;
+  double Nn = a * a / hypot(a * cos(lat), b * sin(lat));
+  *x = (Nn + alt) * cos(lat) * cos(lon);
+  *y = (Nn + alt) * cos(lat) * sin(lon);
+  *z = (Nn * (b / a) * (b / a) + alt) * sin(lat);
+}
+
+static int launch_step(ac_env* h, const float* d_actions) {
+  DevPtrs p = h->dp;
+  p.actions = d_actions ? d_actions : h->d_actions;
+  dim3 block(64), grid((h->N + 63) / 64);
+  if (h->cfg.task == AC_TASK_SINGLECOMBAT) hipLaunchKernelGGL(step_kernel_1v1<AC_TASK_SINGLECOMBAT>, grid, block, 0, h->stream, p, h->dc);
+  else hipLaunchKernelGGL(step_kernel_1v1<AC_TASK_SHOOT_MISSILE>, grid, block, 0, h->stream, p, h->dc);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+static int launch_reset(ac_env* h) {
+  dim3 block(64), grid((h->N + 63) / 64);
+  if (h->obs_dim == 15) hipLaunchKernelGGL(reset_all_kernel<15>, grid, block, 0, h->stream, h->dp, h->dc);
+  else hipLaunchKernelGGL(reset_all_kernel<21>, grid, block, 0, h->stream, h->dp, h->dc);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" {
+
+const char* ac_last_error(void) { return g_err.c_str(); }
+const char* ac_version(void) { return "aircombat-hip 0.1 (gfx950)"; }
+const char* ac_state_field_name(int i) { return (i >= 0 && i < AC_STATE_LEN && kStateNames[i]) ? kStateNames[i] : ""; }
+
+int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_t seed, ac_env_t** out) {
+  (void)seed;  // the 1v1 tasks draw no random numbers (fixed initial conditions, no chaff)
+  if (!cfg || !out) return fail("ac_create: null argument");
+  if (cfg->task != AC_TASK_SINGLECOMBAT && cfg->task != AC_TASK_SHOOT_MISSILE)
+    return fail("ac_create: task not available on the HIP path (supported: AC_TASK_SINGLECOMBAT, AC_TASK_SHOOT_MISSILE)");
+  if (cfg->n_agents != 2 || cfg->n_ego != 1) return fail("ac_create: 1v1 tasks need n_agents == 2 and n_ego == 1");
+  if (n_envs <= 0) return fail("ac_create: n_envs must be positive");
+  if (cfg->sim_freq != 60) return fail("ac_create: sim_freq must be 60 (the FDM tick is compiled for 1/60 s)");
+  for (int i = 0; i < 2; ++i)
+    if (cfg->num_missiles[i] < 0 || cfg->num_missiles[i] > AC_MAX_MISSILES_PER_AGENT) return fail("ac_create: num_missiles out of range");
+  int ndev = 0;
+  HIP_OK(hipGetDeviceCount(&ndev));
+  if (device_id < 0 || device_id >= ndev) return fail("ac_create: no such HIP device");
+  HIP_OK(hipSetDevice(device_id));
+  ac_env* h = new ac_env();
+  memset(h, 0, sizeof *h);
+  h->cfg = *cfg; h->E = n_envs; h->A = cfg->n_agents; h->N = n_envs * cfg->n_agents; h->device = device_id;
+  h->obs_dim = (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : 21;
+  h->act_dim = (cfg->task == AC_TASK_SHOOT_MISSILE) ? 5 : 4;
+  DevCfg& c = h->dc;
+  memset(&c, 0, sizeof c);
+  c.task = cfg->task; c.A = h->A; c.n_ego = cfg->n_ego; c.substeps = cfg->agent_interaction_steps; c.max_steps = cfg->max_steps;
+  c.obs_dim = h->obs_dim; c.act_dim = h->act_dim; c.N = h->N;
+  c.msl_slots = (cfg->task == AC_TASK_SHOOT_MISSILE) ? AC_MAX_MISSILES_PER_AGENT : 0;
+  c.altitude_limit = (float)cfg->altitude_limit; c.acc_x = (float)cfg->acc_limit_x; c.acc_y = (float)cfg->acc_limit_y; c.acc_z = (float)cfg->acc_limit_z;
+  c.posture_scale = (float)cfg->posture_scale; c.altitude_scale = (float)cfg->altitude_scale; c.event_scale = (float)cfg->event_scale;
+  c.missile_posture_scale = (float)cfg->missile_posture_scale; c.shoot_penalty_scale = (float)cfg->shoot_penalty_scale;
+  c.posture_pot = cfg->posture_potential; c.altitude_pot = cfg->altitude_potential; c.event_pot = cfg->event_potential; c.shoot_pot = cfg->shoot_penalty_potential;
+  c.alt_safe = (float)cfg->alt_safe; c.alt_danger = (float)cfg->alt_danger; c.alt_kv = (float)cfg->alt_kv;
+  c.max_attack_angle = (float)cfg->max_attack_angle; c.max_attack_distance = (float)cfg->max_attack_distance;
+  c.min_attack_interval = cfg->min_attack_interval; c.use_artillery = cfg->use_artillery;
+  c.lock_len = (int)(1.0 / ((double)cfg->agent_interaction_steps / cfg->sim_freq));
+  for (int i = 0; i < AC_MAX_AGENTS; ++i) c.num_missiles[i] = cfg->num_missiles[i];
+  geodetic2ecef_m(cfg->center_lat, cfg->center_lon, cfg->center_alt, &c.P0x, &c.P0y, &c.P0z);
+  c.sLat0 = sin(cfg->center_lat * M_PI / 180.0); c.cLat0 = cos(cfg->center_lat * M_PI / 180.0);
+  c.sLon0 = sin(cfg->center_lon * M_PI / 180.0); c.cLon0 = cos(cfg->center_lon * M_PI / 180.0);
+
+  HIP_OK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIP_OK(hipEventCreate(&h->ev0));
+  HIP_OK(hipEventCreate(&h->ev1));
+  const size_t N = (size_t)h->N;
+  DevPtrs& p = h->dp;
+  HIP_OK(hipMalloc(&p.F, sizeof(float) * NF * N));
+  HIP_OK(hipMalloc(&p.I, sizeof(int) * NI * N));
+  HIP_OK(hipMalloc(&p.D, sizeof(double) * ND * N));
+  const size_t ms = c.msl_slots > 0 ? (size_t)c.msl_slots : 1;
+  HIP_OK(hipMalloc(&p.MF, sizeof(float) * ms * NMF * N));
+  HIP_OK(hipMalloc(&p.MI, sizeof(int) * ms * NMI * N));
+  HIP_OK(hipMalloc(&p.obs, sizeof(float) * N * h->obs_dim));
+  HIP_OK(hipMalloc(&p.rew, sizeof(float) * N));
+  HIP_OK(hipMalloc(&p.done, N));
+  HIP_OK(hipMalloc(&p.info, sizeof(int) * 4 * h->E));
+  HIP_OK(hipMalloc(&h->d_actions, sizeof(float) * N * h->act_dim));
+  HIP_OK(hipMemset(h->d_actions, 0, sizeof(float) * N * h->act_dim));
+  std::vector<float> tab(F16_TAB_LEN);
+  for (int i = 0; i < F16_TAB_LEN; ++i) tab[i] = (float)F16_TAB[i];
+  HIP_OK(hipMalloc(&h->d_tab, sizeof(float) * F16_TAB_LEN));
+  HIP_OK(hipMemcpy(h->d_tab, tab.data(), sizeof(float) * F16_TAB_LEN, hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc(&h->d_tF, sizeof(float) * ((size_t)NF * h->A + (size_t)h->A * h->obs_dim)));
+  HIP_OK(hipMalloc(&h->d_tI, sizeof(int) * NI * h->A));
+  HIP_OK(hipMalloc(&h->d_tD, sizeof(double) * ND * h->A));
+  p.tF = h->d_tF; p.tI = h->d_tI; p.tD = h->d_tD; p.tab = h->d_tab; p.actions = h->d_actions;
+  InitArgs ia;
+  for (int i = 0; i < AC_MAX_AGENTS; ++i) ia.ic[i] = cfg->init[i];
+  if (cfg->task == AC_TASK_SINGLECOMBAT)
+    hipLaunchKernelGGL(init_kernel_1v1<AC_TASK_SINGLECOMBAT>, dim3(1), dim3(64), 0, h->stream, ia, h->dc, h->d_tab, h->d_tF, h->d_tI, h->d_tD);
+  else
+    hipLaunchKernelGGL(init_kernel_1v1<AC_TASK_SHOOT_MISSILE>, dim3(1), dim3(64), 0, h->stream, ia, h->dc, h->d_tab, h->d_tF, h->d_tI, h->d_tD);
+  HIP_OK(hipGetLastError());
+  if (launch_reset(h)) return -1;
+  HIP_OK(hipStreamSynchronize(h->stream));
+  *out = h;
+  return 0;
+}
+
+int ac_destroy(ac_env_t* h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  void* bufs[] = {h->dp.F, h->dp.I, h->dp.D, h->dp.MF, h->dp.MI, h->dp.obs, h->dp.rew, h->dp.done, h->dp.info,
+                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD};
+  for (void* b : bufs) (void)hipFree(b);
+  (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
+  (void)hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+int ac_obs_dim(const ac_env_t* h) { return h ? h->obs_dim : -1; }
+int ac_act_dim(const ac_env_t* h) { return h ? h->act_dim : -1; }
+int ac_num_envs(const ac_env_t* h) { return h ? h->E : -1; }
+int ac_num_agents(const ac_env_t* h) { return h ? h->A : -1; }
+
+int ac_reset(ac_env_t* h, float* obs) {
+  if (!h) return fail("ac_reset: null handle");
+  HIP_OK(hipSetDevice(h->device));
+  if (launch_reset(h)) return -1;
+  if (obs) HIP_OK(hipMemcpyAsync(obs, h->dp.obs, sizeof(float) * (size_t)h->N * h->obs_dim, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int ac_step(ac_env_t* h, const float* actions, float* obs, float* rewards, uint8_t* dones, int32_t* info) {
+  if (!h || !actions) return fail("ac_step: null argument");
+  HIP_OK(hipSetDevice(h->device));
+  const size_t N = (size_t)h->N;
+  HIP_OK(hipMemcpyAsync(h->d_actions, actions, sizeof(float) * N * h->act_dim, hipMemcpyHostToDevice, h->stream));
+  if (launch_step(h, nullptr)) return -1;
+  if (obs) HIP_OK(hipMemcpyAsync(obs, h->dp.obs, sizeof(float) * N * h->obs_dim, hipMemcpyDeviceToHost, h->stream));
+  if (rewards) HIP_OK(hipMemcpyAsync(rewards, h->dp.rew, sizeof(float) * N, hipMemcpyDeviceToHost, h->stream));
+  if (dones) HIP_OK(hipMemcpyAsync(dones, h->dp.done, N, hipMemcpyDeviceToHost, h->stream));
+  if (info) HIP_OK(hipMemcpyAsync(info, h->dp.info, sizeof(int) * 4 * h->E, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int ac_step_async_device(ac_env_t* h, const float* d_actions) {
+  if (!h) return fail("ac_step_async_device: null handle");
+  HIP_OK(hipSetDevice(h->device));
+  return launch_step(h, d_actions);
+}
+int ac_device_buffers(ac_env_t* h, float** d_actions, float** d_obs, float** d_rewards, uint8_t** d_dones, int32_t** d_info) {
+  if (!h) return fail("ac_device_buffers: null handle");
+  if (d_actions) *d_actions = h->d_actions;
+  if (d_obs) *d_obs = h->dp.obs;
+  if (d_rewards) *d_rewards = h->dp.rew;
+  if (d_dones) *d_dones = h->dp.done;
+  if (d_info) *d_info = h->dp.info;
+  return 0;
+}
+void* ac_stream(ac_env_t* h) { return h ? (void*)h->stream : nullptr; }
+int ac_sync(ac_env_t* h) {
+  if (!h) return fail("ac_sync: null handle");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+int ac_timing_begin(ac_env_t* h) {
+  if (!h) return fail("ac_timing_begin: null handle");
+  HIP_OK(hipEventRecord(h->ev0, h->stream));
+  return 0;
+}
+int ac_timing_end(ac_env_t* h, float* total_ms) {
+  if (!h || !total_ms) return fail("ac_timing_end: null argument");
+  HIP_OK(hipEventRecord(h->ev1, h->stream));
+  HIP_OK(hipEventSynchronize(h->ev1));
+  HIP_OK(hipEventElapsedTime(total_ms, h->ev0, h->ev1));
+  return 0;
+}
+
+// state vector layout: rx ry rz | float fields | task floats | eng ticks | task ints   (names: ac_state_field_name)
+static int check_idx(ac_env_t* h, int env, int agent) {
+  if (!h) return fail("null handle");
+  if (env < 0 || env >= h->E || agent < 0 || agent >= h->A) return fail("env/agent index out of range");
+  return 0;
+}
+int ac_get_state(ac_env_t* h, int32_t env, int32_t agent, double* out) {
+  if (check_idx(h, env, agent) || !out) return fail("ac_get_state: bad argument");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  const size_t N = h->N, n = (size_t)env * h->A + agent;
+  int k = 0;
+  for (int f = 0; f < ND; ++f) { double v; HIP_OK(hipMemcpy(&v, h->dp.D + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
+  for (int f = 0; f < NF; ++f) { float v; HIP_OK(hipMemcpy(&v, h->dp.F + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
+  for (int f = 0; f < NI; ++f) { int v; HIP_OK(hipMemcpy(&v, h->dp.I + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
+  for (; k < AC_STATE_LEN; ++k) out[k] = 0.0;
+  return 0;
+}
+int ac_set_state(ac_env_t* h, int32_t env, int32_t agent, const double* in) {
+  if (check_idx(h, env, agent) || !in) return fail("ac_set_state: bad argument");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  const size_t N = h->N, n = (size_t)env * h->A + agent;
+  int k = 0;
+  for (int f = 0; f < ND; ++f) { double v = in[k++]; HIP_OK(hipMemcpy(h->dp.D + f * N + n, &v, sizeof v, hipMemcpyHostToDevice)); }
+  for (int f = 0; f < NF; ++f) { float v = (float)in[k++]; HIP_OK(hipMemcpy(h->dp.F + f * N + n, &v, sizeof v, hipMemcpyHostToDevice)); }
+  for (int f = 0; f < NI; ++f) { int v = (int)llround(in[k++]); HIP_OK(hipMemcpy(h->dp.I + f * N + n, &v, sizeof v, hipMemcpyHostToDevice)); }
+  return 0;
+}
+int ac_set_status(ac_env_t* h, int32_t env, int32_t agent, int32_t status) {
+  if (check_idx(h, env, agent)) return -1;
+  if (status < AC_ALIVE || status > AC_SHOTDOWN) return fail("ac_set_status: bad status");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  const size_t N = h->N, n = (size_t)env * h->A + agent;
+  int v = status;
+  HIP_OK(hipMemcpy(h->dp.I + (size_t)FI_status * N + n, &v, sizeof v, hipMemcpyHostToDevice));
+  return 0;
+}
+
+__global__ void entity_kernel(DevPtrs P, DevCfg c, int n, double* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  State s; Task t; Derived d; Props pr;
+  load_state(P.F, P.I, P.D, c.N, n, s, t);
+  f16::locate(s, d); f16::body_frame(s, d);
+  make_props(s, d, c, pr);
+  const double R2D = 180.0 / 3.14159265358979323846;
+  out[0] = atan2(d.sLon64, d.cLon64) * R2D; out[1] = atan2(d.sLat64, d.cLat64) * R2D; out[2] = pr.alt_m;
+  out[3] = atan2f(pr.sphi, pr.cphi); out[4] = asinf(pr.stht);
+  float psi = atan2f(pr.m12, pr.m11); if (psi < 0.0f) psi += 2.0f * f16::kPi;
+  out[5] = psi; out[6] = pr.vn; out[7] = pr.ve; out[8] = pr.vd; out[9] = pr.n; out[10] = pr.e; out[11] = pr.u;
+}
+int ac_get_entity(ac_env_t* h, int32_t env, int32_t agent, double out[12]) {
+  if (check_idx(h, env, agent) || !out) return fail("ac_get_entity: bad argument");
+  HIP_OK(hipSetDevice(h->device));
+  double* d_out;
+  HIP_OK(hipMalloc(&d_out, sizeof(double) * 12));
+  hipLaunchKernelGGL(entity_kernel, dim3(1), dim3(64), 0, h->stream, h->dp, h->dc, env * h->A + agent, d_out);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipMemcpy(out, d_out, sizeof(double) * 12, hipMemcpyDeviceToHost));
+  HIP_OK(hipFree(d_out));
+  return 0;
+}
+int ac_get_missile(ac_env_t* h, int32_t env, int32_t agent, int32_t k, double out[12]) {
+  if (check_idx(h, env, agent) || !out) return fail("ac_get_missile: bad argument");
+  if (k < 0 || k >= h->dc.msl_slots) return fail("ac_get_missile: no such missile slot");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  const size_t N = h->N, n = (size_t)env * h->A + agent;
+  int st;
+  HIP_OK(hipMemcpy(&st, h->dp.MI + ((size_t)k * NMI + MI_status) * N + n, sizeof st, hipMemcpyDeviceToHost));
+  out[0] = st;
+  static const int order[10] = {MF_px, MF_py, MF_pz, MF_vx, MF_vy, MF_vz, MF_theta, MF_psi, MF_t, MF_m};
+  for (int i = 0; i < 10; ++i) {
+    float v;
+    HIP_OK(hipMemcpy(&v, h->dp.MF + ((size_t)k * NMF + order[i]) * N + n, sizeof v, hipMemcpyDeviceToHost));
+    out[1 + i] = v;
+  }
+  out[11] = 0.0;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,552 @@
+// MI355X (gfx950) device-side F-16 flight dynamics: one wavefront lane per aircraft.
+//
+// What this replaces: the per-aircraft `jsbsim.FGFDMExec.run()` call the reference makes from
+// envs/JSBSim/core/simulatior.py:210-229 (AircraftSimulator.run) six times per env step, i.e. one JSBSim
+// executive tick (data/src/FGFDMExec.cpp:407-431) of the F-16 model data/aircraft/f16/f16.xml.
+//
+// Formulation (deliberately not JSBSim's object graph):
+//  * fp32 everywhere except the three ECI position words, the Earth-angle rotation and the ECEF->geodetic
+//    reduction, which stay fp64 (|r| ~ 2e7 ft: fp32 would quantise position to ~2 ft).
+//  * no Tl2b / Tec2b / Euler angles per tick: the FCS only needs cos(theta)cos(phi) = <body z, local down>,
+//    ground speed comes from the ECI-relative velocity projected on the local north/east unit vectors, and
+//    J2 gravity is evaluated directly in ECI (the formula is invariant under rotation about the polar axis).
+//  * all 25 one-dimensional alpha tables and the 12-row two-dimensional tables share one alpha breakpoint
+//    search per tick; tables live in LDS (staged once per workgroup) and are gathered with ds_read_b32.
+//  * integrators are the reference's own: quaternion and inertial body rates rectangular Euler, inertial
+//    velocity Adams-Bashforth-2, inertial position Adams-Bashforth-3 (data/src/models/FGPropagate.cpp:93-96).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "f16_tables.h"
+
+namespace f16 {
+
+// ---- unit constants (published values; JSBSim keeps them in FGJSBBase.h)
+constexpr float kFt2M = 0.3048f;
+constexpr float kInch2Ft = 1.0f / 12.0f;
+constexpr float kLb2Slug = 1.0f / 32.174049f;
+constexpr float kKts2Fps = 1.68781f;
+constexpr float kG0 = 32.174049f;  // 9.80665 / 0.3048
+constexpr float kPi = 3.14159265358979f;
+// Earth model, data/src/models/FGInertial.cpp:56-60
+constexpr double kOmega = 0.00007292115;
+constexpr double kGM = 14.0764417572E15;
+constexpr double kJ2 = 1.08262982E-03;
+constexpr double kA = 20925646.32546;
+constexpr double kB = 20855486.5951;
+// FCS components keep the executive's load-time dt of 1/120 s (FGFCSComponent.cpp:58, FGFDMExec.cpp:96,
+// simulatior.py:165-169 calls set_dt only after load_model): PID derivative and actuator rate limits use it.
+constexpr float kFcsDt = 1.0f / 120.0f;
+
+// ---- engine state bits
+enum : int { ENG_PHASE_MASK = 7, ENG_RUNNING = 8, ENG_CUTOFF = 16, ENG_STARVED = 32, ENG_AUG = 64 };
+enum : int { PH_OFF = 0, PH_RUN = 1, PH_START = 3, PH_TRIM = 6 };
+
+// Complete dynamic state of one aircraft: everything the next tick depends on.
+struct State {
+  double rx, ry, rz;                       // ECI position [ft]
+  float vx, vy, vz;                        // ECI velocity [ft/s]
+  float q0, q1, q2, q3;                    // ECI -> body quaternion
+  float wp, wq, wr;                        // inertial body rates PQRi [rad/s]
+  float hv1x, hv1y, hv1z, hv2x, hv2y, hv2z;  // inertial velocity one and two ticks ago (AB3 history)
+  float ha1x, ha1y, ha1z;                  // inertial acceleration one tick ago (AB2 history)
+  float wdx, wdy, wdz;                     // PQRi-dot of the last tick
+  float aix, aiy, aiz;                     // inertial acceleration of the last tick
+  float bax, bay, baz;                     // body specific force / mass of the last tick
+  float da, de, dr, thr;                   // commands (clipped)
+  float pin_r, pin_p, pin_y;               // PID previous inputs
+  float pi_r, pi_p, pi_y;                  // PID integrator totals
+  float tef, ail, elev, sbdeg;             // kinematic (rate-limited) outputs
+  float alpha, mach, vckts, vg;            // FGAuxiliary outputs of the last tick (the FCS runs before it)
+  float ap, aq, ar;                        // aero body rates of the last tick
+  float npx, npy, npz;                     // pilot-station load factors of the last tick
+  float n1, n2, n2norm, ff;                // turbine
+  float tank0, tank1;                      // internal tanks [lb]
+  int eng;                                 // phase | flags
+  int ticks;                               // executive ticks since reset (sim time = ticks/60)
+};
+
+// What one tick exposes to the environment layer.
+struct Derived {
+  float sinLat, cosLat, sinLon, cosLon;    // geodetic latitude / longitude of the vehicle
+  float h_sl_ft;                           // radius - sea-level radius [ft]
+  float u, v, w;                           // body velocity [ft/s]
+  float p, q, r;                           // body rates relative to ECEF [rad/s]
+  float vn, ve, vd;                        // local NED velocity [ft/s]
+  float n_eci[3], e_eci[3], d_eci[3];      // local north / east / down unit vectors in ECI
+  float T[9];                              // ECI -> body
+  float vc_fps;                            // calibrated airspeed [ft/s]
+  float veci;                              // |v_eci|
+  double X, Y, Z;                          // ECEF position [ft]
+  double sLat64, cLat64, sLon64, cLon64;   // fp64 copies for the geodetic -> NED reduction of the env layer
+};
+
+struct Tab {
+  const float* t;  // LDS copy of F16_TAB
+  __device__ __forceinline__ float operator[](int i) const { return t[i]; }
+};
+
+__device__ __forceinline__ float clampf(float lo, float v, float hi) { return fminf(fmaxf(v, lo), hi); }
+__device__ __forceinline__ float lerpf(float a, float b, float f) { return fmaf(f, b - a, a); }
+
+// Breakpoint search: returns r in [1, n-1] with x[r-1] < key <= x[r] (clamped), and the fraction in [0,1].
+// Equivalent to FGTable::GetValue's stateful walk (data/src/math/FGTable.cpp:443-516): interpolation is
+// continuous at breakpoints so the choice of segment at an exact breakpoint does not change the value.
+template <int N>
+__device__ __forceinline__ void bracket(const Tab& T, int off, float key, int& r, float& f) {
+  r = 1;
+#pragma unroll
+  for (int i = 1; i < N - 1; ++i) r += (T[off + i] < key) ? 1 : 0;
+  float x0 = T[off + r - 1], x1 = T[off + r];
+  f = clampf(0.0f, (key - x0) / (x1 - x0), 1.0f);
+}
+template <int N>
+__device__ __forceinline__ float tab1(const Tab& T, int off, float key) {
+  int r; float f;
+  bracket<N>(T, off, key, r, f);
+  return lerpf(T[off + N + r - 1], T[off + N + r], f);
+}
+// 1-D table on a pre-bracketed axis
+template <int N>
+__device__ __forceinline__ float tab1i(const Tab& T, int off, int r, float f) {
+  return lerpf(T[off + N + r - 1], T[off + N + r], f);
+}
+// 2-D table (row-major values after NR row keys and NC column keys) on pre-bracketed axes
+template <int NR, int NC>
+__device__ __forceinline__ float tab2i(const Tab& T, int off, int r, float rf, int c, float cf) {
+  const int v = off + NR + NC;
+  float a0 = T[v + (r - 1) * NC + c - 1], a1 = T[v + r * NC + c - 1];
+  float b0 = T[v + (r - 1) * NC + c], b1 = T[v + r * NC + c];
+  return lerpf(lerpf(a0, a1, rf), lerpf(b0, b1, rf), cf);
+}
+#define F16_T1(NAME, key) tab1<T_##NAME##_NR>(T, T_##NAME##_OFF, (key))
+#define F16_T1A(NAME) tab1i<T_##NAME##_NR>(T, T_##NAME##_OFF, ia, fa)
+#define F16_T2(NAME, c, cf) tab2i<T_##NAME##_NR, T_##NAME##_NC>(T, T_##NAME##_OFF, ia, fa, (c), (cf))
+
+// ---------------------------------------------------------------- standard atmosphere 1976 (geopotential layers)
+// data/src/models/atmosphere/FGStandardAtmosphere.cpp:66-74,152-222,244-268 — only the three layers an F-16 can reach.
+struct Atmos { float T, P, rho, a; };
+__device__ __forceinline__ Atmos atmosphere(float h_ft) {
+  const float Re = 20855531.5f;                 // 6356766 m in ft
+  const float R = 1716.557158f;                 // Rstar/Mair = 8.31432*kgtoslug/(1.8*0.3048^2) / (28.9645*kgtoslug/1000)
+  const float g0R = kG0 / R;
+  float gp = h_ft * Re / (Re + h_ft);
+  Atmos A;
+  if (gp < 36089.2388f) {
+    const float L = (389.97f - 518.67f) / 36089.2388f;
+    A.T = 518.67f + L * gp;                     // also the extrapolation JSBSim uses below sea level
+    A.P = 2116.228f * __powf(518.67f / A.T, g0R / L);
+  } else if (gp < 65616.7979f) {
+    const float Pb = 472.680579f;                // breakpoint pressure at 36089.2388 ft from the layer formula (:460-481)
+    A.T = 389.97f;
+    A.P = Pb * __expf(-g0R * (gp - 36089.2388f) / 389.97f);
+  } else {
+    const float Pb = 114.344890f;                // breakpoint pressure at 65616.7979 ft
+    const float L = (411.57f - 389.97f) / (104986.8766f - 65616.7979f);
+    A.T = 389.97f + L * (gp - 65616.7979f);
+    A.P = Pb * __powf(389.97f / A.T, g0R / L);
+  }
+  A.rho = A.P / (R * A.T);
+  A.a = sqrtf(1.4f * R * A.T);
+  return A;
+}
+
+// Calibrated airspeed from Mach (data/src/FGJSBBase.cpp:245-296): pitot total pressure, then the sea-level inverse.
+__device__ __forceinline__ float vcas_from_mach(float mach, float p) {
+  const float psl = 2116.228f, asl = 1116.448558f;  // sqrt(1.4 * R * 518.67)
+  float pt;
+  if (mach < 1.0f) pt = p * powf(1.0f + 0.2f * mach * mach, 3.5f);
+  else pt = p * 166.92158009316827f * powf(mach, 7.0f) / powf(7.0f * mach * mach - 1.0f, 2.5f);
+  float A = (pt - p) / psl + 1.0f;
+  float M = sqrtf(5.0f * (powf(A, 1.0f / 3.5f) - 1.0f));
+  if (M > 1.0f) {
+    for (int i = 0; i < 10; ++i) M = 0.8812848543473311f * sqrtf(A * powf(1.0f - 1.0f / (7.0f * M * M), 2.5f));
+  }
+  return asl * M;
+}
+
+// Rate limiter through two detents at [-lim.., lim] (FGKinemat.cpp:99-170 specialised to a single segment).
+__device__ __forceinline__ float slew(float out, float in, float lo, float hi, float rate) {
+  in = clampf(lo, in, hi);
+  float step = rate * kFcsDt;
+  float d = in - out;
+  return (fabsf(d) <= step) ? in : out + copysignf(step, d);
+}
+// The trailing-edge-flap kinematic has detents {-1, 0, 1} with times {3, 0, 3}: the (-1,0] segment has zero
+// transit time (the output jumps to the input whenever the segment it starts in is that one), the (0,1] segment
+// moves at 1/3 per second. Follows the detent search of FGKinemat.cpp:116-140 inside one FCS tick.
+__device__ __forceinline__ float tef_kinematic(float out, float in) {
+  in = clampf(-1.0f, in, 1.0f);
+  float dt0 = kFcsDt;
+  for (int it = 0; it < 3 && dt0 > 0.0f && in != out; ++it) {
+    // segment index: 1 => [-1,0], 2 => [0,1]
+    int ind = (in < out) ? ((0.0f < out) ? 2 : 1) : ((0.0f <= out) ? 2 : 1);
+    if (ind == 1) { out = in; break; }
+    const float rate = 1.0f / 3.0f;
+    float thisIn = clampf(0.0f, in, 1.0f);
+    float thisDt = fabsf((thisIn - out) / rate);
+    if (dt0 < thisDt) { out += (out < in) ? dt0 * rate : -dt0 * rate; dt0 = 0.0f; }
+    else { out = thisIn; dt0 -= thisDt; }
+  }
+  return out;
+}
+// FGPID::Run (FGPID.cpp:154-204) with the Adams-Bashforth-2 integrator the f16 <ki> elements default to.
+__device__ __forceinline__ float pid(float in, float& in_prev, float& itot, bool trig_zero, float kp, float ki, float kd) {
+  float dval = (in - in_prev) * (1.0f / kFcsDt);
+  if (trig_zero) itot += ki * kFcsDt * (1.5f * in - 0.5f * in_prev);
+  in_prev = in;
+  return kp * in + itot + kd * dval;
+}
+__device__ __forceinline__ float seek(float v, float target, float accel, float decel, float dt) {
+  if (v > target) v = fmaxf(v - dt * decel, target);
+  else if (v < target) v = fminf(v + dt * accel, target);
+  return v;
+}
+
+// ECI position -> ECEF, geodetic latitude (Fukushima 2006 as in data/src/math/FGLocation.cpp:283-317),
+// altitude above the sea-level radius, and the local-frame unit vectors expressed in ECI.
+__device__ __forceinline__ void locate(const State& s, Derived& d) {
+  // Earth position angle is tiny (< 0.1 rad over an episode): series in fp64 is exact to < 1e-15.
+  double epa = kOmega * (double)s.ticks * (1.0 / 60.0);
+  double e2 = epa * epa;
+  double ce = 1.0 - e2 * (0.5 - e2 * (1.0 / 24.0 - e2 * (1.0 / 720.0)));
+  double se = epa * (1.0 - e2 * (1.0 / 6.0 - e2 * (1.0 / 120.0 - e2 * (1.0 / 5040.0))));
+  double X = ce * s.rx + se * s.ry, Y = -se * s.rx + ce * s.ry, Z = s.rz;
+  d.X = X; d.Y = Y; d.Z = Z;
+  double rxy2 = X * X + Y * Y;
+  double rxy = sqrt(rxy2), rad = sqrt(rxy2 + Z * Z);
+  const double ec = kB / kA, ec2 = ec * ec, ee = 1.0 - ec2, c = kA * ee;
+  double s0 = fabs(Z), zc = ec * s0, c0 = ec * rxy, c02 = c0 * c0, s02 = s0 * s0, a02 = c02 + s02;
+  double a0 = sqrt(a02), a03 = a02 * a0;
+  double s1 = zc * a03 + c * s02 * s0, c1 = rxy * a03 - c * c02 * c0, cs = c * c0 * s0;
+  double b0 = 1.5 * cs * ((rxy * s0 - zc * c0) * a0 - cs);
+  s1 = s1 * a03 - b0 * s0;
+  double cc = ec * (c1 * a03 - b0 * c0);
+  double inv = 1.0 / sqrt(s1 * s1 + cc * cc);
+  double sinLat = (Z >= 0.0 ? s1 : -s1) * inv, cosLat = cc * inv;
+  double cgc = rxy / rad;
+  double slr = kA * ec / sqrt(1.0 - ee * cgc * cgc);
+  d.h_sl_ft = (float)(rad - slr);
+  double irxy = 1.0 / rxy;
+  double cosLon = X * irxy, sinLon = Y * irxy;
+  d.sinLat = (float)sinLat; d.cosLat = (float)cosLat; d.sinLon = (float)sinLon; d.cosLon = (float)cosLon;
+  d.sLat64 = sinLat; d.cLat64 = cosLat; d.sLon64 = sinLon; d.cLon64 = cosLon;
+  // local unit vectors in ECEF, then rotated back by the Earth angle into ECI
+  float cef = (float)ce, sef = (float)se;
+  float nx = -d.cosLon * d.sinLat, ny = -d.sinLon * d.sinLat, nz = d.cosLat;
+  float ex = -d.sinLon, ey = d.cosLon;
+  float dx = -d.cosLon * d.cosLat, dy = -d.sinLon * d.cosLat, dz = -d.sinLat;
+  d.n_eci[0] = cef * nx - sef * ny; d.n_eci[1] = sef * nx + cef * ny; d.n_eci[2] = nz;
+  d.e_eci[0] = cef * ex - sef * ey; d.e_eci[1] = sef * ex + cef * ey; d.e_eci[2] = 0.0f;
+  d.d_eci[0] = cef * dx - sef * dy; d.d_eci[1] = sef * dx + cef * dy; d.d_eci[2] = dz;
+}
+
+__device__ __forceinline__ void body_frame(const State& s, Derived& d) {
+  float q0 = s.q0, q1 = s.q1, q2 = s.q2, q3 = s.q3;
+  float* T = d.T;
+  T[0] = q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3; T[1] = 2.0f * (q1 * q2 + q0 * q3); T[2] = 2.0f * (q1 * q3 - q0 * q2);
+  T[3] = 2.0f * (q1 * q2 - q0 * q3); T[4] = q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3; T[5] = 2.0f * (q2 * q3 + q0 * q1);
+  T[6] = 2.0f * (q1 * q3 + q0 * q2); T[7] = 2.0f * (q2 * q3 - q0 * q1); T[8] = q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3;
+  const float om = (float)kOmega;
+  // velocity relative to the rotating Earth, in ECI axes: v - Omega x r
+  float rvx = s.vx + om * (float)s.ry, rvy = s.vy - om * (float)s.rx, rvz = s.vz;
+  d.u = T[0] * rvx + T[1] * rvy + T[2] * rvz;
+  d.v = T[3] * rvx + T[4] * rvy + T[5] * rvz;
+  d.w = T[6] * rvx + T[7] * rvy + T[8] * rvz;
+  d.p = s.wp - om * T[2]; d.q = s.wq - om * T[5]; d.r = s.wr - om * T[8];
+  d.vn = d.n_eci[0] * rvx + d.n_eci[1] * rvy + d.n_eci[2] * rvz;
+  d.ve = d.e_eci[0] * rvx + d.e_eci[1] * rvy;
+  d.vd = d.d_eci[0] * rvx + d.d_eci[1] * rvy + d.d_eci[2] * rvz;
+  d.veci = sqrtf(s.vx * s.vx + s.vy * s.vy + s.vz * s.vz);
+}
+
+// One executive tick. DT_ZERO = true reproduces the two "integration suspended" passes of FGFDMExec::RunIC
+// (data/src/FGFDMExec.cpp:636-669): nothing integrates, the turbine runs its Trim() branch, the FCS still steps.
+// TANK_ARM_ORIGIN = true is the very first of those passes: FGMassBalance has not run yet, so the tank inertia the
+// executive loads for it (FGFDMExec.cpp:572 before FGMassBalance::Run) is taken about the structural origin; that pass's
+// angular acceleration reaches the FCS of the first real tick through the pilot-station load factor.
+template <bool DT_ZERO, bool TANK_ARM_ORIGIN = false>
+__device__ __forceinline__ void tick(State& s, Derived& d, const Tab& T) {
+  constexpr float dt = DT_ZERO ? 0.0f : (1.0f / 60.0f);
+  // ---------------- Propagate (FGPropagate.cpp:218-290, :336-360)
+  if (!DT_ZERO) {
+    float qd0 = -0.5f * (s.q1 * s.wp + s.q2 * s.wq + s.q3 * s.wr);
+    float qd1 = 0.5f * (s.q0 * s.wp - s.q3 * s.wq + s.q2 * s.wr);
+    float qd2 = 0.5f * (s.q3 * s.wp + s.q0 * s.wq - s.q1 * s.wr);
+    float qd3 = 0.5f * (-s.q2 * s.wp + s.q1 * s.wq + s.q0 * s.wr);
+    float a0 = fmaf(dt, qd0, s.q0), a1 = fmaf(dt, qd1, s.q1), a2 = fmaf(dt, qd2, s.q2), a3 = fmaf(dt, qd3, s.q3);
+    float rn = rsqrtf(a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3);
+    s.q0 = a0 * rn; s.q1 = a1 * rn; s.q2 = a2 * rn; s.q3 = a3 * rn;
+    s.wp = fmaf(dt, s.wdx, s.wp); s.wq = fmaf(dt, s.wdy, s.wq); s.wr = fmaf(dt, s.wdz, s.wr);
+    const float k = dt / 12.0f;
+    s.rx += (double)(k * (23.0f * s.vx - 16.0f * s.hv1x + 5.0f * s.hv2x));
+    s.ry += (double)(k * (23.0f * s.vy - 16.0f * s.hv1y + 5.0f * s.hv2y));
+    s.rz += (double)(k * (23.0f * s.vz - 16.0f * s.hv1z + 5.0f * s.hv2z));
+    s.hv2x = s.hv1x; s.hv2y = s.hv1y; s.hv2z = s.hv1z;
+    s.hv1x = s.vx; s.hv1y = s.vy; s.hv1z = s.vz;
+    s.vx += dt * (1.5f * s.aix - 0.5f * s.ha1x);
+    s.vy += dt * (1.5f * s.aiy - 0.5f * s.ha1y);
+    s.vz += dt * (1.5f * s.aiz - 0.5f * s.ha1z);
+    s.ha1x = s.aix; s.ha1y = s.aiy; s.ha1z = s.aiz;
+    s.ticks += 1;
+  }
+  locate(s, d);
+  body_frame(s, d);
+  const float* Tb = d.T;
+
+  // ---------------- Inertial: WGS84 + J2 gravity, evaluated in ECI (FGInertial.cpp:193-213)
+  float rxf = (float)s.rx, ryf = (float)s.ry, rzf = (float)s.rz;
+  float r2 = rxf * rxf + ryf * ryf + rzf * rzf;
+  float ir = rsqrtf(r2);
+  float sl = rzf * ir;
+  float adr = (float)kA * ir;
+  float pre = 1.5f * (float)kJ2 * adr * adr;
+  float gmr2 = (float)kGM * ir * ir;
+  float kxy = -gmr2 * (1.0f + pre * (1.0f - 5.0f * sl * sl)) * ir;
+  float kz = -gmr2 * (1.0f + pre * (3.0f - 5.0f * sl * sl)) * ir;
+  float gx = kxy * rxf, gy = kxy * ryf, gz = kz * rzf;
+
+  // ---------------- Atmosphere
+  Atmos A = atmosphere(d.h_sl_ft);
+
+  // ---------------- FCS (f16.xml:317-992; inputs from FGAuxiliary are last tick's)
+  const float alpha_p = s.alpha, mach_p = s.mach, vckts_p = s.vckts;
+  // flaps
+  float tef_rad = (vckts_p < 250.0f) ? 0.349f : ((mach_p > 0.9f) ? -0.0349f : 0.0f);
+  s.tef = tef_kinematic(s.tef, 2.864789f * tef_rad);
+  // roll
+  float roll_err = s.da - 0.31821f * s.ap;
+  float roll_pid = pid(roll_err, s.pin_r, s.pi_r, vckts_p < 20.0f, 3.0f, 0.0005f, -0.00125f);
+  float roll_cmd = clampf(-1.0f, roll_pid + s.da, 1.0f);
+  float aileron_rad = 0.375f * roll_cmd;
+  s.ail = slew(s.ail, roll_cmd, -1.0f, 1.0f, 2.0f / 0.3f);
+  float ail_sc = s.ail * F16_T1(FCS_AILERON_SPEED_COMPENSATED, mach_p);
+  float flaperon_rad = 1.4324f * (clampf(-1.0f, -s.tef - ail_sc, 1.0f) + clampf(-1.0f, s.tef - ail_sc, 1.0f));
+  // pitch: cos(theta)cos(phi) is the projection of body z on local down
+  float cthcph = Tb[6] * d.d_eci[0] + Tb[7] * d.d_eci[1] + Tb[8] * d.d_eci[2];
+  float elev_lim = clampf(-1.0f, s.de, 0.44f);
+  float elev_sched = elev_lim * F16_T1(FCS_ELEVATOR_SCHEDULER, alpha_p);
+  float pitch_err = elev_sched + 6.2f * s.aq - 0.020f * (s.npz - cthcph);
+  float g_pid = clampf(-1.0f, pid(pitch_err, s.pin_p, s.pi_p, vckts_p < 5.0f, 0.3f, 0.025f, 0.0f), 1.0f);
+  float pitch_sched = clampf(-1.0f, elev_sched + 1.0472f * alpha_p + g_pid, 1.0f);
+  s.elev = slew(s.elev, pitch_sched, -1.0f, 1.0f, 2.0f / 0.3f);
+  float elevator_rad = 0.436f * s.elev;
+  // yaw: the PID writes fcs/rudder-pos-norm, the kinematic re-reads that property as its own output
+  float yaw_err = s.dr + s.ar * F16_T1(FCS_YAW_RATE_NORM, s.vg) + 0.25f * s.npy;
+  float yaw_pid = clampf(-1.0f, pid(yaw_err, s.pin_y, s.pi_y, vckts_p < 10.0f, 0.1055f, 0.00001f, 0.00005f), 1.0f);
+  float yaw_sched = clampf(-1.0f, s.dr + yaw_pid, 1.0f);
+  float rudder_rad = 0.524f * slew(yaw_pid, yaw_sched, -1.0f, 1.0f, 2.0f / 0.4f);
+  // gear stays down (FGFCS.cpp:81, never commanded): gear-pos-norm = 1, gear-wow = 0
+  float lef_rad = (alpha_p > 0.0873f) ? 0.262f : ((mach_p > 0.9f) ? -0.0349f : 0.0f);
+  float throttle_pos = 2.0f * s.thr;
+  // speedbrake auto-deploy: alpha >= 53 deg and body v <= 18 ft/s; scheduler gain 0.71667 with the gear commanded down
+  float sb_in = ((alpha_p * 57.29577951f >= 53.0f) && (d.v <= 18.0f)) ? 0.71667f * 60.0f : 0.0f;
+  s.sbdeg = slew(s.sbdeg, sb_in, 0.0f, 60.0f, 60.0f);
+  float sb_rad = s.sbdeg * 0.01745329252f;
+
+  // ---------------- MassBalance (FGMassBalance.cpp:181-262); tanks 2/3 are empty external tanks
+  float fuel = s.tank0 + s.tank1;
+  float weight = (float)F16_EMPTYWT + (float)F16_PM0_WEIGHT + fuel;
+  float mass = kLb2Slug * weight;
+  float iw = 1.0f / weight;
+  float cgx = ((float)(F16_EMPTYWT * F16_CG_X + F16_PM0_WEIGHT * F16_PM0_X) + (float)F16_TANK0_X * fuel) * iw;
+  float cgy = ((float)F16_TANK0_Y * s.tank0 + (float)F16_TANK1_Y * s.tank1) * iw;
+  float cgz = ((float)(F16_EMPTYWT * F16_CG_Z + F16_PM0_WEIGHT * F16_PM0_Z) + (float)F16_TANK0_Z * fuel) * iw;
+  float Jxx = (float)F16_IXX, Jyy = (float)F16_IYY, Jzz = (float)F16_IZZ, Jxy = 0.0f, Jxz = (float)F16_IXZ, Jyz = 0.0f;
+  {
+    // parallel-axis terms of empty mass, pilot and the two tanks about the current CG (structural -> body arms)
+    const float ms[4] = {kLb2Slug * (float)F16_EMPTYWT, kLb2Slug * (float)F16_PM0_WEIGHT, kLb2Slug * s.tank0, kLb2Slug * s.tank1};
+    const float px[4] = {(float)F16_CG_X, (float)F16_PM0_X, (float)F16_TANK0_X, (float)F16_TANK1_X};
+    const float py[4] = {(float)F16_CG_Y, (float)F16_PM0_Y, (float)F16_TANK0_Y, (float)F16_TANK1_Y};
+    const float pz[4] = {(float)F16_CG_Z, (float)F16_PM0_Z, (float)F16_TANK0_Z, (float)F16_TANK1_Z};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool origin = TANK_ARM_ORIGIN && i >= 2;
+      float x = kInch2Ft * ((origin ? 0.0f : cgx) - px[i]), y = kInch2Ft * (py[i] - (origin ? 0.0f : cgy)), z = kInch2Ft * ((origin ? 0.0f : cgz) - pz[i]);
+      float m = ms[i];
+      Jxx += m * (y * y + z * z); Jyy += m * (x * x + z * z); Jzz += m * (x * x + y * y);
+      Jxy -= m * x * y; Jxz -= m * x * z; Jyz -= m * y * z;
+    }
+  }
+
+  // ---------------- Auxiliary (FGAuxiliary.cpp:134-232)
+  float muw = d.u * d.u + d.w * d.w, vt2 = muw + d.v * d.v;
+  float vt = sqrtf(vt2);
+  float alpha = 0.0f, beta = 0.0f, ca = 1.0f, sa = 0.0f, cb = 1.0f, sb = 0.0f;
+  if (vt > 0.001f) {
+    float suw = sqrtf(muw);
+    beta = atan2f(d.v, suw);
+    cb = suw / vt; sb = d.v / vt;
+    if (muw >= 1e-6f) { alpha = atan2f(d.w, d.u); ca = d.u / suw; sa = d.w / suw; }
+  }
+  float qbar = 0.5f * A.rho * vt2;
+  float mach = vt / A.a;
+  float vg = sqrtf(d.vn * d.vn + d.ve * d.ve);
+  float vc = (mach > 0.0f) ? vcas_from_mach(mach, A.P) : 0.0f;
+  d.vc_fps = vc;
+  // pilot-station load factors from LAST tick's accelerations and the inertial rates (:205-217)
+  float ex = kInch2Ft * (cgx - (float)F16_EYEPOINT_X), ey = kInch2Ft * ((float)F16_EYEPOINT_Y - cgy), ez = kInch2Ft * (cgz - (float)F16_EYEPOINT_Z);
+  float t1x = s.wdy * ez - s.wdz * ey, t1y = s.wdz * ex - s.wdx * ez, t1z = s.wdx * ey - s.wdy * ex;
+  float cx = s.wq * ez - s.wr * ey, cy = s.wr * ex - s.wp * ez, cz = s.wp * ey - s.wq * ex;
+  float t2x = s.wq * cz - s.wr * cy, t2y = s.wr * cx - s.wp * cz, t2z = s.wp * cy - s.wq * cx;
+  float npx = (s.bax + t1x + t2x) * (1.0f / kG0), npy = (s.bay + t1y + t2y) * (1.0f / kG0), npz = (s.baz + t1z + t2z) * (1.0f / kG0);
+
+  // ---------------- Propulsion: F100-PW-229 turbine (FGTurbine.cpp:107-270,400-411), AugMethod 2
+  int im, jh; float fm, fh;
+  bracket<T_ENG_MILTHRUST_NR>(T, T_ENG_MILTHRUST_OFF, mach, im, fm);
+  // density altitude equals geometric altitude in the standard atmosphere the reference flies in
+  bracket<T_ENG_MILTHRUST_NC>(T, T_ENG_MILTHRUST_OFF + T_ENG_MILTHRUST_NR, d.h_sl_ft, jh, fh);
+  float mil_f = tab2i<T_ENG_MILTHRUST_NR, T_ENG_MILTHRUST_NC>(T, T_ENG_MILTHRUST_OFF, im, fm, jh, fh);
+  int ii; float fi;
+  bracket<T_ENG_IDLETHRUST_NR>(T, T_ENG_IDLETHRUST_OFF, mach, ii, fi);
+  float idle_f = tab2i<T_ENG_IDLETHRUST_NR, T_ENG_IDLETHRUST_NC>(T, T_ENG_IDLETHRUST_OFF, ii, fi, jh, fh);
+  int ig; float fg;
+  bracket<T_ENG_AUGTHRUST_NR>(T, T_ENG_AUGTHRUST_OFF, mach, ig, fg);
+  float aug_f = tab2i<T_ENG_AUGTHRUST_NR, T_ENG_AUGTHRUST_NC>(T, T_ENG_AUGTHRUST_OFF, ig, fg, jh, fh);
+  float thrust;
+  {
+    const float MIL = (float)F16_ENG_MILTHRUST, MAXT = (float)F16_ENG_MAXTHRUST;
+    const float IN1 = (float)F16_ENG_IDLEN1, IN2 = (float)F16_ENG_IDLEN2;
+    const float N1f = (float)(F16_ENG_MAXN1 - F16_ENG_IDLEN1), N2f = (float)(F16_ENG_MAXN2 - F16_ENG_IDLEN2);
+    const float idle_ff = 757.648518f;  // pow(milthrust, 0.2) * 107 (FGTurbine.cpp:522)
+    float tp = throttle_pos, aug_cmd = 0.0f;
+    if (tp > 1.0f) { aug_cmd = tp - 1.0f; tp = 1.0f; }
+    int phase = s.eng & ENG_PHASE_MASK;
+    bool running = s.eng & ENG_RUNNING, cutoff = s.eng & ENG_CUTOFF, starved = s.eng & ENG_STARVED, augm = s.eng & ENG_AUG;
+    if (phase == PH_TRIM && !DT_ZERO) {
+      if (running && !starved) { phase = PH_RUN; s.n2 = IN2 + tp * N2f; s.n1 = IN1 + tp * N1f; cutoff = false; }
+      else { phase = PH_OFF; cutoff = true; }
+    }
+    if (qbar > 30.0f && !running && !cutoff && s.n2 > 15.0f) phase = PH_START;
+    if (cutoff) phase = PH_OFF;
+    if (DT_ZERO) phase = PH_TRIM;
+    if (starved) phase = PH_OFF;
+    float idle = MIL * idle_f, mil = (MIL - idle) * mil_f;
+    thrust = 0.0f;
+    if (phase == PH_RUN) {
+      running = true;
+      float dens_ratio = A.rho * (1.0f / 0.00237691175f);  // sea-level density 2116.228 / (R * 518.67)
+      float n = fminf(1.0f, s.n2norm + 0.1f);
+      float den = 1.0f / (1.0f + 3.0f * (1.0f - n) * (1.0f - n) * (1.0f - n) + (1.0f - dens_ratio));
+      const float base = 90.0f / ((float)F16_ENG_BYPASSRATIO + 3.0f);
+      s.n2 = seek(s.n2, IN2 + tp * N2f, base * den, 3.0f * base * den, dt);
+      s.n1 = seek(s.n1, IN1 + tp * N1f, base * den, 2.4f * base * den, dt);
+      s.n2norm = (s.n2 - IN2) / N2f;
+      thrust = idle + mil * s.n2norm * s.n2norm;
+      if (!augm) {
+        float tsfc = (float)F16_ENG_TSFC * sqrtf(A.T * (1.0f / 389.7f)) * (0.84f + (1.0f - s.n2norm) * (1.0f - s.n2norm));
+        s.ff = fmaxf(seek(s.ff, thrust * tsfc, 1000.0f, 10000.0f, dt), idle_ff);
+      }
+      if (aug_cmd > 0.0f) {
+        augm = true;
+        thrust += (MAXT * aug_f - thrust) * aug_cmd;
+        s.ff = seek(s.ff, thrust * (float)F16_ENG_ATSFC, 5000.0f, 10000.0f, dt);
+      } else augm = false;
+      if (cutoff || starved) phase = PH_OFF;
+    } else if (phase == PH_TRIM) {
+      thrust = idle + mil * tp * tp;
+      if (aug_cmd > 0.0f) thrust += (MAXT * aug_f - thrust) * aug_cmd;
+    } else if (phase == PH_START) {
+      if (s.n2 > 15.0f && !starved) {
+        if (s.n2 < IN2) {
+          s.n2 = seek(s.n2, IN2, 2.0f, s.n2 * 0.5f, dt);
+          s.n1 = seek(s.n1, IN1, 1.4f, s.n1 * 0.5f, dt);
+          s.ff = idle_ff * s.n2 / IN2;
+          if (qbar < 30.0f) phase = PH_OFF;
+        } else { phase = PH_RUN; running = true; }
+      } else phase = PH_OFF;
+    } else {  // Off(): spin down towards windmilling
+      running = false;
+      s.ff = seek(s.ff, 0.0f, 1000.0f, 10000.0f, dt);
+      s.n1 = seek(s.n1, qbar * 0.1f, s.n1 * 0.5f + 0.1f, s.n1 * 0.5f, dt);
+      s.n2 = seek(s.n2, qbar * (1.0f / 15.0f), s.n2 * 0.5f + 0.1f, s.n2 * 0.5f, dt);
+      augm = false;
+    }
+    // ConsumeFuel (FGPropulsion.cpp:164-258): equal draw from every tank that still holds fuel
+    int nfuel = (s.tank0 > 0.0f ? 1 : 0) + (s.tank1 > 0.0f ? 1 : 0);
+    starved = (nfuel == 0);
+    if (!starved && !DT_ZERO) {
+      float need = s.ff * (1.0f / 3600.0f) * dt / (float)nfuel;
+      if (s.tank0 > 0.0f) s.tank0 = (s.tank0 - need >= 0.0f) ? s.tank0 - need : 0.0f;
+      if (s.tank1 > 0.0f) s.tank1 = (s.tank1 - need >= 0.0f) ? s.tank1 - need : 0.0f;
+    }
+    s.eng = phase | (running ? ENG_RUNNING : 0) | (cutoff ? ENG_CUTOFF : 0) | (starved ? ENG_STARVED : 0) | (augm ? ENG_AUG : 0);
+  }
+  // thrust along body x through the structural origin: arm from the CG
+  float tx = kInch2Ft * (cgx - (float)F16_THRUSTER_X), ty = kInch2Ft * ((float)F16_THRUSTER_Y - cgy), tz = kInch2Ft * (cgz - (float)F16_THRUSTER_Z);
+  (void)tx;
+  float Mpy = tz * thrust, Mpz = -ty * thrust;
+
+  // ---------------- Aerodynamics (FGAerodynamics.cpp:132-300; f16.xml:994-1925)
+  float Fx, Fy, Fz, Mx, My, Mz;
+  {
+    const float Sw = (float)F16_WINGAREA, bw = (float)F16_WINGSPAN, cbar = (float)F16_CHORD;
+    float i2v = (vt != 0.0f) ? 0.5f / vt : 0.0f;
+    float bi2vel = bw * i2v, ci2vel = cbar * i2v;
+    float qS = qbar * Sw;
+    int ia; float fa;
+    bracket<12>(T, T_CDDLEF_OFF, alpha, ia, fa);            // the alpha axis every alpha table shares
+    int ide; float fde;
+    bracket<T_CDDH_NC>(T, T_CDDH_OFF + T_CDDH_NR, elevator_rad, ide, fde);
+    int ib13; float fb13;
+    bracket<T_CLB_NC>(T, T_CLB_OFF + T_CLB_NR, beta, ib13, fb13);
+    int ib7; float fb7;
+    bracket<T_CLDA_NC>(T, T_CLDA_OFF + T_CLDA_NR, beta, ib7, fb7);
+    // hoverbmac > 1.1 everywhere above the 2500 m floor, kCLge = 1 there; keep the table for low floors
+    // (h above the ellipsoid ~ h_sl to within the geoid-free model; the reference point offset is < 2 ft)
+    float kge = F16_T1(KCLGE, d.h_sl_ft * (1.0f / (float)F16_WINGSPAN));
+    float p = d.p, q = d.q, r = d.r;
+    float CD = F16_T2(CDDH, ide, fde) + F16_T1(CDMACH, mach) + lef_rad * F16_T1A(CDDLEF) + flaperon_rad * (float)F16_K_CDDFLAPS +
+               (float)F16_K_CDGEAR + sb_rad * F16_T1A(CDDSB) + q * ci2vel * (F16_T1A(CDQ) + lef_rad * F16_T1A(CDQ_DLEF));
+    float CY = beta * ((float)F16_K_CYB + F16_T1(CYB_M, mach)) + aileron_rad * (float)F16_K_CYDA + rudder_rad * (float)F16_K_CYDR +
+               bi2vel * (p * F16_T1A(CYP) + r * F16_T1A(CYR));
+    float CL = kge * (F16_T2(CLDH, ide, fde) + lef_rad * F16_T1A(CLDLEF) + flaperon_rad * (float)F16_K_CLDFLAPS + sb_rad * F16_T1A(CLDSB) +
+                      q * ci2vel * F16_T1A(CLQ)) + q * ci2vel * sb_rad * F16_T1A(CLQ_DSB);
+    float Cl = F16_T2(CLB, ib13, fb13) + beta * F16_T1(CLB_M, mach) + bi2vel * (p * F16_T1A(CLP) + r * F16_T1A(CLR)) +
+               aileron_rad * (F16_T2(CLDA, ib7, fb7) + alpha * F16_T1(CLDA_M, mach)) +
+               rudder_rad * (F16_T2(CLDR, ib7, fb7) + alpha * F16_T1(CLDR_M, mach));
+    float Cm = F16_T2(CMDH, ide, fde) + alpha * F16_T1(CMA_M, mach) + sb_rad * F16_T1A(CMDSB) + ci2vel * q * F16_T1A(CMQ);
+    float Cn = F16_T2(CNB, ib13, fb13) + beta * F16_T1(CNB_M, mach) + bi2vel * (p * F16_T1A(CNP) + r * F16_T1A(CNR)) +
+               aileron_rad * (F16_T1(CNDA_M, mach) + F16_T2(CNDA, ib7, fb7)) +
+               rudder_rad * (F16_T2(CNDR, ib7, fb7) + alpha * F16_T1(CNDR_M, mach));
+    float D = qS * CD, Y = qS * CY, L = qS * CL;
+    // wind -> body: F = Tw2b * (-D, Y, -L)
+    Fx = ca * cb * (-D) - ca * sb * Y + sa * L;
+    Fy = sb * (-D) + cb * Y;
+    Fz = sa * cb * (-D) - sa * sb * Y - ca * L;
+    // moments about the aero reference point, transferred to the CG
+    float ax = kInch2Ft * (cgx - (float)F16_AERORP_X), ay = kInch2Ft * ((float)F16_AERORP_Y - cgy), az = kInch2Ft * (cgz - (float)F16_AERORP_Z);
+    Mx = qS * bw * Cl + (ay * Fz - az * Fy);
+    My = qS * cbar * Cm + (az * Fx - ax * Fz);
+    Mz = qS * bw * Cn + (ax * Fy - ay * Fx);
+  }
+
+  // ---------------- Accelerations (FGAccelerations.cpp:138-208)
+  {
+    float Tx = Fx + thrust, Ty = Fy, Tz = Fz;
+    float Lm = Mx, Mm = My + Mpy, Nm = Mz + Mpz;
+    // J * wi, wi x (J wi)   (J has negated products off the diagonal: J12 = -Ixy ... stored here as Jxy = J(1,2))
+    float hx = Jxx * s.wp + Jxy * s.wq + Jxz * s.wr;
+    float hy = Jxy * s.wp + Jyy * s.wq + Jyz * s.wr;
+    float hz = Jxz * s.wp + Jyz * s.wq + Jzz * s.wr;
+    float rx_ = Lm - (s.wq * hz - s.wr * hy), ry_ = Mm - (s.wr * hx - s.wp * hz), rz_ = Nm - (s.wp * hy - s.wq * hx);
+    // symmetric 3x3 inverse by cofactors
+    float c00 = Jyy * Jzz - Jyz * Jyz, c01 = Jxz * Jyz - Jxy * Jzz, c02 = Jxy * Jyz - Jxz * Jyy;
+    float c11 = Jxx * Jzz - Jxz * Jxz, c12 = Jxy * Jxz - Jxx * Jyz, c22 = Jxx * Jyy - Jxy * Jxy;
+    float idet = 1.0f / (Jxx * c00 + Jxy * c01 + Jxz * c02);
+    s.wdx = (c00 * rx_ + c01 * ry_ + c02 * rz_) * idet;
+    s.wdy = (c01 * rx_ + c11 * ry_ + c12 * rz_) * idet;
+    s.wdz = (c02 * rx_ + c12 * ry_ + c22 * rz_) * idet;
+    float im_ = 1.0f / mass;
+    s.bax = Tx * im_; s.bay = Ty * im_; s.baz = Tz * im_;
+    // inertial acceleration: Tb2i * a_body + g_eci
+    s.aix = Tb[0] * s.bax + Tb[3] * s.bay + Tb[6] * s.baz + gx;
+    s.aiy = Tb[1] * s.bax + Tb[4] * s.bay + Tb[7] * s.baz + gy;
+    s.aiz = Tb[2] * s.bax + Tb[5] * s.bay + Tb[8] * s.baz + gz;
+  }
+  // publish this tick's auxiliary outputs for the next tick's FCS
+  s.alpha = alpha; s.mach = mach; s.vckts = vc * (1.0f / kKts2Fps); s.vg = vg;
+  s.ap = d.p; s.aq = d.q; s.ar = d.r;
+  s.npx = npx; s.npy = npy; s.npz = npz;
+}
+
+}  // namespace f16

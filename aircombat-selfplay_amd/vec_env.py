@@ -1,0 +1,201 @@
+"""HipVecEnv — the reference's VecEnv surface on top of libaircombat_hip.so.
+
+Mirrors ``SubprocVecEnv`` / ``DummyVecEnv`` of the reference (envs/env_wrappers.py:48-320): attributes ``num_envs``,
+``num_agents``, ``observation_space``, ``action_space``; methods ``reset()``, ``step(actions)``, ``step_async`` /
+``step_wait``, ``close()``; the same return shapes ``obs[E,A,obs_dim]``, ``rewards[E,A,1]``, ``dones[E,A,1]`` (bool),
+``infos`` (ndarray of dict), and the same auto-reset rule (env_wrappers.py:191-204). Outputs are float32
+(the buffers cast to float32 on insert, algorithms/utils/buffer.py:52-58).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .capi import (AcConfig, AC_STATE_LEN, AC_TASK_SINGLECOMBAT, AC_TASK_SHOOT_MISSILE, load_library)
+from .config import config_from_yaml, default_config
+
+DONE_MESSAGES = {
+    0: "", 1: "altitude is too low", 2: "is on an extreme state", 3: "acceleration is too high", 4: "has been shot down",
+    5: "has crashed", 6: "mission completed", 7: "step limits", 8: "unreached heading",
+}
+
+
+class _Box:
+    """Minimal stand-in for gymnasium.spaces.Box when gymnasium is not installed (attributes the runners read)."""
+
+    def __init__(self, low, high, shape):
+        self.low = np.full(shape, low, dtype=np.float32)
+        self.high = np.full(shape, high, dtype=np.float32)
+        self.shape = tuple(shape)
+        self.dtype = np.float32
+
+    def __repr__(self):
+        return f"Box({self.low.min()}, {self.high.max()}, {self.shape}, float32)"
+
+
+class _MultiDiscrete:
+    def __init__(self, nvec):
+        self.nvec = np.asarray(nvec, dtype=np.int64)
+        self.shape = self.nvec.shape
+        self.dtype = np.int64
+
+    def __repr__(self):
+        return f"MultiDiscrete({self.nvec.tolist()})"
+
+
+class _Discrete:
+    def __init__(self, n):
+        self.n = int(n)
+        self.shape = ()
+        self.dtype = np.int64
+
+
+class _Tuple(tuple):
+    pass
+
+
+def _spaces():
+    try:
+        from gymnasium import spaces  # the reference's own dependency, used when present
+        return spaces.Box, spaces.MultiDiscrete, spaces.Discrete, spaces.Tuple
+    except Exception:  # not installed in this image
+        return (lambda low, high, shape: _Box(low, high, shape)), _MultiDiscrete, _Discrete, (lambda xs: _Tuple(xs))
+
+
+class HipVecEnv:
+    """E parallel 1v1 air-combat envs advanced by one HIP kernel launch per ``step``."""
+
+    def __init__(self, config, num_envs, device_id=0, seed=0, lib=None):
+        if not isinstance(config, AcConfig):
+            raise TypeError("config must be an AcConfig (see config_from_yaml / default_config)")
+        self.lib = lib or load_library()
+        self.config = config
+        self.num_envs = int(num_envs)
+        self.num_agents = int(config.n_agents)
+        handle = C.c_void_p()
+        self.lib.check(self.lib.ac_create(C.byref(config), self.num_envs, int(device_id), int(seed), C.byref(handle)), "ac_create")
+        self._h = handle
+        self.closed = False
+        self.waiting = False
+        self.obs_dim = self.lib.ac_obs_dim(self._h)
+        self.act_dim = self.lib.ac_act_dim(self._h)
+        Box, MultiDiscrete, Discrete, Tuple = _spaces()
+        self.observation_space = Box(low=-10, high=10.0, shape=(self.obs_dim,))
+        if config.task == AC_TASK_SHOOT_MISSILE:
+            self.action_space = Tuple([MultiDiscrete([41, 41, 41, 30]), Discrete(2)])
+        else:
+            self.action_space = MultiDiscrete([41, 41, 41, 30])
+        E, A = self.num_envs, self.num_agents
+        # reusable host buffers; returned arrays are views that stay valid until the next step()/reset()
+        self._actions = np.zeros((E, A, self.act_dim), dtype=np.float32)
+        self._obs = np.zeros((E, A, self.obs_dim), dtype=np.float32)
+        self._rew = np.zeros((E, A, 1), dtype=np.float32)
+        self._done = np.zeros((E, A, 1), dtype=np.uint8)
+        self._info = np.zeros((E, 4), dtype=np.int32)
+
+    # ---- reference surface
+    def reset(self):
+        self._assert_not_closed()
+        self.lib.check(self.lib.ac_reset(self._h, self._obs.ctypes.data), "ac_reset")
+        return self._obs.copy()
+
+    def step_async(self, actions):
+        self._assert_not_closed()
+        a = np.asarray(actions, dtype=np.float32)
+        if a.shape != self._actions.shape:
+            a = a.reshape(self._actions.shape)  # nested lists [E][A][act_dim] from the runners
+        np.copyto(self._actions, a)
+        self.waiting = True
+
+    def step_wait(self):
+        self._assert_not_closed()
+        self.lib.check(self.lib.ac_step(self._h, self._actions.ctypes.data, self._obs.ctypes.data, self._rew.ctypes.data,
+                                        self._done.ctypes.data, self._info.ctypes.data), "ac_step")
+        self.waiting = False
+        infos = np.empty(self.num_envs, dtype=object)
+        cur, code = self._info[:, 0], self._info[:, 1]
+        for i in range(self.num_envs):
+            d = {"current_step": int(cur[i])}
+            if code[i]:
+                d["done_condition"] = DONE_MESSAGES.get(int(code[i]), "")
+            infos[i] = d
+        return self._obs.copy(), self._rew.copy(), self._done.astype(bool), infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def render(self, mode="txt", filepath="./JSBSimRecording.txt.acmi"):
+        raise NotImplementedError("ACMI rendering is SURVEY row N3 (not on the step() hot path)")
+
+    def close(self):
+        if self.closed:
+            return
+        self.lib.ac_destroy(self._h)
+        self._h = None
+        self.closed = True
+
+    def _assert_not_closed(self):
+        assert not self.closed, "Trying to operate on a HipVecEnv after calling close()"
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- device-resident path: obs / actions as torch tensors on the env's GPU
+    def device_tensors(self):
+        """torch views (no copy) of the handle's device buffers: actions, obs, rewards, dones, info."""
+        import torch
+
+        ptrs = [C.c_void_p() for _ in range(5)]
+        self.lib.check(self.lib.ac_device_buffers(self._h, *[C.byref(p) for p in ptrs]), "ac_device_buffers")
+        E, A = self.num_envs, self.num_agents
+
+        def view(ptr, shape, typestr, dtype):
+            holder = type("_Buf", (), {})()
+            holder.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr.value, False), "version": 2}
+            return torch.as_tensor(holder, device="cuda").view(dtype) if False else torch.as_tensor(holder, device="cuda")
+
+        act = view(ptrs[0], (E, A, self.act_dim), "<f4", None)
+        obs = view(ptrs[1], (E, A, self.obs_dim), "<f4", None)
+        rew = view(ptrs[2], (E, A, 1), "<f4", None)
+        done = view(ptrs[3], (E, A, 1), "|u1", None)
+        info = view(ptrs[4], (E, 4), "<i4", None)
+        return act, obs, rew, done, info
+
+    def step_device(self, d_actions_ptr=None):
+        """Asynchronous step on device-resident actions; results stay in the device buffers."""
+        self.lib.check(self.lib.ac_step_async_device(self._h, d_actions_ptr), "ac_step_async_device")
+
+    def sync(self):
+        self.lib.check(self.lib.ac_sync(self._h), "ac_sync")
+
+    # ---- test / render access (mirrors env.agents[uid] reads and env.agents[uid].crash())
+    def get_state(self, env, agent):
+        out = (C.c_double * AC_STATE_LEN)()
+        self.lib.check(self.lib.ac_get_state(self._h, env, agent, out), "ac_get_state")
+        return np.array(out[:], dtype=np.float64)
+
+    def set_state(self, env, agent, vec):
+        buf = (C.c_double * AC_STATE_LEN)(*[float(v) for v in vec])
+        self.lib.check(self.lib.ac_set_state(self._h, env, agent, buf), "ac_set_state")
+
+    def set_status(self, env, agent, status):
+        self.lib.check(self.lib.ac_set_status(self._h, env, agent, status), "ac_set_status")
+
+    def get_entity(self, env, agent):
+        out = (C.c_double * 12)()
+        self.lib.check(self.lib.ac_get_entity(self._h, env, agent, out), "ac_get_entity")
+        return np.array(out[:], dtype=np.float64)
+
+    def get_missile(self, env, agent, k):
+        out = (C.c_double * 12)()
+        self.lib.check(self.lib.ac_get_missile(self._h, env, agent, k, out), "ac_get_missile")
+        return np.array(out[:], dtype=np.float64)
+
+
+def make_env(scenario=None, num_envs=1, task=None, device_id=0, seed=0):
+    """``scenario``: path of a scenario YAML (reference format) or None for the 1v1 block of WVR_selfplay.yaml."""
+    cfg = config_from_yaml(scenario, task=task) if scenario else default_config(task or "singlecombat")
+    return HipVecEnv(cfg, num_envs, device_id=device_id, seed=seed)

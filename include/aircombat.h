@@ -1,0 +1,117 @@
+/* aircombat.h — C ABI of the MI355X-native vectorised air-combat step().
+ *
+ * Drop-in boundary for the reference's VecEnv hot path. Each entry point names the reference interface it
+ * replaces ("R/" = junghoseong/aircombat-selfplay). Plain pointers and sizes only; the caller owns every buffer.
+ * All functions return 0 on success or a negative error code; ac_last_error() gives the message.
+ * Blocking unless the name says _async. One handle drives one GPU; handles are not thread-safe.
+ *
+ * Array conventions (E = n_envs, A = n_agents, row-major, agents ordered ego team first then enemy team,
+ * exactly like BaseEnv._pack, R/envs/JSBSim/envs/env_base.py:269-283):
+ *   actions  float32 [E][A][act_dim]   integer-valued indices, as the runners hand them over
+ *   obs      float32 [E][A][obs_dim]
+ *   rewards  float32 [E][A]
+ *   dones    uint8   [E][A]
+ *   info     int32   [E][4] = {current_step, done_code, heading_turn_counts, episode_was_reset}
+ */
+#ifndef AIRCOMBAT_H
+#define AIRCOMBAT_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AC_MAX_AGENTS 8
+#define AC_MAX_MISSILES_PER_AGENT 4
+
+/* task semantics, R/envs/JSBSim/tasks/ */
+enum {
+  AC_TASK_HEADING = 0,        /* heading_task.py HeadingTask (oracle-only this round; ac_create refuses it) */
+  AC_TASK_SINGLECOMBAT = 1,   /* singlecombat_task.py:16-207 SingleCombatTask: obs 15, act [41,41,41,30] */
+  AC_TASK_DODGE_MISSILE = 2,  /* singlecombat_with_missile_task.py:12-124 rule-based launch: obs 21, act 4 */
+  AC_TASK_SHOOT_MISSILE = 3   /* singlecombat_with_missile_task.py:147-204 learned shoot bit: obs 21, act 5 */
+};
+/* AircraftSimulator status, R/envs/JSBSim/core/simulatior.py:93-95 */
+enum { AC_ALIVE = 0, AC_CRASH = 1, AC_SHOTDOWN = 2 };
+/* which termination condition fired (info['done_condition'] of R/envs/JSBSim/termination_conditions/) */
+enum { AC_DONE_NONE = 0, AC_DONE_LOW_ALTITUDE = 1, AC_DONE_EXTREME_STATE = 2, AC_DONE_OVERLOAD = 3, AC_DONE_SHOTDOWN = 4,
+       AC_DONE_CRASHED = 5, AC_DONE_MISSION_COMPLETE = 6, AC_DONE_TIMEOUT = 7, AC_DONE_UNREACH_HEADING = 8 };
+
+/* init_state block of a scenario YAML (R/envs/JSBSim/configs/, keys ic_*), defaults of simulatior.py:192-208 */
+typedef struct ac_init_state {
+  double lon_deg, lat_geod_deg, h_sl_ft, psi_deg, u_fps, v_fps, w_fps, p_rad_sec, q_rad_sec, r_rad_sec;
+} ac_init_state_t;
+
+/* Scalars of one scenario YAML as parsed by parse_config (R/envs/JSBSim/utils/utils.py:7-23) */
+typedef struct ac_config {
+  int32_t task;
+  int32_t n_agents;                 /* aircraft per env */
+  int32_t n_ego;                    /* first n_ego aircraft are team A */
+  int32_t sim_freq;                 /* 60 */
+  int32_t agent_interaction_steps;  /* 6 */
+  int32_t max_steps;
+  double center_lon, center_lat, center_alt;   /* battle_field_center */
+  double altitude_limit;            /* m, LowAltitude */
+  double acc_limit_x, acc_limit_y, acc_limit_z;
+  ac_init_state_t init[AC_MAX_AGENTS];
+  int32_t num_missiles[AC_MAX_AGENTS];
+  double posture_scale;  int32_t posture_potential;
+  double altitude_scale; int32_t altitude_potential;
+  double event_scale;    int32_t event_potential;
+  double missile_posture_scale;
+  double shoot_penalty_scale; int32_t shoot_penalty_potential;
+  double alt_safe, alt_danger, alt_kv;
+  double max_attack_angle, max_attack_distance; int32_t min_attack_interval;
+  int32_t use_artillery;
+} ac_config_t;
+
+typedef struct ac_env ac_env_t;
+
+/* Number of doubles in the per-aircraft state vector of ac_get_state / ac_set_state, and the field names. */
+#define AC_STATE_LEN 80
+const char* ac_state_field_name(int i);
+
+/* replaces SubprocVecEnv.__init__ (R/envs/env_wrappers.py:231-267): builds E envs on one GPU, runs every
+ * aircraft's initial-condition pass (AircraftSimulator.reload, simulatior.py:152-190) on the device */
+int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_t seed, ac_env_t** out);
+/* replaces SubprocVecEnv.close (env_wrappers.py:300-310) */
+int ac_destroy(ac_env_t* h);
+int ac_obs_dim(const ac_env_t* h);
+int ac_act_dim(const ac_env_t* h);
+int ac_num_envs(const ac_env_t* h);
+int ac_num_agents(const ac_env_t* h);
+
+/* replaces SubprocVecEnv.reset (env_wrappers.py:284-290) -> obs[E][A][obs_dim] into a HOST buffer */
+int ac_reset(ac_env_t* h, float* obs);
+/* replaces SubprocVecEnv.step = step_async + step_wait (env_wrappers.py:269-282) with HOST buffers.
+ * Envs whose agents are all done are reset inside the call and return the reset observation with the
+ * terminal reward/done, like worker() does (env_wrappers.py:191-204). */
+int ac_step(ac_env_t* h, const float* actions, float* obs, float* rewards, uint8_t* dones, int32_t* info);
+
+/* Device-resident variant of the same step: d_actions is a DEVICE pointer (or NULL to use the
+ * handle's own action buffer); results stay in the handle's device buffers; asynchronous on the handle's stream. */
+int ac_step_async_device(ac_env_t* h, const float* d_actions);
+int ac_device_buffers(ac_env_t* h, float** d_actions, float** d_obs, float** d_rewards, uint8_t** d_dones, int32_t** d_info);
+void* ac_stream(ac_env_t* h);   /* hipStream_t the kernels are launched on */
+int ac_sync(ac_env_t* h);
+
+/* test/render access, mirrors env.agents[uid] property reads and env.agents[uid].crash() (R/tests/test_jsbsim.py:147-186) */
+int ac_get_state(ac_env_t* h, int32_t env, int32_t agent, double* out /* [AC_STATE_LEN] */);
+int ac_set_state(ac_env_t* h, int32_t env, int32_t agent, const double* in /* [AC_STATE_LEN] */);
+int ac_set_status(ac_env_t* h, int32_t env, int32_t agent, int32_t status);
+/* lon deg, lat deg, alt m, roll, pitch, yaw rad, vN, vE, vDown m/s, N, E, U m  (BaseSimulator getters, simulatior.py:47-61) */
+int ac_get_entity(ac_env_t* h, int32_t env, int32_t agent, double out[12]);
+/* missile k of an agent: status, N,E,U, vN,vE,vU, theta, psi, t, mass (MissileSimulator, simulatior.py:393-608) */
+int ac_get_missile(ac_env_t* h, int32_t env, int32_t agent, int32_t k, double out[12]);
+
+/* timing helper for the bench: average device milliseconds per step kernel over the last n ac_step* calls, measured
+ * with HIP events on the handle's stream */
+int ac_timing_begin(ac_env_t* h);
+int ac_timing_end(ac_env_t* h, float* total_ms);
+
+const char* ac_last_error(void);
+const char* ac_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -211,6 +211,7 @@ static void aircraft_run(const OrEnv* e, OrAircraft* a) { /* simulatior.py:210-2
   f16_tick(&a->fdm, 1.0 / e->cfg.sim_freq);
   update_properties(e, a);
 }
+void or_env_refresh_cache(OrEnv* e, int i) { update_properties(e, &e->ac[i]); }
 static int extreme_state(const OrAircraft* a) { /* catalog.py:386-416 */
   const F16State* s = &a->fdm;
   int ev = norm3(s->v_eci) >= 1e10;

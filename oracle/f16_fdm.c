@@ -732,6 +732,14 @@ void f16_tick(F16State* s, double dt) {
   accelerations_run(s);
 }
 
+void f16_refresh_derived(F16State* s) {
+  s->sim_time = (double)s->ticks / 60.0;
+  s->epa = OMEGA_E * s->sim_time;
+  propagate_derived(s);
+  massbalance_run(s); /* first call rebuilds the CG from the tanks, second the inertia about it */
+  massbalance_run(s);
+}
+
 void f16_set_controls(F16State* s, double ail, double ele, double rud, double thr) {
   /* catalog.py:189-197 bounds applied by simulatior.py:307-311 */
   s->da_cmd = clampd(-1.0, ail, 1.0);

@@ -81,6 +81,9 @@ void f16_reset(F16State* s, const F16Init* ic);     /* simulatior.py:152-190 */
 void f16_set_controls(F16State* s, double aileron, double elevator, double rudder, double throttle); /* simulatior.py:299-319 + catalog.py bounds */
 void f16_tick(F16State* s, double dt);              /* FGFDMExec::Run, FGFDMExec.cpp:407-431; dt = 0 => integration suspended */
 
+/* after overwriting the integrator state by hand (tests): rebuild every derived quantity the next tick reads */
+void f16_refresh_derived(F16State* s);
+
 /* table helpers exposed for unit tests */
 double f16_tab1(int off, int nr, double key);
 double f16_tab2(int off, int nr, int nc, double rkey, double ckey);
