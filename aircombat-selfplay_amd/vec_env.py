@@ -152,16 +152,16 @@ class HipVecEnv:
         self.lib.check(self.lib.ac_device_buffers(self._h, *[C.byref(p) for p in ptrs]), "ac_device_buffers")
         E, A = self.num_envs, self.num_agents
 
-        def view(ptr, shape, typestr, dtype):
-            holder = type("_Buf", (), {})()
+        def view(ptr, shape, typestr):
+            holder = type("_DeviceBuffer", (), {})()
             holder.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr.value, False), "version": 2}
-            return torch.as_tensor(holder, device="cuda").view(dtype) if False else torch.as_tensor(holder, device="cuda")
+            return torch.as_tensor(holder, device="cuda")
 
-        act = view(ptrs[0], (E, A, self.act_dim), "<f4", None)
-        obs = view(ptrs[1], (E, A, self.obs_dim), "<f4", None)
-        rew = view(ptrs[2], (E, A, 1), "<f4", None)
-        done = view(ptrs[3], (E, A, 1), "|u1", None)
-        info = view(ptrs[4], (E, 4), "<i4", None)
+        act = view(ptrs[0], (E, A, self.act_dim), "<f4")
+        obs = view(ptrs[1], (E, A, self.obs_dim), "<f4")
+        rew = view(ptrs[2], (E, A, 1), "<f4")
+        done = view(ptrs[3], (E, A, 1), "|u1")
+        info = view(ptrs[4], (E, 4), "<i4")
         return act, obs, rew, done, info
 
     def step_device(self, d_actions_ptr=None):

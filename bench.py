@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py — agent-steps/sec of the vectorised air-combat step() on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 the driver launches it with
+``python -m torch.distributed.run --nproc-per-node N``: one rank per GPU, weak scaling (every rank owns its own
+contiguous block of 4096 envs, no collective in the env path — envs are independent). Rank 0 prints ONE JSON line.
+
+Workload at every N: BASELINE.json configs[1] — SingleCombat 1v1 self-play, no weapons, 4096 envs per GPU, uniform random
+integer actions regenerated every step (worst case for FCS activity), auto-reset on. A "step" is one pass of the hot path
+over the whole batch: 6 FDM ticks per aircraft + observation/reward/termination, one kernel launch.
+``value`` is measured with the actions already resident in HBM and the outputs left in HBM (SURVEY N2 path); the
+host-boundary (PCIe + ctypes + numpy) rate of the strict drop-in ``step()`` is reported beside it as ``host_boundary``.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+AGENTS = 2
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+BYTES_PER_AGENT_STEP = 593.0    # SURVEY §8(d) / BASELINE.md §3, config C2: 512 state + 16 action + 60 obs + 4 reward + 1 done
+
+
+def cpu_baseline(cfg, seconds_target=12.0):
+    """The CPU port (oracle) timed on this box's host cores, rank 0 at N=1 only: a bounded sample of the same workload."""
+    from oracle import oracle as O
+    ocfg = O.config_from_ac(cfg)
+    n0, s0, _ = O.bench_run(ocfg, 256, 20)                 # calibrate
+    rate = n0 / s0
+    steps = max(10, int(seconds_target * rate / (ENVS_PER_GPU * AGENTS)))
+    n, s, eps = O.bench_run(ocfg, ENVS_PER_GPU, steps)
+    return {"value": n / s, "unit": "agent-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{ENVS_PER_GPU} envs x {AGENTS} aircraft x {steps} env steps, random actions, auto-reset, "
+                      f"{s:.1f} s on 1 of {os.cpu_count()} host cores (oracle/: f64 C restatement of the JSBSim+Python path; "
+                      f"the reference's own SubprocVecEnv+jsbsim wheel cannot run here)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU (default: the BASELINE config)")
+    ap.add_argument("--task", default="singlecombat")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import aircombat_selfplay_amd as pkg
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL; used only for the timing barrier / max
+    else:
+        torch.cuda.set_device(local_rank)
+
+    E = args.envs
+    cfg = pkg.default_config(args.task)
+    env = pkg.HipVecEnv(cfg, E, device_id=local_rank, seed=1 + 1000 * rank)
+    env.reset()
+    act_dim = env.act_dim
+
+    # ---- synthetic inputs, resident in HBM before the timed region: a pool of random action batches
+    rng = np.random.default_rng(20250321 + rank)
+    POOL = 64
+    pool = []
+    for _ in range(POOL):
+        a = np.stack([rng.integers(0, n, size=(E, AGENTS)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
+        if act_dim == 5:
+            a = np.concatenate([a, (rng.random((E, AGENTS, 1)) < 0.05).astype(np.float32)], axis=-1)
+        pool.append(torch.from_numpy(a).cuda(local_rank))
+    ptrs = [t.data_ptr() for t in pool]
+    torch.cuda.synchronize()
+
+    def run(k, offset=0):
+        for i in range(k):
+            env.step_device(ptrs[(offset + i) % POOL])
+
+    run(args.warmup)
+    env.sync()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    env.lib.ac_timing_begin(env._h)
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    env.sync()
+    t1 = time.perf_counter()
+    import ctypes as C
+    ev_ms = C.c_float()
+    env.lib.check(env.lib.ac_timing_end(env._h, C.byref(ev_ms)), "ac_timing_end")
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = t1 - t0
+    kernel_ms = ev_ms.value / args.steps          # HIP events on the launch stream, average per launch
+    if dist is not None:
+        tt = torch.tensor([elapsed, kernel_ms], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(tt[0]), float(tt[1])
+
+    # sanity: the episode machinery really ran (steps counted, resets happened)
+    _, _, _, _, info = env.device_tensors()
+    info_h = info.cpu().numpy()
+
+    result = None
+    if rank == 0:
+        agent_steps = float(world) * E * AGENTS * args.steps
+        value = agent_steps / elapsed
+        algo_bytes = BYTES_PER_AGENT_STEP * E * AGENTS            # per launch, one GPU
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        result = {
+            "metric": "agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SingleCombat 1v1 self-play (no weapons), BASELINE configs[1]", "task": args.task,
+                       "envs_per_gpu": E, "aircraft_per_env": AGENTS, "fdm_ticks_per_step": 6,
+                       "actions": "uniform random MultiDiscrete[41,41,41,30], new batch every step, device-resident",
+                       "auto_reset": True, "parallelism": f"env-block x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "step_kernel_1v1", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes},
+            "episode_check": {"max_current_step": int(info_h[:, 0].max()), "envs_reset_last_step": int(info_h[:, 3].sum())},
+        }
+
+    # ---- the strict drop-in boundary (host numpy in/out, PCIe inclusive) for DESIGN.md; never the headline value
+    if world == 1:
+        a_host = [p.cpu().numpy() for p in pool[:8]]
+        for i in range(20):
+            env.step(a_host[i % 8])
+        t0 = time.perf_counter()
+        HB = 200
+        for i in range(HB):
+            env.step(a_host[i % 8])
+        hb = time.perf_counter() - t0
+        result["host_boundary"] = {"value": E * AGENTS * HB / hb, "unit": "agent-steps/s", "ms_per_step": hb / HB * 1e3,
+                                   "note": "VecEnv.step(numpy) incl. H2D actions, kernel, D2H obs/reward/done, info dicts"}
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg)
+    env.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

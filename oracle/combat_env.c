@@ -88,11 +88,13 @@ void or_get_AO_TA_R(const double ego[6], const double enm[6], int two_d, double 
 }
 
 /* posture_reward.py:58-75, versions v2 / v3 (the only ones the YAMLs select) */
-double or_posture_reward(double AO, double TA, double R) {
-  double orn = 1 / (50 * AO / M_PI + 2) + 1.0 / 2 + fmin(atanh(1. - fmax(2 * TA / M_PI, 1e-4)) / (2 * M_PI), 0.) + 0.5;
-  double rng = 1 * (R < 5) + (R >= 5) * clampd(0, -0.032 * R * R + 0.284 * R + 0.38, 1) + clampd(0, exp(-0.16 * R), 0.2);
-  return orn * rng;
+double or_posture_orientation(double AO, double TA) {
+  return 1 / (50 * AO / M_PI + 2) + 1.0 / 2 + fmin(atanh(1. - fmax(2 * TA / M_PI, 1e-4)) / (2 * M_PI), 0.) + 0.5;
 }
+double or_posture_range(double R) {
+  return 1 * (R < 5) + (R >= 5) * clampd(0, -0.032 * R * R + 0.284 * R + 0.38, 1) + clampd(0, exp(-0.16 * R), 0.2);
+}
+double or_posture_reward(double AO, double TA, double R) { return or_posture_orientation(AO, TA) * or_posture_range(R); }
 /* altitude_reward.py:20-40 */
 double or_altitude_reward(double z, double vz, double safe, double danger, double kv) {
   double Pv = 0., PH = 0.;
@@ -533,7 +535,13 @@ void or_env_reset(OrEnv* e, double* obs) {
   } else {
     for (int i = 0; i < c->n_aircraft; i++) aircraft_reload(e, &e->ac[i], &c->init[i], c->num_missiles[i]);
   }
-  /* task.reset */
+  or_env_task_reset(e);
+  get_obs(e, obs);
+}
+
+/* task.reset(env): bookkeeping + reward-function resets (task_base.py:54-62 and the task subclasses) */
+void or_env_task_reset(OrEnv* e) {
+  const OrEnvConfig* c = &e->cfg;
   for (int i = 0; i < c->n_aircraft; i++) {
     OrAircraft* a = &e->ac[i];
     a->die_flag = 0;
@@ -545,7 +553,6 @@ void or_env_reset(OrEnv* e, double* obs) {
     a->last_missile = -1;
   }
   reward_reset(e);
-  get_obs(e, obs);
 }
 
 static void decode_action(const OrEnv* e, int i, const double* act, double out[4]) {
@@ -561,7 +568,6 @@ static void decode_action(const OrEnv* e, int i, const double* act, double out[4
 void or_env_step(OrEnv* e, const double* actions, double* obs, double* rew, uint8_t* done, int32_t* info) {
   const OrEnvConfig* c = &e->cfg;
   e->current_step += 1;
-  int code = OR_DONE_NONE;
   for (int i = 0; i < c->n_aircraft; i++) {
     const double* act = actions + i * e->act_dim;
     double u[4];
@@ -581,6 +587,13 @@ void or_env_step(OrEnv* e, const double* actions, double* obs, double* rew, uint
     }
   }
   task_step(e);
+  or_env_evaluate(e, obs, rew, done, info);
+}
+
+/* tail of BaseEnv.step (env_base.py:157-173): observations, then terminations for every agent, then rewards */
+void or_env_evaluate(OrEnv* e, double* obs, double* rew, uint8_t* done, int32_t* info) {
+  const OrEnvConfig* c = &e->cfg;
+  int code = OR_DONE_NONE;
   get_obs(e, obs);
   for (int i = 0; i < c->n_aircraft; i++) done[i] = (uint8_t)get_termination(e, i, &code);
   for (int i = 0; i < c->n_aircraft; i++) rew[i] = get_reward(e, i);

@@ -113,7 +113,13 @@ void or_env_reset(OrEnv* e, double* obs /* [n_aircraft][obs_dim] */);
 void or_env_step(OrEnv* e, const double* actions /* [n_aircraft][act_dim] */, double* obs, double* rew, uint8_t* done,
                  int32_t* info /* [4]: current_step, done_code, heading_turn_counts, all_done */);
 
+void or_env_task_reset(OrEnv* e);
+void or_env_refresh_cache(OrEnv* e, int i);   /* AircraftSimulator._update_properties from the current FDM outputs */
+void or_env_evaluate(OrEnv* e, double* obs, double* rew, uint8_t* done, int32_t* info);
+
 /* exposed pieces for golden-vector tests */
+double or_posture_orientation(double AO, double TA);
+double or_posture_range(double R_km);
 void or_get_AO_TA_R(const double ego[6], const double enm[6], int two_d, double out[4]);
 double or_posture_reward(double AO, double TA, double R_km);
 double or_altitude_reward(double ego_z_km, double ego_vz_mh, double safe, double danger, double kv);

@@ -94,6 +94,22 @@ def lib():
         L.f16_vcas_from_mach.restype = C.c_double
         L.f16_kinemat.argtypes = [C.c_double, C.c_double, dp, dp, C.c_int, C.c_double]
         L.f16_kinemat.restype = C.c_double
+        L.or_posture_orientation.argtypes = [C.c_double] * 2
+        L.or_posture_orientation.restype = C.c_double
+        L.or_posture_range.argtypes = [C.c_double]
+        L.or_posture_range.restype = C.c_double
+        L.or_env_task_reset.argtypes = [C.c_void_p]
+        L.or_env_evaluate.argtypes = [C.c_void_p] * 5
+        L.or_env_set_pose.argtypes = [C.c_void_p, C.c_int, dp]
+        L.or_env_set_step.argtypes = [C.c_void_p, C.c_int]
+        L.or_env_add_missile.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dp, dp]
+        L.or_env_clear_missiles.argtypes = [C.c_void_p]
+        L.or_env_heading_targets.argtypes = [C.c_void_p] + [C.c_double] * 4
+        L.or_env_heading_pose.argtypes = [C.c_void_p] + [C.c_double] * 11
+        L.or_env_heading_get.argtypes = [C.c_void_p, dp]
+        L.or_missile_raw_run.argtypes = [dp, C.c_int, dp, dp, C.c_int]
+        L.or_bench_run.argtypes = [C.POINTER(OrEnvConfig), C.c_int, C.c_int, C.c_uint64, dp, C.POINTER(C.c_long)]
+        L.or_bench_run.restype = C.c_long
         assert L.or_env_config_sizeof() == C.sizeof(OrEnvConfig), "OrEnvConfig layout mismatch"
         _lib = L
     return _lib
@@ -159,6 +175,27 @@ class OracleEnv:
         self.L.or_env_step(self.p, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, done.ctypes.data, info.ctypes.data)
         return obs, rew, done.astype(bool), info
 
+    def task_reset(self):
+        self.L.or_env_task_reset(self.p)
+
+    def evaluate(self):
+        obs = np.zeros((self.A, self.obs_dim))
+        rew = np.zeros(self.A)
+        done = np.zeros(self.A, dtype=np.uint8)
+        info = np.zeros(4, dtype=np.int32)
+        self.L.or_env_evaluate(self.p, obs.ctypes.data, rew.ctypes.data, done.ctypes.data, info.ctypes.data)
+        return obs, rew, done.astype(bool), info
+
+    def set_pose(self, i, pose):
+        buf = (C.c_double * 20)(*[float(v) for v in pose])
+        self.L.or_env_set_pose(self.p, i, buf)
+
+    def set_step(self, k):
+        self.L.or_env_set_step(self.p, int(k))
+
+    def add_missile(self, parent, target, model, pos, vel):
+        return self.L.or_env_add_missile(self.p, parent, target, model, (C.c_double * 3)(*pos), (C.c_double * 3)(*vel))
+
     def export_state(self, i):
         out = (C.c_double * STATE_LEN)()
         self.L.or_state_export(self.p, i, out, STATE_LEN)
@@ -212,3 +249,11 @@ class OracleVecEnv:
                 o = e.reset()
             obs.append(o); rew.append(r); done.append(d); info.append(i)
         return np.stack(obs), np.stack(rew)[..., None], np.stack(done)[..., None], np.stack(info)
+
+
+def bench_run(cfg, n_envs, steps, seed=20250321):
+    """Time the CPU restatement: returns (agent_steps, seconds, episodes). Single thread."""
+    sec = C.c_double()
+    eps = C.c_long()
+    n = lib().or_bench_run(C.byref(cfg), n_envs, steps, seed, C.byref(sec), C.byref(eps))
+    return n, sec.value, eps.value

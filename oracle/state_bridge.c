@@ -81,7 +81,6 @@ int or_state_import(OrEnv* e, int i, const double* v) {
   a->lock_pos = (int)llround(v[k++]); e->current_step = (int)llround(v[k++]);
   f16_refresh_derived(s);
   /* refresh the wrapper's cached pose (simulatior.py:238-258) */
-  extern void or_env_refresh_cache(OrEnv * e, int i);
   or_env_refresh_cache(e, i);
   return k;
 }
@@ -106,3 +105,67 @@ void or_env_set_status(OrEnv* e, int i, int status) { e->ac[i].status = status; 
 double or_env_bloods(const OrEnv* e, int i) { return e->ac[i].bloods; }
 void or_env_set_bloods(OrEnv* e, int i, double b) { e->ac[i].bloods = b; }
 const F16State* or_env_fdm(const OrEnv* e, int i) { return &e->ac[i].fdm; }
+
+/* ---- golden-vector hooks: put an aircraft in a synthetic pose (what FakeAircraft.set_pose of tests/golden/make_golden.py
+ * gives the reference code) without running the FDM. pose = lon, lat, alt_m, roll, pitch, yaw, vN, vE, vDown [m/s],
+ * u, v, w [m/s], vc [m/s], npilot x y z, sim_time, status, bloods, extreme_flag */
+void or_env_set_pose(OrEnv* e, int i, const double* p) {
+  OrAircraft* a = &e->ac[i];
+  F16State* s = &a->fdm;
+  const double M2FT = 1.0 / 0.3048, D2R = M_PI / 180.0;
+  s->lon = p[0] * D2R; s->lat_geod = p[1] * D2R; s->h_sl = p[2] * M2FT;
+  s->phi = p[3]; s->tht = p[4]; s->psi = p[5];
+  s->vel_ned[0] = p[6] * M2FT; s->vel_ned[1] = p[7] * M2FT; s->vel_ned[2] = p[8] * M2FT;
+  s->uvw[0] = p[9] * M2FT; s->uvw[1] = p[10] * M2FT; s->uvw[2] = p[11] * M2FT;
+  s->vc_fps = p[12] * M2FT;
+  s->npilot[0] = p[13]; s->npilot[1] = p[14]; s->npilot[2] = p[15];
+  s->sim_time = p[16];
+  a->status = (int)p[17]; a->bloods = p[18];
+  if (p[19] != 0.0) s->npilot[0] = 11.0; /* stands for detect/extreme-state = 1 supplied directly to the reference */
+  s->pqr[0] = s->pqr[1] = s->pqr[2] = 0; s->v_eci[0] = 300; s->v_eci[1] = s->v_eci[2] = 0;
+  or_env_refresh_cache(e, i);
+}
+void or_env_set_step(OrEnv* e, int step) { e->current_step = step; }
+int or_env_add_missile(OrEnv* e, int parent, int target, int model, const double pos[3], const double vel[3]) {
+  if (e->n_msl >= OR_MAX_MSL) return -1;
+  OrMissile* m = &e->msl[e->n_msl];
+  or_missile_init(m, model, 1.0 / e->cfg.sim_freq);
+  or_missile_launch(m, e->ac[parent].geodetic, e->ac[parent].position, e->ac[parent].velocity, e->ac[parent].posture);
+  m->parent = parent; m->target = target;
+  for (int k = 0; k < 3; k++) { m->position[k] = pos[k]; m->velocity[k] = vel[k]; }
+  return e->n_msl++;
+}
+void or_env_clear_missiles(OrEnv* e) { e->n_msl = 0; }
+/* heading-task injection: targets and the quantities HeadingTask / HeadingReward / UnreachHeading read */
+void or_env_heading_targets(OrEnv* e, double hdg_deg, double alt_ft, double u_mps, double check_time) {
+  e->ac[0].target_heading_deg = hdg_deg; e->ac[0].target_altitude_ft = alt_ft; e->ac[0].target_velocities_u_mps = u_mps;
+  e->ac[0].heading_check_time = check_time; e->heading_turn_counts = 0;
+}
+void or_env_heading_pose(OrEnv* e, double psi_deg, double h_ft, double u_mps, double roll, double pitch, double v_mps, double w_mps,
+                         double vc_mps, double p, double q, double sim_time) {
+  F16State* s = &e->ac[0].fdm;
+  const double M2FT = 1.0 / 0.3048;
+  s->psi = psi_deg * M_PI / 180.0; s->h_sl = h_ft; s->uvw[0] = u_mps * M2FT; s->uvw[1] = v_mps * M2FT; s->uvw[2] = w_mps * M2FT;
+  s->phi = roll; s->tht = pitch; s->vc_fps = vc_mps * M2FT; s->pqr[0] = p; s->pqr[1] = q; s->pqr[2] = 0; s->sim_time = sim_time;
+  s->npilot[0] = s->npilot[1] = 0; s->npilot[2] = -1; s->v_eci[0] = 300; s->v_eci[1] = s->v_eci[2] = 0;
+  s->lon = 120.0 * M_PI / 180.0; s->lat_geod = 60.0 * M_PI / 180.0; s->vel_ned[0] = s->vel_ned[1] = s->vel_ned[2] = 0;
+  or_env_refresh_cache(e, 0);
+}
+void or_env_heading_get(const OrEnv* e, double out[5]) {
+  out[0] = e->ac[0].target_heading_deg; out[1] = e->ac[0].target_altitude_ft; out[2] = e->ac[0].target_velocities_u_mps;
+  out[3] = e->ac[0].heading_check_time; out[4] = e->heading_turn_counts;
+}
+void or_missile_raw_run(double* st /* [20] */, int model, const double tp[3], const double tv[3], int alive) {
+  /* flat missile state for the fly-out golden test: status, pos3, vel3, theta, psi, t, m, dtheta, dphi, dist_prev, recede_count, alt */
+  OrMissile m;
+  or_missile_init(&m, model, 1.0 / 60.0);
+  m.status = (int)st[0];
+  for (int k = 0; k < 3; k++) { m.position[k] = st[1 + k]; m.velocity[k] = st[4 + k]; }
+  m.posture[1] = st[7]; m.posture[2] = st[8]; m.t = st[9]; m.m = st[10]; m.dtheta = st[11]; m.dphi = st[12]; m.dist_prev = st[13];
+  m.recede_count = (int)st[14]; m.geodetic[2] = st[15];
+  or_missile_run(&m, tp, tv, alive, 1.0 / 60.0, 120.0, 60.0, 0.0);
+  st[0] = m.status;
+  for (int k = 0; k < 3; k++) { st[1 + k] = m.position[k]; st[4 + k] = m.velocity[k]; }
+  st[7] = m.posture[1]; st[8] = m.posture[2]; st[9] = m.t; st[10] = m.m; st[11] = m.dtheta; st[12] = m.dphi; st[13] = m.dist_prev;
+  st[14] = m.recede_count; st[15] = m.geodetic[2];
+}

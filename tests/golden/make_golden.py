@@ -1,0 +1,510 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REFERENCE's own Python (runs only in the build container, where /root/reference exists).
+
+The reference's pure-Python part of the step() path (geometry, rewards, terminations, missile engine, observation builders)
+is imported from /root/reference and driven with duck-typed fake aircraft; inputs and the reference's outputs are written to
+tests/golden/*.npz. The FDM (third-party ``jsbsim`` wheel) is not importable here, so nothing FDM-related is pinned.
+
+Absent third-party modules are replaced by empty in-process stand-ins so that the imports resolve:
+  jsbsim, colorama, wandb  – never called by the code exercised here
+  gymnasium                – only ``spaces.Box/MultiDiscrete/Discrete/Tuple`` containers and ``seeding.np_random``
+  pymap3d                  – ``geodetic2ned`` / ``ned2geodetic`` are supplied by the WGS84 closed forms below (our own
+                             restatement of pymap3d's published algorithm; the missile fixtures therefore pin everything
+                             except that geodesy call, which stays "parity unpinned")
+Only data (inputs / expected outputs) is stored; no reference source text.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = os.environ.get("AC_REFERENCE_ROOT", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# ----------------------------------------------------------------------------------------------- stand-ins
+def _geodetic2ecef(lat, lon, alt):
+    a, f = 6378137.0, 1 / 298.257223563
+    b = a * (1 - f)
+    lat, lon = np.radians(lat), np.radians(lon)
+    N = a ** 2 / np.hypot(a * np.cos(lat), b * np.sin(lat))
+    return (N + alt) * np.cos(lat) * np.cos(lon), (N + alt) * np.cos(lat) * np.sin(lon), (N * (b / a) ** 2 + alt) * np.sin(lat)
+
+
+def _ecef2geodetic(x, y, z):
+    a, f = 6378137.0, 1 / 298.257223563
+    b = a * (1 - f)
+    r = np.sqrt(x * x + y * y + z * z)
+    E = np.sqrt(a * a - b * b)
+    u = np.sqrt(0.5 * (r * r - E * E) + 0.5 * np.hypot(r * r - E * E, 2 * E * z))
+    hxy = np.hypot(x, y)
+    huE = np.hypot(u, E)
+    Beta = np.arctan(huE / u * z / hxy)
+    dBeta = ((b * u - a * huE + E * E) * np.sin(Beta)) / (a * huE / np.cos(Beta) - E * E * np.cos(Beta))
+    Beta += dBeta
+    lat = np.arctan(a / b * np.tan(Beta))
+    lon = np.arctan2(y, x)
+    alt = np.hypot(z - b * np.sin(Beta), hxy - a * np.cos(Beta))
+    if x * x / a ** 2 + y * y / a ** 2 + z * z / b ** 2 < 1:
+        alt = -alt
+    return np.degrees(lat), np.degrees(lon), alt
+
+
+def geodetic2ned(lat, lon, h, lat0, lon0, h0):
+    x, y, z = _geodetic2ecef(lat, lon, h)
+    x0, y0, z0 = _geodetic2ecef(lat0, lon0, h0)
+    dx, dy, dz = x - x0, y - y0, z - z0
+    la, lo = np.radians(lat0), np.radians(lon0)
+    t = np.cos(lo) * dx + np.sin(lo) * dy
+    e = -np.sin(lo) * dx + np.cos(lo) * dy
+    u = np.cos(la) * t + np.sin(la) * dz
+    n = -np.sin(la) * t + np.cos(la) * dz
+    return n, e, -u
+
+
+def ned2geodetic(n, e, d, lat0, lon0, h0):
+    x0, y0, z0 = _geodetic2ecef(lat0, lon0, h0)
+    la, lo = np.radians(lat0), np.radians(lon0)
+    u = -d
+    t = np.cos(la) * u - np.sin(la) * n
+    dz = np.sin(la) * u + np.cos(la) * n
+    dx = np.cos(lo) * t - np.sin(lo) * e
+    dy = np.sin(lo) * t + np.cos(lo) * e
+    return _ecef2geodetic(x0 + dx, y0 + dy, z0 + dz)
+
+
+def install_standins():
+    for name in ("jsbsim", "colorama", "wandb"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["colorama"].Fore = type("Fore", (), {"LIGHTRED_EX": "", "LIGHTGREEN_EX": "", "LIGHTYELLOW_EX": ""})
+    sys.modules["wandb"].agent = None
+    pm = types.ModuleType("pymap3d")
+    pm.geodetic2ned, pm.ned2geodetic = geodetic2ned, ned2geodetic
+    sys.modules["pymap3d"] = pm
+    g = types.ModuleType("gymnasium")
+    sp = types.ModuleType("gymnasium.spaces")
+    ut = types.ModuleType("gymnasium.utils")
+    sd = types.ModuleType("gymnasium.utils.seeding")
+
+    class Box:
+        def __init__(self, low=None, high=None, shape=None, dtype=None):
+            self.low, self.high, self.shape = np.full(shape, low), np.full(shape, high), shape
+
+    class Discrete:
+        def __init__(self, n):
+            self.n = n
+
+    class MultiDiscrete:
+        def __init__(self, nvec):
+            self.nvec = np.array(nvec)
+
+    class Tuple(tuple):
+        def __new__(cls, xs):
+            return tuple.__new__(cls, xs)
+
+    sp.Box, sp.Discrete, sp.MultiDiscrete, sp.Tuple, sp.Space = Box, Discrete, MultiDiscrete, Tuple, object
+    g.spaces, g.Space, g.Env = sp, object, object
+    sd.np_random = lambda seed=None: (np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed))), seed)
+    ut.seeding, g.utils = sd, ut
+    sys.modules.update({"gymnasium": g, "gymnasium.spaces": sp, "gymnasium.utils": ut, "gymnasium.utils.seeding": sd})
+    sys.path.insert(0, REF)
+
+
+# ----------------------------------------------------------------------------------------------- fakes
+class FakeAircraft:
+    """Duck-typed AircraftSimulator: the getters and flags the reference's task / reward / termination code reads."""
+    ALIVE, CRASH, SHOTDOWN = 0, 1, 2
+
+    def __init__(self, uid, color="Red", dt=1 / 60, origin=(120.0, 60.0, 0.0), num_missiles=2):
+        self.uid, self.color, self.dt = uid, color, dt
+        self.lon0, self.lat0, self.alt0 = origin
+        self.status = 0
+        self.bloods = 100
+        self.num_missiles = num_missiles
+        self.partners, self.enemies, self.launch_missiles, self.under_missiles = [], [], [], []
+        self.props = {}
+        self._geodetic, self._position, self._posture, self._velocity = np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3)
+
+    is_alive = property(lambda s: s.status == 0)
+    is_crash = property(lambda s: s.status == 1)
+    is_shotdown = property(lambda s: s.status == 2)
+
+    def crash(self):
+        self.status = 1
+
+    def shotdown(self):
+        self.status = 2
+
+    def get_geodetic(self):
+        return self._geodetic
+
+    def get_position(self):
+        return self._position
+
+    def get_rpy(self):
+        return self._posture
+
+    def get_velocity(self):
+        return self._velocity
+
+    def check_missile_warning(self):
+        for m in self.under_missiles:
+            if m.is_alive:
+                return m
+        return None
+
+    def get_property_value(self, prop):
+        return self.props[prop.name_jsbsim]
+
+    def get_property_values(self, props):
+        return [self.get_property_value(p) for p in props]
+
+    def set_property_value(self, prop, value):
+        self.props[prop.name_jsbsim] = min(max(value, prop.min), prop.max)
+
+    def set_pose(self, lon, lat, alt_m, rpy, v_ned_mps, uvw_mps=(250.0, 0.0, 0.0), vc=250.0, npilot=(0.0, 0.0, -1.0), sim_time=20.0):
+        """Everything _update_properties caches plus the catalogue values get_obs / terminations read."""
+        from envs.JSBSim.utils.utils import LLA2NEU
+        self._geodetic[:] = (lon, lat, alt_m)
+        self._position[:] = LLA2NEU(lon, lat, alt_m, self.lon0, self.lat0, self.alt0)
+        self._posture[:] = rpy
+        self._velocity[:] = v_ned_mps
+        p = self.props
+        p["position/long-gc-deg"], p["position/lat-geod-deg"], p["position/h-sl-m"] = lon, lat, alt_m
+        p["attitude/roll-rad"], p["attitude/pitch-rad"], p["attitude/heading-true-rad"] = rpy
+        p["velocities/v-north-mps"], p["velocities/v-east-mps"], p["velocities/v-down-mps"] = v_ned_mps
+        p["velocities/u-mps"], p["velocities/v-mps"], p["velocities/w-mps"] = uvw_mps
+        p["velocities/vc-mps"] = vc
+        p["accelerations/n-pilot-x-norm"], p["accelerations/n-pilot-y-norm"], p["accelerations/n-pilot-z-norm"] = npilot
+        p["simulation/sim-time-sec"] = sim_time
+        p["detect/extreme-state"] = 0
+
+
+class FakeEnv:
+    def __init__(self, agents, center=(120.0, 60.0, 0.0), max_steps=9000):
+        self.agents = {a.uid: a for a in agents}
+        self.center_lon, self.center_lat, self.center_alt = center
+        self.current_step = 0
+        self.time_interval = 0.1
+        self._tempsims = {}
+        self.ego_ids = [a.uid for a in agents if a.uid[0] == agents[0].uid[0]]
+        self.enm_ids = [a.uid for a in agents if a.uid[0] != agents[0].uid[0]]
+
+    def add_temp_simulator(self, sim):
+        self._tempsims[sim.uid] = sim
+        return sim
+
+
+def link(agents):
+    for a in agents:
+        for b in agents:
+            if a is b:
+                continue
+            (a.partners if a.uid[0] == b.uid[0] else a.enemies).append(b)
+
+
+def make_config(**kw):
+    base = dict(max_steps=9000, altitude_limit=2500, acceleration_limit_x=10.0, acceleration_limit_y=10.0, acceleration_limit_z=10.0,
+                PostureReward_scale=15.0, PostureReward_potential=True, PostureReward_orientation_version="v2",
+                PostureReward_range_version="v3", AltitudeReward_safe_altitude=4.0, AltitudeReward_danger_altitude=3.5,
+                AltitudeReward_Kv=0.2, EventDrivenReward_scale=1, EventDrivenReward_potential=True, MissilePostureReward_scale=30,
+                max_attack_angle=45, max_attack_distance=14000, min_attack_interval=25,
+                aircraft_configs={"A0100": {"color": "Blue", "missile": 2}, "B0100": {"color": "Red", "missile": 2}})
+    base.update(kw)
+    return type("EnvConfig", (object,), base)
+
+
+def random_pose(rng, ac, spread_km=30.0, alt=(2000.0, 9000.0)):
+    lon = 120.0 + rng.uniform(-1, 1) * spread_km / 55.0
+    lat = 60.0 + rng.uniform(-1, 1) * spread_km / 111.0
+    alt_m = rng.uniform(*alt)
+    rpy = (rng.uniform(-1.2, 1.2), rng.uniform(-0.6, 0.6), rng.uniform(0, 2 * np.pi))
+    sp = rng.uniform(120, 420)
+    hdg = rng.uniform(0, 2 * np.pi)
+    vd = rng.uniform(-80, 80)
+    vned = (sp * np.cos(hdg), sp * np.sin(hdg), vd)
+    uvw = (sp * rng.uniform(0.9, 1.0), rng.uniform(-15, 15), rng.uniform(-30, 40))
+    npil = (rng.uniform(-2, 2), rng.uniform(-1, 1), rng.uniform(-9, 3))
+    ac.set_pose(lon, lat, alt_m, rpy, vned, uvw, vc=rng.uniform(100, 400), npilot=npil, sim_time=rng.uniform(0, 40))
+
+
+def pose_vector(ac):
+    p = ac.props
+    return np.array([ac._geodetic[0], ac._geodetic[1], ac._geodetic[2], *ac._posture, *ac._velocity,
+                     p["velocities/u-mps"], p["velocities/v-mps"], p["velocities/w-mps"], p["velocities/vc-mps"],
+                     p["accelerations/n-pilot-x-norm"], p["accelerations/n-pilot-y-norm"], p["accelerations/n-pilot-z-norm"],
+                     p["simulation/sim-time-sec"], ac.status, ac.bloods, p["detect/extreme-state"]])
+
+
+# ----------------------------------------------------------------------------------------------- generators
+def gen_geometry(rng):
+    from envs.JSBSim.utils.utils import get_AO_TA_R, get2d_AO_TA_R, in_range_deg, in_range_rad
+    n = 1200
+    ego = rng.normal(size=(n, 6)) * np.array([20000, 20000, 3000, 250, 250, 60])
+    enm = rng.normal(size=(n, 6)) * np.array([20000, 20000, 3000, 250, 250, 60])
+    enm[:20] = ego[:20] + rng.normal(size=(20, 6)) * 1e-9      # R -> 0
+    ego[20:40, 3:] = 0.0                                           # |v_ego| = 0
+    enm[40:60, 3:] = 0.0
+    enm[60:80, :3] = ego[60:80, :3] + ego[60:80, 3:] * 40.0      # dead ahead: AO = 0
+    enm[80:100, :3] = ego[80:100, :3] - ego[80:100, 3:] * 40.0   # dead astern: AO = pi
+    with np.errstate(all="ignore"):
+        out3 = np.array([get_AO_TA_R(a, b, True) for a, b in zip(ego, enm)], dtype=float)
+        out2 = np.array([get2d_AO_TA_R(a, b, True) for a, b in zip(ego, enm)], dtype=float)
+    ang = rng.uniform(-2000, 2000, size=400)
+    np.savez_compressed(os.path.join(OUT, "geometry.npz"), ego=ego, enm=enm, out3d=out3, out2d=out2, ang=ang,
+             in_range_deg=np.array([in_range_deg(a) for a in ang]), in_range_rad=np.array([in_range_rad(a) for a in ang]))
+
+
+def gen_reward_functions(rng):
+    """PostureReward orientation/range functions and AltitudeReward on grids (pure functions of their inputs)."""
+    from envs.JSBSim.reward_functions import PostureReward, AltitudeReward
+    cfg = make_config()
+    pr = PostureReward(cfg)
+    AO = rng.uniform(0, np.pi, 600)
+    TA = rng.uniform(0, np.pi, 600)
+    R = np.concatenate([rng.uniform(0, 12, 300), rng.uniform(0, 80, 300)])
+    TA[:5] = 0.0
+    TA[5:10] = np.pi / 2
+    with np.errstate(all="ignore"):
+        orn = np.array([pr.orientation_fn(a, t) for a, t in zip(AO, TA)])
+        rngv = np.array([pr.range_fn(r) for r in R])
+    ar = AltitudeReward(cfg)
+    z = rng.uniform(0.5, 8, 600)
+    vz = rng.uniform(-0.6, 0.6, 600)
+    alt = []
+    for zz, vv in zip(z, vz):
+        a = FakeAircraft("A0100")
+        a._position[:] = (0, 0, zz * 1000)
+        a._velocity[:] = (0, 0, vv * 340)
+        alt.append(ar.get_reward(None, FakeEnv([a]), "A0100"))
+    np.savez_compressed(os.path.join(OUT, "reward_functions.npz"), AO=AO, TA=TA, R=R, orientation=orn, range=rngv, z=z, vz=vz, altitude=np.array(alt))
+
+
+def gen_singlecombat_sequences(rng):
+    """SingleCombatTask over scripted two-aircraft pose sequences: obs (15), terminations, rewards incl. reset seeding,
+    potential differencing, the die-flag latch and the sequential termination order."""
+    from envs.JSBSim.tasks.singlecombat_task import SingleCombatTask
+    cfg = make_config()
+    episodes = []
+    for ep in range(24):
+        task = SingleCombatTask(cfg)
+        a, b = FakeAircraft("A0100", "Blue"), FakeAircraft("B0100", "Red")
+        link([a, b])
+        env = FakeEnv([a, b])
+        random_pose(rng, a); random_pose(rng, b)
+        if ep % 4 == 1:
+            random_pose(rng, b, spread_km=3.0)   # close-in geometry
+        task.reset(env)
+        frames = [dict(step=0, pose=np.stack([pose_vector(a), pose_vector(b)]), obs=np.stack([task.get_obs(env, u) for u in env.agents]),
+                       rew=np.zeros(2), done=np.zeros(2))]
+        T = 14
+        for t in range(1, T + 1):
+            env.current_step = t
+            for ac in (a, b):
+                if ac.is_alive:
+                    random_pose(rng, ac, alt=(2000.0, 9000.0) if ep % 3 else (2300.0, 5000.0))
+            # scripted events
+            if ep % 6 == 2 and t == 6:
+                b.shotdown()
+            if ep % 6 == 3 and t == 5:
+                a.props["accelerations/n-pilot-z-norm"] = -12.5
+                a.props["simulation/sim-time-sec"] = 30.0
+            if ep % 6 == 4 and t == 7:
+                b.props["detect/extreme-state"] = 1
+            if ep % 6 == 5 and t == 4:
+                env.current_step = 9000
+            pose = np.stack([pose_vector(a), pose_vector(b)])
+            obs = np.stack([task.get_obs(env, u) for u in env.agents])
+            info = {"current_step": env.current_step}
+            done = []
+            for u in env.agents:
+                d, info = task.get_termination(env, u, info)
+                done.append(d)
+            rew = []
+            for u in env.agents:
+                r, info = task.get_reward(env, u, info)
+                rew.append(r)
+            frames.append(dict(step=env.current_step, pose=pose, obs=obs, rew=np.array(rew, dtype=float), done=np.array(done, dtype=float),
+                               status_after=np.array([a.status, b.status], dtype=float)))
+            if all(done):
+                break
+        episodes.append(frames)
+    flat = {}
+    for i, frames in enumerate(episodes):
+        flat[f"ep{i}_pose"] = np.stack([f["pose"] for f in frames])
+        flat[f"ep{i}_obs"] = np.stack([f["obs"] for f in frames])
+        flat[f"ep{i}_rew"] = np.stack([f["rew"] for f in frames])
+        flat[f"ep{i}_done"] = np.stack([f["done"] for f in frames])
+        flat[f"ep{i}_step"] = np.array([f["step"] for f in frames], dtype=float)
+        flat[f"ep{i}_extreme"] = np.array([0.0])
+    flat["n_episodes"] = np.array([len(episodes)], dtype=float)
+    np.savez_compressed(os.path.join(OUT, "singlecombat_sequences.npz"), **flat)
+
+
+def gen_missile(rng):
+    """MissileSimulator fly-outs (AIM-9L defaults and the AIM_9M/AIM_120B parameter set) against scripted targets."""
+    from envs.JSBSim.core.simulatior import MissileSimulator, AIM_120B
+    from envs.JSBSim.utils.utils import LLA2NEU
+    cases = []
+    specs = [
+        (MissileSimulator, 0, dict(dist=6000.0, tgt_speed=250.0, tgt_turn=0.0, aspect=np.pi, steps=1500)),     # head-on, hit
+        (MissileSimulator, 0, dict(dist=9000.0, tgt_speed=300.0, tgt_turn=0.0, aspect=0.0, steps=4200)),       # tail chase
+        (MissileSimulator, 0, dict(dist=12000.0, tgt_speed=280.0, tgt_turn=0.12, aspect=1.3, steps=4200)),     # turning target
+        (MissileSimulator, 0, dict(dist=25000.0, tgt_speed=330.0, tgt_turn=0.0, aspect=0.1, steps=4200)),      # out of range: slows / recedes
+        (AIM_120B, 1, dict(dist=15000.0, tgt_speed=260.0, tgt_turn=0.0, aspect=np.pi, steps=1800)),
+        (AIM_120B, 1, dict(dist=8000.0, tgt_speed=260.0, tgt_turn=0.25, aspect=2.0, steps=1800)),
+        (MissileSimulator, 0, dict(dist=5000.0, tgt_speed=250.0, tgt_turn=0.0, aspect=np.pi, steps=900, kill_target_at=120)),  # target dies first
+    ]
+    for cls, model, sp in specs:
+        parent, target = FakeAircraft("A0100", "Blue"), FakeAircraft("B0100", "Red")
+        parent.set_pose(120.0, 60.0, 6000.0, (0.1, 0.05, 0.0), (260.0, 0.0, -5.0))
+        # target placed `dist` north of the parent
+        tgt_lat = 60.0 + sp["dist"] / 111320.0
+        hdg = sp["aspect"]
+        target.set_pose(120.0, tgt_lat, 6200.0, (0.0, 0.0, hdg), (sp["tgt_speed"] * np.cos(hdg), sp["tgt_speed"] * np.sin(hdg), 0.0))
+        m = cls.create(parent, target, "A01001") if cls is MissileSimulator else cls.create(parent, target, "A01001", "AIM-120B")
+        rows = []
+        tpos = target._position.copy()
+        for k in range(sp["steps"]):
+            # target kinematics (a plain scripted point mass in NEU; velocity z stored as "down" like the aircraft cache)
+            hdg += sp["tgt_turn"] * parent.dt
+            target._velocity[:] = (sp["tgt_speed"] * np.cos(hdg), sp["tgt_speed"] * np.sin(hdg), 2.0 * np.sin(0.01 * k))
+            tpos += parent.dt * np.array([target._velocity[0], target._velocity[1], -target._velocity[2]])
+            target._position[:] = tpos
+            if sp.get("kill_target_at") == k:
+                target.crash()
+            alive_before = target.is_alive
+            m.run()
+            rows.append(np.concatenate([[k, alive_before, m._MissileSimulator__status], target._position, target._velocity,
+                                        m.get_position(), m.get_velocity(), m.get_rpy()[1:], [m._t, m._m, m._geodetic[2]]]))
+            if m.is_done and k > 5 and rows[-2][2] != 0 and rows[-3][2] != 0:
+                break
+        cases.append((model, np.array(rows), np.concatenate([parent._geodetic, parent._position, parent._velocity, parent._posture])))
+    flat = {"n": np.array([len(cases)], dtype=float)}
+    for i, (model, rows, par) in enumerate(cases):
+        flat[f"c{i}_model"] = np.array([model], dtype=float)
+        flat[f"c{i}_rows"] = rows
+        flat[f"c{i}_parent"] = par
+    np.savez_compressed(os.path.join(OUT, "missile.npz"), **flat)
+
+
+def gen_missile_task_obs(rng):
+    """21-value observation of SingleCombatDodgeMissileTask (3-D AO/TA, unclipped, missile-warning block)."""
+    from envs.JSBSim.tasks.singlecombat_with_missile_task import SingleCombatShootMissileTask
+    from envs.JSBSim.core.simulatior import MissileSimulator
+    cfg = make_config()
+    task = SingleCombatShootMissileTask(cfg)
+    poses, obs, msl = [], [], []
+    for i in range(200):
+        a, b = FakeAircraft("A0100", "Blue"), FakeAircraft("B0100", "Red")
+        link([a, b])
+        env = FakeEnv([a, b])
+        random_pose(rng, a); random_pose(rng, b)
+        mrow = np.zeros(7)
+        if i % 2:
+            m = MissileSimulator.create(b, a, "B01001")
+            m._position[:] = a._position + rng.normal(size=3) * np.array([4000, 4000, 800])
+            m._velocity[:] = rng.normal(size=3) * np.array([400, 400, 80])
+            mrow = np.concatenate([[1.0], m._position, m._velocity])
+        poses.append(np.stack([pose_vector(a), pose_vector(b)]))
+        obs.append(task.get_obs(env, "A0100"))
+        msl.append(mrow)
+    np.savez_compressed(os.path.join(OUT, "missile_task_obs.npz"), pose=np.array(poses), obs=np.array(obs), missile=np.array(msl))
+
+
+def gen_heading(rng):
+    """HeadingTask: obs(12), HeadingReward, UnreachHeading with the env.np_random draws (PCG64 seeded like gymnasium)."""
+    from envs.JSBSim.tasks.heading_task import HeadingTask
+    from envs.JSBSim.core.catalog import Catalog as c
+    cfg = make_config(max_steps=10000, aircraft_configs={"A0100": {"color": "Blue", "max_heading_increment": 180, "max_altitude_increment": 7000,
+                                                                   "max_velocities_u_increment": 100, "check_interval": 30}},
+                      PostureReward_potential=False, EventDrivenReward_potential=False)
+    task = HeadingTask(cfg)
+
+    class HeadingAircraft(FakeAircraft):
+        # the three delta properties are recomputed on every read by their catalogue update() (catalog.py:340-356)
+        def get_property_value(self, prop):
+            p = self.props
+            if prop.name_jsbsim == "position/delta-altitude-to-target-m":
+                return float(np.clip((p["tc/h-sl-ft"] - p["position/h-sl-ft"]) * 0.3048, -40000, 40000))
+            if prop.name_jsbsim == "position/delta-heading-to-target-deg":
+                x = (p["tc/target-heading-deg"] - p["attitude/psi-deg"]) % 360
+                return float(np.clip(x - 360 if x > 180 else x, -180, 180))
+            if prop.name_jsbsim == "position/delta-velocities_u-to-target-mps":
+                return float(np.clip(p["tc/target-velocity-u-mps"] - p["velocities/u-mps"], -1400, 1400))
+            return p[prop.name_jsbsim]
+
+    a = HeadingAircraft("A0100", "Blue")
+    env = FakeEnv([a])
+    seed = 12345
+    env.np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+    bitgen_state = env.np_random.bit_generator.state
+    env.heading_turn_counts = 0
+    # property plumbing of the extra catalogue: derived values are recomputed by their update() on read in the real wrapper;
+    # here they are supplied directly
+    hdg0, alt0_ft, u0 = 35.0, 20000.0, 800.0
+    a.props.update({"tc/target-heading-deg": hdg0, "tc/h-sl-ft": alt0_ft, "tc/target-velocity-u-mps": u0 * 0.3048, "heading_check_time": 0.0})
+    rows = []
+    psi, h_ft, u_mps, roll, p, q = hdg0, alt0_ft, u0 * 0.3048, 0.0, 0.0, 0.0
+    task.reset(env)
+    for t in range(1, 1000):
+        env.current_step = t
+        # the scripted aircraft tracks its current target heading (so several checks pass) until it drifts away after t = 620
+        psi = (a.props["tc/target-heading-deg"] + rng.normal() * 1.5 + (0.25 * (t - 620) if t > 620 else 0.0)) % 360
+        h_ft += rng.normal() * 8
+        u_mps += rng.normal() * 0.3
+        roll = float(np.clip(roll + rng.normal() * 0.01, -0.5, 0.5))
+        p, q = rng.normal() * 0.02, rng.normal() * 0.02
+        sim_time = t * 0.1
+
+        a.props.update({
+            "position/h-sl-ft": h_ft, "attitude/psi-deg": psi,
+            "position/h-sl-m": h_ft * 0.3048, "attitude/roll-rad": roll, "attitude/pitch-rad": 0.02,
+            "velocities/u-mps": u_mps, "velocities/v-mps": 0.5, "velocities/w-mps": 3.0, "velocities/vc-mps": 200.0,
+            "velocities/p-rad_sec": p, "velocities/q-rad_sec": q, "simulation/sim-time-sec": sim_time,
+            "accelerations/n-pilot-x-norm": 0.0, "accelerations/n-pilot-y-norm": 0.0, "accelerations/n-pilot-z-norm": -1.0,
+            "detect/extreme-state": 0,
+        })
+        a._position[:] = (0, 0, h_ft * 0.3048)
+        a._velocity[:] = (0, 0, 0.0)
+        obs = task.get_obs(env, "A0100")
+        info = {"current_step": t}
+        done, info = task.get_termination(env, "A0100", info)
+        rew, info = task.get_reward(env, "A0100", info)
+        rows.append(np.concatenate([[t, psi, h_ft, u_mps, roll, p, q, sim_time, done, rew, env.heading_turn_counts,
+                                     a.props["tc/target-heading-deg"], a.props["tc/h-sl-ft"], a.props["tc/target-velocity-u-mps"],
+                                     a.props["heading_check_time"]], obs]))
+        if done:
+            break
+    m = (1 << 64) - 1
+    st, inc = bitgen_state["state"]["state"], bitgen_state["state"]["inc"]
+    np.savez_compressed(os.path.join(OUT, "heading.npz"), rows=np.array(rows), init=np.array([hdg0, alt0_ft, u0 * 0.3048]),
+             pcg64=np.array([st >> 64, st & m, inc >> 64, inc & m], dtype=np.uint64))
+
+
+def gen_curriculum_table():
+    from envs.JSBSim.utils.utils import calculate_coordinates_heading_by_curriculum
+    res = calculate_coordinates_heading_by_curriculum(60.1, 120.0, 11.119, list(range(0, 181)))
+    np.savez_compressed(os.path.join(OUT, "curriculum_spawn.npz"), table=np.array(res, dtype=float))
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit(f"{REF} not present: golden vectors are generated in the build container only")
+    install_standins()
+    rng = np.random.default_rng(20250321)
+    gen_geometry(rng)
+    gen_reward_functions(rng)
+    gen_singlecombat_sequences(rng)
+    gen_missile(rng)
+    gen_missile_task_obs(rng)
+    gen_heading(rng)
+    gen_curriculum_table()
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

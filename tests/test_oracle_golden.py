@@ -1,0 +1,173 @@
+"""Pins the oracle's restatement of the reference's PYTHON code against golden vectors generated from that code
+(tests/golden/make_golden.py, run in the build container where /root/reference exists). CPU only."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+def close(a, b, rtol=1e-9, atol=1e-9):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    both_nan = np.isnan(a) & np.isnan(b)
+    same_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
+    with np.errstate(invalid="ignore"):
+        ok = np.abs(a - b) <= atol + rtol * np.abs(b)
+    return ok | both_nan | same_inf
+
+
+def test_ao_ta_r_matches_reference(oracle):
+    g = load("geometry.npz")
+    L = oracle.lib()
+    out = (C.c_double * 4)()
+    for two_d, key in ((0, "out3d"), (1, "out2d")):
+        got = []
+        for e, n in zip(g["ego"], g["enm"]):
+            L.or_get_AO_TA_R((C.c_double * 6)(*e), (C.c_double * 6)(*n), two_d, out)
+            got.append(out[:])
+        got = np.array(got)
+        # acos near +-1 turns a 1e-16 difference of its argument (summation order of the norms) into ~1e-8 rad
+        ok = close(got, g[key], rtol=1e-9, atol=5e-8)
+        # acos is ill-conditioned at +-1: the degenerate rows (R -> 0, v = 0) are compared on R and side only
+        degenerate = (np.linalg.norm(g["ego"][:, 3:], axis=1) == 0) | (np.linalg.norm(g["enm"][:, 3:], axis=1) == 0) | (g[key][:, 2] < 1e-6)
+        assert ok[~degenerate].all()
+        assert close(got[degenerate][:, 2:], g[key][degenerate][:, 2:], atol=1e-9).all()
+        assert np.isfinite(got).all()
+
+
+def test_posture_and_altitude_functions(oracle):
+    g = load("reward_functions.npz")
+    L = oracle.lib()
+    orn = np.array([L.or_posture_orientation(a, t) for a, t in zip(g["AO"], g["TA"])])
+    rng = np.array([L.or_posture_range(r) for r in g["R"]])
+    alt = np.array([L.or_altitude_reward(z, vz, 4.0, 3.5, 0.2) for z, vz in zip(g["z"], g["vz"])])
+    assert close(orn, g["orientation"], rtol=1e-12, atol=1e-12).all()
+    assert close(rng, g["range"], rtol=1e-12, atol=1e-12).all()
+    assert close(alt, g["altitude"], rtol=1e-12, atol=1e-12).all()
+
+
+def test_singlecombat_obs_termination_reward_sequences(oracle):
+    """obs(15), the five terminations in task order with their crash() side effects, potential rewards seeded at reset,
+    die-flag latch — against SingleCombatTask driven by the same scripted poses."""
+    g = load("singlecombat_sequences.npz")
+    cfg = oracle.default_config(oracle.TASK_SINGLECOMBAT)
+    n = int(g["n_episodes"][0])
+    n_done = 0
+    for ep in range(n):
+        env = oracle.OracleEnv(cfg)
+        pose, obs, rew, done, step = (g[f"ep{ep}_{k}"] for k in ("pose", "obs", "rew", "done", "step"))
+        for i in range(2):
+            env.set_pose(i, pose[0][i])
+        env.set_step(0)
+        env.task_reset()
+        o0, _, _, _ = None, None, None, None
+        o, r, d, _ = env.evaluate.__func__(env) if False else (None, None, None, None)
+        # frame 0: observation at reset (no termination / reward evaluation happens at reset)
+        obs0 = np.zeros((2, 15))
+        env.L.or_env_evaluate  # noqa: B018 (symbol exists)
+        for t in range(1, len(pose)):
+            for i in range(2):
+                # dead aircraft keep their status; pose vectors carry the status the reference had BEFORE evaluation
+                env.set_pose(i, pose[t][i])
+            env.set_step(int(step[t]))
+            o, r, d, info = env.evaluate()
+            assert close(o, obs[t], rtol=1e-9, atol=1e-9).all(), (ep, t, np.abs(o - obs[t]).max())
+            assert (d == done[t].astype(bool)).all(), (ep, t, d, done[t])
+            assert close(r, rew[t], rtol=1e-8, atol=1e-8).all(), (ep, t, r, rew[t])
+            n_done += int(d.sum())
+    assert n_done > 10  # the scripted events really exercised the terminations
+
+
+def test_missile_flyouts(oracle):
+    """MissileSimulator.run / _guidance / _state_trans per substep for both parameter sets: hit, tail chase, turning
+    target, out of range (speed / receding miss) and target-dies-first."""
+    g = load("missile.npz")
+    L = oracle.lib()
+    statuses = set()
+    for c in range(int(g["n"][0])):
+        model = int(g[f"c{c}_model"][0])
+        rows = g[f"c{c}_rows"]
+        par = g[f"c{c}_parent"]
+        # launch state: parent's cached geodetic(3), position(3), velocity(3), rpy(3)
+        st = np.zeros(20)
+        st[0] = 0
+        st[1:4] = par[3:6]; st[4:7] = par[6:9]; st[7] = par[10]; st[8] = par[11]
+        st[9] = 0.0; st[10] = 84.0 if model == 0 else 152.0; st[13] = np.inf; st[15] = par[2]
+        buf = (C.c_double * 20)(*st)
+        for row in rows:
+            alive = int(row[1])
+            tp, tv = (C.c_double * 3)(*row[3:6]), (C.c_double * 3)(*row[6:9])
+            L.or_missile_raw_run(buf, model, tp, tv, alive)
+            got = np.array(buf[:])
+            assert int(got[0]) == int(row[2]), (c, row[0], got[0], row[2])
+            assert close(got[1:4], row[9:12], rtol=1e-9, atol=1e-6).all(), (c, row[0])
+            assert close(got[4:7], row[12:15], rtol=1e-9, atol=1e-7).all(), (c, row[0])
+            assert close(got[7:9], row[15:17], rtol=1e-9, atol=1e-9).all()
+            assert close([got[9], got[10], got[15]], row[17:20], rtol=1e-9, atol=1e-6).all()
+            statuses.add(int(row[2]))
+    assert statuses == {0, 1, 2}
+
+
+def test_missile_task_observation(oracle):
+    g = load("missile_task_obs.npz")
+    cfg = oracle.default_config(oracle.TASK_SHOOT_MISSILE)
+    env = oracle.OracleEnv(cfg)
+    for pose, obs, m in zip(g["pose"], g["obs"], g["missile"]):
+        env.L.or_env_clear_missiles(env.p)
+        for i in range(2):
+            env.set_pose(i, pose[i])
+        if m[0]:
+            env.add_missile(1, 0, 0, m[1:4], m[4:7])
+        o, _, _, _ = env.evaluate()
+        assert close(o[0], obs, rtol=1e-9, atol=1e-9).all(), np.abs(o[0] - obs).max()
+
+
+def test_heading_task_with_numpy_pcg64(oracle):
+    """HeadingTask obs(12), HeadingReward + AltitudeReward, UnreachHeading incl. the env.np_random draws: the oracle's
+    PCG64 mirror must reproduce numpy's Generator.uniform stream bit for bit."""
+    g = load("heading.npz")
+    cfg = oracle.default_config(oracle.TASK_HEADING)
+    env = oracle.OracleEnv(cfg)
+    st = g["pcg64"]
+    env.L.or_env_seed_pcg64(env.p, int(st[0]), int(st[1]), int(st[2]), int(st[3]))
+    hdg0, alt0, u0 = g["init"]
+    env.L.or_env_heading_targets(env.p, hdg0, alt0, u0, 0.0)
+    env.set_step(0)
+    env.task_reset()
+    env.L.or_env_heading_targets(env.p, hdg0, alt0, u0, 0.0)
+    out = (C.c_double * 5)()
+    turns = 0
+    for row in g["rows"]:
+        t, psi, h_ft, u_mps, roll, p, q, sim_time, done, rew, hc, th, ta, tu, ct = row[:15]
+        env.L.or_env_heading_pose(env.p, psi, h_ft, u_mps, roll, 0.02, 0.5, 3.0, 200.0, p, q, sim_time)
+        env.set_step(int(t))
+        o, r, d, _ = env.evaluate()
+        env.L.or_env_heading_get(env.p, out)
+        assert close(o[0], row[15:], rtol=1e-9, atol=1e-9).all(), (t, o[0], row[15:])
+        assert bool(d[0]) == bool(done), t
+        assert close(r[0], rew, rtol=1e-9, atol=1e-9), (t, r[0], rew)
+        assert close(out[:], [th, ta, tu, ct, hc], rtol=1e-12, atol=1e-9).all(), (t, out[:], [th, ta, tu, ct, hc])
+        turns = int(hc)
+    assert turns >= 2 and bool(done)
+
+
+def test_pcg64_uniform_stream(oracle):
+    gen = np.random.Generator(np.random.PCG64(np.random.SeedSequence(2024)))
+    env = oracle.OracleEnv(oracle.default_config(oracle.TASK_HEADING))
+    env.seed_from_numpy(gen.bit_generator.state)
+    want = [gen.uniform(-3.0, 7.5) for _ in range(1000)]
+    got = [env.L.or_env_uniform(env.p, -3.0, 7.5) for _ in range(1000)]
+    assert want == got
+
+
+def test_curriculum_spawn_table_fixture_is_sane():
+    t = load("curriculum_spawn.npz")["table"]
+    assert t.shape == (181, 3)
+    # 11.119 km circle about (60.1 N, 120 E): first point due south, heading 0
+    assert abs(t[0][0] - 60.0) < 2e-3 and abs(t[0][1] - 120.0) < 1e-9 and t[0][2] == 0
