@@ -54,19 +54,11 @@ def main():
     import torch
     import aircombat_selfplay_amd as pkg
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank = pkg.sharding.dist_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL; used only for the timing barrier / max
-    else:
-        torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)
+    dist = pkg.sharding.init_process_group("nccl")  # RCCL; used only for the timing barrier / max-over-ranks
 
     E = args.envs
     cfg = pkg.default_config(args.task)
@@ -108,10 +100,7 @@ def main():
         dist.barrier()
     elapsed = t1 - t0
     kernel_ms = ev_ms.value / args.steps          # HIP events on the launch stream, average per launch
-    if dist is not None:
-        tt = torch.tensor([elapsed, kernel_ms], device=f"cuda:{local_rank}", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(tt[0]), float(tt[1])
+    elapsed, kernel_ms = pkg.sharding.max_over_ranks([elapsed, kernel_ms], dist, device=f"cuda:{local_rank}")
 
     # sanity: the episode machinery really ran (steps counted, resets happened)
     _, _, _, _, info = env.device_tensors()

@@ -1,0 +1,65 @@
+"""N>1 path on CPU: two ranks over gloo. Each rank owns a contiguous env block; the concatenation of the blocks equals the
+single-process result (envs are independent, no data-path collective); barrier + max-over-ranks behave as bench.py needs."""
+import os
+import socket
+
+import numpy as np
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total_envs, steps, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import aircombat_selfplay_amd as pkg
+    from oracle import oracle as O   # the CPU engine stands in for the GPU block in this CPU-only test
+    dist = pkg.sharding.init_process_group("gloo")
+    assert dist is not None and pkg.sharding.dist_env() == (rank, world, rank)
+    start, count = pkg.sharding.env_block(rank, world, total_envs)
+    env = O.OracleVecEnv(O.default_config(O.TASK_SINGLECOMBAT), count)
+    env.reset()
+    rng = np.random.default_rng(99)
+    acts = [np.stack([rng.integers(0, n, size=(total_envs, 2)) for n in (41, 41, 41, 30)], axis=-1) for _ in range(steps)]
+    pkg.sharding.barrier(dist)
+    for a in acts:
+        obs, rew, done, info = env.step(a[start:start + count])
+    mx = pkg.sharding.max_over_ranks([float(rank + 1), 10.0 - rank], dist)
+    assert mx == [float(world), 10.0]
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), obs=obs, rew=rew, start=start, count=count)
+    pkg.sharding.barrier(dist)
+    dist.destroy_process_group()
+
+
+def test_two_rank_env_blocks_match_single_process(tmp_path, pkg, oracle):
+    total, steps, world = 6, 12, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, total, steps, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    assert [int(p["start"]) for p in parts] == [0, 3] and sum(int(p["count"]) for p in parts) == total
+    env = oracle.OracleVecEnv(oracle.default_config(oracle.TASK_SINGLECOMBAT), total)
+    env.reset()
+    rng = np.random.default_rng(99)
+    for _ in range(steps):
+        a = np.stack([rng.integers(0, n, size=(total, 2)) for n in (41, 41, 41, 30)], axis=-1)
+        obs, rew, done, info = env.step(a)
+    assert (np.concatenate([p["obs"] for p in parts]) == obs).all()
+    assert (np.concatenate([p["rew"] for p in parts]) == rew).all()
+
+
+def test_env_block_partition(pkg):
+    for world in (1, 2, 3, 8):
+        for total in (8, 13, 4096, 32768):
+            blocks = [pkg.sharding.env_block(r, world, total) for r in range(world)]
+            assert blocks[0][0] == 0 and sum(c for _, c in blocks) == total
+            for (s0, c0), (s1, _) in zip(blocks, blocks[1:]):
+                assert s0 + c0 == s1
+            assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
