@@ -94,7 +94,7 @@ struct DevPtrs {
   float* F; int* I; double* D;           // live state, SoA [field][N]
   float* MF; int* MI;                    // missiles, SoA [slot][field][N]
   const float* tF; const int* tI; const double* tD;  // reset template, [field][A]
-  const float* tab;                      // F16_TAB as fp32 in HBM (staged to LDS per workgroup)
+  const float* tab;                      // F16_PACK as fp32 in HBM (staged to LDS per workgroup)
   const float* actions;                  // [N][act_dim]
   float* obs; float* rew; uint8_t* done; int* info;
 };
@@ -361,8 +361,8 @@ __global__ __launch_bounds__(64) void step_kernel_1v1(DevPtrs P, DevCfg c) {
   constexpr bool HAS_MSL = TT::HAS_MSL;
   constexpr int MSLOTS = TT::MSLOTS;
   constexpr int OBS = TT::OBS;
-  __shared__ float lds_tab[F16_TAB_LEN];
-  for (int i = threadIdx.x; i < F16_TAB_LEN; i += blockDim.x) lds_tab[i] = P.tab[i];
+  __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
+  for (int i = threadIdx.x; i < F16_PACK_LEN; i += blockDim.x) lds_tab[i] = P.tab[i];
   __syncthreads();
   const Tab T{lds_tab};
   const int N = c.N;
@@ -403,7 +403,8 @@ __global__ __launch_bounds__(64) void step_kernel_1v1(DevPtrs P, DevCfg c) {
       have_pose = true;
     }
     if (HAS_MSL) {
-      if (!have_pose) { f16::locate(s, d); f16::body_frame(s, d); have_pose = true; }  // frozen pose of a dead aircraft
+      f16::locate(s, d);                                       // fp64 geodetic reduction for the NEU pose of this substep
+      if (!have_pose) { f16::body_frame(s, d); have_pose = true; }  // frozen pose of a dead aircraft
       make_props(s, d, c, pr);
       float tx = __shfl_xor(pr.n, 1), ty = __shfl_xor(pr.e, 1), tz = __shfl_xor(pr.u, 1);
       float tvx = __shfl_xor(pr.vn, 1), tvy = __shfl_xor(pr.ve, 1), tvz = __shfl_xor(pr.vd, 1);
@@ -419,8 +420,11 @@ __global__ __launch_bounds__(64) void step_kernel_1v1(DevPtrs P, DevCfg c) {
       if (__shfl_xor((int)hit_now, 1) && t.status == AC_ALIVE) t.status = AC_SHOTDOWN;
     }
   }
-  if (!have_pose) { f16::locate(s, d); f16::body_frame(s, d); }
-  if (!HAS_MSL || c.substeps == 0) make_props(s, d, c, pr);
+  if (!HAS_MSL || c.substeps == 0) {
+    f16::locate(s, d);
+    if (!have_pose) f16::body_frame(s, d);
+    make_props(s, d, c, pr);
+  }
   Enemy E = exchange_1v1(pr);
 
   // ---- task.step
@@ -631,11 +635,9 @@ __device__ void initial_state(const ac_init_state_t& ic, const Tab& T, State& s,
   s.eng = f16::PH_RUN | f16::ENG_RUNNING;
   {
     f16::Atmos A = f16::atmosphere(d.h_sl_ft);
-    int im, jh, ii; float fm, fh, fi;
-    f16::bracket<T_ENG_MILTHRUST_NC>(T, T_ENG_MILTHRUST_OFF + T_ENG_MILTHRUST_NR, d.h_sl_ft, jh, fh);
-    f16::bracket<T_ENG_IDLETHRUST_NR>(T, T_ENG_IDLETHRUST_OFF, s.mach, ii, fi);
-    (void)im; (void)fm;
-    float idle = (float)F16_ENG_MILTHRUST * f16::tab2i<T_ENG_IDLETHRUST_NR, T_ENG_IDLETHRUST_NC>(T, T_ENG_IDLETHRUST_OFF, ii, fi, jh, fh);
+    float idle_f, mil_f, aug_f;
+    f16::engine_factors(T, s.mach, d.h_sl_ft, idle_f, mil_f, aug_f);
+    float idle = (float)F16_ENG_MILTHRUST * idle_f;
     float tsfc = (float)F16_ENG_TSFC * sqrtf(A.T * (1.0f / 389.7f)) * (0.84f + 1.0f);
     float target = idle * tsfc;            // thrust at N2norm = 0 is the idle thrust
     float ff = (target > 0.0f) ? target : 0.0f;  // Seek from 0 never goes below 0 here: a negative target is approached from above only
@@ -647,8 +649,8 @@ template <int TASK>
 __global__ void init_kernel_1v1(InitArgs ia, DevCfg c, const float* tab, float* tF, int* tI, double* tD) {
   using TT = TaskTraits<TASK>;
   constexpr int OBS = TT::OBS;
-  __shared__ float lds_tab[F16_TAB_LEN];
-  for (int i = threadIdx.x; i < F16_TAB_LEN; i += blockDim.x) lds_tab[i] = tab[i];
+  __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
+  for (int i = threadIdx.x; i < F16_PACK_LEN; i += blockDim.x) lds_tab[i] = tab[i];
   __syncthreads();
   const Tab T{lds_tab};
   const int slot = threadIdx.x & 1;
@@ -657,6 +659,7 @@ __global__ void init_kernel_1v1(InitArgs ia, DevCfg c, const float* tab, float* 
   t.bloods = 100.0f; t.status = AC_ALIVE;
   t.remaining = c.num_missiles[slot]; t.pre_remaining = c.num_missiles[slot];
   t.last_missile = -1; t.last_shoot_time = -c.min_attack_interval;
+  f16::locate(s, d);
   make_props(s, d, c, pr);
   Enemy E = exchange_1v1(pr);
   Incoming inc{false, 0, 0, 0, 0, 0, 0};
@@ -800,10 +803,10 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   HIP_OK(hipMalloc(&p.info, sizeof(int) * 4 * h->E));
   HIP_OK(hipMalloc(&h->d_actions, sizeof(float) * N * h->act_dim));
   HIP_OK(hipMemset(h->d_actions, 0, sizeof(float) * N * h->act_dim));
-  std::vector<float> tab(F16_TAB_LEN);
-  for (int i = 0; i < F16_TAB_LEN; ++i) tab[i] = (float)F16_TAB[i];
-  HIP_OK(hipMalloc(&h->d_tab, sizeof(float) * F16_TAB_LEN));
-  HIP_OK(hipMemcpy(h->d_tab, tab.data(), sizeof(float) * F16_TAB_LEN, hipMemcpyHostToDevice));
+  std::vector<float> tab(F16_PACK_LEN);
+  for (int i = 0; i < F16_PACK_LEN; ++i) tab[i] = (float)F16_PACK[i];
+  HIP_OK(hipMalloc(&h->d_tab, sizeof(float) * F16_PACK_LEN));
+  HIP_OK(hipMemcpy(h->d_tab, tab.data(), sizeof(float) * F16_PACK_LEN, hipMemcpyHostToDevice));
   HIP_OK(hipMalloc(&h->d_tF, sizeof(float) * ((size_t)NF * h->A + (size_t)h->A * h->obs_dim)));
   HIP_OK(hipMalloc(&h->d_tI, sizeof(int) * NI * h->A));
   HIP_OK(hipMalloc(&h->d_tD, sizeof(double) * ND * h->A));

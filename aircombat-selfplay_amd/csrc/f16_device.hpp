@@ -67,7 +67,6 @@ struct State {
 
 // What one tick exposes to the environment layer.
 struct Derived {
-  float sinLat, cosLat, sinLon, cosLon;    // geodetic latitude / longitude of the vehicle
   float h_sl_ft;                           // radius - sea-level radius [ft]
   float u, v, w;                           // body velocity [ft/s]
   float p, q, r;                           // body rates relative to ECEF [rad/s]
@@ -80,47 +79,45 @@ struct Derived {
   double sLat64, cLat64, sLon64, cLon64;   // fp64 copies for the geodetic -> NED reduction of the env layer
 };
 
+// LDS copy of F16_PACK (tools/gen_f16_tables.py): tables that share breakpoint axes are interleaved so one lane fetches
+// all values it needs at a breakpoint with a single 16-byte ds_read_b128.
 struct Tab {
-  const float* t;  // LDS copy of F16_TAB
+  const float* t;  // 16-byte aligned
   __device__ __forceinline__ float operator[](int i) const { return t[i]; }
+  __device__ __forceinline__ float4 v4(int i) const { return *reinterpret_cast<const float4*>(t + i); }
+  __device__ __forceinline__ float2 v2(int i) const { return *reinterpret_cast<const float2*>(t + i); }
 };
 
 __device__ __forceinline__ float clampf(float lo, float v, float hi) { return fminf(fmaxf(v, lo), hi); }
 __device__ __forceinline__ float lerpf(float a, float b, float f) { return fmaf(f, b - a, a); }
+__device__ __forceinline__ float4 lerp4(float4 a, float4 b, float f) {
+  return make_float4(lerpf(a.x, b.x, f), lerpf(a.y, b.y, f), lerpf(a.z, b.z, f), lerpf(a.w, b.w, f));
+}
 
-// Breakpoint search: returns r in [1, n-1] with x[r-1] < key <= x[r] (clamped), and the fraction in [0,1].
-// Equivalent to FGTable::GetValue's stateful walk (data/src/math/FGTable.cpp:443-516): interpolation is
-// continuous at breakpoints so the choice of segment at an exact breakpoint does not change the value.
+// Segment index of `key` on a breakpoint axis known at compile time: r in [1, N-1] with x[r-1] < key <= x[r] (clamped at
+// both ends). Pure compare/add on immediates — no memory access, so the dependent LDS reads of a tick can all be issued in
+// one batch. Equivalent to FGTable::GetValue's walk (data/src/math/FGTable.cpp:443-516): the interpolant is continuous at
+// breakpoints, so which of two adjacent segments an exact breakpoint falls in does not change the value.
 template <int N>
-__device__ __forceinline__ void bracket(const Tab& T, int off, float key, int& r, float& f) {
-  r = 1;
+__device__ __forceinline__ int seg_index(const float (&x)[N], float key) {
+  int r = 1;
 #pragma unroll
-  for (int i = 1; i < N - 1; ++i) r += (T[off + i] < key) ? 1 : 0;
-  float x0 = T[off + r - 1], x1 = T[off + r];
-  f = clampf(0.0f, (key - x0) / (x1 - x0), 1.0f);
+  for (int i = 1; i < N - 1; ++i) r += (x[i] < key) ? 1 : 0;
+  return r;
 }
+// clamped interpolation fraction on the segment whose end points were read from LDS
+__device__ __forceinline__ float seg_frac(float x0, float x1, float key) { return clampf(0.0f, (key - x0) / (x1 - x0), 1.0f); }
+// tiny schedule tables held as immediates (FCS gains): compare/select chain
 template <int N>
-__device__ __forceinline__ float tab1(const Tab& T, int off, float key) {
-  int r; float f;
-  bracket<N>(T, off, key, r, f);
-  return lerpf(T[off + N + r - 1], T[off + N + r], f);
+__device__ __forceinline__ float tabc(const float (&x)[N], const float (&y)[N], float key) {
+  float x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
+#pragma unroll
+  for (int i = 1; i < N - 1; ++i) {
+    bool b = x[i] < key;
+    x0 = b ? x[i] : x0; x1 = b ? x[i + 1] : x1; y0 = b ? y[i] : y0; y1 = b ? y[i + 1] : y1;
+  }
+  return lerpf(y0, y1, seg_frac(x0, x1, key));
 }
-// 1-D table on a pre-bracketed axis
-template <int N>
-__device__ __forceinline__ float tab1i(const Tab& T, int off, int r, float f) {
-  return lerpf(T[off + N + r - 1], T[off + N + r], f);
-}
-// 2-D table (row-major values after NR row keys and NC column keys) on pre-bracketed axes
-template <int NR, int NC>
-__device__ __forceinline__ float tab2i(const Tab& T, int off, int r, float rf, int c, float cf) {
-  const int v = off + NR + NC;
-  float a0 = T[v + (r - 1) * NC + c - 1], a1 = T[v + r * NC + c - 1];
-  float b0 = T[v + (r - 1) * NC + c], b1 = T[v + r * NC + c];
-  return lerpf(lerpf(a0, a1, rf), lerpf(b0, b1, rf), cf);
-}
-#define F16_T1(NAME, key) tab1<T_##NAME##_NR>(T, T_##NAME##_OFF, (key))
-#define F16_T1A(NAME) tab1i<T_##NAME##_NR>(T, T_##NAME##_OFF, ia, fa)
-#define F16_T2(NAME, c, cf) tab2i<T_##NAME##_NR, T_##NAME##_NC>(T, T_##NAME##_OFF, ia, fa, (c), (cf))
 
 // ---------------------------------------------------------------- standard atmosphere 1976 (geopotential layers)
 // data/src/models/atmosphere/FGStandardAtmosphere.cpp:66-74,152-222,244-268 — only the three layers an F-16 can reach.
@@ -154,12 +151,12 @@ __device__ __forceinline__ Atmos atmosphere(float h_ft) {
 __device__ __forceinline__ float vcas_from_mach(float mach, float p) {
   const float psl = 2116.228f, asl = 1116.448558f;  // sqrt(1.4 * R * 518.67)
   float pt;
-  if (mach < 1.0f) pt = p * powf(1.0f + 0.2f * mach * mach, 3.5f);
-  else pt = p * 166.92158009316827f * powf(mach, 7.0f) / powf(7.0f * mach * mach - 1.0f, 2.5f);
+  if (mach < 1.0f) pt = p * __powf(1.0f + 0.2f * mach * mach, 3.5f);
+  else pt = p * 166.92158009316827f * __powf(mach, 7.0f) / __powf(7.0f * mach * mach - 1.0f, 2.5f);
   float A = (pt - p) / psl + 1.0f;
-  float M = sqrtf(5.0f * (powf(A, 1.0f / 3.5f) - 1.0f));
+  float M = sqrtf(5.0f * (__powf(A, 1.0f / 3.5f) - 1.0f));
   if (M > 1.0f) {
-    for (int i = 0; i < 10; ++i) M = 0.8812848543473311f * sqrtf(A * powf(1.0f - 1.0f / (7.0f * M * M), 2.5f));
+    for (int i = 0; i < 10; ++i) M = 0.8812848543473311f * sqrtf(A * __powf(1.0f - 1.0f / (7.0f * M * M), 2.5f));
   }
   return asl * M;
 }
@@ -202,8 +199,41 @@ __device__ __forceinline__ float seek(float v, float target, float accel, float 
   return v;
 }
 
-// ECI position -> ECEF, geodetic latitude (Fukushima 2006 as in data/src/math/FGLocation.cpp:283-317),
-// altitude above the sea-level radius, and the local-frame unit vectors expressed in ECI.
+// Where the vehicle is: altitude above the sea-level radius and the local north / east / down unit vectors in ECI.
+// The local frame only needs the DIRECTION of the geodetic normal, so the per-tick form works in the inertial
+// meridian plane (inertial longitude = atan2(ry, rx); rotating to ECEF and back by the Earth angle cancels) with
+// Fukushima's one-step reduction (data/src/math/FGLocation.cpp:283-317) on coordinates normalised by the semi-major
+// axis in fp32. Only |r| needs fp64 (2e7 ft against a sub-foot altitude budget); the sea-level radius
+// a*ec/sqrt(1 - e2*cos^2(lat_gc)) (FGLocation.cpp:243-249) is expanded about b so that its fp32 part is < 0.01 ft.
+__device__ __forceinline__ void locate_fast(const State& s, Derived& d) {
+  double rr = s.rx * s.rx + s.ry * s.ry + s.rz * s.rz;
+  double rad = sqrt(rr);
+  float ia = (float)(1.0 / kA);
+  float px = (float)s.rx * ia, py = (float)s.ry * ia, z = (float)s.rz * ia;   // O(1) coordinates
+  float p2 = px * px + py * py;
+  float irp = rsqrtf(p2);
+  float p = p2 * irp;
+  float cosLon = px * irp, sinLon = py * irp;
+  const float ec = (float)(kB / kA), e2 = (float)(1.0 - (kB / kA) * (kB / kA));
+  float s0 = fabsf(z), zc = ec * s0, c0 = ec * p, c02 = c0 * c0, s02 = s0 * s0, a02 = c02 + s02;
+  float a0 = sqrtf(a02), a03 = a02 * a0;
+  float s1 = zc * a03 + e2 * s02 * s0, c1 = p * a03 - e2 * c02 * c0, cs = e2 * c0 * s0;
+  float b0 = 1.5f * cs * ((p * s0 - zc * c0) * a0 - cs);
+  s1 = s1 * a03 - b0 * s0;
+  float cc = ec * (c1 * a03 - b0 * c0);
+  float inv = rsqrtf(s1 * s1 + cc * cc);
+  float sinLat = copysignf(s1, z) * inv, cosLat = cc * inv;
+  // sea-level radius: b * (1 - x)^(-1/2), x = e2 * cos^2(geocentric latitude) <= 0.0067
+  float cg2 = p2 / (p2 + z * z);
+  float x = e2 * cg2;
+  float ser = x * (0.5f + x * (0.375f + x * (0.3125f + x * 0.2734375f)));
+  d.h_sl_ft = (float)(rad - kB) - (float)kB * ser;
+  d.n_eci[0] = -cosLon * sinLat; d.n_eci[1] = -sinLon * sinLat; d.n_eci[2] = cosLat;
+  d.e_eci[0] = -sinLon; d.e_eci[1] = cosLon; d.e_eci[2] = 0.0f;
+  d.d_eci[0] = -cosLon * cosLat; d.d_eci[1] = -sinLon * cosLat; d.d_eci[2] = -sinLat;
+}
+// fp64 form for the environment layer (geodetic -> NED of the aircraft position, once per env step): ECEF position,
+// geodetic direction cosines and longitude cosines to full precision.
 __device__ __forceinline__ void locate(const State& s, Derived& d) {
   // Earth position angle is tiny (< 0.1 rad over an episode): series in fp64 is exact to < 1e-15.
   double epa = kOmega * (double)s.ticks * (1.0 / 60.0);
@@ -228,13 +258,13 @@ __device__ __forceinline__ void locate(const State& s, Derived& d) {
   d.h_sl_ft = (float)(rad - slr);
   double irxy = 1.0 / rxy;
   double cosLon = X * irxy, sinLon = Y * irxy;
-  d.sinLat = (float)sinLat; d.cosLat = (float)cosLat; d.sinLon = (float)sinLon; d.cosLon = (float)cosLon;
   d.sLat64 = sinLat; d.cLat64 = cosLat; d.sLon64 = sinLon; d.cLon64 = cosLon;
-  // local unit vectors in ECEF, then rotated back by the Earth angle into ECI
+  // local unit vectors in ECEF, rotated back by the Earth angle into ECI
   float cef = (float)ce, sef = (float)se;
-  float nx = -d.cosLon * d.sinLat, ny = -d.sinLon * d.sinLat, nz = d.cosLat;
-  float ex = -d.sinLon, ey = d.cosLon;
-  float dx = -d.cosLon * d.cosLat, dy = -d.sinLon * d.cosLat, dz = -d.sinLat;
+  float sLa = (float)sinLat, cLa = (float)cosLat, sLo = (float)sinLon, cLo = (float)cosLon;
+  float nx = -cLo * sLa, ny = -sLo * sLa, nz = cLa;
+  float ex = -sLo, ey = cLo;
+  float dx = -cLo * cLa, dy = -sLo * cLa, dz = -sLa;
   d.n_eci[0] = cef * nx - sef * ny; d.n_eci[1] = sef * nx + cef * ny; d.n_eci[2] = nz;
   d.e_eci[0] = cef * ex - sef * ey; d.e_eci[1] = sef * ex + cef * ey; d.e_eci[2] = 0.0f;
   d.d_eci[0] = cef * dx - sef * dy; d.d_eci[1] = sef * dx + cef * dy; d.d_eci[2] = dz;
@@ -257,6 +287,19 @@ __device__ __forceinline__ void body_frame(const State& s, Derived& d) {
   d.ve = d.e_eci[0] * rvx + d.e_eci[1] * rvy;
   d.vd = d.d_eci[0] * rvx + d.d_eci[1] * rvy + d.d_eci[2] * rvz;
   d.veci = sqrtf(s.vx * s.vx + s.vy * s.vy + s.vz * s.vz);
+}
+
+// F100-PW-229 thrust-factor tables (engine/F100-PW-229.xml:27-83): Mach rows are exact multiples of 0.2, altitude columns
+// of 10000 ft (density altitude equals geometric altitude in the standard atmosphere the reference flies in); the
+// idle / mil / aug factors are interleaved per grid point, rows past a table's last Mach repeat it (FGTable clamps).
+__device__ __forceinline__ void engine_factors(const Tab& T, float mach, float h_ft, float& idle_f, float& mil_f, float& aug_f) {
+  float mr = mach * 5.0f, hc = (h_ft + 10000.0f) * 1e-4f;
+  int rm = max(1, min(13, (int)floorf(mr) + 1)), jc = max(1, min(7, (int)floorf(hc) + 1));
+  float fm = clampf(0.0f, mr - (float)(rm - 1), 1.0f), fh = clampf(0.0f, hc - (float)(jc - 1), 1.0f);
+  int base = P_ENG_OFF + ((rm - 1) * 8 + (jc - 1)) * 4;
+  float4 e00 = T.v4(base), e01 = T.v4(base + 4), e10 = T.v4(base + 32), e11 = T.v4(base + 36);
+  float4 e = lerp4(lerp4(e00, e10, fm), lerp4(e01, e11, fm), fh);
+  idle_f = e.x; mil_f = e.y; aug_f = e.z;
 }
 
 // One executive tick. DT_ZERO = true reproduces the two "integration suspended" passes of FGFDMExec::RunIC
@@ -289,7 +332,7 @@ __device__ __forceinline__ void tick(State& s, Derived& d, const Tab& T) {
     s.ha1x = s.aix; s.ha1y = s.aiy; s.ha1z = s.aiz;
     s.ticks += 1;
   }
-  locate(s, d);
+  locate_fast(s, d);
   body_frame(s, d);
   const float* Tb = d.T;
 
@@ -319,19 +362,22 @@ __device__ __forceinline__ void tick(State& s, Derived& d, const Tab& T) {
   float roll_cmd = clampf(-1.0f, roll_pid + s.da, 1.0f);
   float aileron_rad = 0.375f * roll_cmd;
   s.ail = slew(s.ail, roll_cmd, -1.0f, 1.0f, 2.0f / 0.3f);
-  float ail_sc = s.ail * F16_T1(FCS_AILERON_SPEED_COMPENSATED, mach_p);
+  constexpr float kAilX[] = C_FCS_AILERON_SPEED_COMPENSATED_X, kAilY[] = C_FCS_AILERON_SPEED_COMPENSATED_Y;
+  float ail_sc = s.ail * tabc(kAilX, kAilY, mach_p);
   float flaperon_rad = 1.4324f * (clampf(-1.0f, -s.tef - ail_sc, 1.0f) + clampf(-1.0f, s.tef - ail_sc, 1.0f));
   // pitch: cos(theta)cos(phi) is the projection of body z on local down
   float cthcph = Tb[6] * d.d_eci[0] + Tb[7] * d.d_eci[1] + Tb[8] * d.d_eci[2];
   float elev_lim = clampf(-1.0f, s.de, 0.44f);
-  float elev_sched = elev_lim * F16_T1(FCS_ELEVATOR_SCHEDULER, alpha_p);
+  constexpr float kElX[] = C_FCS_ELEVATOR_SCHEDULER_X, kElY[] = C_FCS_ELEVATOR_SCHEDULER_Y;
+  float elev_sched = elev_lim * tabc(kElX, kElY, alpha_p);
   float pitch_err = elev_sched + 6.2f * s.aq - 0.020f * (s.npz - cthcph);
   float g_pid = clampf(-1.0f, pid(pitch_err, s.pin_p, s.pi_p, vckts_p < 5.0f, 0.3f, 0.025f, 0.0f), 1.0f);
   float pitch_sched = clampf(-1.0f, elev_sched + 1.0472f * alpha_p + g_pid, 1.0f);
   s.elev = slew(s.elev, pitch_sched, -1.0f, 1.0f, 2.0f / 0.3f);
   float elevator_rad = 0.436f * s.elev;
   // yaw: the PID writes fcs/rudder-pos-norm, the kinematic re-reads that property as its own output
-  float yaw_err = s.dr + s.ar * F16_T1(FCS_YAW_RATE_NORM, s.vg) + 0.25f * s.npy;
+  constexpr float kYwX[] = C_FCS_YAW_RATE_NORM_X, kYwY[] = C_FCS_YAW_RATE_NORM_Y;
+  float yaw_err = s.dr + s.ar * tabc(kYwX, kYwY, s.vg) + 0.25f * s.npy;
   float yaw_pid = clampf(-1.0f, pid(yaw_err, s.pin_y, s.pi_y, vckts_p < 10.0f, 0.1055f, 0.00001f, 0.00005f), 1.0f);
   float yaw_sched = clampf(-1.0f, s.dr + yaw_pid, 1.0f);
   float rudder_rad = 0.524f * slew(yaw_pid, yaw_sched, -1.0f, 1.0f, 2.0f / 0.4f);
@@ -391,17 +437,8 @@ __device__ __forceinline__ void tick(State& s, Derived& d, const Tab& T) {
   float npx = (s.bax + t1x + t2x) * (1.0f / kG0), npy = (s.bay + t1y + t2y) * (1.0f / kG0), npz = (s.baz + t1z + t2z) * (1.0f / kG0);
 
   // ---------------- Propulsion: F100-PW-229 turbine (FGTurbine.cpp:107-270,400-411), AugMethod 2
-  int im, jh; float fm, fh;
-  bracket<T_ENG_MILTHRUST_NR>(T, T_ENG_MILTHRUST_OFF, mach, im, fm);
-  // density altitude equals geometric altitude in the standard atmosphere the reference flies in
-  bracket<T_ENG_MILTHRUST_NC>(T, T_ENG_MILTHRUST_OFF + T_ENG_MILTHRUST_NR, d.h_sl_ft, jh, fh);
-  float mil_f = tab2i<T_ENG_MILTHRUST_NR, T_ENG_MILTHRUST_NC>(T, T_ENG_MILTHRUST_OFF, im, fm, jh, fh);
-  int ii; float fi;
-  bracket<T_ENG_IDLETHRUST_NR>(T, T_ENG_IDLETHRUST_OFF, mach, ii, fi);
-  float idle_f = tab2i<T_ENG_IDLETHRUST_NR, T_ENG_IDLETHRUST_NC>(T, T_ENG_IDLETHRUST_OFF, ii, fi, jh, fh);
-  int ig; float fg;
-  bracket<T_ENG_AUGTHRUST_NR>(T, T_ENG_AUGTHRUST_OFF, mach, ig, fg);
-  float aug_f = tab2i<T_ENG_AUGTHRUST_NR, T_ENG_AUGTHRUST_NC>(T, T_ENG_AUGTHRUST_OFF, ig, fg, jh, fh);
+  float mil_f, idle_f, aug_f;
+  engine_factors(T, mach, d.h_sl_ft, idle_f, mil_f, aug_f);
   float thrust;
   {
     const float MIL = (float)F16_ENG_MILTHRUST, MAXT = (float)F16_ENG_MAXTHRUST;
@@ -483,31 +520,52 @@ __device__ __forceinline__ void tick(State& s, Derived& d, const Tab& T) {
     float i2v = (vt != 0.0f) ? 0.5f / vt : 0.0f;
     float bi2vel = bw * i2v, ci2vel = cbar * i2v;
     float qS = qbar * Sw;
-    int ia; float fa;
-    bracket<12>(T, T_CDDLEF_OFF, alpha, ia, fa);            // the alpha axis every alpha table shares
-    int ide; float fde;
-    bracket<T_CDDH_NC>(T, T_CDDH_OFF + T_CDDH_NR, elevator_rad, ide, fde);
-    int ib13; float fb13;
-    bracket<T_CLB_NC>(T, T_CLB_OFF + T_CLB_NR, beta, ib13, fb13);
-    int ib7; float fb7;
-    bracket<T_CLDA_NC>(T, T_CLDA_OFF + T_CLDA_NR, beta, ib7, fb7);
-    // hoverbmac > 1.1 everywhere above the 2500 m floor, kCLge = 1 there; keep the table for low floors
-    // (h above the ellipsoid ~ h_sl to within the geoid-free model; the reference point offset is < 2 ft)
-    float kge = F16_T1(KCLGE, d.h_sl_ft * (1.0f / (float)F16_WINGSPAN));
+    // segment indices from immediates, then every LDS read of the tick in one batch
+    constexpr float kAX[] = C_ALPHA_X, kDX[] = C_DE_X, kB13X[] = C_B13_X, kB7X[] = C_B7_X, kMX[] = C_MACH_X;
+    const int ia = seg_index(kAX, alpha), ide = seg_index(kDX, elevator_rad), ib13 = seg_index(kB13X, beta),
+              ib7 = seg_index(kB7X, beta), im = seg_index(kMX, mach);
+    const float fa = seg_frac(T[P_ALPHA_X_OFF + ia - 1], T[P_ALPHA_X_OFF + ia], alpha);
+    const float fde = seg_frac(T[P_DE_X_OFF + ide - 1], T[P_DE_X_OFF + ide], elevator_rad);
+    const float fb13 = seg_frac(T[P_B13_X_OFF + ib13 - 1], T[P_B13_X_OFF + ib13], beta);
+    const float fb7 = seg_frac(T[P_B7_X_OFF + ib7 - 1], T[P_B7_X_OFF + ib7], beta);
+    const float fmach = seg_frac(T[P_MACH_X_OFF + im - 1], T[P_MACH_X_OFF + im], mach);
+    const int a1 = P_A1_OFF + (ia - 1) * P_A1_STRIDE;
+    float4 g0 = lerp4(T.v4(a1), T.v4(a1 + 16), fa);            // CDDlef CDq CDq_Dlef CLDlef
+    float4 g1 = lerp4(T.v4(a1 + 4), T.v4(a1 + 20), fa);        // CYp CYr Clp Clr
+    float4 g2 = lerp4(T.v4(a1 + 8), T.v4(a1 + 24), fa);        // CLq Cmq Cnp Cnr
+    float4 g3 = make_float4(0.f, 0.f, 0.f, 0.f);               // CDDsb CLDsb CLq_Dsb CmDsb: only with the speedbrake out
+    if (sb_rad != 0.0f) g3 = lerp4(T.v4(a1 + 12), T.v4(a1 + 28), fa);
+    const int ae = P_AE_OFF + ((ia - 1) * 5 + (ide - 1)) * 4;
+    float4 ge = lerp4(lerp4(T.v4(ae), T.v4(ae + 20), fa), lerp4(T.v4(ae + 4), T.v4(ae + 24), fa), fde);      // CDDh CLDh CmDh
+    const int ab13 = P_AB13_OFF + ((ia - 1) * 13 + (ib13 - 1)) * 2;
+    float2 h00 = T.v2(ab13), h01 = T.v2(ab13 + 2), h10 = T.v2(ab13 + 26), h11 = T.v2(ab13 + 28);
+    float clb = lerpf(lerpf(h00.x, h10.x, fa), lerpf(h01.x, h11.x, fa), fb13);
+    float cnb = lerpf(lerpf(h00.y, h10.y, fa), lerpf(h01.y, h11.y, fa), fb13);
+    const int ab7 = P_AB7_OFF + ((ia - 1) * 7 + (ib7 - 1)) * 4;
+    float4 g7 = lerp4(lerp4(T.v4(ab7), T.v4(ab7 + 28), fa), lerp4(T.v4(ab7 + 4), T.v4(ab7 + 32), fa), fb7);  // Clda Cldr Cnda Cndr
+    const int am = P_M_OFF + (im - 1) * P_M_STRIDE;
+    float4 m0 = lerp4(T.v4(am), T.v4(am + 12), fmach);         // CDmach CYb_M Clb_M Clda_M
+    float4 m1 = lerp4(T.v4(am + 4), T.v4(am + 16), fmach);     // Cldr_M Cma_M Cnb_M Cnda_M
+    float cndr_m = lerpf(T[am + 8], T[am + 20], fmach);        // Cndr_M
+    // hoverbmac > 1.1 everywhere above the 2500 m floor, kCLge = 1 there; the table only matters for very low floors
+    // (altitude above the sea-level radius stands in for AGL; the reference-point offset is < 2 ft)
+    float hb = d.h_sl_ft * (1.0f / (float)F16_WINGSPAN);
+    float kge = 1.0f;
+    if (hb < 1.1f) {
+      constexpr float kGX[] = {0.0f, 0.1f, 0.15f, 0.2f, 0.3f, 0.4f, 0.5f, 0.6f, 0.7f, 0.8f, 0.9f, 1.0f, 1.1f};
+      int ig = seg_index(kGX, hb);
+      kge = lerpf(T[P_KCLGE_Y_OFF + ig - 1], T[P_KCLGE_Y_OFF + ig], seg_frac(T[P_KCLGE_X_OFF + ig - 1], T[P_KCLGE_X_OFF + ig], hb));
+    }
     float p = d.p, q = d.q, r = d.r;
-    float CD = F16_T2(CDDH, ide, fde) + F16_T1(CDMACH, mach) + lef_rad * F16_T1A(CDDLEF) + flaperon_rad * (float)F16_K_CDDFLAPS +
-               (float)F16_K_CDGEAR + sb_rad * F16_T1A(CDDSB) + q * ci2vel * (F16_T1A(CDQ) + lef_rad * F16_T1A(CDQ_DLEF));
-    float CY = beta * ((float)F16_K_CYB + F16_T1(CYB_M, mach)) + aileron_rad * (float)F16_K_CYDA + rudder_rad * (float)F16_K_CYDR +
-               bi2vel * (p * F16_T1A(CYP) + r * F16_T1A(CYR));
-    float CL = kge * (F16_T2(CLDH, ide, fde) + lef_rad * F16_T1A(CLDLEF) + flaperon_rad * (float)F16_K_CLDFLAPS + sb_rad * F16_T1A(CLDSB) +
-                      q * ci2vel * F16_T1A(CLQ)) + q * ci2vel * sb_rad * F16_T1A(CLQ_DSB);
-    float Cl = F16_T2(CLB, ib13, fb13) + beta * F16_T1(CLB_M, mach) + bi2vel * (p * F16_T1A(CLP) + r * F16_T1A(CLR)) +
-               aileron_rad * (F16_T2(CLDA, ib7, fb7) + alpha * F16_T1(CLDA_M, mach)) +
-               rudder_rad * (F16_T2(CLDR, ib7, fb7) + alpha * F16_T1(CLDR_M, mach));
-    float Cm = F16_T2(CMDH, ide, fde) + alpha * F16_T1(CMA_M, mach) + sb_rad * F16_T1A(CMDSB) + ci2vel * q * F16_T1A(CMQ);
-    float Cn = F16_T2(CNB, ib13, fb13) + beta * F16_T1(CNB_M, mach) + bi2vel * (p * F16_T1A(CNP) + r * F16_T1A(CNR)) +
-               aileron_rad * (F16_T1(CNDA_M, mach) + F16_T2(CNDA, ib7, fb7)) +
-               rudder_rad * (F16_T2(CNDR, ib7, fb7) + alpha * F16_T1(CNDR_M, mach));
+    float qc = q * ci2vel;
+    float CD = ge.x + m0.x + lef_rad * g0.x + flaperon_rad * (float)F16_K_CDDFLAPS + (float)F16_K_CDGEAR + sb_rad * g3.x +
+               qc * (g0.y + lef_rad * g0.z);
+    float CY = beta * ((float)F16_K_CYB + m0.y) + aileron_rad * (float)F16_K_CYDA + rudder_rad * (float)F16_K_CYDR +
+               bi2vel * (p * g1.x + r * g1.y);
+    float CL = kge * (ge.y + lef_rad * g0.w + flaperon_rad * (float)F16_K_CLDFLAPS + sb_rad * g3.y + qc * g2.x) + qc * sb_rad * g3.z;
+    float Cl = clb + beta * m0.z + bi2vel * (p * g1.z + r * g1.w) + aileron_rad * (g7.x + alpha * m0.w) + rudder_rad * (g7.y + alpha * m1.x);
+    float Cm = ge.z + alpha * m1.y + sb_rad * g3.w + qc * g2.y;
+    float Cn = cnb + beta * m1.z + bi2vel * (p * g2.z + r * g2.w) + aileron_rad * (m1.w + g7.z) + rudder_rad * (g7.w + alpha * cndr_m);
     float D = qS * CD, Y = qS * CY, L = qS * CL;
     // wind -> body: F = Tw2b * (-D, Y, -L)
     Fx = ca * cb * (-D) - ca * sb * Y + sa * L;

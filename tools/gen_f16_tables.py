@@ -142,6 +142,107 @@ def main():
         lines.append("  " + ", ".join("%r" % v for v in blob[i:i + 8]) + ",")
     lines.append("};")
     lines.append("")
+
+    # ------------------------------------------------------------------ packed layout for the HIP kernel
+    # Tables that share their breakpoint axes are interleaved so that one wavefront lane fetches every value it
+    # needs at a breakpoint with one 16-byte LDS read (ds_read_b128) instead of one 4-byte read per table:
+    #   PA1  [12 alpha][16]      : 16 one-dimensional alpha tables in four groups of four
+    #   PAE  [12 alpha][5 de][4] : CDDh, CLDh, CmDh, pad            (alpha x elevator)
+    #   PAB13[12 alpha][13 b][2] : Clb, Cnb                          (alpha x beta, 5-degree grid)
+    #   PAB7 [12 alpha][7 b][4]  : Clda, Cldr, Cnda, Cndr            (alpha x beta, 10-degree grid)
+    #   PM   [NM mach][12]       : the nine Mach tables resampled on the union of their breakpoints (a piecewise-linear
+    #                              function with clamped ends is exactly representable on any finer grid)
+    #   PENG [14 mach][8 alt][4] : idle, mil, aug thrust factors, pad (rows beyond a table's last Mach repeat it: clamp)
+    T = {name: t for name, t, _ in tables}
+
+    def t1(name):
+        t = T[name]
+        return t["data"][:t["nr"]], t["data"][t["nr"]:]
+
+    def t2(name):
+        t = T[name]
+        nr, nc = t["nr"], t["nc"]
+        return t["data"][:nr], t["data"][nr:nr + nc], [t["data"][nr + nc + r * nc:nr + nc + (r + 1) * nc] for r in range(nr)]
+
+    def interp_clamped(x, y, key):
+        if key <= x[0]:
+            return y[0]
+        if key >= x[-1]:
+            return y[-1]
+        for i in range(1, len(x)):
+            if key <= x[i]:
+                f = (key - x[i - 1]) / (x[i] - x[i - 1])
+                return y[i - 1] + f * (y[i] - y[i - 1])
+
+    alpha_axis = t1("CDDLEF")[0]
+    groups1 = ["CDDLEF", "CDQ", "CDQ_DLEF", "CLDLEF", "CYP", "CYR", "CLP", "CLR", "CLQ", "CMQ", "CNP", "CNR",
+               "CDDSB", "CLDSB", "CLQ_DSB", "CMDSB"]
+    for g in groups1:
+        assert t1(g)[0] == alpha_axis, g
+    pack = []
+    offs = {}
+
+    def put(name, vals):
+        while len(pack) % 4:
+            pack.append(0.0)
+        offs[name] = len(pack)
+        pack.extend(vals)
+
+    put("ALPHA_X", alpha_axis)
+    de_axis = t2("CDDH")[1]
+    b13_axis = t2("CLB")[1]
+    b7_axis = t2("CLDA")[1]
+    put("DE_X", de_axis)
+    put("B13_X", b13_axis)
+    put("B7_X", b7_axis)
+    put("A1", [t1(g)[1][r] for r in range(12) for g in groups1])
+    for nm in ("CDDH", "CLDH", "CMDH"):
+        assert t2(nm)[0] == alpha_axis and t2(nm)[1] == de_axis
+    put("AE", [v for r in range(12) for c in range(5) for v in (t2("CDDH")[2][r][c], t2("CLDH")[2][r][c], t2("CMDH")[2][r][c], 0.0)])
+    for nm in ("CLB", "CNB"):
+        assert t2(nm)[0] == alpha_axis and t2(nm)[1] == b13_axis
+    put("AB13", [v for r in range(12) for c in range(13) for v in (t2("CLB")[2][r][c], t2("CNB")[2][r][c])])
+    for nm in ("CLDA", "CLDR", "CNDA", "CNDR"):
+        assert t2(nm)[0] == alpha_axis and t2(nm)[1] == b7_axis
+    put("AB7", [v for r in range(12) for c in range(7) for v in (t2("CLDA")[2][r][c], t2("CLDR")[2][r][c], t2("CNDA")[2][r][c], t2("CNDR")[2][r][c])])
+    mach_tabs = ["CDMACH", "CYB_M", "CLB_M", "CLDA_M", "CLDR_M", "CMA_M", "CNB_M", "CNDA_M", "CNDR_M"]
+    mach_axis = sorted(set(x for m in mach_tabs for x in t1(m)[0]))
+    put("MACH_X", mach_axis)
+    put("M", [v for xm in mach_axis for v in ([interp_clamped(*t1(m), xm) for m in mach_tabs] + [0.0, 0.0, 0.0])])
+    eng = {k: t2(k) for k in ("ENG_IDLETHRUST", "ENG_MILTHRUST", "ENG_AUGTHRUST")}
+    alt_axis = eng["ENG_MILTHRUST"][1]
+    assert all(e[1] == alt_axis for e in eng.values())
+    assert alt_axis == [-10000.0 + 10000.0 * i for i in range(8)]
+    eng_rows = 14
+    for k, (rk, ck, vv) in eng.items():
+        assert all(abs(rk[i] - 0.2 * i) < 1e-12 for i in range(len(rk))), k
+    put("ENG", [v for r in range(eng_rows) for c in range(8) for v in (
+        eng["ENG_IDLETHRUST"][2][min(r, 5)][c], eng["ENG_MILTHRUST"][2][min(r, 7)][c], eng["ENG_AUGTHRUST"][2][min(r, 13)][c], 0.0)])
+    put("KCLGE_X", t1("KCLGE")[0])
+    put("KCLGE_Y", t1("KCLGE")[1])
+    while len(pack) % 4:
+        pack.append(0.0)
+    lines.append("/* ---- packed, axis-interleaved layout staged in LDS by the HIP kernel (see tools/gen_f16_tables.py) */")
+    for k, v in offs.items():
+        lines.append("#define P_%s_OFF %d" % (k, v))
+    lines.append("#define P_MACH_N %d" % len(mach_axis))
+    lines.append("#define P_A1_STRIDE 16")
+    lines.append("#define P_M_STRIDE 12")
+    lines.append("#define F16_PACK_LEN %d" % len(pack))
+    lines.append("static const double F16_PACK[F16_PACK_LEN] = {")
+    for i in range(0, len(pack), 8):
+        lines.append("  " + ", ".join("%r" % v for v in pack[i:i + 8]) + ",")
+    lines.append("};")
+    # small FCS schedules as compile-time constants (looked up with compare/select chains, no memory access)
+    for nm in ("FCS_AILERON_SPEED_COMPENSATED", "FCS_ELEVATOR_SCHEDULER", "FCS_YAW_RATE_NORM"):
+        x, y = t1(nm)
+        lines.append("#define C_%s_N %d" % (nm, len(x)))
+        lines.append("#define C_%s_X {%s}" % (nm, ", ".join("%rf" % v for v in x)))
+        lines.append("#define C_%s_Y {%s}" % (nm, ", ".join("%rf" % v for v in y)))
+    for nm, ax in (("ALPHA", alpha_axis), ("DE", de_axis), ("B13", b13_axis), ("B7", b7_axis), ("MACH", mach_axis)):
+        lines.append("#define C_%s_N %d" % (nm, len(ax)))
+        lines.append("#define C_%s_X {%s}" % (nm, ", ".join("%rf" % v for v in ax)))
+    lines.append("")
     lines.append("#endif /* F16_TABLES_H */")
     text = "\n".join(lines) + "\n"
     for o in OUTS:
