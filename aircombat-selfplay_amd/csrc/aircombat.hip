@@ -29,7 +29,7 @@ using f16::clampf;
   X(vx) X(vy) X(vz) X(q0) X(q1) X(q2) X(q3) X(wp) X(wq) X(wr) X(hv1x) X(hv1y) X(hv1z) X(hv2x) X(hv2y) X(hv2z)   \
   X(ha1x) X(ha1y) X(ha1z) X(wdx) X(wdy) X(wdz) X(aix) X(aiy) X(aiz) X(bax) X(bay) X(baz) X(da) X(de) X(dr)       \
   X(thr) X(pin_r) X(pin_p) X(pin_y) X(pi_r) X(pi_p) X(pi_y) X(tef) X(ail) X(elev) X(sbdeg) X(alpha) X(mach)      \
-  X(vckts) X(vg) X(ap) X(aq) X(ar) X(npx) X(npy) X(npz) X(n1) X(n2) X(n2norm) X(ff) X(tank0) X(tank1)
+  X(qc) X(vg) X(ap) X(aq) X(ar) X(npx) X(npy) X(npz) X(n1) X(n2) X(n2norm) X(ff) X(tank0) X(tank1)
 #define AC_TF_FIELDS(X) X(bloods) X(pre_posture) X(pre_altitude) X(pre_event) X(pre_shoot)
 #define AC_TI_FIELDS(X)                                                                                  \
   X(status) X(die_flag) X(remaining) X(pre_remaining) X(shoot_action) X(last_missile) X(last_shoot_time) \
@@ -161,7 +161,7 @@ __device__ __forceinline__ void make_props(const State& s, const Derived& d, con
   p.alt_m = clampf(-500.0f, d.h_sl_ft * f16::kFt2M, 26000.0f);
   p.vn = mps(d.vn); p.ve = mps(d.ve); p.vd = mps(d.vd);
   p.ub = mps(d.u); p.vb = mps(d.v); p.wb = mps(d.w);
-  p.vc = clampf(0.0f, s.vckts * f16::kKts2Fps * f16::kFt2M, 1400.0f);
+  p.vc = clampf(0.0f, f16::vcas_from_impact_pressure(s.qc) * f16::kFt2M, 1400.0f);
   // LLA2NEU(lon, lat_geod, h_sl_m): the reference feeds the sea-level altitude to pymap3d.geodetic2ned as if it
   // were ellipsoidal height (simulatior.py:240-245, utils.py:30-41). fp64: differences of 6.4e6 m ECEF coordinates.
   const double a = 6378137.0, b = 6356752.314245179;  // pymap3d WGS84: a, a*(1-1/298.257223563)
@@ -300,6 +300,26 @@ __device__ __forceinline__ void missile_run(Msl& m, const MslParam& P, float tx,
   }
 }
 
+// Stage the 7 KB table pack into LDS: every lane issues all of its 16-byte global loads before the first LDS store, so
+// the workgroup pays one L2 round trip instead of one per loop iteration.
+__device__ __forceinline__ void stage_tables(float* lds, const float* __restrict__ g) {
+  constexpr int NV = F16_PACK_LEN / 4;               // float4 count (the pack is padded to a multiple of 4)
+  constexpr int PER = (NV + 63) / 64;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4 v[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    int i = threadIdx.x + k * 64;
+    v[k] = (i < NV) ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    int i = threadIdx.x + k * 64;
+    if (i < NV) reinterpret_cast<float4*>(lds)[i] = v[k];
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------ 1v1 observation
 // singlecombat_task.py:88-139 (15 values, 2-D AO/TA, clipped to +-10) and
 // singlecombat_with_missile_task.py:31-99 (21 values, 3-D AO/TA, unclipped, missile-warning block).
@@ -355,15 +375,17 @@ struct TaskTraits {
 
 // ------------------------------------------------------------------------------------------------ the step kernel
 // One lane per aircraft, the two aircraft of a 1v1 env in lanes (2k, 2k+1).
-template <int TASK>
-__global__ __launch_bounds__(64) void step_kernel_1v1(DevPtrs P, DevCfg c) {
+// Occupancy: WPE = waves per SIMD the register allocation is bounded for. WPE = 2 (256 VGPRs, 12 dwords of scratch) lets two
+// waves share a SIMD and fill its 2-cycle issue rate: +38 % throughput once there are more waves than SIMDs. WPE = 1 keeps
+// everything in registers (269 incl. accumulation VGPRs): 5 % less latency when each SIMD has at most one wave (E*A <= 65536).
+template <int TASK, int WPE>
+__global__ __launch_bounds__(64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) {
   using TT = TaskTraits<TASK>;
   constexpr bool HAS_MSL = TT::HAS_MSL;
   constexpr int MSLOTS = TT::MSLOTS;
   constexpr int OBS = TT::OBS;
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
-  for (int i = threadIdx.x; i < F16_PACK_LEN; i += blockDim.x) lds_tab[i] = P.tab[i];
-  __syncthreads();
+  stage_tables(lds_tab, P.tab);
   const Tab T{lds_tab};
   const int N = c.N;
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -650,8 +672,7 @@ __global__ void init_kernel_1v1(InitArgs ia, DevCfg c, const float* tab, float* 
   using TT = TaskTraits<TASK>;
   constexpr int OBS = TT::OBS;
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
-  for (int i = threadIdx.x; i < F16_PACK_LEN; i += blockDim.x) lds_tab[i] = tab[i];
-  __syncthreads();
+  stage_tables(lds_tab, tab);
   const Tab T{lds_tab};
   const int slot = threadIdx.x & 1;
   State s; Derived d; Task t{}; Props pr;
@@ -730,8 +751,14 @@ static int launch_step(ac_env* h, const float* d_actions) {
   DevPtrs p = h->dp;
   p.actions = d_actions ? d_actions : h->d_actions;
   dim3 block(64), grid((h->N + 63) / 64);
-  if (h->cfg.task == AC_TASK_SINGLECOMBAT) hipLaunchKernelGGL(step_kernel_1v1<AC_TASK_SINGLECOMBAT>, grid, block, 0, h->stream, p, h->dc);
-  else hipLaunchKernelGGL(step_kernel_1v1<AC_TASK_SHOOT_MISSILE>, grid, block, 0, h->stream, p, h->dc);
+  const bool one_wave_per_simd = grid.x <= 1024;  // 256 CUs x 4 SIMDs
+  if (h->cfg.task == AC_TASK_SINGLECOMBAT) {
+    if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 1>), grid, block, 0, h->stream, p, h->dc);
+    else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 2>), grid, block, 0, h->stream, p, h->dc);
+  } else {
+    if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 1>), grid, block, 0, h->stream, p, h->dc);
+    else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 2>), grid, block, 0, h->stream, p, h->dc);
+  }
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -56,7 +56,7 @@ struct State {
   float pin_r, pin_p, pin_y;               // PID previous inputs
   float pi_r, pi_p, pi_y;                  // PID integrator totals
   float tef, ail, elev, sbdeg;             // kinematic (rate-limited) outputs
-  float alpha, mach, vckts, vg;            // FGAuxiliary outputs of the last tick (the FCS runs before it)
+  float alpha, mach, qc, vg;               // FGAuxiliary outputs of the last tick (the FCS runs before it); qc = pitot impact pressure [psf]
   float ap, aq, ar;                        // aero body rates of the last tick
   float npx, npy, npz;                     // pilot-station load factors of the last tick
   float n1, n2, n2norm, ff;                // turbine
@@ -73,7 +73,6 @@ struct Derived {
   float vn, ve, vd;                        // local NED velocity [ft/s]
   float n_eci[3], e_eci[3], d_eci[3];      // local north / east / down unit vectors in ECI
   float T[9];                              // ECI -> body
-  float vc_fps;                            // calibrated airspeed [ft/s]
   float veci;                              // |v_eci|
   double X, Y, Z;                          // ECEF position [ft]
   double sLat64, cLat64, sLon64, cLon64;   // fp64 copies for the geodetic -> NED reduction of the env layer
@@ -147,19 +146,27 @@ __device__ __forceinline__ Atmos atmosphere(float h_ft) {
   return A;
 }
 
-// Calibrated airspeed from Mach (data/src/FGJSBBase.cpp:245-296): pitot total pressure, then the sea-level inverse.
-__device__ __forceinline__ float vcas_from_mach(float mach, float p) {
-  const float psl = 2116.228f, asl = 1116.448558f;  // sqrt(1.4 * R * 518.67)
+// Calibrated airspeed (data/src/FGJSBBase.cpp:245-296) = sea-level speed whose pitot impact pressure equals the measured
+// one. The impact pressure qc = pt - p is cheap (one pow) and is what the per-tick code carries: the FCS only compares the
+// calibrated airspeed against fixed thresholds, and vc is monotonic in qc, so "vc-kts lt V" <=> "qc < qc_sl(V)". The inverse
+// (with its 10-step supersonic fixed point) runs once per env step when the observation needs vc itself.
+__device__ __forceinline__ float pitot_impact_pressure(float mach, float p) {
   float pt;
   if (mach < 1.0f) pt = p * __powf(1.0f + 0.2f * mach * mach, 3.5f);
   else pt = p * 166.92158009316827f * __powf(mach, 7.0f) / __powf(7.0f * mach * mach - 1.0f, 2.5f);
-  float A = (pt - p) / psl + 1.0f;
-  float M = sqrtf(5.0f * (__powf(A, 1.0f / 3.5f) - 1.0f));
+  return pt - p;
+}
+__device__ __forceinline__ float vcas_from_impact_pressure(float qc) {
+  const float psl = 2116.228f, asl = 1116.448558f;  // sqrt(1.4 * R * 518.67)
+  float A = qc / psl + 1.0f;
+  float M = sqrtf(fmaxf(0.0f, 5.0f * (__powf(A, 1.0f / 3.5f) - 1.0f)));
   if (M > 1.0f) {
     for (int i = 0; i < 10; ++i) M = 0.8812848543473311f * sqrtf(A * __powf(1.0f - 1.0f / (7.0f * M * M), 2.5f));
   }
   return asl * M;
 }
+// sea-level impact pressures of the FCS airspeed thresholds: psl * ((1 + 0.2 (V kts / asl)^2)^3.5 - 1)
+constexpr float kQc250 = 219.261788f, kQc20 = 1.35453246f, kQc10 = 0.338575078f, kQc5 = 0.0846401425f;
 
 // Rate limiter through two detents at [-lim.., lim] (FGKinemat.cpp:99-170 specialised to a single segment).
 __device__ __forceinline__ float slew(float out, float in, float lo, float hi, float rate) {
@@ -352,13 +359,13 @@ __device__ __forceinline__ void tick(State& s, Derived& d, const Tab& T) {
   Atmos A = atmosphere(d.h_sl_ft);
 
   // ---------------- FCS (f16.xml:317-992; inputs from FGAuxiliary are last tick's)
-  const float alpha_p = s.alpha, mach_p = s.mach, vckts_p = s.vckts;
+  const float alpha_p = s.alpha, mach_p = s.mach, qc_p = s.qc;
   // flaps
-  float tef_rad = (vckts_p < 250.0f) ? 0.349f : ((mach_p > 0.9f) ? -0.0349f : 0.0f);
+  float tef_rad = (qc_p < kQc250) ? 0.349f : ((mach_p > 0.9f) ? -0.0349f : 0.0f);
   s.tef = tef_kinematic(s.tef, 2.864789f * tef_rad);
   // roll
   float roll_err = s.da - 0.31821f * s.ap;
-  float roll_pid = pid(roll_err, s.pin_r, s.pi_r, vckts_p < 20.0f, 3.0f, 0.0005f, -0.00125f);
+  float roll_pid = pid(roll_err, s.pin_r, s.pi_r, qc_p < kQc20, 3.0f, 0.0005f, -0.00125f);
   float roll_cmd = clampf(-1.0f, roll_pid + s.da, 1.0f);
   float aileron_rad = 0.375f * roll_cmd;
   s.ail = slew(s.ail, roll_cmd, -1.0f, 1.0f, 2.0f / 0.3f);
@@ -371,14 +378,14 @@ __device__ __forceinline__ void tick(State& s, Derived& d, const Tab& T) {
   constexpr float kElX[] = C_FCS_ELEVATOR_SCHEDULER_X, kElY[] = C_FCS_ELEVATOR_SCHEDULER_Y;
   float elev_sched = elev_lim * tabc(kElX, kElY, alpha_p);
   float pitch_err = elev_sched + 6.2f * s.aq - 0.020f * (s.npz - cthcph);
-  float g_pid = clampf(-1.0f, pid(pitch_err, s.pin_p, s.pi_p, vckts_p < 5.0f, 0.3f, 0.025f, 0.0f), 1.0f);
+  float g_pid = clampf(-1.0f, pid(pitch_err, s.pin_p, s.pi_p, qc_p < kQc5, 0.3f, 0.025f, 0.0f), 1.0f);
   float pitch_sched = clampf(-1.0f, elev_sched + 1.0472f * alpha_p + g_pid, 1.0f);
   s.elev = slew(s.elev, pitch_sched, -1.0f, 1.0f, 2.0f / 0.3f);
   float elevator_rad = 0.436f * s.elev;
   // yaw: the PID writes fcs/rudder-pos-norm, the kinematic re-reads that property as its own output
   constexpr float kYwX[] = C_FCS_YAW_RATE_NORM_X, kYwY[] = C_FCS_YAW_RATE_NORM_Y;
   float yaw_err = s.dr + s.ar * tabc(kYwX, kYwY, s.vg) + 0.25f * s.npy;
-  float yaw_pid = clampf(-1.0f, pid(yaw_err, s.pin_y, s.pi_y, vckts_p < 10.0f, 0.1055f, 0.00001f, 0.00005f), 1.0f);
+  float yaw_pid = clampf(-1.0f, pid(yaw_err, s.pin_y, s.pi_y, qc_p < kQc10, 0.1055f, 0.00001f, 0.00005f), 1.0f);
   float yaw_sched = clampf(-1.0f, s.dr + yaw_pid, 1.0f);
   float rudder_rad = 0.524f * slew(yaw_pid, yaw_sched, -1.0f, 1.0f, 2.0f / 0.4f);
   // gear stays down (FGFCS.cpp:81, never commanded): gear-pos-norm = 1, gear-wow = 0
@@ -427,8 +434,7 @@ __device__ __forceinline__ void tick(State& s, Derived& d, const Tab& T) {
   float qbar = 0.5f * A.rho * vt2;
   float mach = vt / A.a;
   float vg = sqrtf(d.vn * d.vn + d.ve * d.ve);
-  float vc = (mach > 0.0f) ? vcas_from_mach(mach, A.P) : 0.0f;
-  d.vc_fps = vc;
+  float qc = (mach > 0.0f) ? pitot_impact_pressure(mach, A.P) : 0.0f;
   // pilot-station load factors from LAST tick's accelerations and the inertial rates (:205-217)
   float ex = kInch2Ft * (cgx - (float)F16_EYEPOINT_X), ey = kInch2Ft * ((float)F16_EYEPOINT_Y - cgy), ez = kInch2Ft * (cgz - (float)F16_EYEPOINT_Z);
   float t1x = s.wdy * ez - s.wdz * ey, t1y = s.wdz * ex - s.wdx * ez, t1z = s.wdx * ey - s.wdy * ex;
@@ -602,7 +608,7 @@ __device__ __forceinline__ void tick(State& s, Derived& d, const Tab& T) {
     s.aiz = Tb[2] * s.bax + Tb[5] * s.bay + Tb[8] * s.baz + gz;
   }
   // publish this tick's auxiliary outputs for the next tick's FCS
-  s.alpha = alpha; s.mach = mach; s.vckts = vc * (1.0f / kKts2Fps); s.vg = vg;
+  s.alpha = alpha; s.mach = mach; s.qc = qc; s.vg = vg;
   s.ap = d.p; s.aq = d.q; s.ar = d.r;
   s.npx = npx; s.npy = npy; s.npz = npz;
 }

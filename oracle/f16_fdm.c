@@ -173,6 +173,8 @@ static double mach_from_impact_pressure(double qc, double p) {
     for (int i = 0; i < 10; i++) M = 0.8812848543473311 * sqrt(A * pow(1 - 1.0 / (7.0 * M * M), 2.5));
   return M;
 }
+double f16_pitot_qc(double mach, double p) { return pitot_total_pressure(mach, p) - p; }
+double f16_vcas_from_qc(double qc) { return sqrt(1.4 * atm_reng() * 518.67) * mach_from_impact_pressure(qc, ATM_SLP); }
 double f16_vcas_from_mach(double mach, double p) {
   double asl = sqrt(1.4 * atm_reng() * 518.67);
   double qc = pitot_total_pressure(mach, p) - p;

@@ -89,6 +89,8 @@ double f16_tab1(int off, int nr, double key);
 double f16_tab2(int off, int nr, int nc, double rkey, double ckey);
 void f16_atmosphere(double h_ft, double* T, double* P, double* rho, double* snd, double* dens_alt);
 double f16_vcas_from_mach(double mach, double p);
+double f16_pitot_qc(double mach, double p);   /* impact pressure pt - p */
+double f16_vcas_from_qc(double qc);
 void f16_geodetic_from_ecef(const double r[3], double* lon, double* lat_gc, double* lat_geod, double* h_geod, double* radius);
 double f16_kinemat(double out, double in, const double* detents, const double* times, int n, double dt);
 

@@ -29,7 +29,7 @@ int or_state_export(const OrEnv* e, int i, double* out, int n) {
   v[k++] = s->pid_roll.in_prev; v[k++] = s->pid_pitch.in_prev; v[k++] = s->pid_yaw.in_prev;
   v[k++] = s->pid_roll.i_total; v[k++] = s->pid_pitch.i_total; v[k++] = s->pid_yaw.i_total;
   v[k++] = s->tef_control; v[k++] = s->left_aileron_pos_norm; v[k++] = s->elevator_pos_norm; v[k++] = s->speedbrake_pos_deg;
-  v[k++] = s->alpha; v[k++] = s->mach; v[k++] = s->vc_fps / KTSTOFPS; v[k++] = s->vg;
+  v[k++] = s->alpha; v[k++] = s->mach; v[k++] = (fabs(s->mach) > 0.0) ? f16_pitot_qc(s->mach, s->P) : 0.0; v[k++] = s->vg;
   for (int j = 0; j < 3; j++) v[k++] = s->aero_pqr[j];
   for (int j = 0; j < 3; j++) v[k++] = s->npilot[j];
   v[k++] = s->n1; v[k++] = s->n2; v[k++] = s->n2norm; v[k++] = s->fuelflow_pph;
@@ -65,7 +65,7 @@ int or_state_import(OrEnv* e, int i, const double* v) {
   s->pid_roll.in_prev = v[k++]; s->pid_pitch.in_prev = v[k++]; s->pid_yaw.in_prev = v[k++];
   s->pid_roll.i_total = v[k++]; s->pid_pitch.i_total = v[k++]; s->pid_yaw.i_total = v[k++];
   s->tef_control = v[k++]; s->left_aileron_pos_norm = v[k++]; s->elevator_pos_norm = v[k++]; s->speedbrake_pos_deg = v[k++];
-  s->alpha = v[k++]; s->mach = v[k++]; s->vc_fps = v[k++] * KTSTOFPS; s->vg = v[k++];
+  s->alpha = v[k++]; s->mach = v[k++]; s->vc_fps = f16_vcas_from_qc(v[k++]); s->vg = v[k++];
   for (int j = 0; j < 3; j++) s->aero_pqr[j] = v[k++];
   for (int j = 0; j < 3; j++) s->npilot[j] = v[k++];
   s->n1 = v[k++]; s->n2 = v[k++]; s->n2norm = v[k++]; s->fuelflow_pph = v[k++];
