@@ -10,7 +10,7 @@ AC_MAX_AGENTS = 8
 AC_MAX_MISSILES_PER_AGENT = 4
 AC_STATE_LEN = 80
 
-AC_TASK_HEADING, AC_TASK_SINGLECOMBAT, AC_TASK_DODGE_MISSILE, AC_TASK_SHOOT_MISSILE = 0, 1, 2, 3
+AC_TASK_HEADING, AC_TASK_SINGLECOMBAT, AC_TASK_DODGE_MISSILE, AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT = 0, 1, 2, 3, 4
 AC_ALIVE, AC_CRASH, AC_SHOTDOWN = 0, 1, 2
 
 

@@ -580,6 +580,172 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ NvN (MultipleCombat)
+// MultipleCombatEnv.step (envs/JSBSim/envs/multiplecombat_env.py:119-182) with MultipleCombatTask
+// (envs/JSBSim/tasks/multiplecombat_task.py:15-151): the A aircraft of an env sit in A adjacent lanes (ego team first),
+// every pairwise quantity is fetched from the owning lane with __shfl. Differences from the 1v1 family reproduced here:
+// rewards are computed BEFORE terminations and only while alive, each agent receives its team's mean reward, the
+// termination order is SafeReturn, ExtremeState, Overload, LowAltitude, Timeout, and observations list partners then enemies.
+__device__ __forceinline__ Enemy gather_pose(const Props& pr, int lane) {
+  Enemy E;
+  E.n = __shfl(pr.n, lane); E.e = __shfl(pr.e, lane); E.u = __shfl(pr.u, lane);
+  E.vn = __shfl(pr.vn, lane); E.ve = __shfl(pr.ve, lane); E.vd = __shfl(pr.vd, lane);
+  E.ub = __shfl(pr.ub, lane); E.alt = __shfl(pr.alt_m, lane);
+  return E;
+}
+// observation (9 + 6*(A-1), clipped) and the raw posture reward (sum over enemies) in one pass over the other aircraft
+template <int A>
+__device__ __forceinline__ float observe_nvn(const Props& pr, int slot, int base_lane, int n_ego, float* ob) {
+  constexpr int OBS = 9 + 6 * (A - 1);
+  ob[0] = pr.alt_m / 5000.0f;
+  ob[1] = pr.sphi; ob[2] = pr.cphi; ob[3] = pr.stht; ob[4] = pr.ctht;
+  ob[5] = pr.ub / 340.0f; ob[6] = pr.vb / 340.0f; ob[7] = pr.wb / 340.0f; ob[8] = pr.vc / 340.0f;
+  const int my_team = slot < n_ego ? 0 : 1;
+  // position of aircraft j in my observation: partners (same team, in env order, skipping me) first, then enemies
+  const int n_mine = my_team == 0 ? n_ego : A - n_ego;
+  float posture = 0.0f;
+#pragma unroll
+  for (int j = 0; j < A; ++j) {
+    Enemy E = gather_pose(pr, base_lane + j);   // every lane takes part in the shuffle
+    const int team_j = j < n_ego ? 0 : 1;
+    if (j == slot) continue;
+    Geo g = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd);
+    int idx;
+    if (team_j == my_team) {
+      int first = my_team == 0 ? 0 : n_ego;
+      idx = (j - first) - (j > slot ? 1 : 0);
+    } else {
+      int first = my_team == 0 ? n_ego : 0;
+      idx = (n_mine - 1) + (j - first);
+      posture += posture_fn(g.AO, g.TA, g.R * 0.001f);
+    }
+    const float v[6] = {(E.ub - pr.ub) / 340.0f, (E.alt - pr.alt_m) / 1000.0f, g.AO, g.TA, g.R / 10000.0f, g.side};
+#pragma unroll
+    for (int q = 0; q < A - 1; ++q)
+      if (q == idx) {
+#pragma unroll
+        for (int m = 0; m < 6; ++m) ob[9 + q * 6 + m] = v[m];
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < OBS; ++k) ob[k] = clampf(-10.0f, ob[k], 10.0f);
+  return posture;
+}
+
+template <int A, int WPE>
+__global__ __launch_bounds__(64, WPE) void step_kernel_nvn(DevPtrs P, DevCfg c) {
+  constexpr int OBS = 9 + 6 * (A - 1);
+  __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
+  stage_tables(lds_tab, P.tab);
+  const Tab T{lds_tab};
+  const int N = c.N;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = n < N;                      // N is a multiple of A, so an env is live or not as a whole
+  const int slot = threadIdx.x % A;
+  const int nn = live ? n : (N - A + slot);     // tail lanes shadow the last env and never store
+  const int base_lane = (threadIdx.x & 63) - slot;
+  const int team = slot < c.n_ego ? 0 : 1;
+
+  State s; Task t; Derived d; Props pr;
+  load_state(P.F, P.I, P.D, N, nn, s, t);
+  const float* act = P.actions + (size_t)nn * c.act_dim;
+  t.cur_step += 1;
+  s.da = clampf(-1.0f, act[0] / 20.0f - 1.0f, 1.0f);   // multiplecombat_task.py:137-145
+  s.de = clampf(-1.0f, act[1] / 20.0f - 1.0f, 1.0f);
+  s.dr = clampf(-1.0f, act[2] / 20.0f - 1.0f, 1.0f);
+  s.thr = clampf(0.0f, act[3] / 58.0f + 0.4f, 0.9f);
+  bool have_pose = false;
+  for (int sub = 0; sub < c.substeps; ++sub) {
+    if (t.status == AC_ALIVE) {
+      if (t.bloods <= 0.0f) t.status = AC_SHOTDOWN;
+      f16::tick<false>(s, d, T);
+      have_pose = true;
+    }
+  }
+  f16::locate(s, d);
+  if (!have_pose) f16::body_frame(s, d);
+  make_props(s, d, c, pr);
+
+  float ob[OBS];
+#pragma unroll
+  for (int k = 0; k < OBS; ++k) ob[k] = 0.0f;
+  float posture = observe_nvn<A>(pr, slot, base_lane, c.n_ego, ob);
+
+  // ---- rewards first (multiplecombat_env.py:166-175), only while alive (multiplecombat_task.py:147-151)
+  float own = 0.0f;
+  if (t.status == AC_ALIVE) {
+    float r_alt = potential(altitude_raw(pr, c), c.altitude_scale, c.altitude_pot, t.pre_altitude);
+    float r_pos = potential(posture, c.posture_scale, c.posture_pot, t.pre_posture);
+    float r_ev = potential(0.0f, c.event_scale, c.event_pot, t.pre_event);  // alive and no missiles in this task: raw value 0
+    own = r_alt + r_pos + r_ev;
+  }
+  float tsum = 0.0f;
+#pragma unroll
+  for (int j = 0; j < A; ++j) {
+    float rj = __shfl(own, base_lane + j);
+    if ((j < c.n_ego ? 0 : 1) == team) tsum += rj;
+  }
+  const float reward = tsum / (float)(team == 0 ? c.n_ego : A - c.n_ego);
+
+  // ---- terminations, agent by agent in env order (multiplecombat_env.py:177-180): agent i sees the final status of agents
+  // before it and the not-yet-evaluated status of agents after it
+  bool done = false;
+  int code = AC_DONE_NONE;
+  int last_code = AC_DONE_NONE;
+  int st[A];
+#pragma unroll
+  for (int j = 0; j < A; ++j) st[j] = __shfl(t.status, base_lane + j);
+  float np_max = fmaxf(fabsf(s.npx), fmaxf(fabsf(s.npy), fabsf(s.npz)));
+  float pqr = sqrtf(d.p * d.p + d.q * d.q + d.r * d.r);
+  const bool extreme = (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);
+  const bool overload = ((float)s.ticks * (1.0f / 60.0f) > 10.0f) &&
+                        (fabsf(s.npx) > c.acc_x || fabsf(s.npy) > c.acc_y || fabsf(s.npz + 1.0f) > c.acc_z);
+  const bool low = pr.alt_m <= c.altitude_limit;
+#pragma unroll
+  for (int i = 0; i < A; ++i) {
+    if (slot == i) {
+      bool enemies_dead = true;
+#pragma unroll
+      for (int j = 0; j < A; ++j)
+        if ((j < c.n_ego ? 0 : 1) != team && st[j] == AC_ALIVE) enemies_dead = false;
+      if (t.status == AC_SHOTDOWN) { code = AC_DONE_SHOTDOWN; done = true; }
+      else if (t.status == AC_CRASH) { code = AC_DONE_CRASHED; done = true; }
+      else if (enemies_dead) { code = AC_DONE_MISSION_COMPLETE; done = true; }   // no missiles in this task
+      else if (extreme) { t.status = AC_CRASH; code = AC_DONE_EXTREME_STATE; done = true; }
+      else if (overload) { t.status = AC_CRASH; code = AC_DONE_OVERLOAD; done = true; }
+      else if (low) { t.status = AC_CRASH; code = AC_DONE_LOW_ALTITUDE; done = true; }
+      else if (t.cur_step >= c.max_steps) { code = AC_DONE_TIMEOUT; done = true; }
+    }
+    int si = __shfl(t.status, base_lane + i);
+    int ci = __shfl(code, base_lane + i);
+#pragma unroll
+    for (int j = 0; j < A; ++j) if (j == i) st[j] = si;
+    if (ci) last_code = ci;
+  }
+  bool all_done = true;
+#pragma unroll
+  for (int j = 0; j < A; ++j) all_done = all_done && (bool)__shfl((int)done, base_lane + j);
+  int step_out = t.cur_step;
+  if (all_done) {
+    load_state(P.tF, P.tI, P.tD, A, slot, s, t);
+    const float* tobs = P.tF + (size_t)NF * A + slot * OBS;
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) ob[k] = tobs[k];
+  }
+  if (live) {
+    store_state(P.F, P.I, P.D, N, n, s, t);
+    float* o = P.obs + (size_t)n * OBS;
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) o[k] = ob[k];
+    P.rew[n] = reward;
+    P.done[n] = done ? 1 : 0;
+    if (slot == 0) {
+      int* inf = P.info + (size_t)(n / A) * 4;
+      inf[0] = step_out; inf[1] = last_code; inf[2] = 0; inf[3] = all_done ? 1 : 0;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ initial conditions
 // AircraftSimulator.reload (simulatior.py:152-190) for the scenario's A aircraft, run once per ac_create:
 // FGInitialCondition setters -> FGPropagate::SetInitialState -> RunIC (two suspended executive passes,
@@ -696,9 +862,36 @@ __global__ void init_kernel_1v1(InitArgs ia, DevCfg c, const float* tab, float* 
   }
 }
 
+template <int A>
+__global__ void init_kernel_nvn(InitArgs ia, DevCfg c, const float* tab, float* tF, int* tI, double* tD) {
+  constexpr int OBS = 9 + 6 * (A - 1);
+  __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
+  stage_tables(lds_tab, tab);
+  const Tab T{lds_tab};
+  const int slot = threadIdx.x % A;
+  const int base_lane = (threadIdx.x & 63) - slot;
+  State s; Derived d; Task t{}; Props pr;
+  initial_state(ia.ic[slot], T, s, d);
+  t.bloods = 100.0f; t.status = AC_ALIVE;
+  t.remaining = c.num_missiles[slot]; t.pre_remaining = c.num_missiles[slot];
+  t.last_missile = -1; t.last_shoot_time = -c.min_attack_interval;
+  f16::locate(s, d);
+  make_props(s, d, c, pr);
+  float ob[OBS];
+  for (int k = 0; k < OBS; ++k) ob[k] = 0.0f;
+  float posture = observe_nvn<A>(pr, slot, base_lane, c.n_ego, ob);
+  if (c.altitude_pot) t.pre_altitude = altitude_raw(pr, c) * c.altitude_scale;
+  if (c.posture_pot) t.pre_posture = posture * c.posture_scale;
+  if (threadIdx.x < A) {
+    store_state(tF, tI, tD, A, slot, s, t);
+    float* tobs = tF + (size_t)NF * A + slot * OBS;
+    for (int k = 0; k < OBS; ++k) tobs[k] = ob[k];
+  }
+}
+
 // reset(): every env takes the template (SubprocVecEnv.reset -> env.reset(), env_base.py:98-113)
-template <int OBS>
 __global__ void reset_all_kernel(DevPtrs P, DevCfg c) {
+  const int OBS = c.obs_dim;
   const int N = c.N;
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
@@ -752,7 +945,15 @@ static int launch_step(ac_env* h, const float* d_actions) {
   p.actions = d_actions ? d_actions : h->d_actions;
   dim3 block(64), grid((h->N + 63) / 64);
   const bool one_wave_per_simd = grid.x <= 1024;  // 256 CUs x 4 SIMDs
-  if (h->cfg.task == AC_TASK_SINGLECOMBAT) {
+  if (h->cfg.task == AC_TASK_MULTICOMBAT) {
+    if (h->A == 4) {
+      if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_nvn<4, 1>), grid, block, 0, h->stream, p, h->dc);
+      else hipLaunchKernelGGL((step_kernel_nvn<4, 2>), grid, block, 0, h->stream, p, h->dc);
+    } else {
+      if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_nvn<8, 1>), grid, block, 0, h->stream, p, h->dc);
+      else hipLaunchKernelGGL((step_kernel_nvn<8, 2>), grid, block, 0, h->stream, p, h->dc);
+    }
+  } else if (h->cfg.task == AC_TASK_SINGLECOMBAT) {
     if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 1>), grid, block, 0, h->stream, p, h->dc);
     else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 2>), grid, block, 0, h->stream, p, h->dc);
   } else {
@@ -764,8 +965,7 @@ static int launch_step(ac_env* h, const float* d_actions) {
 }
 static int launch_reset(ac_env* h) {
   dim3 block(64), grid((h->N + 63) / 64);
-  if (h->obs_dim == 15) hipLaunchKernelGGL(reset_all_kernel<15>, grid, block, 0, h->stream, h->dp, h->dc);
-  else hipLaunchKernelGGL(reset_all_kernel<21>, grid, block, 0, h->stream, h->dp, h->dc);
+  hipLaunchKernelGGL(reset_all_kernel, grid, block, 0, h->stream, h->dp, h->dc);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -779,12 +979,15 @@ const char* ac_state_field_name(int i) { return (i >= 0 && i < AC_STATE_LEN && k
 int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_t seed, ac_env_t** out) {
   (void)seed;  // the 1v1 tasks draw no random numbers (fixed initial conditions, no chaff)
   if (!cfg || !out) return fail("ac_create: null argument");
-  if (cfg->task != AC_TASK_SINGLECOMBAT && cfg->task != AC_TASK_SHOOT_MISSILE)
-    return fail("ac_create: task not available on the HIP path (supported: AC_TASK_SINGLECOMBAT, AC_TASK_SHOOT_MISSILE)");
-  if (cfg->n_agents != 2 || cfg->n_ego != 1) return fail("ac_create: 1v1 tasks need n_agents == 2 and n_ego == 1");
+  if (cfg->task != AC_TASK_SINGLECOMBAT && cfg->task != AC_TASK_SHOOT_MISSILE && cfg->task != AC_TASK_MULTICOMBAT)
+    return fail("ac_create: task not available on the HIP path (supported: AC_TASK_SINGLECOMBAT, AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT)");
+  if (cfg->task == AC_TASK_MULTICOMBAT) {
+    if ((cfg->n_agents != 4 && cfg->n_agents != 8) || cfg->n_ego <= 0 || cfg->n_ego >= cfg->n_agents)
+      return fail("ac_create: AC_TASK_MULTICOMBAT needs n_agents in {4, 8} and 0 < n_ego < n_agents");
+  } else if (cfg->n_agents != 2 || cfg->n_ego != 1) return fail("ac_create: 1v1 tasks need n_agents == 2 and n_ego == 1");
   if (n_envs <= 0) return fail("ac_create: n_envs must be positive");
   if (cfg->sim_freq != 60) return fail("ac_create: sim_freq must be 60 (the FDM tick is compiled for 1/60 s)");
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < cfg->n_agents; ++i)
     if (cfg->num_missiles[i] < 0 || cfg->num_missiles[i] > AC_MAX_MISSILES_PER_AGENT) return fail("ac_create: num_missiles out of range");
   int ndev = 0;
   HIP_OK(hipGetDeviceCount(&ndev));
@@ -793,7 +996,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   ac_env* h = new ac_env();
   memset(h, 0, sizeof *h);
   h->cfg = *cfg; h->E = n_envs; h->A = cfg->n_agents; h->N = n_envs * cfg->n_agents; h->device = device_id;
-  h->obs_dim = (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : 21;
+  h->obs_dim = (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   h->act_dim = (cfg->task == AC_TASK_SHOOT_MISSILE) ? 5 : 4;
   DevCfg& c = h->dc;
   memset(&c, 0, sizeof c);
@@ -840,7 +1043,11 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   p.tF = h->d_tF; p.tI = h->d_tI; p.tD = h->d_tD; p.tab = h->d_tab; p.actions = h->d_actions;
   InitArgs ia;
   for (int i = 0; i < AC_MAX_AGENTS; ++i) ia.ic[i] = cfg->init[i];
-  if (cfg->task == AC_TASK_SINGLECOMBAT)
+  if (cfg->task == AC_TASK_MULTICOMBAT && h->A == 4)
+    hipLaunchKernelGGL(init_kernel_nvn<4>, dim3(1), dim3(64), 0, h->stream, ia, h->dc, h->d_tab, h->d_tF, h->d_tI, h->d_tD);
+  else if (cfg->task == AC_TASK_MULTICOMBAT)
+    hipLaunchKernelGGL(init_kernel_nvn<8>, dim3(1), dim3(64), 0, h->stream, ia, h->dc, h->d_tab, h->d_tF, h->d_tI, h->d_tD);
+  else if (cfg->task == AC_TASK_SINGLECOMBAT)
     hipLaunchKernelGGL(init_kernel_1v1<AC_TASK_SINGLECOMBAT>, dim3(1), dim3(64), 0, h->stream, ia, h->dc, h->d_tab, h->d_tF, h->d_tI, h->d_tD);
   else
     hipLaunchKernelGGL(init_kernel_1v1<AC_TASK_SHOOT_MISSILE>, dim3(1), dim3(64), 0, h->stream, ia, h->dc, h->d_tab, h->d_tF, h->d_tI, h->d_tD);

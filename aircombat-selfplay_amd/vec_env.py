@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-from .capi import (AcConfig, AC_STATE_LEN, AC_TASK_SINGLECOMBAT, AC_TASK_SHOOT_MISSILE, load_library)
+from .capi import (AcConfig, AC_STATE_LEN, AC_TASK_SINGLECOMBAT, AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT, load_library)
 from .config import config_from_yaml, default_config
 
 DONE_MESSAGES = {
@@ -195,7 +195,32 @@ class HipVecEnv:
         return np.array(out[:], dtype=np.float64)
 
 
+class HipShareVecEnv(HipVecEnv):
+    """The Share* VecEnv family (envs/env_wrappers.py:323-462) for MultipleCombat: ``reset()`` -> ``(obs, share_obs)``,
+    ``step()`` -> ``(obs, share_obs, rewards, dones, infos)``. ``share_obs[e, a]`` is the concatenation of all agents'
+    observations of env ``e`` (BaseEnv.get_state, env_base.py:183-189), i.e. ``obs`` flattened per env; it is returned as a
+    read-only broadcast view (the buffers copy on insert)."""
+
+    def __init__(self, config, num_envs, device_id=0, seed=0, lib=None):
+        super().__init__(config, num_envs, device_id=device_id, seed=seed, lib=lib)
+        Box = _spaces()[0]
+        self.share_observation_space = Box(low=-10, high=10.0, shape=(self.num_agents * self.obs_dim,))
+
+    def _share(self, obs):
+        E, A, D = obs.shape
+        return np.broadcast_to(obs.reshape(E, 1, A * D), (E, A, A * D))
+
+    def reset(self):
+        obs = super().reset()
+        return obs, self._share(obs)
+
+    def step_wait(self):
+        obs, rew, done, infos = super().step_wait()
+        return obs, self._share(obs), rew, done, infos
+
+
 def make_env(scenario=None, num_envs=1, task=None, device_id=0, seed=0):
     """``scenario``: path of a scenario YAML (reference format) or None for the 1v1 block of WVR_selfplay.yaml."""
     cfg = config_from_yaml(scenario, task=task) if scenario else default_config(task or "singlecombat")
-    return HipVecEnv(cfg, num_envs, device_id=device_id, seed=seed)
+    cls = HipShareVecEnv if cfg.task == AC_TASK_MULTICOMBAT else HipVecEnv
+    return cls(cfg, num_envs, device_id=device_id, seed=seed)

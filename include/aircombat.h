@@ -28,7 +28,9 @@ enum {
   AC_TASK_HEADING = 0,        /* heading_task.py HeadingTask (oracle-only this round; ac_create refuses it) */
   AC_TASK_SINGLECOMBAT = 1,   /* singlecombat_task.py:16-207 SingleCombatTask: obs 15, act [41,41,41,30] */
   AC_TASK_DODGE_MISSILE = 2,  /* singlecombat_with_missile_task.py:12-124 rule-based launch: obs 21, act 4 */
-  AC_TASK_SHOOT_MISSILE = 3   /* singlecombat_with_missile_task.py:147-204 learned shoot bit: obs 21, act 5 */
+  AC_TASK_SHOOT_MISSILE = 3,  /* singlecombat_with_missile_task.py:147-204 learned shoot bit: obs 21, act 5 */
+  AC_TASK_MULTICOMBAT = 4     /* multiplecombat_task.py:15-151 MultipleCombatTask under MultipleCombatEnv.step (NvN, n_agents 4 or 8):
+                                 obs 9+6*(A-1), act [41,41,41,30]; share_obs is obs flattened per env (env_base.py:183-189) */
 };
 /* AircraftSimulator status, R/envs/JSBSim/core/simulatior.py:93-95 */
 enum { AC_ALIVE = 0, AC_CRASH = 1, AC_SHOTDOWN = 2 };

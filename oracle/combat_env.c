@@ -18,6 +18,10 @@ int or_env_obs_dim(int task) {
     default: return 21;
   }
 }
+int or_env_obs_dim_n(int task, int n_aircraft) {
+  if (task == OR_TASK_MULTICOMBAT) return 9 + (n_aircraft - 1) * 6; /* multiplecombat_task.py:95-98 */
+  return or_env_obs_dim(task);
+}
 int or_env_act_dim(int task) { return task == OR_TASK_SHOOT_MISSILE ? 5 : 4; }
 
 void or_env_default_config(OrEnvConfig* c, int task) {
@@ -33,6 +37,16 @@ void or_env_default_config(OrEnvConfig* c, int task) {
   c->alt_safe = 4.0; c->alt_danger = 3.5; c->alt_kv = 0.2;
   c->max_attack_angle = 45; c->max_attack_distance = 14000; c->min_attack_interval = 25;
   for (int i = 0; i < OR_MAX_AC; i++) f16_default_init(&c->init[i]);
+  if (task == OR_TASK_MULTICOMBAT) {
+    /* aircraft block of R/configs/scenario2/scenario2_nvn.yaml:15-62 (2v2) */
+    c->n_aircraft = 4; c->n_ego = 2; c->max_steps = 9000;
+    c->event_potential = 0; /* that YAML sets no EventDrivenReward_potential */
+    c->init[1].lon_deg = 120.01;
+    c->init[2].lat_geod_deg = 60.1; c->init[2].psi_deg = 180.0;
+    c->init[3].lon_deg = 120.01; c->init[3].lat_geod_deg = 60.1; c->init[3].psi_deg = 180.0;
+    c->min_attack_interval = 125;
+    return;
+  }
   if (task == OR_TASK_HEADING) {
     /* R/configs/singlecontrol/heading.yaml */
     c->n_aircraft = 1; c->n_ego = 1; c->max_steps = 10000;
@@ -227,7 +241,7 @@ static int extreme_state(const OrAircraft* a) { /* catalog.py:386-416 */
 void or_env_init(OrEnv* e, const OrEnvConfig* c) {
   memset(e, 0, sizeof *e);
   e->cfg = *c;
-  e->obs_dim = or_env_obs_dim(c->task);
+  e->obs_dim = or_env_obs_dim_n(c->task, c->n_aircraft);
   e->act_dim = or_env_act_dim(c->task);
   for (int i = 0; i < c->n_aircraft; i++) e->ac[i].team = (i < c->n_ego) ? 0 : 1;
   e->mp_prev_missile = -1;
@@ -287,9 +301,35 @@ static void obs_combat(const OrEnv* e, int i, double* o) { /* singlecombat_task.
     o[17] = r[0]; o[18] = r[1]; o[19] = r[2] / 10000; o[20] = r[3];
   }
 }
+static void obs_multicombat(const OrEnv* e, int i, double* o) { /* multiplecombat_task.py:105-135: partners then enemies, clipped */
+  const OrAircraft* a = &e->ac[i];
+  int dim = e->obs_dim;
+  for (int k = 0; k < dim; k++) o[k] = 0;
+  double ef[6], nf[6], r[4];
+  feature6(a, ef);
+  o[0] = h_sl_m(a) / 5000;
+  o[1] = sin(a->fdm.phi); o[2] = cos(a->fdm.phi); o[3] = sin(a->fdm.tht); o[4] = cos(a->fdm.tht);
+  o[5] = mps(a->fdm.uvw[0]) / 340; o[6] = mps(a->fdm.uvw[1]) / 340; o[7] = mps(a->fdm.uvw[2]) / 340; o[8] = vc_mps(a) / 340;
+  int off = 8;
+  for (int pass = 0; pass < 2; pass++) /* partners (same team) in order, then enemies in order (env_base.py:79-88) */
+    for (int k = 0; k < e->cfg.n_aircraft; k++) {
+      if (k == i) continue;
+      int same = e->ac[k].team == a->team;
+      if ((pass == 0) != same) continue;
+      const OrAircraft* b = &e->ac[k];
+      feature6(b, nf);
+      or_get_AO_TA_R(ef, nf, 0, r);
+      o[off + 1] = (mps(b->fdm.uvw[0]) - mps(a->fdm.uvw[0])) / 340;
+      o[off + 2] = (h_sl_m(b) - h_sl_m(a)) / 1000;
+      o[off + 3] = r[0]; o[off + 4] = r[1]; o[off + 5] = r[2] / 10000; o[off + 6] = r[3];
+      off += 6;
+    }
+  for (int k = 0; k < dim; k++) o[k] = clampd(-10, o[k], 10);
+}
 static void get_obs(const OrEnv* e, double* obs) {
   for (int i = 0; i < e->cfg.n_aircraft; i++) {
     if (e->cfg.task == OR_TASK_HEADING) obs_heading(e, i, obs + i * e->obs_dim);
+    else if (e->cfg.task == OR_TASK_MULTICOMBAT) obs_multicombat(e, i, obs + i * e->obs_dim);
     else obs_combat(e, i, obs + i * e->obs_dim);
   }
 }
@@ -362,6 +402,7 @@ static double rw_heading(OrEnv* e, int i) { /* heading_reward.py:18-71 */
 static double task_reward_terms(OrEnv* e, int i) {
   switch (e->cfg.task) {
     case OR_TASK_HEADING: { double r = rw_heading(e, i); return r + rw_altitude(e, i); }
+    case OR_TASK_MULTICOMBAT: /* same three terms, multiplecombat_task.py:27-31 */
     case OR_TASK_SINGLECOMBAT: { double r = rw_altitude(e, i); r += rw_posture(e, i); return r + rw_event(e, i); }
     case OR_TASK_DODGE_MISSILE: { double r = rw_posture(e, i); r += rw_missile_posture(e, i); r += rw_altitude(e, i); return r + rw_event(e, i); }
     default: { double r = rw_posture(e, i); r += rw_altitude(e, i); r += rw_event(e, i); return r + rw_shoot_penalty(e, i); }
@@ -369,6 +410,8 @@ static double task_reward_terms(OrEnv* e, int i) {
 }
 static double get_reward(OrEnv* e, int i) { /* singlecombat_task.py:190-195; heading task uses BaseTask.get_reward */
   if (e->cfg.task == OR_TASK_HEADING) return task_reward_terms(e, i);
+  if (e->cfg.task == OR_TASK_MULTICOMBAT) /* multiplecombat_task.py:147-151: only while alive */
+    return e->ac[i].status == OR_ALIVE ? task_reward_terms(e, i) : 0.0;
   if (e->ac[i].die_flag) return 0.0;
   e->ac[i].die_flag = e->ac[i].status != OR_ALIVE;
   return task_reward_terms(e, i);
@@ -451,6 +494,8 @@ static int t_unreach_heading(OrEnv* e, int i, int* code) { /* unreach_heading.py
 static int get_termination(OrEnv* e, int i, int* code) {
   if (e->cfg.task == OR_TASK_HEADING) /* heading_task.py:20-26 */
     return t_unreach_heading(e, i, code) || t_extreme(e, i, code) || t_overload(e, i, code) || t_low_altitude(e, i, code) || t_timeout(e, i, code);
+  if (e->cfg.task == OR_TASK_MULTICOMBAT) /* multiplecombat_task.py:33-39 */
+    return t_safe_return(e, i, code) || t_extreme(e, i, code) || t_overload(e, i, code) || t_low_altitude(e, i, code) || t_timeout(e, i, code);
   /* singlecombat_task.py:34-40 */
   return t_low_altitude(e, i, code) || t_extreme(e, i, code) || t_overload(e, i, code) || t_safe_return(e, i, code) || t_timeout(e, i, code);
 }
@@ -595,6 +640,16 @@ void or_env_evaluate(OrEnv* e, double* obs, double* rew, uint8_t* done, int32_t*
   const OrEnvConfig* c = &e->cfg;
   int code = OR_DONE_NONE;
   get_obs(e, obs);
+  if (c->task == OR_TASK_MULTICOMBAT) { /* MultipleCombatEnv.step, multiplecombat_env.py:160-182: rewards, team mean, then dones */
+    double sum[2] = {0, 0}; int cnt[2] = {0, 0};
+    for (int i = 0; i < c->n_aircraft; i++) { rew[i] = get_reward(e, i); sum[e->ac[i].team] += rew[i]; cnt[e->ac[i].team]++; }
+    for (int i = 0; i < c->n_aircraft; i++) rew[i] = sum[e->ac[i].team] / cnt[e->ac[i].team];
+    for (int i = 0; i < c->n_aircraft; i++) done[i] = (uint8_t)get_termination(e, i, &code);
+    int alld = 1;
+    for (int i = 0; i < c->n_aircraft; i++) alld = alld && done[i];
+    if (info) { info[0] = e->current_step; info[1] = code; info[2] = e->heading_turn_counts; info[3] = alld; }
+    return;
+  }
   for (int i = 0; i < c->n_aircraft; i++) done[i] = (uint8_t)get_termination(e, i, &code);
   for (int i = 0; i < c->n_aircraft; i++) rew[i] = get_reward(e, i);
   int all = 1;

@@ -19,7 +19,8 @@ extern "C" {
 #define OR_MAX_AC 8
 #define OR_MAX_MSL 64
 
-enum { OR_TASK_HEADING = 0, OR_TASK_SINGLECOMBAT = 1, OR_TASK_DODGE_MISSILE = 2, OR_TASK_SHOOT_MISSILE = 3 };
+enum { OR_TASK_HEADING = 0, OR_TASK_SINGLECOMBAT = 1, OR_TASK_DODGE_MISSILE = 2, OR_TASK_SHOOT_MISSILE = 3,
+       OR_TASK_MULTICOMBAT = 4 /* MultipleCombatTask (multiplecombat_task.py:15-151) under MultipleCombatEnv.step */ };
 enum { OR_ALIVE = 0, OR_CRASH = 1, OR_SHOTDOWN = 2 };
 enum { OR_MSL_INACTIVE = -1, OR_MSL_LAUNCHED = 0, OR_MSL_HIT = 1, OR_MSL_MISS = 2 };
 /* done reason codes written to info (first condition that fired for the LAST agent evaluated, like info['done_condition']) */
@@ -102,7 +103,8 @@ typedef struct {
   int obs_dim, act_dim;
 } OrEnv;
 
-int or_env_obs_dim(int task);
+int or_env_obs_dim(int task);   /* for OR_TASK_MULTICOMBAT use or_env_obs_dim_n */
+int or_env_obs_dim_n(int task, int n_aircraft);
 int or_env_act_dim(int task);
 void or_env_default_config(OrEnvConfig* c, int task);
 void or_env_init(OrEnv* e, const OrEnvConfig* c);

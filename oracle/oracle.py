@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 OR_MAX_AC = 8
-TASK_HEADING, TASK_SINGLECOMBAT, TASK_DODGE_MISSILE, TASK_SHOOT_MISSILE = 0, 1, 2, 3
+TASK_HEADING, TASK_SINGLECOMBAT, TASK_DODGE_MISSILE, TASK_SHOOT_MISSILE, TASK_MULTICOMBAT = 0, 1, 2, 3, 4
 STATE_LEN = 80
 
 
@@ -68,6 +68,7 @@ def lib():
         L.or_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.or_env_obs_dim.argtypes = [C.c_int]
         L.or_env_act_dim.argtypes = [C.c_int]
+        L.or_env_obs_dim_n.argtypes = [C.c_int, C.c_int]
         L.or_state_export.argtypes = [C.c_void_p, C.c_int, dp, C.c_int]
         L.or_state_import.argtypes = [C.c_void_p, C.c_int, dp]
         L.or_env_get_pose.argtypes = [C.c_void_p, C.c_int, dp]
@@ -151,7 +152,7 @@ class OracleEnv:
         self.p = C.cast(self._buf, C.c_void_p)
         L.or_env_init(self.p, C.byref(cfg))
         self.A = cfg.n_aircraft
-        self.obs_dim = L.or_env_obs_dim(cfg.task)
+        self.obs_dim = L.or_env_obs_dim_n(cfg.task, cfg.n_aircraft)
         self.act_dim = L.or_env_act_dim(cfg.task)
         if pcg64_state is not None:
             self.seed_from_numpy(pcg64_state)

@@ -483,6 +483,64 @@ def gen_heading(rng):
              pcg64=np.array([st >> 64, st & m, inc >> 64, inc & m], dtype=np.uint64))
 
 
+
+def gen_multicombat_sequences(rng):
+    """MultipleCombatTask (2v2) over scripted four-aircraft pose sequences. The tail of MultipleCombatEnv.step
+    (multiplecombat_env.py:160-182: obs, rewards for every agent, team mean, then terminations) is replayed here around the
+    reference's task object, because the env class itself cannot be built without the jsbsim wheel."""
+    from envs.JSBSim.tasks.multiplecombat_task import MultipleCombatTask
+    acs = {u: {"color": "Blue" if u[0] == "A" else "Red", "missile": 0} for u in ("A0100", "A0200", "B0100", "B0200")}
+    cfg = make_config(aircraft_configs=acs, EventDrivenReward_potential=False)
+    flat = {}
+    n_ep = 16
+    for ep in range(n_ep):
+        task = MultipleCombatTask(cfg)
+        agents = [FakeAircraft(u, acs[u]["color"]) for u in acs]
+        link(agents)
+        env = FakeEnv(agents)
+        for a in agents:
+            random_pose(rng, a, spread_km=12.0 if ep % 2 else 40.0)
+        task.reset(env)
+        poses, obss, rews, dones, steps = [np.stack([pose_vector(a) for a in agents])], [np.stack([task.get_obs(env, u) for u in env.agents])], [np.zeros(4)], [np.zeros(4)], [0]
+        for t in range(1, 13):
+            env.current_step = t
+            for a in agents:
+                if a.is_alive:
+                    random_pose(rng, a, spread_km=12.0 if ep % 2 else 40.0, alt=(2000.0, 9000.0) if ep % 3 else (2300.0, 5000.0))
+            if ep % 5 == 1 and t == 4:
+                agents[2].shotdown()
+            if ep % 5 == 1 and t == 7:
+                agents[3].shotdown()
+            if ep % 5 == 2 and t == 5:
+                agents[0].props["detect/extreme-state"] = 1
+            if ep % 5 == 3 and t == 6:
+                agents[1].props["accelerations/n-pilot-y-norm"] = 10.5
+                agents[1].props["simulation/sim-time-sec"] = 25.0
+            if ep % 5 == 4 and t == 8:
+                env.current_step = 9000
+            pose = np.stack([pose_vector(a) for a in agents])
+            obs = np.stack([task.get_obs(env, u) for u in env.agents])
+            info = {"current_step": env.current_step}
+            rewards = {}
+            for u in env.agents:
+                r, info = task.get_reward(env, u, info)
+                rewards[u] = [r]
+            ego = np.mean([rewards[u] for u in env.ego_ids])
+            enm = np.mean([rewards[u] for u in env.enm_ids])
+            rew = np.array([ego if u in env.ego_ids else enm for u in env.agents])
+            done = []
+            for u in env.agents:
+                d, info = task.get_termination(env, u, info)
+                done.append(d)
+            poses.append(pose); obss.append(obs); rews.append(rew); dones.append(np.array(done, dtype=float)); steps.append(env.current_step)
+            if all(done):
+                break
+        flat[f"ep{ep}_pose"] = np.stack(poses); flat[f"ep{ep}_obs"] = np.stack(obss); flat[f"ep{ep}_rew"] = np.stack(rews)
+        flat[f"ep{ep}_done"] = np.stack(dones); flat[f"ep{ep}_step"] = np.array(steps, dtype=float)
+    flat["n_episodes"] = np.array([n_ep], dtype=float)
+    np.savez_compressed(os.path.join(OUT, "multicombat_sequences.npz"), **flat)
+
+
 def gen_curriculum_table():
     from envs.JSBSim.utils.utils import calculate_coordinates_heading_by_curriculum
     res = calculate_coordinates_heading_by_curriculum(60.1, 120.0, 11.119, list(range(0, 181)))
@@ -501,6 +559,7 @@ def main():
     gen_missile_task_obs(rng)
     gen_heading(rng)
     gen_curriculum_table()
+    gen_multicombat_sequences(np.random.default_rng(77))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -25,6 +25,22 @@ def obs_close(a, b, scale=1.0):
     return np.abs(a - b) <= scale * (2e-4 + 2e-4 * np.abs(b))
 
 
+def nvn_obs_close(a, b):
+    """Observation comparison that knows the conditioning of the relative-geometry block [du, dh, AO, TA, R, side]:
+    acos amplifies an fp32 rounding of its argument by 1/sin(angle), and the side flag is the sign of a cross product that
+    vanishes when the other aircraft is dead ahead or astern (the NvN scenarios start exactly line-abreast on a meridian)."""
+    ok = obs_close(a, b)
+    n_other = (b.shape[-1] - 9) // 6
+    for k in range(n_other):
+        o = 9 + 6 * k
+        for col in (o + 2, o + 3):
+            tol = 2e-4 + 3e-7 / np.maximum(np.sin(b[..., col]), 1e-4)
+            ok[..., col] = np.abs(a[..., col] - b[..., col]) <= tol
+        degenerate = np.sin(b[..., o + 2]) < 2e-3
+        ok[..., o + 5] |= degenerate
+    return ok
+
+
 @pytest.mark.parametrize("task", ["singlecombat", "singlecombat_shoot"])
 def test_reset_matches_oracle(pkg, oracle, task):
     cfg = pkg.default_config(task)
@@ -113,4 +129,48 @@ def test_crash_and_shotdown_semantics(pkg):
     assert rew[0, 0, 0] < -100
     assert done[0].all() and not done[1].any()
     assert info[0]["current_step"] == 1
+    env.close()
+
+
+@pytest.mark.parametrize("per_side", [2, 4])
+def test_nvn_multicombat_matches_oracle(pkg, oracle, per_side):
+    """MultipleCombat 2v2 / 4v4: teacher-forced steps with the env's order of operations (rewards before terminations,
+    team means, SafeReturn first), share_obs, auto-reset."""
+    cfg = pkg.default_nvn_config(per_side)
+    A = 2 * per_side
+    # The shipped YAML starts both teams exactly head-on on one meridian (TA = pi, AO = 0): PostureReward's atanh term and
+    # the side flag are singular there, so numerical parity is only meaningful off that measure-zero geometry. Stagger it.
+    for i in range(A):
+        cfg.init[i].lon_deg += 0.013 * (i % 3) + (0.02 if i >= per_side else 0.0)
+        cfg.init[i].psi_deg = (7.0 + 3.0 * i) if i < per_side else (171.0 + 2.0 * i)
+        cfg.init[i].h_sl_ft += 300.0 * i
+    E = 6
+    env = pkg.HipShareVecEnv(cfg, E)
+    ocfg = oracle.config_from_ac(cfg)
+    ref = oracle.OracleVecEnv(ocfg, E)
+    obs, share = env.reset()
+    robs = ref.reset()
+    assert obs.shape == (E, A, 9 + 6 * (A - 1)) and share.shape == (E, A, A * obs.shape[-1])
+    assert nvn_obs_close(obs, robs).all(), np.abs(obs - robs).max()
+    assert (share[:, 0] == obs.reshape(E, -1)).all() and (share[:, A - 1] == share[:, 0]).all()
+    rng = np.random.default_rng(5)
+    n_done = 0
+    for step in range(80):
+        for e in range(E):
+            for a in range(A):
+                env.set_state(e, a, ref.envs[e].export_state(a))
+        act = np.stack([rng.integers(0, n, size=(E, A)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
+        if step == 30:
+            env.set_status(1, A - 1, 2); ref.envs[1].set_status(A - 1, 2)      # an enemy is shot down
+        if step == 40:
+            for a in range(per_side, A):
+                env.set_status(2, a, 1); ref.envs[2].set_status(a, 1)          # the whole enemy team crashes
+        obs, share, rew, done, info = env.step(act)
+        robs, rrew, rdone, rinfo = ref.step(act)
+        ok = nvn_obs_close(obs, robs)
+        assert ok.all(), (step, np.argwhere(~ok)[:4], obs[~ok][:4], robs[~ok][:4])
+        assert (np.abs(rew - rrew) <= 5e-3 + 1e-3 * np.abs(rrew)).all(), (step, np.abs(rew - rrew).max())
+        assert (done == rdone).all(), (step, done[..., 0], rdone[..., 0])
+        n_done += int(done.sum())
+    assert n_done > 0
     env.close()

@@ -171,3 +171,28 @@ def test_curriculum_spawn_table_fixture_is_sane():
     assert t.shape == (181, 3)
     # 11.119 km circle about (60.1 N, 120 E): first point due south, heading 0
     assert abs(t[0][0] - 60.0) < 2e-3 and abs(t[0][1] - 120.0) < 1e-9 and t[0][2] == 0
+
+
+def test_multicombat_2v2_sequences(oracle):
+    """MultipleCombatTask under MultipleCombatEnv.step's order: obs(27), rewards BEFORE terminations, reward only while alive,
+    team-mean rewards, termination order SafeReturn first."""
+    g = load("multicombat_sequences.npz")
+    cfg = oracle.default_config(oracle.TASK_MULTICOMBAT)
+    n_done = 0
+    for ep in range(int(g["n_episodes"][0])):
+        env = oracle.OracleEnv(cfg)
+        pose, obs, rew, done, step = (g[f"ep{ep}_{k}"] for k in ("pose", "obs", "rew", "done", "step"))
+        for i in range(4):
+            env.set_pose(i, pose[0][i])
+        env.set_step(0)
+        env.task_reset()
+        for t in range(1, len(pose)):
+            for i in range(4):
+                env.set_pose(i, pose[t][i])
+            env.set_step(int(step[t]))
+            o, r, d, info = env.evaluate()
+            assert close(o, obs[t], rtol=1e-9, atol=5e-8).all(), (ep, t, np.abs(o - obs[t]).max())
+            assert close(r, rew[t], rtol=1e-8, atol=1e-7).all(), (ep, t, r, rew[t])
+            assert (d == done[t].astype(bool)).all(), (ep, t, d, done[t])
+            n_done += int(d.sum())
+    assert n_done > 10
