@@ -20,9 +20,14 @@ int or_env_obs_dim(int task) {
 }
 int or_env_obs_dim_n(int task, int n_aircraft) {
   if (task == OR_TASK_MULTICOMBAT) return 9 + (n_aircraft - 1) * 6; /* multiplecombat_task.py:95-98 */
+  if (task == OR_TASK_SCENARIO_NVN) return 9 + 6 * (n_aircraft / 2) + 6 * (n_aircraft / 2) + 6; /* scenario2_task.py:244-254 */
+  if (task == OR_TASK_WVR) return 15; /* HierarchicalSingleCombatTask keeps SingleCombatTask's 15-value observation */
   return or_env_obs_dim(task);
 }
-int or_env_act_dim(int task) { return task == OR_TASK_SHOOT_MISSILE ? 5 : 4; }
+int or_env_act_dim(int task) {
+  if (task == OR_TASK_SCENARIO1 || task == OR_TASK_SCENARIO_NVN) return 8; /* 4 low-level controls + [gun, AIM-9M, AIM-120B, chaff] */
+  return task == OR_TASK_SHOOT_MISSILE ? 5 : 4;
+}
 
 void or_env_default_config(OrEnvConfig* c, int task) {
   memset(c, 0, sizeof *c);
@@ -36,9 +41,11 @@ void or_env_default_config(OrEnvConfig* c, int task) {
   c->heading_scale = 1.0; c->missile_posture_scale = 30.0; c->shoot_penalty_scale = 1.0;
   c->alt_safe = 4.0; c->alt_danger = 3.5; c->alt_kv = 0.2;
   c->max_attack_angle = 45; c->max_attack_distance = 14000; c->min_attack_interval = 25;
+  c->relative_altitude_scale = 1.0; c->relative_altitude_KH = 1.0; c->gun_scale = 1.0; c->chaff_seed = 1;
   for (int i = 0; i < OR_MAX_AC; i++) f16_default_init(&c->init[i]);
-  if (task == OR_TASK_MULTICOMBAT) {
+  if (task == OR_TASK_MULTICOMBAT || task == OR_TASK_SCENARIO_NVN) {
     /* aircraft block of R/configs/scenario2/scenario2_nvn.yaml:15-62 (2v2) */
+    for (int i = 0; i < 4; i++) c->num_missiles[i] = 2;
     c->n_aircraft = 4; c->n_ego = 2; c->max_steps = 9000;
     c->event_potential = 0; /* that YAML sets no EventDrivenReward_potential */
     c->init[1].lon_deg = 120.01;
@@ -76,6 +83,15 @@ static uint64_t pcg64_next(OrEnv* e) {
 double or_env_uniform(OrEnv* e, double lo, double hi) {
   double u = (double)(pcg64_next(e) >> 11) * (1.0 / 9007199254740992.0);
   return lo + (hi - lo) * u;
+}
+
+/* The reference draws the decoy outcome from the GLOBAL, unseeded np.random (env_base.py:153): only statistical parity is
+ * possible. Oracle and kernel both use this counter-based generator (splitmix64 of seed, env-local draw counter) so that they
+ * can be compared draw for draw. */
+static double chaff_uniform(OrEnv* e) {
+  uint64_t z = e->cfg.chaff_seed * 0x9E3779B97F4A7C15ULL + (e->chaff_draws++) * 0xD1B54A32D192ED03ULL;
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 27; z *= 0x94D049BB133111EBULL; z ^= z >> 31;
+  return (double)(z >> 40) * (1.0 / 16777216.0);
 }
 
 /* ------------------------------------------------------------------ utils.py:58-103 */
@@ -283,11 +299,12 @@ static void obs_combat(const OrEnv* e, int i, double* o) { /* singlecombat_task.
   o[0] = h_sl_m(a) / 5000;
   o[1] = sin(a->fdm.phi); o[2] = cos(a->fdm.phi); o[3] = sin(a->fdm.tht); o[4] = cos(a->fdm.tht);
   o[5] = mps(a->fdm.uvw[0]) / 340; o[6] = mps(a->fdm.uvw[1]) / 340; o[7] = mps(a->fdm.uvw[2]) / 340; o[8] = vc_mps(a) / 340;
-  or_get_AO_TA_R(ef, nf, e->cfg.task == OR_TASK_SINGLECOMBAT, r);
+  const int two_d = e->cfg.task == OR_TASK_SINGLECOMBAT || e->cfg.task == OR_TASK_WVR;
+  or_get_AO_TA_R(ef, nf, two_d, r);
   o[9] = (mps(en->fdm.uvw[0]) - mps(a->fdm.uvw[0])) / 340;
   o[10] = (h_sl_m(en) - h_sl_m(a)) / 1000;
   o[11] = r[0]; o[12] = r[1]; o[13] = r[2] / 10000; o[14] = r[3];
-  if (e->cfg.task == OR_TASK_SINGLECOMBAT) {
+  if (two_d) {
     for (int k = 0; k < 15; k++) o[k] = clampd(-10, o[k], 10);
     return;
   }
@@ -326,10 +343,44 @@ static void obs_multicombat(const OrEnv* e, int i, double* o) { /* multiplecomba
     }
   for (int k = 0; k < dim; k++) o[k] = clampd(-10, o[k], 10);
 }
+static void obs_scenario_nvn(const OrEnv* e, int i, double* o) { /* scenario2_task.py:256-316: not clipped, missile block right after the enemies */
+  const OrAircraft* a = &e->ac[i];
+  int dim = e->obs_dim;
+  for (int k = 0; k < dim; k++) o[k] = 0;
+  double ef[6], nf[6], r[4];
+  feature6(a, ef);
+  o[0] = h_sl_m(a) / 5000;
+  o[1] = sin(a->fdm.phi); o[2] = cos(a->fdm.phi); o[3] = sin(a->fdm.tht); o[4] = cos(a->fdm.tht);
+  o[5] = mps(a->fdm.uvw[0]) / 340; o[6] = mps(a->fdm.uvw[1]) / 340; o[7] = mps(a->fdm.uvw[2]) / 340; o[8] = vc_mps(a) / 340;
+  int off = 8;
+  for (int pass = 0; pass < 2; pass++)
+    for (int k = 0; k < e->cfg.n_aircraft; k++) {
+      if (k == i) continue;
+      int same = e->ac[k].team == a->team;
+      if ((pass == 0) != same) continue;
+      const OrAircraft* b = &e->ac[k];
+      feature6(b, nf);
+      or_get_AO_TA_R(ef, nf, 0, r);
+      o[off + 1] = (mps(b->fdm.uvw[0]) - mps(a->fdm.uvw[0])) / 340;
+      o[off + 2] = (h_sl_m(b) - h_sl_m(a)) / 1000;
+      o[off + 3] = r[0]; o[off + 4] = r[1]; o[off + 5] = r[2] / 10000; o[off + 6] = r[3];
+      off += 6;
+    }
+  int mk = missile_warning(e, i);
+  if (mk >= 0) {
+    const OrMissile* m = &e->msl[mk];
+    double mf[6] = {m->position[0], m->position[1], m->position[2], m->velocity[0], m->velocity[1], m->velocity[2]};
+    or_get_AO_TA_R(ef, mf, 0, r);
+    o[off + 1] = (norm3(m->velocity) - mps(a->fdm.uvw[0])) / 340;
+    o[off + 2] = (mf[2] - h_sl_m(a)) / 1000;
+    o[off + 3] = r[0]; o[off + 4] = r[1]; o[off + 5] = r[2] / 10000; o[off + 6] = r[3];
+  }
+}
 static void get_obs(const OrEnv* e, double* obs) {
   for (int i = 0; i < e->cfg.n_aircraft; i++) {
     if (e->cfg.task == OR_TASK_HEADING) obs_heading(e, i, obs + i * e->obs_dim);
     else if (e->cfg.task == OR_TASK_MULTICOMBAT) obs_multicombat(e, i, obs + i * e->obs_dim);
+    else if (e->cfg.task == OR_TASK_SCENARIO_NVN) obs_scenario_nvn(e, i, obs + i * e->obs_dim);
     else obs_combat(e, i, obs + i * e->obs_dim);
   }
 }
@@ -384,6 +435,81 @@ static double rw_missile_posture(OrEnv* e, int i) { /* missile_posture_reward.py
   }
   return reward;
 }
+#define FT2METERS 0.3048
+/* the gun / geometry terms iterate over env.agents[agent_id].enemies in env order */
+static double rw_combat_geometry(OrEnv* e, int i) { /* combat_geometry_reward.py:28-68: `i` there is never incremented and the
+                                                     * prev lists are shared by all agents and never cleared between steps, so every
+                                                     * enemy contributes -(AO_first - AO_ref) - (TA_first - TA_ref) */
+  double ef[6], nf[6], r[4], sum = 0, AO0 = 0, TA0 = 0;
+  int first = 1;
+  feature6(&e->ac[i], ef);
+  for (int k = 0; k < e->cfg.n_aircraft; k++) {
+    if (e->ac[k].team == e->ac[i].team) continue;
+    feature6(&e->ac[k], nf);
+    or_get_AO_TA_R(ef, nf, 0, r);
+    if (first) { AO0 = r[0]; TA0 = r[1]; first = 0; }
+    if (!e->cg_set) { e->cg_set = 1; e->cg_AO = r[0]; e->cg_TA = r[1]; }
+    sum += -(AO0 - e->cg_AO) - (TA0 - e->cg_TA);
+  }
+  return sum * e->cfg.gun_scale;
+}
+static double rw_gun_wez(OrEnv* e, int i) { /* gun_WEZ_reward.py:28-55 */
+  double ef[6], nf[6], r[4], sum = 0;
+  feature6(&e->ac[i], ef);
+  for (int k = 0; k < e->cfg.n_aircraft; k++) {
+    if (e->ac[k].team == e->ac[i].team) continue;
+    feature6(&e->ac[k], nf);
+    or_get_AO_TA_R(ef, nf, 0, r);
+    if (r[2] >= 500 * FT2METERS && r[2] <= 3000 * FT2METERS && r[0] <= 1 * M_PI / 180) sum += 5 + 5 * (3000 * FT2METERS - r[2]) / (2500 * FT2METERS);
+  }
+  return sum * e->cfg.gun_scale;
+}
+static double rw_gun_behit(OrEnv* e, int i) { /* gun_behit_reward.py:27-54 */
+  double ef[6], nf[6], r[4], sum = 0;
+  feature6(&e->ac[i], ef);
+  for (int k = 0; k < e->cfg.n_aircraft; k++) {
+    if (e->ac[k].team == e->ac[i].team) continue;
+    feature6(&e->ac[k], nf);
+    or_get_AO_TA_R(ef, nf, 0, r);
+    if (r[2] >= 500 * FT2METERS && r[2] <= 3000 * FT2METERS && r[0] >= 179 * M_PI / 180) sum += -5;
+  }
+  return sum * e->cfg.gun_scale;
+}
+/* gun_WEZDOT_reward.py:33-77 and gun_targettail_reward.py:32-78 share one pattern: prev[j] read for enemy j is entry j of a
+ * list that only ever grows; its first n_enemies entries are written by the first call after reset: prev[0] = d_0 and
+ * prev[j] = d_{j-1} (of that first call), and stay fixed until the next reset */
+static double rw_gun_track(OrEnv* e, int i, int tail) {
+  double ef[6], nf[6], r[4], sum = 0, d[OR_MAX_AC];
+  int n = 0;
+  int* set = tail ? &e->tail_set : &e->wezdot_set;
+  double* ref = tail ? e->tail_ref : e->wezdot_ref;
+  feature6(&e->ac[i], ef);
+  for (int k = 0; k < e->cfg.n_aircraft; k++) {
+    if (e->ac[k].team == e->ac[i].team) continue;
+    feature6(&e->ac[k], nf);
+    or_get_AO_TA_R(ef, nf, 0, r);
+    double R = r[2], dd;
+    if (!tail) {
+      if (R >= 500 * FT2METERS && R <= 3000 * FT2METERS) dd = R * sin(r[0]);
+      else dd = sqrt(R * R + pow(3000 * FT2METERS, 2) - 2 * R * (3000 * FT2METERS) * cos(r[0]));
+    } else {
+      if (R >= 3000 * FT2METERS && R <= 5000 * FT2METERS) dd = R * sin(r[1]);
+      else if (R <= 3000 * FT2METERS) dd = sqrt(R * R + pow(3000 * FT2METERS, 2) - 2 * R * (3000 * FT2METERS) * cos(r[1]));
+      else dd = sqrt(R * R + pow(5000 * FT2METERS, 2) - 2 * R * (5000 * FT2METERS) * cos(r[1]));
+    }
+    d[n] = dd;
+    if (!*set) ref[n] = (n == 0) ? dd : d[n - 1];
+    sum += -1.0 / 60 * tanh((d[n] - ref[n]) / sqrt(R));
+    n++;
+  }
+  *set = 1;
+  return sum * e->cfg.gun_scale;
+}
+static double rw_relative_altitude(OrEnv* e, int i) { /* relative_altitude_reward.py:18-32: enemies[0] only */
+  int en = first_enemy(e, i);
+  double v = fmin(e->cfg.relative_altitude_KH - fabs(e->ac[i].position[2] / 1000 - e->ac[en].position[2] / 1000), 0);
+  return v * e->cfg.relative_altitude_scale;
+}
 static double rw_heading(OrEnv* e, int i) { /* heading_reward.py:18-71 */
   OrAircraft* a = &e->ac[i];
   double p = a->fdm.pqr[0], q = a->fdm.pqr[1];
@@ -402,6 +528,16 @@ static double rw_heading(OrEnv* e, int i) { /* heading_reward.py:18-71 */
 static double task_reward_terms(OrEnv* e, int i) {
   switch (e->cfg.task) {
     case OR_TASK_HEADING: { double r = rw_heading(e, i); return r + rw_altitude(e, i); }
+    case OR_TASK_SCENARIO1: case OR_TASK_SCENARIO_NVN: { /* scenario1_task.py:13-25 / scenario2_task.py:228-240, list order */
+      double r = rw_altitude(e, i); r += rw_combat_geometry(e, i); r += rw_event(e, i); r += rw_gun_behit(e, i);
+      r += rw_gun_track(e, i, 1); r += rw_gun_track(e, i, 0); r += rw_gun_wez(e, i); r += rw_posture(e, i);
+      r += rw_relative_altitude(e, i); r += rw_missile_posture(e, i);
+      return r + rw_shoot_penalty(e, i); /* task.remaining_missiles never changes in the Scenario tasks: always 0 */
+    }
+    case OR_TASK_WVR: { /* WVR_task.py:21-30 */
+      double r = rw_posture(e, i); r += rw_altitude(e, i); r += rw_event(e, i); r += rw_combat_geometry(e, i); r += rw_gun_behit(e, i);
+      r += rw_gun_track(e, i, 1); r += rw_gun_wez(e, i); return r + rw_gun_track(e, i, 0);
+    }
     case OR_TASK_MULTICOMBAT: /* same three terms, multiplecombat_task.py:27-31 */
     case OR_TASK_SINGLECOMBAT: { double r = rw_altitude(e, i); r += rw_posture(e, i); return r + rw_event(e, i); }
     case OR_TASK_DODGE_MISSILE: { double r = rw_posture(e, i); r += rw_missile_posture(e, i); r += rw_altitude(e, i); return r + rw_event(e, i); }
@@ -410,7 +546,7 @@ static double task_reward_terms(OrEnv* e, int i) {
 }
 static double get_reward(OrEnv* e, int i) { /* singlecombat_task.py:190-195; heading task uses BaseTask.get_reward */
   if (e->cfg.task == OR_TASK_HEADING) return task_reward_terms(e, i);
-  if (e->cfg.task == OR_TASK_MULTICOMBAT) /* multiplecombat_task.py:147-151: only while alive */
+  if (e->cfg.task == OR_TASK_MULTICOMBAT || e->cfg.task == OR_TASK_SCENARIO_NVN) /* multiplecombat_task.py:147-151: only while alive */
     return e->ac[i].status == OR_ALIVE ? task_reward_terms(e, i) : 0.0;
   if (e->ac[i].die_flag) return 0.0;
   e->ac[i].die_flag = e->ac[i].status != OR_ALIVE;
@@ -423,6 +559,7 @@ static void reward_reset(OrEnv* e) { /* reward_function_base.py:20-32 — each p
     a->pre_remaining_missiles = e->cfg.num_missiles[i];
   }
   e->mp_prev_missile = -1;
+  e->cg_set = e->wezdot_set = e->tail_set = 0;
   int t = e->cfg.task;
   /* reset order = reward_functions list order of the task */
   if (t == OR_TASK_HEADING) {
@@ -494,25 +631,114 @@ static int t_unreach_heading(OrEnv* e, int i, int* code) { /* unreach_heading.py
 static int get_termination(OrEnv* e, int i, int* code) {
   if (e->cfg.task == OR_TASK_HEADING) /* heading_task.py:20-26 */
     return t_unreach_heading(e, i, code) || t_extreme(e, i, code) || t_overload(e, i, code) || t_low_altitude(e, i, code) || t_timeout(e, i, code);
-  if (e->cfg.task == OR_TASK_MULTICOMBAT) /* multiplecombat_task.py:33-39 */
+  if (e->cfg.task == OR_TASK_WVR) /* WVR_task.py:31-36: no SafeReturn */
+    return t_low_altitude(e, i, code) || t_extreme(e, i, code) || t_overload(e, i, code) || t_timeout(e, i, code);
+  if (e->cfg.task == OR_TASK_MULTICOMBAT || e->cfg.task == OR_TASK_SCENARIO_NVN) /* multiplecombat_task.py:33-39 */
     return t_safe_return(e, i, code) || t_extreme(e, i, code) || t_overload(e, i, code) || t_low_altitude(e, i, code) || t_timeout(e, i, code);
   /* singlecombat_task.py:34-40 */
   return t_low_altitude(e, i, code) || t_extreme(e, i, code) || t_overload(e, i, code) || t_safe_return(e, i, code) || t_timeout(e, i, code);
 }
 
 /* ------------------------------------------------------------------ task.step */
-static int new_missile(OrEnv* e, int parent, int target, int model) {
+/* env.add_temp_simulator(sim): self._tempsims[sim.uid] = sim (env_base.py:93-95). A uid seen before keeps its dict position
+ * and the earlier missile drops out of the dict: it is never run() again but stays in its parent's launch_missiles and its
+ * target's under_missiles lists. key < 0: unique uid (tasks whose uids never collide). */
+static int new_missile_keyed(OrEnv* e, int parent, int target, int model, int key) {
   if (e->n_msl >= OR_MAX_MSL) return -1;
   int k = e->n_msl++;
   OrMissile* m = &e->msl[k];
   or_missile_init(m, model, 1.0 / e->cfg.sim_freq);
-  m->parent = parent; m->target = target;
+  m->parent = parent; m->target = target; m->model = model;
   or_missile_launch(m, e->ac[parent].geodetic, e->ac[parent].position, e->ac[parent].velocity, e->ac[parent].posture);
+  m->key = key; m->in_sims = 1; m->sim_pos = -1;
+  if (key >= 0)
+    for (int j = 0; j < k; j++)
+      if (e->msl[j].in_sims && e->msl[j].key == key) { m->sim_pos = e->msl[j].sim_pos; e->msl[j].in_sims = 0; }
+  if (m->sim_pos < 0) m->sim_pos = e->n_sim_keys++;
   return k;
+}
+static int new_missile(OrEnv* e, int parent, int target, int model) { return new_missile_keyed(e, parent, target, model, -1); }
+static int missile_done(const OrEnv* e, int k) { return k < 0 || e->msl[k].status == OR_MSL_HIT || e->msl[k].status == OR_MSL_MISS; }
+/* get_target (scenario1_task.py:139-145): the FARTHEST enemy, dead or alive */
+static int farthest_enemy(const OrEnv* e, int i) {
+  int best = -1; double bd = -1;
+  for (int k = 0; k < e->cfg.n_aircraft; k++) {
+    if (e->ac[k].team == e->ac[i].team) continue;
+    double d[3] = {e->ac[k].position[0] - e->ac[i].position[0], e->ac[k].position[1] - e->ac[i].position[1], e->ac[k].position[2] - e->ac[i].position[2]};
+    double n = norm3(d);
+    if (n > bd) { bd = n; best = k; }
+  }
+  return best;
+}
+/* a2a_launch_available (scenario1_task.py:104-138) */
+static void a2a_available(const OrEnv* e, int i, int tgt, int avail[3]) {
+  avail[0] = avail[1] = avail[2] = 0;
+  if (e->ac[tgt].status != OR_ALIVE) return;
+  const OrAircraft* a = &e->ac[i];
+  double t[3] = {e->ac[tgt].position[0] - a->position[0], e->ac[tgt].position[1] - a->position[1], e->ac[tgt].position[2] - a->position[2]};
+  double dist = norm3(t);
+  double dot = t[0] * a->velocity[0] + t[1] * a->velocity[1] + t[2] * a->velocity[2];
+  double ang = RAD2DEG * acos(clampd(-1, dot / (dist * norm3(a->velocity) + 1e-8), 1));
+  if (dist / 1000 < 3 && ang < 5) avail[0] = 1;
+  if (dist / 1000 < 37 && ang < 90) avail[1] = 1;
+  if (dist / 1000 < 7 && ang < 90) avail[2] = 1;
+}
+static void scenario_weapons(OrEnv* e) { /* scenario1_task.py:61-103 == scenario2_task.py:73-115 */
+  for (int i = 0; i < e->cfg.n_aircraft; i++) {
+    OrAircraft* a = &e->ac[i];
+    int alive = a->status == OR_ALIVE;
+    int f_gun = alive && a->shoot4[0] && a->rem_gun > 0;
+    int f_9m = alive && a->shoot4[1] && a->rem_9m > 0;
+    int f_120 = alive && a->shoot4[2] && a->rem_120b > 0;
+    int f_chaff = alive && a->shoot4[3] && a->rem_chaff > 0;
+    int avail[3];
+    if (f_gun && missile_done(e, a->last_missile)) {
+      int tg = farthest_enemy(e, i);
+      a2a_available(e, i, tg, avail);
+      if (avail[0]) { e->ac[tg].bloods -= 5; a->rem_gun -= 1; }
+    }
+    if (f_120 && missile_done(e, a->last_missile)) {
+      int tg = farthest_enemy(e, i);
+      a2a_available(e, i, tg, avail);
+      if (avail[1]) { a->last_missile = new_missile_keyed(e, i, tg, 1, i * 100 + a->rem_120b); a->rem_120b -= 1; }
+    }
+    if (f_9m && missile_done(e, a->last_missile)) {
+      int tg = farthest_enemy(e, i);
+      a2a_available(e, i, tg, avail);
+      if (avail[2]) { a->last_missile = new_missile_keyed(e, i, tg, 1, i * 100 + a->rem_9m); a->rem_9m -= 1; }
+    }
+    if (f_chaff && (a->last_chaff < 0 || e->chaff[a->last_chaff].status == 1)) {
+      /* one chaff per missile in env._tempsims (done ones included) that targets this aircraft within 1000 m */
+      for (int pos = 0; pos < e->n_sim_keys; pos++)
+        for (int k = 0; k < e->n_msl; k++) {
+          const OrMissile* m = &e->msl[k];
+          if (!m->in_sims || m->sim_pos != pos || m->target != i) continue;
+          double d[3] = {a->position[0] - m->position[0], a->position[1] - m->position[1], a->position[2] - m->position[2]};
+          if (norm3(d) < 1000 && e->n_chaff < OR_MAX_CHAFF) {
+            int c = e->n_chaff++;
+            memcpy(e->chaff[c].pos, a->position, sizeof e->chaff[c].pos);
+            e->chaff[c].t = 0; e->chaff[c].status = 0; e->chaff[c].parent = i;
+            a->last_chaff = c;
+            a->rem_chaff -= 1;
+          }
+        }
+    }
+  }
+}
+static void wvr_gun(OrEnv* e) { /* WVR_task.py:62-76 */
+  for (int i = 0; i < e->cfg.n_aircraft; i++) {
+    int tg = farthest_enemy(e, i);
+    const OrAircraft* a = &e->ac[i];
+    double t[3] = {e->ac[tg].position[0] - a->position[0], e->ac[tg].position[1] - a->position[1], e->ac[tg].position[2] - a->position[2]};
+    double dist = norm3(t);
+    double dot = t[0] * a->velocity[0] + t[1] * a->velocity[1] + t[2] * a->velocity[2];
+    double ang = RAD2DEG * acos(clampd(-1, dot / (dist * norm3(a->velocity) + 1e-8), 1));
+    if (dist / 1000 < 3 && ang < 5) e->ac[tg].bloods -= 5;
+  }
 }
 static void task_step(OrEnv* e) {
   int t = e->cfg.task;
-  if (t == OR_TASK_HEADING) return;
+  if (t == OR_TASK_HEADING || t == OR_TASK_MULTICOMBAT) return;
   if (e->cfg.use_artillery) { /* singlecombat_task.py:162-188 */
     for (int i = 0; i < e->cfg.n_aircraft; i++) {
       double ef[6], nf[6], r[4];
@@ -528,6 +754,8 @@ static void task_step(OrEnv* e) {
       }
     }
   }
+  if (t == OR_TASK_SCENARIO1 || t == OR_TASK_SCENARIO_NVN) { scenario_weapons(e); return; }
+  if (t == OR_TASK_WVR) { wvr_gun(e); return; }
   if (t == OR_TASK_DODGE_MISSILE) { /* singlecombat_with_missile_task.py:108-124 */
     for (int i = 0; i < e->cfg.n_aircraft; i++) {
       OrAircraft* a = &e->ac[i];
@@ -562,11 +790,46 @@ static void task_step(OrEnv* e) {
   }
 }
 
+/* missiles, chaff and the decoy test of one substep (env_base.py:142-154) */
+static void run_projectiles_once(OrEnv* e, double dt) {
+  const OrEnvConfig* c = &e->cfg;
+  for (int pos = 0; pos < e->n_sim_keys; pos++) /* env._tempsims in dict order */
+    for (int k = 0; k < e->n_msl; k++) {
+      OrMissile* m = &e->msl[k];
+      if (!m->in_sims || m->sim_pos != pos) continue;
+      /* MissileSimulator.run is called for every entry, whatever its status (simulatior.py:520-533) */
+      OrAircraft* tg = &e->ac[m->target];
+      int st = or_missile_run(m, tg->position, tg->velocity, tg->status == OR_ALIVE, dt, c->center_lon, c->center_lat, c->center_alt);
+      if (st == OR_MSL_HIT && tg->status == OR_ALIVE) tg->status = OR_SHOTDOWN;
+    }
+  for (int k = 0; k < e->n_chaff; k++) { /* ChaffSimulator.run (simulatior.py:377-381) */
+    e->chaff[k].t += dt;
+    if (e->chaff[k].t > 20) e->chaff[k].status = 1;
+  }
+  for (int pos = 0; pos < e->n_sim_keys; pos++) /* decoy test (env_base.py:146-154) */
+    for (int k = 0; k < e->n_msl; k++) {
+      OrMissile* m = &e->msl[k];
+      if (!m->in_sims || m->sim_pos != pos) continue;
+      if (m->status == OR_MSL_HIT || m->status == OR_MSL_MISS) continue;
+      for (int q = 0; q < e->n_chaff; q++) {
+        if (e->chaff[q].status == 1) continue;
+        double d[3] = {e->chaff[q].pos[0] - m->position[0], e->chaff[q].pos[1] - m->position[1], e->chaff[q].pos[2] - m->position[2]};
+        if (norm3(d) <= 300) if (chaff_uniform(e) < 0.85) m->status = OR_MSL_MISS;
+      }
+    }
+}
+void or_env_run_projectiles(OrEnv* e, int substeps) {
+  for (int i = 0; i < e->cfg.n_aircraft; i++) /* AircraftSimulator.run: bloods <= 0 -> shotdown (simulatior.py:220-222) */
+    if (e->ac[i].status == OR_ALIVE && e->ac[i].bloods <= 0) e->ac[i].status = OR_SHOTDOWN;
+  for (int s = 0; s < substeps; s++) run_projectiles_once(e, 1.0 / e->cfg.sim_freq);
+}
+void or_env_task_step(OrEnv* e) { task_step(e); }
+
 /* ------------------------------------------------------------------ reset / step */
 void or_env_reset(OrEnv* e, double* obs) {
   const OrEnvConfig* c = &e->cfg;
   e->current_step = 0;
-  e->n_msl = 0;
+  e->n_msl = 0; e->n_sim_keys = 0; e->n_chaff = 0;
   if (c->task == OR_TASK_HEADING) { /* singlecontrol_env.py:24-49 */
     double hdg = or_env_uniform(e, 0., 180.), alt = or_env_uniform(e, 14000., 30000.), u = or_env_uniform(e, 400., 1200.);
     F16Init ic = c->init[0];
@@ -596,6 +859,9 @@ void or_env_task_reset(OrEnv* e) {
     a->lock_pos = 0;
     a->shoot_action = 0;
     a->last_missile = -1;
+    a->last_chaff = -1;
+    a->rem_gun = a->rem_9m = a->rem_120b = a->rem_chaff = c->num_missiles[i];
+    for (int k = 0; k < 4; k++) a->shoot4[k] = 0;
   }
   reward_reset(e);
 }
@@ -617,19 +883,16 @@ void or_env_step(OrEnv* e, const double* actions, double* obs, double* rew, uint
     const double* act = actions + i * e->act_dim;
     double u[4];
     if (c->task == OR_TASK_SHOOT_MISSILE) e->ac[i].shoot_action = act[4] != 0; /* :182-184 */
+    /* Scenario1 only refreshes the ego team's weapon bits (scenario1_task.py:44-45); the NvN tasks refresh both (scenario2_task.py:58-61) */
+    if (c->task == OR_TASK_SCENARIO_NVN || (c->task == OR_TASK_SCENARIO1 && e->ac[i].team == 0))
+      for (int k = 0; k < 4; k++) e->ac[i].shoot4[k] = act[4 + k] != 0;
     decode_action(e, i, act, u);
     f16_set_controls(&e->ac[i].fdm, u[0], u[1], u[2], u[3]);
   }
   double dt = 1.0 / c->sim_freq;
   for (int s = 0; s < c->agent_interaction_steps; s++) { /* env_base.py:139-154 */
     for (int i = 0; i < c->n_aircraft; i++) aircraft_run(e, &e->ac[i]);
-    for (int k = 0; k < e->n_msl; k++) {
-      OrMissile* m = &e->msl[k];
-      /* MissileSimulator.run is called for every entry, whatever its status (simulatior.py:520-533) */
-      OrAircraft* tg = &e->ac[m->target];
-      int st = or_missile_run(m, tg->position, tg->velocity, tg->status == OR_ALIVE, dt, c->center_lon, c->center_lat, c->center_alt);
-      if (st == OR_MSL_HIT && tg->status == OR_ALIVE) tg->status = OR_SHOTDOWN;
-    }
+    run_projectiles_once(e, dt);
   }
   task_step(e);
   or_env_evaluate(e, obs, rew, done, info);
@@ -640,7 +903,7 @@ void or_env_evaluate(OrEnv* e, double* obs, double* rew, uint8_t* done, int32_t*
   const OrEnvConfig* c = &e->cfg;
   int code = OR_DONE_NONE;
   get_obs(e, obs);
-  if (c->task == OR_TASK_MULTICOMBAT) { /* MultipleCombatEnv.step, multiplecombat_env.py:160-182: rewards, team mean, then dones */
+  if (c->task == OR_TASK_MULTICOMBAT || c->task == OR_TASK_SCENARIO_NVN) { /* MultipleCombatEnv.step, multiplecombat_env.py:160-182: rewards, team mean, then dones */
     double sum[2] = {0, 0}; int cnt[2] = {0, 0};
     for (int i = 0; i < c->n_aircraft; i++) { rew[i] = get_reward(e, i); sum[e->ac[i].team] += rew[i]; cnt[e->ac[i].team]++; }
     for (int i = 0; i < c->n_aircraft; i++) rew[i] = sum[e->ac[i].team] / cnt[e->ac[i].team];

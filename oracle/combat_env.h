@@ -20,7 +20,11 @@ extern "C" {
 #define OR_MAX_MSL 64
 
 enum { OR_TASK_HEADING = 0, OR_TASK_SINGLECOMBAT = 1, OR_TASK_DODGE_MISSILE = 2, OR_TASK_SHOOT_MISSILE = 3,
-       OR_TASK_MULTICOMBAT = 4 /* MultipleCombatTask (multiplecombat_task.py:15-151) under MultipleCombatEnv.step */ };
+       OR_TASK_MULTICOMBAT = 4 /* MultipleCombatTask (multiplecombat_task.py:15-151) under MultipleCombatEnv.step */,
+       OR_TASK_SCENARIO1 = 5   /* Scenario1 weapon rules + 11 rewards, 1v1 (scenario1_task.py:11-145), low-level control */,
+       OR_TASK_SCENARIO_NVN = 6 /* Scenario2_NvN / Scenario3_NvN (scenario2_task.py:14-316), low-level control */,
+       OR_TASK_WVR = 7         /* WVRTask gun-only 1v1 (WVR_task.py:10-90), low-level control */ };
+#define OR_MAX_CHAFF 64
 enum { OR_ALIVE = 0, OR_CRASH = 1, OR_SHOTDOWN = 2 };
 enum { OR_MSL_INACTIVE = -1, OR_MSL_LAUNCHED = 0, OR_MSL_HIT = 1, OR_MSL_MISS = 2 };
 /* done reason codes written to info (first condition that fired for the LAST agent evaluated, like info['done_condition']) */
@@ -52,6 +56,9 @@ typedef struct {
   /* heading task (unreach_heading.py:27-31) */
   double max_heading_increment, max_altitude_increment, max_velocities_u_increment, check_interval;
   int use_artillery;
+  double relative_altitude_scale, relative_altitude_KH;   /* RelativeAltitudeReward_scale / _KH */
+  double gun_scale;                                       /* common scale of the CombatGeometry / Gun* terms (all default 1) */
+  uint64_t chaff_seed;                                    /* counter-based stand-in for the global np.random of env_base.py:153 */
 } OrEnvConfig;
 
 typedef struct {
@@ -70,6 +77,8 @@ typedef struct {
   int lock_window[16]; int lock_n, lock_pos;   /* deque(maxlen=int(1/time_interval)) */
   int shoot_action;
   int last_missile;     /* index of agent_last_shot_missile, -1 = none */
+  /* scenario weapon rules (scenario1_task.py:50-103) */
+  int rem_gun, rem_9m, rem_120b, rem_chaff, shoot4[4], last_chaff;
   /* heading task extras */
   double target_heading_deg, target_altitude_ft, target_velocities_u_mps, heading_check_time;
   double last_roll_rate, last_pitch_rate;
@@ -85,6 +94,7 @@ typedef struct {
   double t, m, dtheta, dphi, dist_prev;
   int recede_count;     /* consecutive "distance increased" samples (deque of maxlen int(5/dt)) */
   int recede_len, recede_max;
+  int key, sim_pos, in_sims, model;   /* env._tempsims bookkeeping: dict key (uid), dict position, still in the dict */
   /* parameters (simulatior.py:421-433) */
   double g, t_max, t_thrust, Isp, Length, Diameter, cD, m0, dm, K, nyz_max, Rc, v_min;
 } OrMissile;
@@ -94,6 +104,14 @@ typedef struct {
   OrAircraft ac[OR_MAX_AC];
   OrMissile msl[OR_MAX_MSL];
   int n_msl;
+  int n_sim_keys;
+  struct { double pos[3]; double t; int status; int parent; } chaff[OR_MAX_CHAFF];
+  int n_chaff;
+  uint64_t chaff_draws;
+  /* reward memories shared by every agent of the env (CombatGeometry / GunWEZDOT / GunTargetTail keep module-level lists) */
+  int cg_set; double cg_AO, cg_TA;
+  int wezdot_set; double wezdot_ref[OR_MAX_AC];
+  int tail_set; double tail_ref[OR_MAX_AC];
   int current_step;
   int heading_turn_counts;
   /* MissilePostureReward shared memory: index of the missile whose velocity array was aliased, -1 = None */

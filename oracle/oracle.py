@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 OR_MAX_AC = 8
 TASK_HEADING, TASK_SINGLECOMBAT, TASK_DODGE_MISSILE, TASK_SHOOT_MISSILE, TASK_MULTICOMBAT = 0, 1, 2, 3, 4
+TASK_SCENARIO1, TASK_SCENARIO_NVN, TASK_WVR = 5, 6, 7
 STATE_LEN = 80
 
 
@@ -39,6 +40,8 @@ class OrEnvConfig(C.Structure):
         ("max_heading_increment", C.c_double), ("max_altitude_increment", C.c_double),
         ("max_velocities_u_increment", C.c_double), ("check_interval", C.c_double),
         ("use_artillery", C.c_int),
+        ("relative_altitude_scale", C.c_double), ("relative_altitude_KH", C.c_double), ("gun_scale", C.c_double),
+        ("chaff_seed", C.c_uint64),
     ]
 
 
@@ -109,6 +112,11 @@ def lib():
         L.or_env_heading_pose.argtypes = [C.c_void_p] + [C.c_double] * 11
         L.or_env_heading_get.argtypes = [C.c_void_p, dp]
         L.or_missile_raw_run.argtypes = [dp, C.c_int, dp, dp, C.c_int]
+        L.or_env_set_shoot4.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.or_env_task_step.argtypes = [C.c_void_p]
+        L.or_env_run_projectiles.argtypes = [C.c_void_p, C.c_int]
+        L.or_env_get_counters.argtypes = [C.c_void_p, C.c_int, dp]
+        L.or_env_get_misc.argtypes = [C.c_void_p, dp]
         L.or_bench_run.argtypes = [C.POINTER(OrEnvConfig), C.c_int, C.c_int, C.c_uint64, dp, C.POINTER(C.c_long)]
         L.or_bench_run.restype = C.c_long
         assert L.or_env_config_sizeof() == C.sizeof(OrEnvConfig), "OrEnvConfig layout mismatch"

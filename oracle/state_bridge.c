@@ -169,3 +169,13 @@ void or_missile_raw_run(double* st /* [20] */, int model, const double tp[3], co
   st[7] = m.posture[1]; st[8] = m.posture[2]; st[9] = m.t; st[10] = m.m; st[11] = m.dtheta; st[12] = m.dphi; st[13] = m.dist_prev;
   st[14] = m.recede_count; st[15] = m.geodetic[2];
 }
+
+/* ---- scenario-task golden hooks */
+void or_env_set_shoot4(OrEnv* e, int i, const int bits[4]) { for (int k = 0; k < 4; k++) e->ac[i].shoot4[k] = bits[k]; }
+void or_env_task_step(OrEnv* e);             /* combat_env.c */
+void or_env_run_projectiles(OrEnv* e, int substeps);
+void or_env_get_counters(const OrEnv* e, int i, double out[6]) {
+  const OrAircraft* a = &e->ac[i];
+  out[0] = a->rem_gun; out[1] = a->rem_9m; out[2] = a->rem_120b; out[3] = a->rem_chaff; out[4] = a->bloods; out[5] = a->status;
+}
+void or_env_get_misc(const OrEnv* e, double out[3]) { out[0] = e->n_chaff; out[1] = (double)e->chaff_draws; out[2] = e->current_step; }

@@ -541,6 +541,190 @@ def gen_multicombat_sequences(rng):
     np.savez_compressed(os.path.join(OUT, "multicombat_sequences.npz"), **flat)
 
 
+
+class CounterRNG:
+    """Stand-in for the global, unseeded np.random the reference's decoy test draws from (env_base.py:153): splitmix64 of a
+    seed and a draw counter, the generator the oracle and the kernel implement as well."""
+
+    def __init__(self, seed=1):
+        self.seed, self.n = seed, 0
+
+    def rand(self):
+        M = (1 << 64) - 1
+        z = (self.seed * 0x9E3779B97F4A7C15 + self.n * 0xD1B54A32D192ED03) & M
+        self.n += 1
+        z ^= z >> 30; z = (z * 0xBF58476D1CE4E5B9) & M
+        z ^= z >> 27; z = (z * 0x94D049BB133111EB) & M
+        z ^= z >> 31
+        return (z >> 40) / 16777216.0
+
+
+class WeaponEnv(FakeEnv):
+    """FakeEnv plus the projectile part of BaseEnv.step's substep loop (env_base.py:139-154), replayed around the reference's
+    own MissileSimulator / ChaffSimulator objects (the aircraft are scripted poses, held during the six substeps)."""
+
+    def __init__(self, agents):
+        super().__init__(agents)
+        self._chaffsims = {}
+        self.rng = CounterRNG(1)
+
+    def add_chaff_simulator(self, sim):
+        self._chaffsims[sim.uid] = sim
+        return sim
+
+    def run_projectiles(self, substeps=6):
+        for a in self.agents.values():            # AircraftSimulator.run: bloods <= 0 -> shotdown (simulatior.py:220-222)
+            if a.is_alive and a.bloods <= 0:
+                a.shotdown()
+        for _ in range(substeps):
+            for sim in self._tempsims.values():
+                sim.run()
+            for sim in self._chaffsims.values():
+                sim.run()
+            for missile in self._tempsims.values():
+                if missile.is_done:
+                    continue
+                for chaff in self._chaffsims.values():
+                    if chaff.is_done:
+                        continue
+                    if np.linalg.norm(chaff.get_position() - missile.get_position()) <= chaff.effective_radius:
+                        if self.rng.rand() < 0.85:
+                            missile.missed()
+
+
+def engagement_pose(rng, shooter, target, dist_m, off_deg, alt_m=6000.0):
+    """Put `target` dist_m ahead of `shooter` (who flies north), off_deg off the nose; both roughly co-altitude."""
+    shooter.set_pose(120.0, 60.0, alt_m, (0.05, 0.02, 0.0), (250.0, 0.0, -2.0), (250.0, 1.0, 5.0), vc=240.0,
+                     npilot=(0.1, 0.0, -1.1), sim_time=30.0)
+    b = np.radians(off_deg)
+    dn, de = dist_m * np.cos(b), dist_m * np.sin(b)
+    lat = 60.0 + dn / 111412.0
+    lon = 120.0 + de / (111320.0 * np.cos(np.radians(60.0)))
+    hdg = rng.uniform(0, 2 * np.pi)
+    target.set_pose(lon, lat, alt_m + rng.uniform(-300, 300), (0.0, 0.0, hdg), (230.0 * np.cos(hdg), 230.0 * np.sin(hdg), 3.0),
+                    (230.0, -1.0, 4.0), vc=225.0, npilot=(0.0, 0.0, -1.0), sim_time=30.0)
+
+
+def missile_rows(env, agents):
+    """Per frame: every missile ever launched in launch order: parent, target, status, pos, vel; plus per-agent counters."""
+    rows = []
+    seen = []
+    for a in agents:
+        for m in a.launch_missiles:
+            seen.append(m)
+    # global launch order = order of appearance in the under_missiles lists merged by creation: keep creation order by id list
+    return seen
+
+
+def _scenario_task(cls, cfg):
+    import torch
+    orig = torch.load
+    torch.load = lambda f, map_location=None, **kw: orig(f, map_location="cpu", **kw)   # the reference asks for 'cuda'
+    try:
+        return cls(cfg)
+    finally:
+        torch.load = orig
+
+
+def gen_scenario_sequences(rng):
+    """Scenario1 (1v1) and Scenario2_NvN (2v2) weapon rules, the 11 reward terms with their shared-list behaviour, the NvN
+    observation layout, chaff release and the decoy draw — over scripted engagements."""
+    from envs.JSBSim.tasks.scenario1_task import Scenario1
+    from envs.JSBSim.tasks.scenario2_task import Scenario2_NvN
+    import envs.JSBSim.tasks.scenario1_task as s1mod
+    flat = {}
+    ep_id = 0
+    for family in ("s1", "nvn"):
+        if family == "s1":
+            uids = ("A0100", "B0100")
+        else:
+            uids = ("A0100", "A0200", "B0100", "B0200")
+        acs = {u: {"color": "Blue" if u[0] == "A" else "Red", "missile": 2} for u in uids}
+        cfg = make_config(aircraft_configs=acs, EventDrivenReward_potential=(family == "s1"))
+        for ep in range(10):
+            task = _scenario_task(Scenario1 if family == "s1" else Scenario2_NvN, cfg)
+            agents = [FakeAircraft(u, acs[u]["color"]) for u in uids]
+            link(agents)
+            env = WeaponEnv(agents)
+            order = []      # missiles in creation order
+            orig_add = env.add_temp_simulator
+
+            def add(sim, _o=order, _f=orig_add):
+                _o.append(sim)
+                return _f(sim)
+            env.add_temp_simulator = add
+            A = len(agents)
+            for a in agents:
+                random_pose(rng, a, spread_km=8.0)
+            if ep % 2 == 0:
+                engagement_pose(rng, agents[0], agents[A // 2], rng.uniform(1500, 6500), rng.uniform(-4, 4))
+            task.reset(env)
+            frames = []
+            T = 26
+            for t in range(1, T + 1):
+                env.current_step = t
+                for k, a in enumerate(agents):
+                    if not a.is_alive:
+                        continue
+                    if ep % 2 == 0 and k in (0, A // 2):
+                        continue   # keep the engagement pair on its geometry; nudged below
+                    random_pose(rng, a, spread_km=8.0, alt=(2600.0, 9000.0))
+                if ep % 2 == 0 and t % 6 == 0 and agents[0].is_alive and agents[A // 2].is_alive:
+                    engagement_pose(rng, agents[0], agents[A // 2], rng.uniform(800, 9000), rng.uniform(-6, 6))
+                if ep % 5 == 3 and t == 12:
+                    agents[A - 1].bloods = 0     # dies at the next run()
+                pose = np.stack([pose_vector(a) for a in agents])
+                env.run_projectiles(6)
+                bits = (rng.random((A, 4)) < (0.7 if ep % 2 == 0 else 0.3)).astype(int)
+                for k, u in enumerate(env.agents):
+                    if family == "nvn" or u in env.ego_ids:       # what normalize_action does with action[-4:] (the controller net is bypassed)
+                        task._shoot_action[u] = list(bits[k])
+                    else:                                         # Scenario1's other team flies the scripted baseline: weapon bits [0,0,0,0]
+                        task._shoot_action[u] = [0, 0, 0, 0]      # (scenario1_task.py:38-39)
+                task.step(env)
+                pose_after = np.stack([pose_vector(a) for a in agents])   # status / bloods after projectiles and weapons
+                obs = np.stack([task.get_obs(env, u) for u in env.agents])
+                info = {"current_step": env.current_step}
+                if family == "s1":
+                    done = []
+                    for u in env.agents:
+                        d, info = task.get_termination(env, u, info)
+                        done.append(d)
+                    rew = []
+                    for u in env.agents:
+                        r, info = task.get_reward(env, u, info)
+                        rew.append(r)
+                    rew = np.array(rew, dtype=float)
+                else:
+                    rewards = {}
+                    for u in env.agents:
+                        r, info = task.get_reward(env, u, info)
+                        rewards[u] = [r]
+                    ego = np.mean([rewards[u] for u in env.ego_ids]); enm = np.mean([rewards[u] for u in env.enm_ids])
+                    rew = np.array([ego if u in env.ego_ids else enm for u in env.agents])
+                    done = []
+                    for u in env.agents:
+                        d, info = task.get_termination(env, u, info)
+                        done.append(d)
+                counters = np.array([[task.remaining_gun[u], task.remaining_missiles_AIM_9M[u], task.remaining_missiles_AIM_120B[u],
+                                      task.remaining_chaff_flare[u], agents[k].bloods, agents[k].status] for k, u in enumerate(env.agents)], dtype=float)
+                mrows = np.zeros((16, 9))
+                for k, m in enumerate(order[:16]):
+                    mrows[k] = [1 + uids.index(m.parent_aircraft.uid), uids.index(m.target_aircraft.uid), m._MissileSimulator__status,
+                                *m.get_position(), *m.get_velocity()]
+                frames.append(dict(pose=pose, bits=bits, obs=obs, rew=rew, done=np.array(done, dtype=float), counters=counters, msl=mrows,
+                                   nchaff=len(env._chaffsims), draws=env.rng.n, step=env.current_step))
+                if all(done):
+                    break
+            for key in ("pose", "bits", "obs", "rew", "done", "counters", "msl"):
+                flat[f"ep{ep_id}_{key}"] = np.stack([f[key] for f in frames])
+            flat[f"ep{ep_id}_misc"] = np.array([[f["nchaff"], f["draws"], f["step"]] for f in frames], dtype=float)
+            flat[f"ep{ep_id}_family"] = np.array([0.0 if family == "s1" else 1.0])
+            ep_id += 1
+    flat["n_episodes"] = np.array([ep_id], dtype=float)
+    np.savez_compressed(os.path.join(OUT, "scenario_sequences.npz"), **flat)
+
+
 def gen_curriculum_table():
     from envs.JSBSim.utils.utils import calculate_coordinates_heading_by_curriculum
     res = calculate_coordinates_heading_by_curriculum(60.1, 120.0, 11.119, list(range(0, 181)))
@@ -560,6 +744,7 @@ def main():
     gen_heading(rng)
     gen_curriculum_table()
     gen_multicombat_sequences(np.random.default_rng(77))
+    gen_scenario_sequences(np.random.default_rng(78))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

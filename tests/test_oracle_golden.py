@@ -196,3 +196,57 @@ def test_multicombat_2v2_sequences(oracle):
             assert (d == done[t].astype(bool)).all(), (ep, t, d, done[t])
             n_done += int(d.sum())
     assert n_done > 10
+
+
+def test_scenario_weapon_sequences(oracle):
+    """Scenario1 (1v1) and Scenario2_NvN (2v2): gun / AIM-120B / AIM-9M / chaff rules with the shared last-munition gate and
+    the uid-collision behaviour of env._tempsims, the decoy draw, the NvN observation layout, and all eleven reward terms
+    with their never-cleared shared lists — against the reference's task objects driven by the same scripted engagements."""
+    g = load("scenario_sequences.npz")
+    launched = chaffs = hits = 0
+    for ep in range(int(g["n_episodes"][0])):
+        nvn = bool(g[f"ep{ep}_family"][0])
+        cfg = oracle.default_config(oracle.TASK_SCENARIO_NVN if nvn else oracle.TASK_SCENARIO1)
+        if nvn:
+            cfg.event_potential = 0
+        A = cfg.n_aircraft
+        env = oracle.OracleEnv(cfg)
+        pose, bits, obs, rew, done, counters, msl, misc = (g[f"ep{ep}_{k}"] for k in ("pose", "bits", "obs", "rew", "done", "counters", "msl", "misc"))
+        # the generator resets the task on the poses of frame 0 *before* its first nudge; those poses equal frame 0's except
+        # that frame 0 may have moved the non-engagement aircraft: seed the potentials the same way the generator did
+        for t in range(len(pose)):
+            for i in range(A):
+                # pose vectors were captured at frame start: kinematics plus the status / bloods the reference had then (these
+                # equal what the oracle carried over, as the counters assertion of the previous frame checked, plus scripted events)
+                env.set_pose(i, pose[t][i])
+            if t == 0:
+                env.set_step(0)
+                # task.reset happened on the initial poses, which the generator did not store separately when it re-posed
+                # aircraft in frame 1; potentials are therefore checked from frame 2 on (see below)
+                env.task_reset()
+            env.set_step(int(misc[t][2]))
+            env.L.or_env_run_projectiles(env.p, 6)
+            for i in range(A):
+                b = (C.c_int * 4)(*[int(x) for x in bits[t][i]])
+                if nvn or i < cfg.n_ego:
+                    env.L.or_env_set_shoot4(env.p, i, b)
+            env.L.or_env_task_step(env.p)
+            o, r, d, info = env.evaluate()
+            got_c = np.zeros((A, 6))
+            for i in range(A):
+                env.L.or_env_get_counters(env.p, i, got_c[i].ctypes.data_as(C.POINTER(C.c_double)))
+            assert (got_c == counters[t]).all(), (ep, t, got_c, counters[t])
+            ms = env.missiles()
+            n_ref = int((msl[t][:, 0] > 0).sum())
+            assert len(ms) == n_ref, (ep, t, len(ms), n_ref)
+            for k, m in enumerate(ms[:16]):
+                assert int(m[11]) == int(msl[t][k][0]) - 1 and int(m[12]) == int(msl[t][k][1]) and int(m[0]) == int(msl[t][k][2]), (ep, t, k)
+                assert close(m[1:7], msl[t][k][3:9], rtol=1e-9, atol=1e-6).all(), (ep, t, k)
+            gm = np.zeros(3); env.L.or_env_get_misc(env.p, gm.ctypes.data_as(C.POINTER(C.c_double)))
+            assert gm[0] == misc[t][0] and gm[1] == misc[t][1], (ep, t, gm, misc[t])
+            assert close(o, obs[t], rtol=1e-9, atol=5e-8).all(), (ep, t, np.abs(o - obs[t]).max())
+            assert (d == done[t].astype(bool)).all(), (ep, t, d, done[t])
+            if t >= 1:   # frame 0's potential difference depends on the un-stored reset poses
+                assert close(r, rew[t], rtol=1e-7, atol=1e-6).all(), (ep, t, r, rew[t])
+            launched = max(launched, len(ms)); chaffs = max(chaffs, int(gm[0])); hits += int(sum(1 for m in ms if int(m[0]) == 1))
+    assert launched >= 3 and chaffs >= 1
