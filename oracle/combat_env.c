@@ -86,11 +86,15 @@ double or_env_uniform(OrEnv* e, double lo, double hi) {
 }
 
 /* The reference draws the decoy outcome from the GLOBAL, unseeded np.random (env_base.py:153): only statistical parity is
- * possible. Oracle and kernel both use this counter-based generator (splitmix64 of seed, env-local draw counter) so that they
- * can be compared draw for draw. */
-static double chaff_uniform(OrEnv* e) {
-  uint64_t z = e->cfg.chaff_seed * 0x9E3779B97F4A7C15ULL + (e->chaff_draws++) * 0xD1B54A32D192ED03ULL;
+ * possible. Oracle and kernel both use this counter-based generator, keyed by WHAT is being tested (substep tick since reset,
+ * missile = launcher + uid number, chaff = releaser + its release index) rather than by a sequential draw counter, so that the
+ * result does not depend on the evaluation order of independent pairs. */
+static double chaff_uniform(OrEnv* e, int tick, int msl_parent, int msl_num, int chaff_parent, int chaff_local) {
+  uint64_t k = ((uint64_t)(uint32_t)tick << 32) | ((uint64_t)(msl_parent & 0xff) << 24) | ((uint64_t)(msl_num & 0xff) << 16) |
+               ((uint64_t)(chaff_parent & 0xff) << 8) | (uint64_t)(chaff_local & 0xff);
+  uint64_t z = e->cfg.chaff_seed * 0x9E3779B97F4A7C15ULL + k * 0xD1B54A32D192ED03ULL;
   z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 27; z *= 0x94D049BB133111EBULL; z ^= z >> 31;
+  e->chaff_draws++;
   return (double)(z >> 40) * (1.0 / 16777216.0);
 }
 
@@ -793,6 +797,7 @@ static void task_step(OrEnv* e) {
 /* missiles, chaff and the decoy test of one substep (env_base.py:142-154) */
 static void run_projectiles_once(OrEnv* e, double dt) {
   const OrEnvConfig* c = &e->cfg;
+  e->sub_tick++;
   for (int pos = 0; pos < e->n_sim_keys; pos++) /* env._tempsims in dict order */
     for (int k = 0; k < e->n_msl; k++) {
       OrMissile* m = &e->msl[k];
@@ -814,7 +819,11 @@ static void run_projectiles_once(OrEnv* e, double dt) {
       for (int q = 0; q < e->n_chaff; q++) {
         if (e->chaff[q].status == 1) continue;
         double d[3] = {e->chaff[q].pos[0] - m->position[0], e->chaff[q].pos[1] - m->position[1], e->chaff[q].pos[2] - m->position[2]};
-        if (norm3(d) <= 300) if (chaff_uniform(e) < 0.85) m->status = OR_MSL_MISS;
+        if (norm3(d) <= 300) {
+          int local = 0;
+          for (int z = 0; z < q; z++) if (e->chaff[z].parent == e->chaff[q].parent) local++;
+          if (chaff_uniform(e, e->sub_tick, m->parent, m->key % 100, e->chaff[q].parent, local) < 0.85) m->status = OR_MSL_MISS;
+        }
       }
     }
 }
@@ -829,7 +838,7 @@ void or_env_task_step(OrEnv* e) { task_step(e); }
 void or_env_reset(OrEnv* e, double* obs) {
   const OrEnvConfig* c = &e->cfg;
   e->current_step = 0;
-  e->n_msl = 0; e->n_sim_keys = 0; e->n_chaff = 0;
+  e->n_msl = 0; e->n_sim_keys = 0; e->n_chaff = 0; e->sub_tick = 0; e->chaff_draws = 0;
   if (c->task == OR_TASK_HEADING) { /* singlecontrol_env.py:24-49 */
     double hdg = or_env_uniform(e, 0., 180.), alt = or_env_uniform(e, 14000., 30000.), u = or_env_uniform(e, 400., 1200.);
     F16Init ic = c->init[0];

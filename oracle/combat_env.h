@@ -108,6 +108,7 @@ typedef struct {
   struct { double pos[3]; double t; int status; int parent; } chaff[OR_MAX_CHAFF];
   int n_chaff;
   uint64_t chaff_draws;
+  int sub_tick;          /* projectile substeps since reset (key of the decoy draw) */
   /* reward memories shared by every agent of the env (CombatGeometry / GunWEZDOT / GunTargetTail keep module-level lists) */
   int cg_set; double cg_AO, cg_TA;
   int wezdot_set; double wezdot_ref[OR_MAX_AC];

@@ -542,16 +542,17 @@ def gen_multicombat_sequences(rng):
 
 
 
-class CounterRNG:
+class KeyedRNG:
     """Stand-in for the global, unseeded np.random the reference's decoy test draws from (env_base.py:153): splitmix64 of a
-    seed and a draw counter, the generator the oracle and the kernel implement as well."""
+    seed and a key naming the (substep, missile, chaff) pair under test — the generator the oracle and the kernel implement."""
 
     def __init__(self, seed=1):
         self.seed, self.n = seed, 0
 
-    def rand(self):
+    def rand(self, tick, msl_parent, msl_num, chaff_parent, chaff_local):
         M = (1 << 64) - 1
-        z = (self.seed * 0x9E3779B97F4A7C15 + self.n * 0xD1B54A32D192ED03) & M
+        k = ((tick & 0xffffffff) << 32) | ((msl_parent & 0xff) << 24) | ((msl_num & 0xff) << 16) | ((chaff_parent & 0xff) << 8) | (chaff_local & 0xff)
+        z = (self.seed * 0x9E3779B97F4A7C15 + k * 0xD1B54A32D192ED03) & M
         self.n += 1
         z ^= z >> 30; z = (z * 0xBF58476D1CE4E5B9) & M
         z ^= z >> 27; z = (z * 0x94D049BB133111EB) & M
@@ -566,7 +567,9 @@ class WeaponEnv(FakeEnv):
     def __init__(self, agents):
         super().__init__(agents)
         self._chaffsims = {}
-        self.rng = CounterRNG(1)
+        self.rng = KeyedRNG(1)
+        self.tick = 0
+        self.uids = [a.uid for a in agents]
 
     def add_chaff_simulator(self, sim):
         self._chaffsims[sim.uid] = sim
@@ -577,6 +580,7 @@ class WeaponEnv(FakeEnv):
             if a.is_alive and a.bloods <= 0:
                 a.shotdown()
         for _ in range(substeps):
+            self.tick += 1
             for sim in self._tempsims.values():
                 sim.run()
             for sim in self._chaffsims.values():
@@ -588,7 +592,10 @@ class WeaponEnv(FakeEnv):
                     if chaff.is_done:
                         continue
                     if np.linalg.norm(chaff.get_position() - missile.get_position()) <= chaff.effective_radius:
-                        if self.rng.rand() < 0.85:
+                        # key: missile = (launcher index, uid number), chaff = (releaser index, its release index)
+                        cp = self.uids.index(chaff.uid[:5])
+                        local = [c.uid for c in self._chaffsims.values() if c.uid[:5] == chaff.uid[:5]].index(chaff.uid)
+                        if self.rng.rand(self.tick, self.uids.index(missile.uid[:5]), int(missile.uid[5:]), cp, local) < 0.85:
                             missile.missed()
 
 
@@ -641,7 +648,7 @@ def gen_scenario_sequences(rng):
             uids = ("A0100", "A0200", "B0100", "B0200")
         acs = {u: {"color": "Blue" if u[0] == "A" else "Red", "missile": 2} for u in uids}
         cfg = make_config(aircraft_configs=acs, EventDrivenReward_potential=(family == "s1"))
-        for ep in range(10):
+        for ep in range(8):
             task = _scenario_task(Scenario1 if family == "s1" else Scenario2_NvN, cfg)
             agents = [FakeAircraft(u, acs[u]["color"]) for u in uids]
             link(agents)
@@ -654,35 +661,59 @@ def gen_scenario_sequences(rng):
                 return _f(sim)
             env.add_temp_simulator = add
             A = len(agents)
+            shooter, target = agents[0], agents[A // 2]
+            # episode kinds: 0 gun duel, 1/2 tail chase with chaff (long: missiles time out / get decoyed, second launches reuse
+            # uids), 3 random poses, 4 head-on at long range, 5 random with a scripted blood loss
+            kind = ep % 6
+            T = {0: 40, 1: 330, 2: 330, 3: 30, 4: 120, 5: 30}[kind]
             for a in agents:
-                random_pose(rng, a, spread_km=8.0)
-            if ep % 2 == 0:
-                engagement_pose(rng, agents[0], agents[A // 2], rng.uniform(1500, 6500), rng.uniform(-4, 4))
+                random_pose(rng, a, spread_km=8.0, alt=(2600.0, 9000.0))
+
+            def chase_pose(t):
+                # both fly north along the 120E meridian; positions advance with time so that missiles and chaff see a moving target
+                sep0 = {0: 2000.0, 1: 6000.0, 2: 4500.0, 4: 30000.0}.get(kind, 5000.0)
+                vs, vt = 255.0, (-240.0 if kind == 4 else 235.0)
+                ys = vs * 0.1 * t
+                yt = sep0 + vt * 0.1 * t
+                off = 25.0 * np.sin(0.05 * t) if kind != 0 else 3.0
+                shooter.set_pose(120.0, 60.0 + ys / 111412.0, 6000.0, (0.02, 0.01, 0.0), (vs, 0.0, -1.0), (vs, 0.5, 4.0), vc=240.0,
+                                 npilot=(0.1, 0.0, -1.05), sim_time=12.0 + 0.1 * t)
+                hdg = np.pi if kind == 4 else 0.0
+                target.set_pose(120.0 + off / 55660.0, 60.0 + yt / 111412.0, 6050.0, (0.0, 0.0, hdg), (vt, 0.0, 1.0), (abs(vt), -0.5, 3.0),
+                                vc=225.0, npilot=(0.0, 0.0, -1.0), sim_time=12.0 + 0.1 * t)
+            if kind in (0, 1, 2, 4):
+                chase_pose(0)
             task.reset(env)
             frames = []
-            T = 26
             for t in range(1, T + 1):
                 env.current_step = t
                 for k, a in enumerate(agents):
                     if not a.is_alive:
                         continue
-                    if ep % 2 == 0 and k in (0, A // 2):
-                        continue   # keep the engagement pair on its geometry; nudged below
-                    random_pose(rng, a, spread_km=8.0, alt=(2600.0, 9000.0))
-                if ep % 2 == 0 and t % 6 == 0 and agents[0].is_alive and agents[A // 2].is_alive:
-                    engagement_pose(rng, agents[0], agents[A // 2], rng.uniform(800, 9000), rng.uniform(-6, 6))
-                if ep % 5 == 3 and t == 12:
+                    if kind in (0, 1, 2, 4) and a in (shooter, target):
+                        continue
+                    if t % 3 == 0 or kind in (3, 5):
+                        random_pose(rng, a, spread_km=8.0, alt=(2600.0, 9000.0))
+                if kind in (0, 1, 2, 4) and shooter.is_alive and target.is_alive:
+                    chase_pose(t)
+                if kind == 5 and t == 12:
                     agents[A - 1].bloods = 0     # dies at the next run()
                 pose = np.stack([pose_vector(a) for a in agents])
                 env.run_projectiles(6)
-                bits = (rng.random((A, 4)) < (0.7 if ep % 2 == 0 else 0.3)).astype(int)
+                if kind == 0:
+                    bits = np.tile(np.array([1, 0, 0, 0]), (A, 1))
+                elif kind in (1, 2, 4):
+                    bits = np.tile(np.array([0, 1, 1, 1]), (A, 1))
+                    if kind == 2:
+                        bits[:, 0] = (t % 2)
+                else:
+                    bits = (rng.random((A, 4)) < 0.4).astype(int)
                 for k, u in enumerate(env.agents):
                     if family == "nvn" or u in env.ego_ids:       # what normalize_action does with action[-4:] (the controller net is bypassed)
                         task._shoot_action[u] = list(bits[k])
                     else:                                         # Scenario1's other team flies the scripted baseline: weapon bits [0,0,0,0]
                         task._shoot_action[u] = [0, 0, 0, 0]      # (scenario1_task.py:38-39)
                 task.step(env)
-                pose_after = np.stack([pose_vector(a) for a in agents])   # status / bloods after projectiles and weapons
                 obs = np.stack([task.get_obs(env, u) for u in env.agents])
                 info = {"current_step": env.current_step}
                 if family == "s1":
@@ -708,17 +739,17 @@ def gen_scenario_sequences(rng):
                         done.append(d)
                 counters = np.array([[task.remaining_gun[u], task.remaining_missiles_AIM_9M[u], task.remaining_missiles_AIM_120B[u],
                                       task.remaining_chaff_flare[u], agents[k].bloods, agents[k].status] for k, u in enumerate(env.agents)], dtype=float)
-                mrows = np.zeros((16, 9))
-                for k, m in enumerate(order[:16]):
+                mrows = np.zeros((12, 9))
+                for k, m in enumerate(order[:12]):
                     mrows[k] = [1 + uids.index(m.parent_aircraft.uid), uids.index(m.target_aircraft.uid), m._MissileSimulator__status,
                                 *m.get_position(), *m.get_velocity()]
                 frames.append(dict(pose=pose, bits=bits, obs=obs, rew=rew, done=np.array(done, dtype=float), counters=counters, msl=mrows,
-                                   nchaff=len(env._chaffsims), draws=env.rng.n, step=env.current_step))
+                                   nchaff=len(env._chaffsims), draws=env.rng.n, step=env.current_step, nmsl=len(order)))
                 if all(done):
                     break
             for key in ("pose", "bits", "obs", "rew", "done", "counters", "msl"):
                 flat[f"ep{ep_id}_{key}"] = np.stack([f[key] for f in frames])
-            flat[f"ep{ep_id}_misc"] = np.array([[f["nchaff"], f["draws"], f["step"]] for f in frames], dtype=float)
+            flat[f"ep{ep_id}_misc"] = np.array([[f["nchaff"], f["draws"], f["step"], f["nmsl"]] for f in frames], dtype=float)
             flat[f"ep{ep_id}_family"] = np.array([0.0 if family == "s1" else 1.0])
             ep_id += 1
     flat["n_episodes"] = np.array([ep_id], dtype=float)
