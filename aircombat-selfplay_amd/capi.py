@@ -8,9 +8,10 @@ import os
 
 AC_MAX_AGENTS = 8
 AC_MAX_MISSILES_PER_AGENT = 4
-AC_STATE_LEN = 80
+AC_STATE_LEN = 128
 
 AC_TASK_HEADING, AC_TASK_SINGLECOMBAT, AC_TASK_DODGE_MISSILE, AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT = 0, 1, 2, 3, 4
+AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN = 5, 6
 AC_ALIVE, AC_CRASH, AC_SHOTDOWN = 0, 1, 2
 
 
@@ -71,6 +72,9 @@ SIGNATURES = {
 
 
 def library_path():
+    override = os.environ.get("AIRCOMBAT_HIP_LIB")   # another build of the same extension (profiling variants); never a fallback
+    if override:
+        return override
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libaircombat_hip.so")
 
 

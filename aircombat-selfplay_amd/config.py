@@ -7,7 +7,7 @@ overload.py:18-20, timeout.py:16), for the tasks the HIP path implements.
 import yaml
 
 from .capi import (AcConfig, AC_MAX_AGENTS, AC_TASK_HEADING, AC_TASK_SINGLECOMBAT, AC_TASK_DODGE_MISSILE,
-                   AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT)
+                   AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN)
 
 TASK_IDS = {
     "heading": AC_TASK_HEADING,
@@ -15,6 +15,10 @@ TASK_IDS = {
     "singlecombat_dodge_missile": AC_TASK_DODGE_MISSILE,
     "singlecombat_shoot": AC_TASK_SHOOT_MISSILE,     # SingleCombatShootMissileTask
     "multiplecombat": AC_TASK_MULTICOMBAT,           # MultipleCombatTask (NvN, no weapons) under MultipleCombatEnv.step
+    "scenario1": AC_TASK_SCENARIO1,                  # Scenario1 weapon rules + 11 rewards, 1v1, low-level control
+    "scenario_nvn": AC_TASK_SCENARIO_NVN,            # Scenario2_NvN / Scenario3_NvN, low-level control
+    "scenario2_nvn": AC_TASK_SCENARIO_NVN,
+    "scenario3_nvn": AC_TASK_SCENARIO_NVN,
 }
 
 # defaults of AircraftSimulator.clear_defalut_condition (simulatior.py:192-208)
@@ -92,7 +96,7 @@ def config_from_yaml(path, task=None):
     return config_from_dict(data, task=task)
 
 
-def default_nvn_config(n_per_side=2):
+def default_nvn_config(n_per_side=2, task="multiplecombat"):
     """The aircraft block of reference configs/scenario2/scenario2_nvn.yaml (2v2) or scenario3/scenario3_nvn.yaml (4v4)
     with the MultipleCombatTask semantics (BASELINE configs C4 / C5 without the weapon rules)."""
     acs = {}
@@ -101,7 +105,7 @@ def default_nvn_config(n_per_side=2):
             acs[f"{team}0{k + 1}00"] = {"color": color, "model": "f16", "missile": 2,
                                       "init_state": {"ic_long_gc_deg": 120.0 + 0.01 * k, "ic_lat_geod_deg": lat, "ic_h_sl_ft": 20000,
                                                      "ic_psi_true_deg": psi, "ic_u_fps": 800.0}}
-    data = {"task": "multiplecombat", "sim_freq": 60, "agent_interaction_steps": 6, "max_steps": 9000, "altitude_limit": 2500,
+    data = {"task": task, "sim_freq": 60, "agent_interaction_steps": 6, "max_steps": 9000, "altitude_limit": 2500,
             "acceleration_limit_x": 10.0, "acceleration_limit_y": 10.0, "acceleration_limit_z": 10.0, "aircraft_configs": acs,
             "max_attack_angle": 45, "max_attack_distance": 14000, "min_attack_interval": 125, "battle_field_center": [120.0, 60.0, 0.0],
             "PostureReward_scale": 15.0, "PostureReward_potential": True, "PostureReward_orientation_version": "v2",
@@ -114,6 +118,10 @@ def default_config(task="singlecombat"):
     """The 1v1 block of reference configs/scenario1/WVR_selfplay.yaml (BASELINE configs C2 / C3)."""
     if task == "multiplecombat":
         return default_nvn_config(2)
+    if task in ("scenario_nvn", "scenario2_nvn"):
+        return default_nvn_config(2, task="scenario_nvn")
+    if task == "scenario3_nvn":
+        return default_nvn_config(4, task="scenario_nvn")
     data = {
         "task": task, "sim_freq": 60, "agent_interaction_steps": 6, "max_steps": 9000, "altitude_limit": 2500,
         "acceleration_limit_x": 10.0, "acceleration_limit_y": 10.0, "acceleration_limit_z": 10.0,

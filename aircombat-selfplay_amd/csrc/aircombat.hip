@@ -59,6 +59,11 @@ static const char* kStateNames[AC_STATE_LEN] = {
 #define X(n) #n,
     AC_F_FIELDS(X) AC_TF_FIELDS(X) "eng", "ticks", AC_TI_FIELDS(X)
 #undef X
+    // read-only tail, present for the scenario tasks only
+    "x_rem_gun", "x_rem_9m", "x_rem_120b", "x_rem_chaff", "x_bits", "x_last_chaff", "x_orphan_hits", "x_mp_prev", "x_ref_set",
+    "x_ch_status0", "x_ch_mult0", "x_ch_status1", "x_ch_mult1", "x_n_ch",
+    "x_cg_AO", "x_cg_TA", "x_wez0", "x_wez1", "x_wez2", "x_wez3", "x_tail0", "x_tail1", "x_tail2", "x_tail3",
+    "x_c0x", "x_c0y", "x_c0z", "x_c0t", "x_c1x", "x_c1y", "x_c1z", "x_c1t",
 };
 
 struct Task {  // per-aircraft task bookkeeping
@@ -70,10 +75,16 @@ struct Task {  // per-aircraft task bookkeeping
 #undef X
 };
 
-struct Msl {
-  float px, py, pz, vx, vy, vz, theta, psi, t, m, dth, dph, dprev;
+// R = float for the 300 m proximity fuse of the 1v1 missile task; R = double for the scenario tasks, whose AIM-120B / AIM-9M
+// fuse radius is 5 m against ~25 m of relative travel per tick: hit-or-miss then hinges on centimetres of a 300-tick
+// integration, and the reference integrates in Python floats (fp64).
+template <typename R>
+struct MslT {
+  R px, py, pz, vx, vy, vz, theta, psi, t, m, dth, dph, dprev;
   int status, recede, order;
 };
+using Msl = MslT<float>;
+using MslD = MslT<double>;
 
 // Device-side scenario constants (passed by value to the kernels).
 struct DevCfg {
@@ -88,11 +99,13 @@ struct DevCfg {
   int num_missiles[AC_MAX_AGENTS];
   // battle-field origin for pymap3d-style geodetic <-> NED (metres, WGS84)
   double P0x, P0y, P0z, sLat0, cLat0, sLon0, cLon0;
+  unsigned long long chaff_seed;  // base of the keyed decoy draw (the env index is added on the device)
 };
 
 struct DevPtrs {
   float* F; int* I; double* D;           // live state, SoA [field][N]
   float* MF; int* MI;                    // missiles, SoA [slot][field][N]
+  double* MD;                            // scenario tasks: the same layout in fp64 instead of MF
   const float* tF; const int* tI; const double* tD;  // reset template, [field][A]
   const float* tab;                      // F16_PACK as fp32 in HBM (staged to LDS per workgroup)
   const float* actions;                  // [N][act_dim]
@@ -126,8 +139,9 @@ __device__ __forceinline__ void store_state(float* F, int* I, double* D, int N, 
 #undef X
   D[0 * N + n] = s.rx; D[1 * N + n] = s.ry; D[2 * N + n] = s.rz;
 }
-__device__ __forceinline__ void load_msl(const float* MF, const int* MI, int N, int n, int slot, Msl& m) {
-  const float* f = MF + (size_t)slot * NMF * N;
+template <typename R>
+__device__ __forceinline__ void load_msl(const R* MF, const int* MI, int N, int n, int slot, MslT<R>& m) {
+  const R* f = MF + (size_t)slot * NMF * N;
   const int* i = MI + (size_t)slot * NMI * N;
   m.px = f[MF_px * N + n]; m.py = f[MF_py * N + n]; m.pz = f[MF_pz * N + n];
   m.vx = f[MF_vx * N + n]; m.vy = f[MF_vy * N + n]; m.vz = f[MF_vz * N + n];
@@ -135,8 +149,9 @@ __device__ __forceinline__ void load_msl(const float* MF, const int* MI, int N, 
   m.dth = f[MF_dth * N + n]; m.dph = f[MF_dph * N + n]; m.dprev = f[MF_dprev * N + n];
   m.status = i[MI_status * N + n]; m.recede = i[MI_recede * N + n]; m.order = i[MI_order * N + n];
 }
-__device__ __forceinline__ void store_msl(float* MF, int* MI, int N, int n, int slot, const Msl& m) {
-  float* f = MF + (size_t)slot * NMF * N;
+template <typename R>
+__device__ __forceinline__ void store_msl(R* MF, int* MI, int N, int n, int slot, const MslT<R>& m) {
+  R* f = MF + (size_t)slot * NMF * N;
   int* i = MI + (size_t)slot * NMI * N;
   f[MF_px * N + n] = m.px; f[MF_py * N + n] = m.py; f[MF_pz * N + n] = m.pz;
   f[MF_vx * N + n] = m.vx; f[MF_vy * N + n] = m.vy; f[MF_vz * N + n] = m.vz;
@@ -149,6 +164,7 @@ __device__ __forceinline__ void store_msl(float* MF, int* MI, int N, int n, int 
 // conversions of the catalogue (catalog.py:292-338).
 struct Props {
   float n, e, u;            // NEU position about the battle-field centre [m]
+  double n64, e64, u64;     // the same before rounding (missile targets of the scenario tasks)
   float vn, ve, vd;         // m/s, clipped to +-700
   float alt_m;              // clipped to [-500, 26000]
   float ub, vb, wb, vc;     // body velocities and calibrated airspeed [m/s], clipped
@@ -171,9 +187,8 @@ __device__ __forceinline__ void make_props(const State& s, const Derived& d, con
   double x = (Nn + h) * cl * co, y = (Nn + h) * cl * so, z = (Nn * (b / a) * (b / a) + h) * sl;
   double dx = x - c.P0x, dy = y - c.P0y, dz = z - c.P0z;
   double t = c.cLon0 * dx + c.sLon0 * dy;
-  p.e = (float)(-c.sLon0 * dx + c.cLon0 * dy);
-  p.u = (float)(c.cLat0 * t + c.sLat0 * dz);
-  p.n = (float)(-c.sLat0 * t + c.cLat0 * dz);
+  p.e64 = -c.sLon0 * dx + c.cLon0 * dy; p.u64 = c.cLat0 * t + c.sLat0 * dz; p.n64 = -c.sLat0 * t + c.cLat0 * dz;
+  p.e = (float)p.e64; p.u = (float)p.u64; p.n = (float)p.n64;
   // Euler sines/cosines from Tl2b = Ti2b * Ti2l^T  (only the five entries GetEuler reads)
   const float* T = d.T;
   float m13 = T[0] * d.d_eci[0] + T[1] * d.d_eci[1] + T[2] * d.d_eci[2];
@@ -234,17 +249,32 @@ __device__ __forceinline__ float potential(float r, float scale, int pot, float&
 }
 
 // ------------------------------------------------------------------------------------------------ missile engine
-struct MslParam { float g, t_max, t_thrust, Isp, Length, Diameter, cD, m0, dm, K, nyz_max, Rc, v_min; int recede_max; };
+// The reference accumulates the missile clock in a Python float (`self._t += self.dt`, simulatior.py:522) and compares it with
+// t_thrust / t_max; 84 additions of 1/60 land a hair ABOVE 1.4, 180 of them a hair below 3.0, so which tick the motor burns
+// out on is a property of that double-precision sum. The thresholds are therefore turned into tick counts at compile time with
+// the same sum, and the device keeps an exact tick count.
+constexpr int first_tick_not_below(double limit) {   // smallest k with t_k >= limit, t_k = k-fold sum of 1/60 in fp64
+  double t = 0.0; int k = 0;
+  do { t += 1.0 / 60.0; ++k; } while (t < limit);
+  return k;
+}
+constexpr int first_tick_above(double limit) {       // smallest k with t_k > limit
+  double t = 0.0; int k = 0;
+  do { t += 1.0 / 60.0; ++k; } while (!(t > limit));
+  return k;
+}
+struct MslParam { float g, t_max, t_thrust, Isp, Length, Diameter, cD, m0, dm, K, nyz_max, Rc, v_min; int recede_max, k_burnout, k_timeout; };
 __device__ __forceinline__ MslParam aim9l() {  // simulatior.py:421-433
-  return MslParam{9.81f, 60.0f, 3.0f, 120.0f, 2.87f, 0.127f, 0.4f, 84.0f, 6.0f, 3.0f, 30.0f, 300.0f, 150.0f, 300};
+  constexpr int kb = first_tick_not_below(3.0), kt = first_tick_above(60.0);
+  return MslParam{9.81f, 60.0f, 3.0f, 120.0f, 2.87f, 0.127f, 0.4f, 84.0f, 6.0f, 3.0f, 30.0f, 300.0f, 150.0f, 300, kb, kt};
 }
 // geodetic height of an NEU point (utils.py:44-55 -> pymap3d.ned2geodetic): ENU -> ECEF offset in fp64, then the
 // closed-form height of Fukushima's reduction (sub-millimetre, like pymap3d's You-2000 form)
-__device__ __forceinline__ float neu_height(float n, float e, float u, const DevCfg& c) {
-  double t = c.cLat0 * (double)u - c.sLat0 * (double)n;
-  double dz = c.sLat0 * (double)u + c.cLat0 * (double)n;
-  double dx = c.cLon0 * t - c.sLon0 * (double)e;
-  double dy = c.sLon0 * t + c.cLon0 * (double)e;
+__device__ __forceinline__ double neu_height64(double n, double e, double u, const DevCfg& c) {
+  double t = c.cLat0 * u - c.sLat0 * n;
+  double dz = c.sLat0 * u + c.cLat0 * n;
+  double dx = c.cLon0 * t - c.sLon0 * e;
+  double dy = c.sLon0 * t + c.cLon0 * e;
   double X = c.P0x + dx, Y = c.P0y + dy, Z = c.P0z + dz;
   const double a = 6378137.0, b = 6356752.314245179, ec = b / a, ec2 = ec * ec, cc0 = a * (1.0 - ec2);
   double rxy = sqrt(X * X + Y * Y);
@@ -255,48 +285,65 @@ __device__ __forceinline__ float neu_height(float n, float e, float u, const Dev
   s1 = s1 * a03 - b0 * s0;
   double cc = ec * (c1 * a03 - b0 * c0);
   double s12 = s1 * s1, cc2 = cc * cc, norm = sqrt(s12 + cc2);
-  return (float)((rxy * cc + s0 * s1 - a * sqrt(ec2 * s12 + cc2)) / norm);
+  return ((rxy * cc + s0 * s1 - a * sqrt(ec2 * s12 + cc2)) / norm);
 }
+__device__ __forceinline__ float neu_height(float n, float e, float u, const DevCfg& c) { return (float)neu_height64(n, e, u, c); }
 // MissileSimulator.run (simulatior.py:520-533) with _guidance (:556-576) and _state_trans (:578-608).
-__device__ __forceinline__ void missile_run(Msl& m, const MslParam& P, float tx, float ty, float tz, float tvx, float tvy, float tvz,
+__device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float m_sin(float x) { return __sinf(x); }
+__device__ __forceinline__ double m_sin(double x) { return sin(x); }
+__device__ __forceinline__ float m_exp(float x) { return __expf(x); }
+__device__ __forceinline__ double m_exp(double x) { return exp(x); }
+__device__ __forceinline__ void m_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+__device__ __forceinline__ void m_sincos(double x, double* s, double* c) { sincos(x, s, c); }
+template <typename R>
+__device__ __forceinline__ R m_clamp(R lo, R x, R hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+template <typename R>
+__device__ __forceinline__ void missile_run(MslT<R>& m, const MslParam& P, R tx, R ty, R tz, R tvx, R tvy, R tvz,
                                             bool target_alive, const DevCfg& c) {
-  const float dt = 1.0f / 60.0f;
-  m.t += dt;
-  float vm = sqrtf(m.vx * m.vx + m.vy * m.vy + m.vz * m.vz);
-  float cth = sqrtf(fmaxf(0.0f, 1.0f - (m.vz / vm) * (m.vz / vm)));  // cos(asin(dz/v))
-  float ddx = tx - m.px, ddy = ty - m.py, ddz = tz - m.pz;
-  float Rxy2 = ddx * ddx + ddy * ddy, Rxy = sqrtf(Rxy2);
-  float R2 = Rxy2 + ddz * ddz, Rxyz = sqrtf(R2);
-  float dbeta = ((tvy - m.vy) * ddx - (tvx - m.vx) * ddy) / Rxy2;
-  float deps = ((tvz - m.vz) * Rxy2 - ddz * (ddx * (tvx - m.vx) + ddy * (tvy - m.vy))) / (R2 * Rxy);
-  float K = fmaxf(P.K * (P.t_max - m.t) / P.t_max, 0.0f);
-  float ny = clampf(-P.nyz_max, K * vm / P.g * cth * dbeta, P.nyz_max);
-  float nz = clampf(-P.nyz_max, K * vm / P.g * deps + cth, P.nyz_max);
+  const R dt = (R)(1.0 / 60.0);
+  const int k = (int)rint((double)m.t * 60.0) + 1;   // ticks since launch, exact (the stored clock is always k/60 rounded once)
+  m.t = (R)k * dt;
+  const bool burning = k < P.k_burnout;              // reference: t < t_thrust
+  const R g = (R)P.g, t_max = (R)P.t_max, nyz_max = (R)P.nyz_max;
+  R vm = m_sqrt(m.vx * m.vx + m.vy * m.vy + m.vz * m.vz);
+  R cth = m_sqrt(fmax((R)0, (R)1 - (m.vz / vm) * (m.vz / vm)));  // cos(asin(dz/v))
+  R ddx = tx - m.px, ddy = ty - m.py, ddz = tz - m.pz;
+  R Rxy2 = ddx * ddx + ddy * ddy, Rxy = m_sqrt(Rxy2);
+  R R2 = Rxy2 + ddz * ddz, Rxyz = m_sqrt(R2);
+  R dbeta = ((tvy - m.vy) * ddx - (tvx - m.vx) * ddy) / Rxy2;
+  R deps = ((tvz - m.vz) * Rxy2 - ddz * (ddx * (tvx - m.vx) + ddy * (tvy - m.vy))) / (R2 * Rxy);
+  R K = fmax((R)P.K * (t_max - m.t) / t_max, (R)0);
+  R ny = m_clamp(-nyz_max, K * vm / g * cth * dbeta, nyz_max);
+  R nz = m_clamp(-nyz_max, K * vm / g * deps + cth, nyz_max);
   m.recede = (Rxyz > m.dprev) ? m.recede + 1 : 0;
   m.dprev = Rxyz;
-  if (Rxyz < P.Rc && target_alive && m.status != MSL_MISS) {
+  if (Rxyz < (R)P.Rc && target_alive && m.status != MSL_MISS) {
     m.status = MSL_HIT;
-  } else if (m.t > P.t_max || vm < P.v_min || m.recede >= P.recede_max || !target_alive) {
+  } else if (k >= P.k_timeout || vm < (R)P.v_min || m.recede >= P.recede_max || !target_alive) {
     m.status = MSL_MISS;
   } else {
     m.px += dt * m.vx; m.py += dt * m.vy; m.pz += dt * m.vz;
-    float alt = neu_height(m.px, m.py, m.pz, c);
-    float Isp = (m.t < P.t_thrust) ? P.Isp : 0.0f;
-    float Tt = P.g * Isp * P.dm;
-    float sd = __sinf(m.dth), sp = __sinf(m.dph);
-    float S = f16::kPi * 0.25f * P.Diameter * P.Diameter + sqrtf(sd * sd + sp * sp) * P.Diameter * P.Length;
-    float rho = 1.225f * __expf(-alt / 9300.0f);
-    float D = 0.5f * P.cD * S * rho * vm * vm;
-    float nx = (Tt - D) / (m.m * P.g);
-    float st, ct; sincosf(m.theta, &st, &ct);
-    float dv = P.g * (nx - st);
-    m.dph = P.g / vm * (ny / ct);
-    m.dth = P.g / vm * (nz - ct);
-    float v = vm + dt * dv;
+    R alt = (R)neu_height64(m.px, m.py, m.pz, c);
+    R Isp = burning ? (R)P.Isp : (R)0;
+    R Tt = g * Isp * (R)P.dm;
+    R sd = m_sin(m.dth), sp = m_sin(m.dph);
+    const R D0 = (R)P.Diameter, L0 = (R)P.Length;
+    R S = (R)3.14159265358979323846 * (R)0.25 * D0 * D0 + m_sqrt(sd * sd + sp * sp) * D0 * L0;
+    R rho = (R)1.225 * m_exp(-alt / (R)9300);
+    R D = (R)0.5 * (R)P.cD * S * rho * vm * vm;
+    R nx = (Tt - D) / (m.m * g);
+    R st, ct; m_sincos(m.theta, &st, &ct);
+    R dv = g * (nx - st);
+    m.dph = g / vm * (ny / ct);
+    m.dth = g / vm * (nz - ct);
+    R v = vm + dt * dv;
     m.psi += dt * m.dph; m.theta += dt * m.dth;
-    float s2, c2, s3, c3; sincosf(m.theta, &s2, &c2); sincosf(m.psi, &s3, &c3);
+    R s2, c2, s3, c3; m_sincos(m.theta, &s2, &c2); m_sincos(m.psi, &s3, &c3);
     m.vx = v * c2 * c3; m.vy = v * c2 * s3; m.vz = v * s2;
-    if (m.t < P.t_thrust) m.m -= dt * P.dm;
+    if (burning) m.m -= dt * (R)P.dm;
   }
 }
 
@@ -889,6 +936,8 @@ __global__ void init_kernel_nvn(InitArgs ia, DevCfg c, const float* tab, float* 
   }
 }
 
+#include "scenario_kernel.hpp"
+
 // reset(): every env takes the template (SubprocVecEnv.reset -> env.reset(), env_base.py:98-113)
 __global__ void reset_all_kernel(DevPtrs P, DevCfg c) {
   const int OBS = c.obs_dim;
@@ -900,8 +949,8 @@ __global__ void reset_all_kernel(DevPtrs P, DevCfg c) {
   load_state(P.tF, P.tI, P.tD, c.A, slot, s, t);
   store_state(P.F, P.I, P.D, N, n, s, t);
   for (int k = 0; k < c.msl_slots; ++k) {
-    Msl m{}; m.status = MSL_INACTIVE;
-    store_msl(P.MF, P.MI, N, n, k, m);
+    if (P.MD) { MslD m{}; m.status = MSL_INACTIVE; store_msl(P.MD, P.MI, N, n, k, m); }
+    else { Msl m{}; m.status = MSL_INACTIVE; store_msl(P.MF, P.MI, N, n, k, m); }
   }
   const float* tobs = P.tF + (size_t)NF * c.A + slot * OBS;
   for (int k = 0; k < OBS; ++k) P.obs[(size_t)n * OBS + k] = tobs[k];
@@ -927,6 +976,7 @@ struct ac_env {
   float* d_actions;
   float* d_tab;
   float* d_tF; int* d_tI; double* d_tD;
+  float* d_XF; int* d_XI;                // scenario-task extension state
   hipEvent_t ev0, ev1;
   bool timing;
 };
@@ -945,7 +995,15 @@ static int launch_step(ac_env* h, const float* d_actions) {
   p.actions = d_actions ? d_actions : h->d_actions;
   dim3 block(64), grid((h->N + 63) / 64);
   const bool one_wave_per_simd = grid.x <= 1024;  // 256 CUs x 4 SIMDs
-  if (h->cfg.task == AC_TASK_MULTICOMBAT) {
+  if (h->cfg.task == AC_TASK_SCENARIO1 || h->cfg.task == AC_TASK_SCENARIO_NVN) {
+#define AC_LAUNCH_SCN(AA)                                                                                                        \
+  do {                                                                                                                           \
+    if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_scenario<AA, 1>), grid, block, 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr); \
+    else hipLaunchKernelGGL((step_kernel_scenario<AA, 2>), grid, block, 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);                  \
+  } while (0)
+    if (h->A == 2) AC_LAUNCH_SCN(2); else if (h->A == 4) AC_LAUNCH_SCN(4); else AC_LAUNCH_SCN(8);
+#undef AC_LAUNCH_SCN
+  } else if (h->cfg.task == AC_TASK_MULTICOMBAT) {
     if (h->A == 4) {
       if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_nvn<4, 1>), grid, block, 0, h->stream, p, h->dc);
       else hipLaunchKernelGGL((step_kernel_nvn<4, 2>), grid, block, 0, h->stream, p, h->dc);
@@ -967,6 +1025,10 @@ static int launch_reset(ac_env* h) {
   dim3 block(64), grid((h->N + 63) / 64);
   hipLaunchKernelGGL(reset_all_kernel, grid, block, 0, h->stream, h->dp, h->dc);
   HIP_OK(hipGetLastError());
+  if (h->d_XF) {
+    hipLaunchKernelGGL(reset_ext_kernel, grid, block, 0, h->stream, h->dc, h->d_XF, h->d_XI);
+    HIP_OK(hipGetLastError());
+  }
   return 0;
 }
 
@@ -977,11 +1039,19 @@ const char* ac_version(void) { return "aircombat-hip 0.1 (gfx950)"; }
 const char* ac_state_field_name(int i) { return (i >= 0 && i < AC_STATE_LEN && kStateNames[i]) ? kStateNames[i] : ""; }
 
 int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_t seed, ac_env_t** out) {
-  (void)seed;  // the 1v1 tasks draw no random numbers (fixed initial conditions, no chaff)
   if (!cfg || !out) return fail("ac_create: null argument");
-  if (cfg->task != AC_TASK_SINGLECOMBAT && cfg->task != AC_TASK_SHOOT_MISSILE && cfg->task != AC_TASK_MULTICOMBAT)
-    return fail("ac_create: task not available on the HIP path (supported: AC_TASK_SINGLECOMBAT, AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT)");
-  if (cfg->task == AC_TASK_MULTICOMBAT) {
+  const bool scenario = cfg->task == AC_TASK_SCENARIO1 || cfg->task == AC_TASK_SCENARIO_NVN;
+  if (cfg->task != AC_TASK_SINGLECOMBAT && cfg->task != AC_TASK_SHOOT_MISSILE && cfg->task != AC_TASK_MULTICOMBAT && !scenario)
+    return fail("ac_create: task not available on the HIP path (supported: AC_TASK_SINGLECOMBAT, AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN)");
+  if (cfg->task == AC_TASK_SCENARIO_NVN) {
+    if ((cfg->n_agents != 4 && cfg->n_agents != 8) || cfg->n_ego * 2 != cfg->n_agents)
+      return fail("ac_create: AC_TASK_SCENARIO_NVN needs n_agents in {4, 8} split into two equal teams");
+  }
+  if (scenario)
+    for (int i = 0; i < cfg->n_agents; ++i)
+      if (cfg->num_missiles[i] != 2) return fail("ac_create: the scenario tasks are built for 'missile: 2' (two munition uids per aircraft), as every shipped YAML has");
+  if (cfg->task == AC_TASK_SCENARIO_NVN) {
+  } else if (cfg->task == AC_TASK_MULTICOMBAT) {
     if ((cfg->n_agents != 4 && cfg->n_agents != 8) || cfg->n_ego <= 0 || cfg->n_ego >= cfg->n_agents)
       return fail("ac_create: AC_TASK_MULTICOMBAT needs n_agents in {4, 8} and 0 < n_ego < n_agents");
   } else if (cfg->n_agents != 2 || cfg->n_ego != 1) return fail("ac_create: 1v1 tasks need n_agents == 2 and n_ego == 1");
@@ -997,12 +1067,14 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   memset(h, 0, sizeof *h);
   h->cfg = *cfg; h->E = n_envs; h->A = cfg->n_agents; h->N = n_envs * cfg->n_agents; h->device = device_id;
   h->obs_dim = (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
-  h->act_dim = (cfg->task == AC_TASK_SHOOT_MISSILE) ? 5 : 4;
+  if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
+  h->act_dim = scenario ? 8 : ((cfg->task == AC_TASK_SHOOT_MISSILE) ? 5 : 4);
   DevCfg& c = h->dc;
   memset(&c, 0, sizeof c);
   c.task = cfg->task; c.A = h->A; c.n_ego = cfg->n_ego; c.substeps = cfg->agent_interaction_steps; c.max_steps = cfg->max_steps;
   c.obs_dim = h->obs_dim; c.act_dim = h->act_dim; c.N = h->N;
-  c.msl_slots = (cfg->task == AC_TASK_SHOOT_MISSILE) ? AC_MAX_MISSILES_PER_AGENT : 0;
+  c.msl_slots = (cfg->task == AC_TASK_SHOOT_MISSILE) ? AC_MAX_MISSILES_PER_AGENT : (scenario ? 2 : 0);
+  c.chaff_seed = seed;
   c.altitude_limit = (float)cfg->altitude_limit; c.acc_x = (float)cfg->acc_limit_x; c.acc_y = (float)cfg->acc_limit_y; c.acc_z = (float)cfg->acc_limit_z;
   c.posture_scale = (float)cfg->posture_scale; c.altitude_scale = (float)cfg->altitude_scale; c.event_scale = (float)cfg->event_scale;
   c.missile_posture_scale = (float)cfg->missile_posture_scale; c.shoot_penalty_scale = (float)cfg->shoot_penalty_scale;
@@ -1026,6 +1098,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   HIP_OK(hipMalloc(&p.D, sizeof(double) * ND * N));
   const size_t ms = c.msl_slots > 0 ? (size_t)c.msl_slots : 1;
   HIP_OK(hipMalloc(&p.MF, sizeof(float) * ms * NMF * N));
+  p.MD = nullptr;
+  if (scenario) HIP_OK(hipMalloc(&p.MD, sizeof(double) * ms * NMF * N));
   HIP_OK(hipMalloc(&p.MI, sizeof(int) * ms * NMI * N));
   HIP_OK(hipMalloc(&p.obs, sizeof(float) * N * h->obs_dim));
   HIP_OK(hipMalloc(&p.rew, sizeof(float) * N));
@@ -1040,10 +1114,20 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   HIP_OK(hipMalloc(&h->d_tF, sizeof(float) * ((size_t)NF * h->A + (size_t)h->A * h->obs_dim)));
   HIP_OK(hipMalloc(&h->d_tI, sizeof(int) * NI * h->A));
   HIP_OK(hipMalloc(&h->d_tD, sizeof(double) * ND * h->A));
+  if (scenario) {
+    HIP_OK(hipMalloc(&h->d_XF, sizeof(float) * NXF * N));
+    HIP_OK(hipMalloc(&h->d_XI, sizeof(int) * NXI * N));
+  }
   p.tF = h->d_tF; p.tI = h->d_tI; p.tD = h->d_tD; p.tab = h->d_tab; p.actions = h->d_actions;
   InitArgs ia;
   for (int i = 0; i < AC_MAX_AGENTS; ++i) ia.ic[i] = cfg->init[i];
-  if (cfg->task == AC_TASK_MULTICOMBAT && h->A == 4)
+  if (scenario && h->A == 2)
+    hipLaunchKernelGGL(init_kernel_scenario<2>, dim3(1), dim3(64), 0, h->stream, ia, h->dc, h->d_tab, h->d_tF, h->d_tI, h->d_tD);
+  else if (scenario && h->A == 4)
+    hipLaunchKernelGGL(init_kernel_scenario<4>, dim3(1), dim3(64), 0, h->stream, ia, h->dc, h->d_tab, h->d_tF, h->d_tI, h->d_tD);
+  else if (scenario)
+    hipLaunchKernelGGL(init_kernel_scenario<8>, dim3(1), dim3(64), 0, h->stream, ia, h->dc, h->d_tab, h->d_tF, h->d_tI, h->d_tD);
+  else if (cfg->task == AC_TASK_MULTICOMBAT && h->A == 4)
     hipLaunchKernelGGL(init_kernel_nvn<4>, dim3(1), dim3(64), 0, h->stream, ia, h->dc, h->d_tab, h->d_tF, h->d_tI, h->d_tD);
   else if (cfg->task == AC_TASK_MULTICOMBAT)
     hipLaunchKernelGGL(init_kernel_nvn<8>, dim3(1), dim3(64), 0, h->stream, ia, h->dc, h->d_tab, h->d_tF, h->d_tI, h->d_tD);
@@ -1062,8 +1146,8 @@ int ac_destroy(ac_env_t* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  void* bufs[] = {h->dp.F, h->dp.I, h->dp.D, h->dp.MF, h->dp.MI, h->dp.obs, h->dp.rew, h->dp.done, h->dp.info,
-                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD};
+  void* bufs[] = {h->dp.F, h->dp.I, h->dp.D, h->dp.MF, h->dp.MD, h->dp.MI, h->dp.obs, h->dp.rew, h->dp.done, h->dp.info,
+                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI};
   for (void* b : bufs) (void)hipFree(b);
   (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
   (void)hipStreamDestroy(h->stream);
@@ -1147,6 +1231,10 @@ int ac_get_state(ac_env_t* h, int32_t env, int32_t agent, double* out) {
   for (int f = 0; f < ND; ++f) { double v; HIP_OK(hipMemcpy(&v, h->dp.D + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
   for (int f = 0; f < NF; ++f) { float v; HIP_OK(hipMemcpy(&v, h->dp.F + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
   for (int f = 0; f < NI; ++f) { int v; HIP_OK(hipMemcpy(&v, h->dp.I + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
+  if (h->d_XF) {  // read-only tail: scenario-task extension (weapon counters, chaff clouds, shared reward references)
+    for (int f = 0; f < NXI; ++f) { int v; HIP_OK(hipMemcpy(&v, h->d_XI + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
+    for (int f = 0; f < NXF; ++f) { float v; HIP_OK(hipMemcpy(&v, h->d_XF + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
+  }
   for (; k < AC_STATE_LEN; ++k) out[k] = 0.0;
   return 0;
 }
@@ -1207,9 +1295,13 @@ int ac_get_missile(ac_env_t* h, int32_t env, int32_t agent, int32_t k, double ou
   out[0] = st;
   static const int order[10] = {MF_px, MF_py, MF_pz, MF_vx, MF_vy, MF_vz, MF_theta, MF_psi, MF_t, MF_m};
   for (int i = 0; i < 10; ++i) {
-    float v;
-    HIP_OK(hipMemcpy(&v, h->dp.MF + ((size_t)k * NMF + order[i]) * N + n, sizeof v, hipMemcpyDeviceToHost));
-    out[1 + i] = v;
+    if (h->dp.MD) {
+      HIP_OK(hipMemcpy(&out[1 + i], h->dp.MD + ((size_t)k * NMF + order[i]) * N + n, sizeof(double), hipMemcpyDeviceToHost));
+    } else {
+      float v;
+      HIP_OK(hipMemcpy(&v, h->dp.MF + ((size_t)k * NMF + order[i]) * N + n, sizeof v, hipMemcpyDeviceToHost));
+      out[1 + i] = v;
+    }
   }
   out[11] = 0.0;
   return 0;

@@ -181,15 +181,24 @@ __device__ __forceinline__ float slew(float out, float in, float lo, float hi, f
 __device__ __forceinline__ float tef_kinematic(float out, float in) {
   in = clampf(-1.0f, in, 1.0f);
   float dt0 = kFcsDt;
-  for (int it = 0; it < 3 && dt0 > 0.0f && in != out; ++it) {
-    // segment index: 1 => [-1,0], 2 => [0,1]
-    int ind = (in < out) ? ((0.0f < out) ? 2 : 1) : ((0.0f <= out) ? 2 : 1);
-    if (ind == 1) { out = in; break; }
+  bool walking = true;
+  // at most three segment hops per tick; written as straight-line selects (no divergent loop in the middle of the tick)
+#pragma unroll
+  for (int it = 0; it < 3; ++it) {
+    const bool go = walking && dt0 > 0.0f && in != out;
+    // segment index: 1 => [-1,0] (zero traverse time: jump), 2 => [0,1]
+    const int ind = (in < out) ? ((0.0f < out) ? 2 : 1) : ((0.0f <= out) ? 2 : 1);
+    const bool jump = ind == 1;
     const float rate = 1.0f / 3.0f;
-    float thisIn = clampf(0.0f, in, 1.0f);
-    float thisDt = fabsf((thisIn - out) / rate);
-    if (dt0 < thisDt) { out += (out < in) ? dt0 * rate : -dt0 * rate; dt0 = 0.0f; }
-    else { out = thisIn; dt0 -= thisDt; }
+    const float thisIn = clampf(0.0f, in, 1.0f);
+    const float thisDt = fabsf((thisIn - out) / rate);
+    const bool partial = dt0 < thisDt;
+    const float moved = out + ((out < in) ? dt0 * rate : -dt0 * rate);
+    const float out_n = jump ? in : (partial ? moved : thisIn);
+    const float dt_n = jump ? dt0 : (partial ? 0.0f : dt0 - thisDt);
+    out = go ? out_n : out;
+    dt0 = go ? dt_n : dt0;
+    walking = go && !jump;
   }
   return out;
 }

@@ -1,0 +1,563 @@
+// Scenario tasks on the device: Scenario1 (1v1) and Scenario2_NvN / Scenario3_NvN (2v2, 4v4) with the reference's weapon
+// rules (gun, AIM-120B, AIM-9M, chaff + decoy) and its eleven reward terms, driven by low-level controls
+// (4 control indices + 4 weapon bits; the hierarchical controller net of the shipped YAMLs is SURVEY row N1).
+// Reference: envs/JSBSim/tasks/scenario1_task.py:11-145, scenario2_task.py:14-316 (Scenario3 is identical with 8 agents),
+// envs/JSBSim/envs/env_base.py:115-173 (1v1 order), multiplecombat_env.py:119-182 (NvN order), core/simulatior.py:327-608,
+// reward_functions/*.py. Included by aircombat.hip after the shared helpers.
+//
+// Lane layout: the A aircraft of an env in A adjacent lanes (ego team first). Every aircraft owns two munition slots — the
+// two uids "agent+2", "agent+1" that env._tempsims can hold for it (an AIM-9M launched after an AIM-120B with the same
+// remaining-count reuses the uid and replaces the dict entry) — and two chaff release events. Anything another aircraft
+// needs (target pose, missile pose, chaff clouds, statuses) is fetched from the owning lane with __shfl.
+#pragma once
+
+// extension state of the scenario tasks, SoA [field][N]
+enum { XI_rem_gun, XI_rem_9m, XI_rem_120b, XI_rem_chaff, XI_bits, XI_last_chaff, XI_orphan_hits, XI_mp_prev, XI_ref_set,
+       XI_ch_status0, XI_ch_mult0, XI_ch_status1, XI_ch_mult1, XI_n_ch, NXI };
+enum { XF_cg_AO, XF_cg_TA, XF_wez0, XF_wez1, XF_wez2, XF_wez3, XF_tail0, XF_tail1, XF_tail2, XF_tail3,
+       XF_c0x, XF_c0y, XF_c0z, XF_c0t, XF_c1x, XF_c1y, XF_c1z, XF_c1t, NXF };
+
+struct Ext {
+  int rem_gun, rem_9m, rem_120b, rem_chaff, bits, last_chaff, orphan_hits, mp_prev, ref_set;
+  int ch_status[2], ch_mult[2], n_ch;
+  float cg_AO, cg_TA, wez[4], tail[4];
+  float cx[2], cy[2], cz[2], ct[2];
+};
+__device__ __forceinline__ void load_ext(const float* XF, const int* XI, int N, int n, Ext& x) {
+  x.rem_gun = XI[XI_rem_gun * N + n]; x.rem_9m = XI[XI_rem_9m * N + n]; x.rem_120b = XI[XI_rem_120b * N + n];
+  x.rem_chaff = XI[XI_rem_chaff * N + n]; x.bits = XI[XI_bits * N + n]; x.last_chaff = XI[XI_last_chaff * N + n];
+  x.orphan_hits = XI[XI_orphan_hits * N + n]; x.mp_prev = XI[XI_mp_prev * N + n]; x.ref_set = XI[XI_ref_set * N + n];
+  x.ch_status[0] = XI[XI_ch_status0 * N + n]; x.ch_mult[0] = XI[XI_ch_mult0 * N + n];
+  x.ch_status[1] = XI[XI_ch_status1 * N + n]; x.ch_mult[1] = XI[XI_ch_mult1 * N + n]; x.n_ch = XI[XI_n_ch * N + n];
+  x.cg_AO = XF[XF_cg_AO * N + n]; x.cg_TA = XF[XF_cg_TA * N + n];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { x.wez[k] = XF[(XF_wez0 + k) * N + n]; x.tail[k] = XF[(XF_tail0 + k) * N + n]; }
+  x.cx[0] = XF[XF_c0x * N + n]; x.cy[0] = XF[XF_c0y * N + n]; x.cz[0] = XF[XF_c0z * N + n]; x.ct[0] = XF[XF_c0t * N + n];
+  x.cx[1] = XF[XF_c1x * N + n]; x.cy[1] = XF[XF_c1y * N + n]; x.cz[1] = XF[XF_c1z * N + n]; x.ct[1] = XF[XF_c1t * N + n];
+}
+__device__ __forceinline__ void store_ext(float* XF, int* XI, int N, int n, const Ext& x) {
+  XI[XI_rem_gun * N + n] = x.rem_gun; XI[XI_rem_9m * N + n] = x.rem_9m; XI[XI_rem_120b * N + n] = x.rem_120b;
+  XI[XI_rem_chaff * N + n] = x.rem_chaff; XI[XI_bits * N + n] = x.bits; XI[XI_last_chaff * N + n] = x.last_chaff;
+  XI[XI_orphan_hits * N + n] = x.orphan_hits; XI[XI_mp_prev * N + n] = x.mp_prev; XI[XI_ref_set * N + n] = x.ref_set;
+  XI[XI_ch_status0 * N + n] = x.ch_status[0]; XI[XI_ch_mult0 * N + n] = x.ch_mult[0];
+  XI[XI_ch_status1 * N + n] = x.ch_status[1]; XI[XI_ch_mult1 * N + n] = x.ch_mult[1]; XI[XI_n_ch * N + n] = x.n_ch;
+  XF[XF_cg_AO * N + n] = x.cg_AO; XF[XF_cg_TA * N + n] = x.cg_TA;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { XF[(XF_wez0 + k) * N + n] = x.wez[k]; XF[(XF_tail0 + k) * N + n] = x.tail[k]; }
+  XF[XF_c0x * N + n] = x.cx[0]; XF[XF_c0y * N + n] = x.cy[0]; XF[XF_c0z * N + n] = x.cz[0]; XF[XF_c0t * N + n] = x.ct[0];
+  XF[XF_c1x * N + n] = x.cx[1]; XF[XF_c1y * N + n] = x.cy[1]; XF[XF_c1z * N + n] = x.cz[1]; XF[XF_c1t * N + n] = x.ct[1];
+}
+__device__ __forceinline__ Ext fresh_ext(int num) {
+  Ext x{};
+  x.rem_gun = x.rem_9m = x.rem_120b = x.rem_chaff = num;
+  x.last_chaff = -1;
+  x.ch_status[0] = x.ch_status[1] = 1;  // no cloud
+  return x;
+}
+
+__device__ __forceinline__ MslParam aim120b() {  // the set both AIM_9M and AIM_120B carry, simulatior.py:659-672,696-709
+  constexpr int kb = first_tick_not_below(1.4), kt = first_tick_above(27.22);
+  return MslParam{9.81f, 27.22f, 1.4f, 1837.0f, 3.66f, 0.18f, 0.02f, 152.0f, 6.0f, 5.0f, 50.0f, 5.0f, 150.0f, 300, kb, kt};
+}
+// decoy draw keyed by what is tested (substep, missile = launcher + uid number, chaff = releaser + release index): the
+// reference uses the global unseeded np.random (env_base.py:153), so only statistical parity with it is possible; the tests'
+// CPU checker implements the same keyed generator so that both sides can be compared draw for draw
+__device__ __forceinline__ float decoy_uniform(unsigned long long seed, int tick, int mp, int mn, int cp, int cl) {
+  unsigned long long k = ((unsigned long long)(unsigned)tick << 32) | ((unsigned long long)(mp & 0xff) << 24) |
+                         ((unsigned long long)(mn & 0xff) << 16) | ((unsigned long long)(cp & 0xff) << 8) | (unsigned long long)(cl & 0xff);
+  unsigned long long z = seed * 0x9E3779B97F4A7C15ULL + k * 0xD1B54A32D192ED03ULL;
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 27; z *= 0x94D049BB133111EBULL; z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+constexpr float kFt2M = 0.3048f;
+
+template <int A>
+struct ScenarioDims {
+  static constexpr bool MULTI = A > 2;
+  static constexpr int OBS = MULTI ? 9 + 6 * (A / 2) + 6 * (A / 2) + 6 : 21;
+  static constexpr int NE = A / 2;   // enemies per agent (teams are equal-sized in every shipped scenario)
+};
+
+// Relative-geometry quantities of every reward term towards the enemies of this lane, in enemy order.
+struct EnemyGeo { float AO, TA, R; };
+
+template <int A, int WPE>
+__global__ __launch_bounds__(64, WPE) void step_kernel_scenario(DevPtrs P, DevCfg c, float* XF, int* XI, const float* tXF, const int* tXI) {
+  using SD = ScenarioDims<A>;
+  constexpr bool MULTI = SD::MULTI;
+  constexpr int OBS = SD::OBS;
+  constexpr int NE = SD::NE;
+  constexpr int MS = 2;  // munition slots (uids) per aircraft
+  __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
+  stage_tables(lds_tab, P.tab);
+  const Tab T{lds_tab};
+  const int N = c.N;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = n < N;
+  const int slot = threadIdx.x % A;
+  const int nn = live ? n : (N - A + slot);
+  const int base = (threadIdx.x & 63) - slot;
+  const int n_ego = c.n_ego;
+  const int team = slot < n_ego ? 0 : 1;
+  const int e_first = team == 0 ? n_ego : 0;   // my enemies are slots e_first .. e_first + NE - 1
+
+  State s; Task t; Derived d; Props pr; Ext x;
+  load_state(P.F, P.I, P.D, N, nn, s, t);
+  load_ext(XF, XI, N, nn, x);
+  MslD ms[MS];
+#pragma unroll
+  for (int k = 0; k < MS; ++k) load_msl(P.MD, P.MI, N, nn, k, ms[k]);
+
+  // ---- actions: 4 control indices + [gun, AIM-9M, AIM-120B, chaff] (scenario1_task.py:33-48: Scenario1 only refreshes the ego
+  // team's bits, its other team flies the scripted baseline with bits 0; scenario2_task.py:58-61 refreshes both teams)
+  const float* act = P.actions + (size_t)nn * c.act_dim;
+  t.cur_step += 1;
+  s.da = clampf(-1.0f, act[0] / 20.0f - 1.0f, 1.0f);
+  s.de = clampf(-1.0f, act[1] / 20.0f - 1.0f, 1.0f);
+  s.dr = clampf(-1.0f, act[2] / 20.0f - 1.0f, 1.0f);
+  s.thr = clampf(0.0f, act[3] / 58.0f + 0.4f, 0.9f);
+  if (MULTI || team == 0)
+    x.bits = (act[4] != 0.0f ? 1 : 0) | (act[5] != 0.0f ? 2 : 0) | (act[6] != 0.0f ? 4 : 0) | (act[7] != 0.0f ? 8 : 0);
+
+  const MslParam MP = aim120b();
+  bool have_pose = false;
+  for (int sub = 0; sub < c.substeps; ++sub) {
+    if (t.status == AC_ALIVE) {
+      if (t.bloods <= 0.0f) t.status = AC_SHOTDOWN;
+      f16::tick<false>(s, d, T);
+      have_pose = true;
+    }
+    f16::locate(s, d);
+    if (!have_pose) { f16::body_frame(s, d); have_pose = true; }
+    make_props(s, d, c, pr);
+    const int tick_id = (t.cur_step - 1) * c.substeps + sub + 1;
+    // ---- missiles: every dict entry is run(), finished ones included (env_base.py:142-143)
+    int hit_tgt[MS];
+#pragma unroll
+    for (int k = 0; k < MS; ++k) {
+      hit_tgt[k] = -1;
+      const int tg = ms[k].order & 15;               // target slot lives in the low bits of `order`
+      const bool used = ms[k].status != MSL_INACTIVE;
+      const int src = base + (used ? tg : slot);
+      double tx = __shfl(pr.n64, src), ty = __shfl(pr.e64, src), tz = __shfl(pr.u64, src);
+      double tvx = (double)__shfl(pr.vn, src), tvy = (double)__shfl(pr.ve, src), tvz = (double)__shfl(pr.vd, src);
+      bool talive = __shfl(t.status, src) == AC_ALIVE;
+      if (used) {
+        missile_run(ms[k], MP, tx, ty, tz, tvx, tvy, tvz, talive, c);
+        if (ms[k].status == MSL_HIT && talive) hit_tgt[k] = tg;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < A; ++j)
+#pragma unroll
+      for (int k = 0; k < MS; ++k) {
+        int h = __shfl(hit_tgt[k], base + j);
+        if (h == slot && t.status == AC_ALIVE) t.status = AC_SHOTDOWN;
+      }
+    // ---- chaff clouds age (ChaffSimulator.run, simulatior.py:377-381), then the decoy test (env_base.py:146-154)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (q < x.n_ch) { x.ct[q] += 1.0f / 60.0f; if (x.ct[q] > 20.0f) x.ch_status[q] = 1; }
+    const unsigned long long any_cloud = __ballot(x.n_ch > 0 && (x.ch_status[0] == 0 || x.ch_status[1] == 0));
+    const unsigned long long env_mask = ((A == 64) ? ~0ull : ((1ull << A) - 1ull)) << base;
+    if (any_cloud & env_mask) {
+#pragma unroll
+      for (int j = 0; j < A; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int src = base + j;
+          int cst = __shfl(x.ch_status[q], src), cm = __shfl(x.ch_mult[q], src), cn = __shfl(x.n_ch, src);
+          float cxx = __shfl(x.cx[q], src), cyy = __shfl(x.cy[q], src), czz = __shfl(x.cz[q], src);
+          int cbase = (q == 0) ? 0 : __shfl(x.ch_mult[0], src);   // release index of the first chaff of this event
+          if (q >= cn || cst != 0) continue;
+#pragma unroll
+          for (int k = 0; k < MS; ++k) {
+            if (ms[k].status != MSL_LAUNCHED) continue;
+            float dx = cxx - (float)ms[k].px, dy = cyy - (float)ms[k].py, dz = czz - (float)ms[k].pz;
+            if (dx * dx + dy * dy + dz * dz <= 300.0f * 300.0f) {
+              for (int m = 0; m < cm; ++m)   // one draw per chaff of the event; the missile stays "not done" only until one succeeds
+                if (ms[k].status == MSL_LAUNCHED && decoy_uniform(c.chaff_seed + (unsigned long long)(nn / A), tick_id, slot, MS - k, j, cbase + m) < 0.85f) ms[k].status = MSL_MISS;
+            }
+          }
+        }
+    }
+  }
+  if (c.substeps == 0) { f16::locate(s, d); f16::body_frame(s, d); make_props(s, d, c, pr); }
+
+  // ---- weapons (scenario1_task.py:61-103): agents act one after another in env order
+  {
+    const float hv = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve + pr.vd * pr.vd);
+    // farthest enemy (get_target, :139-145): poses and statuses do not change while the weapons are evaluated
+    int tg = e_first; float bd = -1.0f, tdx = 0, tdy = 0, tdz = 0; int tg_status = AC_ALIVE;
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int src = base + e_first + q;
+      float ex = __shfl(pr.n, src) - pr.n, ey = __shfl(pr.e, src) - pr.e, ez = __shfl(pr.u, src) - pr.u;
+      int est = __shfl(t.status, src);
+      float dd = sqrtf(ex * ex + ey * ey + ez * ez);
+      if (dd > bd) { bd = dd; tg = e_first + q; tdx = ex; tdy = ey; tdz = ez; tg_status = est; }
+    }
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+      float gun_dmg = 0.0f; int gun_tgt = -1;
+      bool launched = false;
+      if (slot == i && t.status == AC_ALIVE) {
+        const float ang = 57.29577951f * acosf(clampf(-1.0f, (tdx * pr.vn + tdy * pr.ve + tdz * pr.vd) / (bd * hv + 1e-8f), 1.0f));
+        const bool talive = tg_status == AC_ALIVE;
+        const bool av_gun = talive && bd * 0.001f < 3.0f && ang < 5.0f;
+        const bool av_120 = talive && bd * 0.001f < 37.0f && ang < 90.0f;
+        const bool av_9m = talive && bd * 0.001f < 7.0f && ang < 90.0f;
+        auto last_done = [&]() {
+          if (t.last_missile < 0) return true;
+          bool dn = true;
+#pragma unroll
+          for (int k = 0; k < MS; ++k) if (k == t.last_missile) dn = ms[k].status == MSL_HIT || ms[k].status == MSL_MISS;
+          return dn;
+        };
+        auto launch = [&](int k) {   // MissileSimulator.launch (:497-514) into the dict entry of uid "agent + (MS - k)"
+          float tht = asinf(pr.stht);
+          float psi = atan2f(pr.m12, pr.m11);
+          if (psi < 0.0f) psi += 2.0f * f16::kPi;
+#pragma unroll
+          for (int q = 0; q < MS; ++q)
+            if (q == k) {
+              if (ms[q].status == MSL_HIT) x.orphan_hits += 1;   // a replaced entry that was HIT stays is_success forever (never run again)
+              ms[q].px = pr.n64; ms[q].py = pr.e64; ms[q].pz = pr.u64; ms[q].vx = pr.vn; ms[q].vy = pr.ve; ms[q].vz = pr.vd;
+              ms[q].theta = tht; ms[q].psi = psi; ms[q].t = 0.0; ms[q].m = MP.m0; ms[q].dth = 0.0; ms[q].dph = 0.0;
+              ms[q].dprev = INFINITY; ms[q].recede = 0; ms[q].status = MSL_LAUNCHED;
+              ms[q].order = (t.cur_step << 8) | (i << 4) | tg;    // launch order (step, agent) and target slot
+            }
+          t.last_missile = k;
+          launched = true;
+        };
+        if ((x.bits & 1) && x.rem_gun > 0 && last_done() && av_gun) { gun_dmg = 5.0f; gun_tgt = tg; x.rem_gun -= 1; }
+        if ((x.bits & 4) && x.rem_120b > 0 && last_done() && av_120) { launch(MS - x.rem_120b); x.rem_120b -= 1; }
+        if ((x.bits & 2) && x.rem_9m > 0 && last_done() && av_9m) { launch(MS - x.rem_9m); x.rem_9m -= 1; }
+      }
+      (void)launched;
+      // gun damage lands on the target's blood right away (:70-73)
+      {
+        int gt = __shfl(gun_tgt, base + i);
+        float gd = __shfl(gun_dmg, base + i);
+        if (gt == slot) t.bloods -= gd;
+      }
+      // chaff (:97-103): one release per dict missile (done ones included) aimed at agent i within 1000 m
+      {
+        int n_rel = 0;
+        const bool can = slot == i && t.status == AC_ALIVE && (x.bits & 8) && x.rem_chaff > 0 &&
+                         (x.last_chaff < 0 || x.ch_status[x.last_chaff & 1] == 1);
+#pragma unroll
+        for (int j = 0; j < A; ++j)
+#pragma unroll
+          for (int k = 0; k < MS; ++k) {
+            const int src = base + j;
+            int mst = __shfl(ms[k].status, src), mtg = __shfl(ms[k].order, src) & 15;
+            float mx = __shfl((float)ms[k].px, src), my = __shfl((float)ms[k].py, src), mz = __shfl((float)ms[k].pz, src);
+            if (can && mst != MSL_INACTIVE && mtg == slot) {
+              float dx = pr.n - mx, dy = pr.e - my, dz = pr.u - mz;
+              if (sqrtf(dx * dx + dy * dy + dz * dz) < 1000.0f) n_rel += 1;
+            }
+          }
+        if (n_rel > 0 && x.n_ch < 2) {
+          const int q = x.n_ch;
+          x.cx[q] = pr.n; x.cy[q] = pr.e; x.cz[q] = pr.u; x.ct[q] = 0.0f; x.ch_status[q] = 0; x.ch_mult[q] = n_rel;
+          x.last_chaff = q; x.n_ch += 1; x.rem_chaff -= n_rel;
+        }
+      }
+    }
+  }
+
+  // ---- geometry towards my enemies (every reward term iterates agent.enemies in env order)
+  EnemyGeo eg[NE];
+  float e_u0 = 0.0f;
+#pragma unroll
+  for (int q = 0; q < NE; ++q) {
+    Enemy E = gather_pose(pr, base + e_first + q);
+    Geo g = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd);
+    eg[q].AO = g.AO; eg[q].TA = g.TA; eg[q].R = g.R;
+    if (q == 0) e_u0 = E.u;
+  }
+  // ---- my first alive incoming missile in launch order (check_missile_warning), and whether any is alive
+  Incoming inc{false, 0, 0, 0, 0, 0, 0};
+  int inc_id = 0;    // 1 + launcher*MS + slot of that missile
+  {
+    int best = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < A; ++j)
+#pragma unroll
+      for (int k = 0; k < MS; ++k) {
+        const int src = base + j;
+        int mst = __shfl(ms[k].status, src), mo = __shfl(ms[k].order, src);
+        float a0 = __shfl((float)ms[k].px, src), a1 = __shfl((float)ms[k].py, src), a2 = __shfl((float)ms[k].pz, src);
+        float a3 = __shfl((float)ms[k].vx, src), a4 = __shfl((float)ms[k].vy, src), a5 = __shfl((float)ms[k].vz, src);
+        if (mst == MSL_LAUNCHED && (mo & 15) == slot && (mo >> 4) < best) {
+          best = mo >> 4; inc.any = true; inc.px = a0; inc.py = a1; inc.pz = a2; inc.vx = a3; inc.vy = a4; inc.vz = a5; inc_id = 1 + j * MS + k;
+        }
+      }
+  }
+  int my_hits = x.orphan_hits;
+#pragma unroll
+  for (int k = 0; k < MS; ++k) if (ms[k].status == MSL_HIT) my_hits += 1;
+
+  // ---- observation
+  float ob[OBS];
+  if (!MULTI) {
+    Enemy E = gather_pose(pr, base + e_first);
+    observe_1v1<AC_TASK_SHOOT_MISSILE>(pr, E, inc, ob);   // Scenario1 keeps the 21-value layout (scenario1_task.py:31-32)
+  } else {
+    // scenario2_task.py:256-316: ego 9, partners, enemies, then the missile block directly after them; not clipped
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) ob[k] = 0.0f;
+    ob[0] = pr.alt_m / 5000.0f;
+    ob[1] = pr.sphi; ob[2] = pr.cphi; ob[3] = pr.stht; ob[4] = pr.ctht;
+    ob[5] = pr.ub / 340.0f; ob[6] = pr.vb / 340.0f; ob[7] = pr.wb / 340.0f; ob[8] = pr.vc / 340.0f;
+    const int n_mine = team == 0 ? n_ego : A - n_ego;
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      Enemy E = gather_pose(pr, base + j);
+      if (j == slot) continue;
+      Geo g = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd);
+      const int team_j = j < n_ego ? 0 : 1;
+      int idx = (team_j == team) ? (j - (team == 0 ? 0 : n_ego)) - (j > slot ? 1 : 0) : (n_mine - 1) + (j - e_first);
+      const float v[6] = {(E.ub - pr.ub) / 340.0f, (E.alt - pr.alt_m) / 1000.0f, g.AO, g.TA, g.R / 10000.0f, g.side};
+#pragma unroll
+      for (int q = 0; q < A - 1; ++q)
+        if (q == idx) {
+#pragma unroll
+          for (int m = 0; m < 6; ++m) ob[9 + q * 6 + m] = v[m];
+        }
+    }
+    if (inc.any) {
+      Geo gm = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, inc.px, inc.py, inc.pz, inc.vx, inc.vy, inc.vz);
+      const int o = 9 + 6 * (A - 1);
+      ob[o + 0] = (sqrtf(inc.vx * inc.vx + inc.vy * inc.vy + inc.vz * inc.vz) - pr.ub) / 340.0f;
+      ob[o + 1] = (inc.pz - pr.alt_m) / 1000.0f;
+      ob[o + 2] = gm.AO; ob[o + 3] = gm.TA; ob[o + 4] = gm.R / 10000.0f; ob[o + 5] = gm.side;
+    }
+  }
+
+  // ---- terminations of the 1v1 family come BEFORE the rewards (env_base.py:159-171)
+  bool done = false;
+  int code = AC_DONE_NONE, last_code = AC_DONE_NONE;
+  float np_max = fmaxf(fabsf(s.npx), fmaxf(fabsf(s.npy), fabsf(s.npz)));
+  float pqr = sqrtf(d.p * d.p + d.q * d.q + d.r * d.r);
+  const bool extreme = (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);
+  const bool overload = ((float)s.ticks * (1.0f / 60.0f) > 10.0f) &&
+                        (fabsf(s.npx) > c.acc_x || fabsf(s.npy) > c.acc_y || fabsf(s.npz + 1.0f) > c.acc_z);
+  const bool low = pr.alt_m <= c.altitude_limit;
+  auto terminations = [&]() {
+    int st[A];
+#pragma unroll
+    for (int j = 0; j < A; ++j) st[j] = __shfl(t.status, base + j);
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+      if (slot == i) {
+        bool enemies_dead = true;
+#pragma unroll
+        for (int j = 0; j < A; ++j) if ((j < n_ego ? 0 : 1) != team && st[j] == AC_ALIVE) enemies_dead = false;
+        if (MULTI) {   // SafeReturn, ExtremeState, Overload, LowAltitude, Timeout (multiplecombat_task.py:33-39)
+          if (t.status == AC_SHOTDOWN) { code = AC_DONE_SHOTDOWN; done = true; }
+          else if (t.status == AC_CRASH) { code = AC_DONE_CRASHED; done = true; }
+          else if (enemies_dead && !inc.any) { code = AC_DONE_MISSION_COMPLETE; done = true; }
+          else if (extreme) { t.status = AC_CRASH; code = AC_DONE_EXTREME_STATE; done = true; }
+          else if (overload) { t.status = AC_CRASH; code = AC_DONE_OVERLOAD; done = true; }
+          else if (low) { t.status = AC_CRASH; code = AC_DONE_LOW_ALTITUDE; done = true; }
+          else if (t.cur_step >= c.max_steps) { code = AC_DONE_TIMEOUT; done = true; }
+        } else {       // LowAltitude, ExtremeState, Overload, SafeReturn, Timeout (singlecombat_task.py:34-40)
+          if (low) { t.status = AC_CRASH; code = AC_DONE_LOW_ALTITUDE; done = true; }
+          else if (extreme) { t.status = AC_CRASH; code = AC_DONE_EXTREME_STATE; done = true; }
+          else if (overload) { t.status = AC_CRASH; code = AC_DONE_OVERLOAD; done = true; }
+          else if (t.status == AC_SHOTDOWN) { code = AC_DONE_SHOTDOWN; done = true; }
+          else if (t.status == AC_CRASH) { code = AC_DONE_CRASHED; done = true; }
+          else if (enemies_dead && !inc.any) { code = AC_DONE_MISSION_COMPLETE; done = true; }
+          else if (t.cur_step >= c.max_steps) { code = AC_DONE_TIMEOUT; done = true; }
+        }
+      }
+      int si = __shfl(t.status, base + i), ci = __shfl(code, base + i);
+#pragma unroll
+      for (int j = 0; j < A; ++j) if (j == i) st[j] = si;
+      if (ci) last_code = ci;
+    }
+  };
+  if (!MULTI) terminations();
+
+  // ---- rewards: eleven terms in list order (scenario1_task.py:13-25); which agents evaluate them differs by family
+  const bool evaluates = MULTI ? (t.status == AC_ALIVE) : !t.die_flag;   // multiplecombat_task.py:147-151 / singlecombat_task.py:190-195
+  if (!MULTI && !t.die_flag) t.die_flag = (t.status != AC_ALIVE) ? 1 : 0;
+  // the shared reference lists are written by the first agent that evaluates after a reset
+  const unsigned long long ev_mask = __ballot(evaluates) & (((A == 64) ? ~0ull : ((1ull << A) - 1ull)) << base);
+  const int first_lane = ev_mask ? (__ffsll((long long)ev_mask) - 1) : base;
+  // per-enemy distances of the two gun-track terms
+  float dwez[NE], dtail[NE];
+#pragma unroll
+  for (int q = 0; q < NE; ++q) {
+    const float R = eg[q].R, r3 = 3000.0f * kFt2M, r5 = 5000.0f * kFt2M;
+    float sA, cA, sT, cT; sincosf(eg[q].AO, &sA, &cA); sincosf(eg[q].TA, &sT, &cT);
+    dwez[q] = (R >= 500.0f * kFt2M && R <= r3) ? R * sA : sqrtf(R * R + r3 * r3 - 2.0f * R * r3 * cA);
+    dtail[q] = (R >= r3 && R <= r5) ? R * sT : ((R <= r3) ? sqrtf(R * R + r3 * r3 - 2.0f * R * r3 * cT) : sqrtf(R * R + r5 * r5 - 2.0f * R * r5 * cT));
+  }
+  if (ev_mask && !(x.ref_set & 1)) {   // first evaluation since reset: everybody copies the first evaluator's values
+    x.cg_AO = __shfl(eg[0].AO, first_lane); x.cg_TA = __shfl(eg[0].TA, first_lane);
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      float w = __shfl(q == 0 ? dwez[0] : dwez[q - 1], first_lane), tl = __shfl(q == 0 ? dtail[0] : dtail[q - 1], first_lane);
+      x.wez[q] = w; x.tail[q] = tl;
+    }
+    x.ref_set = 7;
+  }
+  float own = 0.0f;
+  // MissilePostureReward's single shared `previous_missile_v` (missile_posture_reward.py:18-46) is walked agent by agent
+  float r_mp = 0.0f;
+  {
+    float sp[MS];
+#pragma unroll
+    for (int k = 0; k < MS; ++k) sp[k] = (float)sqrt(ms[k].vx * ms[k].vx + ms[k].vy * ms[k].vy + ms[k].vz * ms[k].vz);
+    int prev = x.mp_prev;   // identical in every lane of the env
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+      int ev_i = __shfl((int)evaluates, base + i), id_i = __shfl(inc_id, base + i);
+      if (!ev_i) continue;
+      if (id_i) {
+        if (!prev) prev = id_i;
+        // speeds of the remembered missile and of agent i's incoming missile
+        float v_prev = 0.0f, v_cur = 0.0f;
+#pragma unroll
+        for (int k = 0; k < MS; ++k) {
+          float a = __shfl(sp[k], base + ((prev - 1) / MS)), b = __shfl(sp[k], base + ((id_i - 1) / MS));
+          if (k == (prev - 1) % MS) v_prev = a;
+          if (k == (id_i - 1) % MS) v_cur = b;
+        }
+        if (slot == i) {
+          float v_dec = (v_prev - v_cur) / 340.0f * c.missile_posture_scale;
+          float va = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve + pr.vd * pr.vd);
+          float ang = (inc.vx * pr.vn + inc.vy * pr.ve + inc.vz * pr.vd) / (v_cur * va);
+          r_mp = (ang < 0.0f) ? ang / (fmaxf(v_dec, 0.0f) + 1.0f) : ang * fmaxf(v_dec, 0.0f);
+        }
+      } else prev = 0;
+    }
+    x.mp_prev = prev;
+  }
+  if (evaluates) {
+    float r_alt = potential(altitude_raw(pr, c), c.altitude_scale, c.altitude_pot, t.pre_altitude);
+    float cg = 0.0f, behit = 0.0f, tailr = 0.0f, wezdot = 0.0f, wez = 0.0f, posture = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const float R = eg[q].R;
+      cg += -(eg[0].AO - x.cg_AO) - (eg[0].TA - x.cg_TA);
+      const bool band = R >= 500.0f * kFt2M && R <= 3000.0f * kFt2M;
+      if (band && eg[q].AO >= 179.0f * f16::kPi / 180.0f) behit += -5.0f;
+      if (band && eg[q].AO <= f16::kPi / 180.0f) wez += 5.0f + 5.0f * (3000.0f * kFt2M - R) / (2500.0f * kFt2M);
+      float isr = rsqrtf(R);
+      tailr += -(1.0f / 60.0f) * tanhf((dtail[q] - x.tail[q]) * isr);
+      wezdot += -(1.0f / 60.0f) * tanhf((dwez[q] - x.wez[q]) * isr);
+      posture += posture_fn(eg[q].AO, eg[q].TA, R * 0.001f);
+    }
+    float ev = ((t.status != AC_ALIVE) ? -200.0f : 0.0f) + 200.0f * (float)my_hits;
+    float r_ev = potential(ev, c.event_scale, c.event_pot, t.pre_event);
+    float r_pos = potential(posture, c.posture_scale, c.posture_pot, t.pre_posture);
+    float r_ra = fminf(1.0f - fabsf(pr.u * 0.001f - e_u0 * 0.001f), 0.0f);
+    own = r_alt + cg + r_ev + behit + tailr + wezdot + wez + r_pos + r_ra + r_mp;   // ShootPenalty never fires: remaining_missiles is constant
+  }
+  float reward = own;
+  if (MULTI) {   // team mean (multiplecombat_env.py:170-175), then the terminations
+    float tsum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < A; ++j) { float rj = __shfl(own, base + j); if ((j < n_ego ? 0 : 1) == team) tsum += rj; }
+    reward = tsum / (float)(team == 0 ? n_ego : A - n_ego);
+    terminations();
+  }
+
+  bool all_done = true;
+#pragma unroll
+  for (int j = 0; j < A; ++j) all_done = all_done && (bool)__shfl((int)done, base + j);
+  int step_out = t.cur_step;
+  if (all_done) {
+    load_state(P.tF, P.tI, P.tD, A, slot, s, t);
+    x = fresh_ext(c.num_missiles[slot]);
+    (void)tXF; (void)tXI;
+#pragma unroll
+    for (int k = 0; k < MS; ++k) { ms[k] = MslD{}; ms[k].status = MSL_INACTIVE; }
+    const float* tobs = P.tF + (size_t)NF * A + slot * OBS;
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) ob[k] = tobs[k];
+  }
+  if (live) {
+    store_state(P.F, P.I, P.D, N, n, s, t);
+    store_ext(XF, XI, N, n, x);
+#pragma unroll
+    for (int k = 0; k < MS; ++k) store_msl(P.MD, P.MI, N, n, k, ms[k]);
+    float* o = P.obs + (size_t)n * OBS;
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) o[k] = ob[k];
+    P.rew[n] = reward;
+    P.done[n] = done ? 1 : 0;
+    if (slot == 0) {
+      int* inf = P.info + (size_t)(n / A) * 4;
+      inf[0] = step_out; inf[1] = last_code; inf[2] = 0; inf[3] = all_done ? 1 : 0;
+    }
+  }
+}
+
+// reset template for the scenario tasks: same initial-condition pass, scenario observation layout, potential seeds
+template <int A>
+__global__ void init_kernel_scenario(InitArgs ia, DevCfg c, const float* tab, float* tF, int* tI, double* tD) {
+  using SD = ScenarioDims<A>;
+  constexpr int OBS = SD::OBS;
+  constexpr int NE = SD::NE;
+  __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
+  stage_tables(lds_tab, tab);
+  const Tab T{lds_tab};
+  const int slot = threadIdx.x % A;
+  const int base = (threadIdx.x & 63) - slot;
+  const int team = slot < c.n_ego ? 0 : 1;
+  const int e_first = team == 0 ? c.n_ego : 0;
+  State s; Derived d; Task t{}; Props pr;
+  initial_state(ia.ic[slot], T, s, d);
+  t.bloods = 100.0f; t.status = AC_ALIVE;
+  t.remaining = c.num_missiles[slot]; t.pre_remaining = c.num_missiles[slot];
+  t.last_missile = -1; t.last_shoot_time = -c.min_attack_interval;
+  f16::locate(s, d);
+  make_props(s, d, c, pr);
+  float ob[OBS];
+  Incoming inc{false, 0, 0, 0, 0, 0, 0};
+  float posture = 0.0f;
+#pragma unroll
+  for (int q = 0; q < NE; ++q) {
+    Enemy E = gather_pose(pr, base + e_first + q);
+    Geo g = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd);
+    posture += posture_fn(g.AO, g.TA, g.R * 0.001f);
+  }
+  if (A == 2) {
+    Enemy E = gather_pose(pr, base + e_first);
+    observe_1v1<AC_TASK_SHOOT_MISSILE>(pr, E, inc, ob);
+  } else {
+    for (int k = 0; k < OBS; ++k) ob[k] = 0.0f;
+    ob[0] = pr.alt_m / 5000.0f;
+    ob[1] = pr.sphi; ob[2] = pr.cphi; ob[3] = pr.stht; ob[4] = pr.ctht;
+    ob[5] = pr.ub / 340.0f; ob[6] = pr.vb / 340.0f; ob[7] = pr.wb / 340.0f; ob[8] = pr.vc / 340.0f;
+    const int n_mine = team == 0 ? c.n_ego : A - c.n_ego;
+    for (int j = 0; j < A; ++j) {
+      Enemy E = gather_pose(pr, base + j);
+      if (j == slot) continue;
+      Geo g = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd);
+      const int team_j = j < c.n_ego ? 0 : 1;
+      int idx = (team_j == team) ? (j - (team == 0 ? 0 : c.n_ego)) - (j > slot ? 1 : 0) : (n_mine - 1) + (j - e_first);
+      ob[9 + idx * 6 + 0] = (E.ub - pr.ub) / 340.0f; ob[9 + idx * 6 + 1] = (E.alt - pr.alt_m) / 1000.0f;
+      ob[9 + idx * 6 + 2] = g.AO; ob[9 + idx * 6 + 3] = g.TA; ob[9 + idx * 6 + 4] = g.R / 10000.0f; ob[9 + idx * 6 + 5] = g.side;
+    }
+  }
+  if (c.altitude_pot) t.pre_altitude = altitude_raw(pr, c) * c.altitude_scale;
+  if (c.posture_pot) t.pre_posture = posture * c.posture_scale;
+  if (threadIdx.x < A) {
+    store_state(tF, tI, tD, A, slot, s, t);
+    float* tobs = tF + (size_t)NF * A + slot * OBS;
+    for (int k = 0; k < OBS; ++k) tobs[k] = ob[k];
+  }
+}
+
+__global__ void reset_ext_kernel(DevCfg c, float* XF, int* XI) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= c.N) return;
+  Ext x = fresh_ext(c.num_missiles[n % c.A]);
+  store_ext(XF, XI, c.N, n, x);
+}

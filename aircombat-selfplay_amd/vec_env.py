@@ -10,7 +10,8 @@ import ctypes as C
 
 import numpy as np
 
-from .capi import (AcConfig, AC_STATE_LEN, AC_TASK_SINGLECOMBAT, AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT, load_library)
+from .capi import (AcConfig, AC_STATE_LEN, AC_TASK_SINGLECOMBAT, AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1,
+                   AC_TASK_SCENARIO_NVN, load_library)
 from .config import config_from_yaml, default_config
 
 DONE_MESSAGES = {
@@ -82,6 +83,9 @@ class HipVecEnv:
         self.observation_space = Box(low=-10, high=10.0, shape=(self.obs_dim,))
         if config.task == AC_TASK_SHOOT_MISSILE:
             self.action_space = Tuple([MultiDiscrete([41, 41, 41, 30]), Discrete(2)])
+        elif config.task in (AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN):
+            # low-level controls + [gun, AIM-9M, AIM-120B, chaff] (scenario1_task.py:29-31 with the controller net bypassed)
+            self.action_space = Tuple([MultiDiscrete([41, 41, 41, 30]), MultiDiscrete([2, 2, 2, 2])])
         else:
             self.action_space = MultiDiscrete([41, 41, 41, 30])
         E, A = self.num_envs, self.num_agents
@@ -222,5 +226,5 @@ class HipShareVecEnv(HipVecEnv):
 def make_env(scenario=None, num_envs=1, task=None, device_id=0, seed=0):
     """``scenario``: path of a scenario YAML (reference format) or None for the 1v1 block of WVR_selfplay.yaml."""
     cfg = config_from_yaml(scenario, task=task) if scenario else default_config(task or "singlecombat")
-    cls = HipShareVecEnv if cfg.task == AC_TASK_MULTICOMBAT else HipVecEnv
+    cls = HipShareVecEnv if cfg.task in (AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO_NVN) else HipVecEnv
     return cls(cfg, num_envs, device_id=device_id, seed=seed)

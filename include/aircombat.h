@@ -29,6 +29,9 @@ enum {
   AC_TASK_SINGLECOMBAT = 1,   /* singlecombat_task.py:16-207 SingleCombatTask: obs 15, act [41,41,41,30] */
   AC_TASK_DODGE_MISSILE = 2,  /* singlecombat_with_missile_task.py:12-124 rule-based launch: obs 21, act 4 */
   AC_TASK_SHOOT_MISSILE = 3,  /* singlecombat_with_missile_task.py:147-204 learned shoot bit: obs 21, act 5 */
+  AC_TASK_SCENARIO1 = 5,      /* scenario1_task.py:11-145 (1v1): gun / AIM-120B / AIM-9M / chaff rules, 11 reward terms; obs 21;
+                                 act 8 = [41,41,41,30] + [gun, AIM-9M, AIM-120B, chaff] (low-level control; the controller net is row N1) */
+  AC_TASK_SCENARIO_NVN = 6,   /* scenario2_task.py / scenario3_task.py *_NvN (2v2, 4v4) under MultipleCombatEnv.step: obs 9+6A+6, act 8 */
   AC_TASK_MULTICOMBAT = 4     /* multiplecombat_task.py:15-151 MultipleCombatTask under MultipleCombatEnv.step (NvN, n_agents 4 or 8):
                                  obs 9+6*(A-1), act [41,41,41,30]; share_obs is obs flattened per env (env_base.py:183-189) */
 };
@@ -69,7 +72,7 @@ typedef struct ac_config {
 typedef struct ac_env ac_env_t;
 
 /* Number of doubles in the per-aircraft state vector of ac_get_state / ac_set_state, and the field names. */
-#define AC_STATE_LEN 80
+#define AC_STATE_LEN 128
 const char* ac_state_field_name(int i);
 
 /* replaces SubprocVecEnv.__init__ (R/envs/env_wrappers.py:231-267): builds E envs on one GPU, runs every

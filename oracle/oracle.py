@@ -130,6 +130,12 @@ def default_config(task):
     return c
 
 
+def copy_config(cfg):
+    c = OrEnvConfig()
+    C.memmove(C.byref(c), C.byref(cfg), C.sizeof(OrEnvConfig))
+    return c
+
+
 def config_from_ac(ac_cfg):
     """Oracle config with the same scalars as a product AcConfig (duck-typed: same field names where they overlap)."""
     c = default_config(int(ac_cfg.task))
@@ -241,8 +247,13 @@ class OracleEnv:
 class OracleVecEnv:
     """E oracle envs behind the reference's VecEnv semantics (auto-reset when every agent is done)."""
 
-    def __init__(self, cfg, num_envs):
-        self.envs = [OracleEnv(cfg) for _ in range(num_envs)]
+    def __init__(self, cfg, num_envs, chaff_seed=None):
+        self.envs = []
+        for e in range(num_envs):
+            if chaff_seed is not None:   # the product keys its decoy draws with seed + env index
+                cfg = copy_config(cfg)
+                cfg.chaff_seed = chaff_seed + e
+            self.envs.append(OracleEnv(cfg))
         self.num_envs = num_envs
         self.num_agents = cfg.n_aircraft
         self.obs_dim, self.act_dim = self.envs[0].obs_dim, self.envs[0].act_dim
