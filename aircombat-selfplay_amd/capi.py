@@ -66,6 +66,7 @@ SIGNATURES = {
     "ac_get_missile": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "ac_timing_begin": (C.c_int, [_p]),
     "ac_timing_end": (C.c_int, [_p, C.POINTER(C.c_float)]),
+    "ac_state_checksum": (C.c_int, [_p, C.POINTER(C.c_uint64)]),
     "ac_last_error": (C.c_char_p, []),
     "ac_version": (C.c_char_p, []),
 }

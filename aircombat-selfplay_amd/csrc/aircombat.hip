@@ -1284,6 +1284,42 @@ int ac_get_entity(ac_env_t* h, int32_t env, int32_t agent, double out[12]) {
   HIP_OK(hipFree(d_out));
   return 0;
 }
+// Order-independent 64-bit digest of the live aircraft state: every lane reads its SoA columns exactly like the step kernel
+// (4 B per lane, coalesced; 8 B for the ECI position), mixes each word with its field index and the lanes' digests are summed.
+__global__ void state_checksum_kernel(DevPtrs P, DevCfg c, unsigned long long* out) {
+  const int N = c.N;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long acc = 0;
+  if (n < N) {
+    auto mix = [](unsigned long long v, unsigned f) {
+      unsigned long long z = v + 0x9E3779B97F4A7C15ULL * (unsigned long long)(f + 1);
+      z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 27; z *= 0x94D049BB133111EBULL; z ^= z >> 31;
+      return z;
+    };
+    for (int f = 0; f < NF; ++f) acc += mix((unsigned long long)__float_as_uint(P.F[(size_t)f * N + n]), f);
+    for (int f = 0; f < NI; ++f) acc += mix((unsigned long long)(unsigned)P.I[(size_t)f * N + n], NF + f);
+    for (int f = 0; f < ND; ++f) acc += mix((unsigned long long)__double_as_longlong(P.D[(size_t)f * N + n]), NF + NI + f);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+int ac_state_checksum(ac_env_t* h, uint64_t* out) {
+  if (!h || !out) return fail("ac_state_checksum: null argument");
+  HIP_OK(hipSetDevice(h->device));
+  unsigned long long* d_out;
+  HIP_OK(hipMalloc(&d_out, sizeof(unsigned long long)));
+  HIP_OK(hipMemsetAsync(d_out, 0, sizeof(unsigned long long), h->stream));
+  dim3 block(64), grid((h->N + 63) / 64);
+  hipLaunchKernelGGL(state_checksum_kernel, grid, block, 0, h->stream, h->dp, h->dc, d_out);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(h->stream));
+  unsigned long long v = 0;
+  HIP_OK(hipMemcpy(&v, d_out, sizeof v, hipMemcpyDeviceToHost));
+  HIP_OK(hipFree(d_out));
+  *out = (uint64_t)v;
+  return 0;
+}
 int ac_get_missile(ac_env_t* h, int32_t env, int32_t agent, int32_t k, double out[12]) {
   if (check_idx(h, env, agent) || !out) return fail("ac_get_missile: bad argument");
   if (k < 0 || k >= h->dc.msl_slots) return fail("ac_get_missile: no such missile slot");

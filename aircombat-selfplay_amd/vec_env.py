@@ -193,6 +193,12 @@ class HipVecEnv:
         self.lib.check(self.lib.ac_get_entity(self._h, env, agent, out), "ac_get_entity")
         return np.array(out[:], dtype=np.float64)
 
+    def state_checksum(self):
+        """64-bit order-independent digest of every aircraft's state (ac_state_checksum)."""
+        out = C.c_uint64()
+        self.lib.check(self.lib.ac_state_checksum(self._h, C.byref(out)), "ac_state_checksum")
+        return int(out.value)
+
     def get_missile(self, env, agent, k):
         out = (C.c_double * 12)()
         self.lib.check(self.lib.ac_get_missile(self._h, env, agent, k, out), "ac_get_missile")

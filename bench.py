@@ -40,6 +40,22 @@ def cpu_baseline(cfg, seconds_target=12.0):
                       f"the reference's own SubprocVecEnv+jsbsim wheel cannot run here)"}
 
 
+def pmc_traffic(task, envs):
+    """HBM bytes per launch of the step kernel from the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
+    runs of this same command, FETCH_SIZE calibrated on the digest kernel's known byte count; tools/pmc_traffic.py writes the
+    summary). Counters cannot be read from inside the process, so this is the committed measurement for the same workload, or
+    null when there is none for it."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    for r in rec.get("runs", []):
+        if r.get("task") == task and r.get("envs_per_gpu") == envs:
+            return r["traffic_bytes_per_launch"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,6 +64,9 @@ def main():
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU (default: the BASELINE config)")
     ap.add_argument("--task", default="singlecombat")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--checksum-calls", type=int, default=0,
+                    help="after the timed region launch the read-only state digest kernel this many times (a dispatch with a known "
+                         "byte count in the step kernel's access pattern, used to calibrate FETCH_SIZE under rocprofv3 --pmc)")
     args = ap.parse_args()
 
     import numpy as np
@@ -102,6 +121,9 @@ def main():
     kernel_ms = ev_ms.value / args.steps          # HIP events on the launch stream, average per launch
     elapsed, kernel_ms = pkg.sharding.max_over_ranks([elapsed, kernel_ms], dist, device=f"cuda:{local_rank}")
 
+    for _ in range(args.checksum_calls):
+        env.state_checksum()
+
     # sanity: the episode machinery really ran (steps counted, resets happened)
     _, _, _, _, info = env.device_tensors()
     info_h = info.cpu().numpy()
@@ -121,7 +143,7 @@ def main():
                        "actions": "uniform random MultiDiscrete[41,41,41,30], new batch every step, device-resident",
                        "auto_reset": True, "parallelism": f"env-block x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.task, E),
                          "kernel": "step_kernel_1v1", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes},
             "episode_check": {"max_current_step": int(info_h[:, 0].max()), "envs_reset_last_step": int(info_h[:, 3].sum())},

@@ -108,6 +108,11 @@ int ac_get_entity(ac_env_t* h, int32_t env, int32_t agent, double out[12]);
 /* missile k of an agent: status, N,E,U, vN,vE,vU, theta, psi, t, mass (MissileSimulator, simulatior.py:393-608) */
 int ac_get_missile(ac_env_t* h, int32_t env, int32_t agent, int32_t k, double out[12]);
 
+/* Order-independent 64-bit digest of all aircraft states on the device (sum over aircraft of a per-field hash): E envs in the
+ * same state give E times the digest of one env (mod 2^64). Test / profiling aid: one read-only pass over the state arrays with
+ * the step kernel's access pattern, (4*63 + 4*12 + 8*3) bytes per aircraft; no reference counterpart. */
+int ac_state_checksum(ac_env_t* h, uint64_t* out);
+
 /* timing helper for the bench: average device milliseconds per step kernel over the last n ac_step* calls, measured
  * with HIP events on the handle's stream */
 int ac_timing_begin(ac_env_t* h);

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes of bench.py (FETCH_SIZE in one, WRITE_SIZE in the other; they do not fit one pass on gfx950)
+into HBM bytes per launch of the step kernel, following MI355X_MICROARCH.md's HBM section: both counters are memory-side
+request tallies in KB; WRITE_SIZE is exact for dword-per-lane stores; FETCH_SIZE is only calibrated by the guide for 16-B
+streaming reads (where it reports half), so it is calibrated here on the state-digest kernel, which reads a known byte count
+(324 B per aircraft) with the step kernel's own 4-B-per-lane SoA pattern.
+
+usage: pmc_traffic.py <fetch_dir> <write_dir> --task singlecombat --envs 4096 --agents 2 [--out profiles/pmc_traffic.json]"""
+import argparse
+import csv
+import glob
+import json
+import os
+from collections import defaultdict
+
+STATE_READ_BYTES = 4 * 63 + 4 * 12 + 8 * 3
+
+
+def per_kernel(directory, counter):
+    acc = defaultdict(list)
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            if row["Counter_Name"] == counter:
+                acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return acc
+
+
+def pick(acc, needle):
+    vals = [v for k, vs in acc.items() if needle in k for v in vs]
+    if not vals:
+        raise SystemExit(f"no dispatches of a kernel containing {needle!r}")
+    return vals
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("fetch_dir"); ap.add_argument("write_dir")
+    ap.add_argument("--task", default="singlecombat"); ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--agents", type=int, default=2)
+    ap.add_argument("--kernel", default="step_kernel")
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    fetch, write = per_kernel(a.fetch_dir, "FETCH_SIZE"), per_kernel(a.write_dir, "WRITE_SIZE")
+    lanes = a.envs * a.agents
+    cal = pick(fetch, "state_checksum_kernel")
+    cal_kb = sum(cal) / len(cal)
+    factor = (STATE_READ_BYTES * lanes / 1024.0) / cal_kb          # true KB per counted KB for this access pattern
+    f = pick(fetch, a.kernel); w = pick(write, a.kernel)
+    f = f[len(f) // 4:]; w = w[len(w) // 4:]                       # drop the warm-up quarter
+    fetch_kb, write_kb = sum(f) / len(f), sum(w) / len(w)
+    rec = {"task": a.task, "envs_per_gpu": a.envs, "aircraft": lanes, "kernel": a.kernel, "dispatches": len(f),
+           "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
+           "fetch_calibration": {"kernel": "state_checksum_kernel", "known_KB": STATE_READ_BYTES * lanes / 1024.0,
+                                 "FETCH_SIZE_KB_raw": cal_kb, "factor": factor, "dispatches": len(cal)},
+           "traffic_bytes_per_launch": (fetch_kb * factor + write_kb) * 1024.0,
+           "bytes_per_aircraft_step": (fetch_kb * factor + write_kb) * 1024.0 / lanes}
+    print(json.dumps(rec, indent=1))
+    if a.out:
+        try:
+            allrec = json.load(open(a.out))
+        except (OSError, ValueError):
+            allrec = {"runs": []}
+        allrec["runs"] = [r for r in allrec["runs"] if not (r["task"] == a.task and r["envs_per_gpu"] == a.envs)] + [rec]
+        json.dump(allrec, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
