@@ -120,27 +120,45 @@ __device__ __forceinline__ float tabc(const float (&x)[N], const float (&y)[N], 
 
 // ---------------------------------------------------------------- standard atmosphere 1976 (geopotential layers)
 // data/src/models/atmosphere/FGStandardAtmosphere.cpp:66-74,152-222,244-268 — only the three layers an F-16 can reach.
+// x^y for x > 0 on the two transcendental units (v_log_f32, v_exp_f32; ~1 ulp each): the library pow spends >100 instructions
+// on special cases none of these call sites can hit. Relative error <= 2e-7 for the exponents used here.
+__device__ __forceinline__ float pow_pos(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+// atan2 for finite arguments, not both zero: odd minimax polynomial of degree 17 on [0, 1] (max error 8e-8 rad in fp32)
+// after the usual min/max reduction.
+__device__ __forceinline__ float atan2_fast(float y, float x) {
+  float ax = fabsf(x), ay = fabsf(y);
+  float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  float a = mn * __builtin_amdgcn_rcpf(mx);
+  float t = a * a;
+  float p = 0.0024489392526447773f;
+  p = fmaf(p, t, -0.014364523813128471f); p = fmaf(p, t, 0.0397086925804615f); p = fmaf(p, t, -0.07227175682783127f);
+  p = fmaf(p, t, 0.10494229197502136f); p = fmaf(p, t, -0.14159545302391052f); p = fmaf(p, t, 0.1998557597398758f);
+  p = fmaf(p, t, -0.33332565426826477f); p = fmaf(p, t, 0.9999998807907104f);
+  float r = p * a;
+  r = (ay > ax) ? 1.57079632679489662f - r : r;
+  r = (x < 0.0f) ? 3.14159265358979324f - r : r;
+  return copysignf(r, y);
+}
+
 struct Atmos { float T, P, rho, a; };
 __device__ __forceinline__ Atmos atmosphere(float h_ft) {
   const float Re = 20855531.5f;                 // 6356766 m in ft
   const float R = 1716.557158f;                 // Rstar/Mair = 8.31432*kgtoslug/(1.8*0.3048^2) / (28.9645*kgtoslug/1000)
   const float g0R = kG0 / R;
   float gp = h_ft * Re / (Re + h_ft);
+  // the three layers as selects over one pow-shaped and one exp-shaped evaluation (no divergent branches in the tick)
+  const bool tropo = gp < 36089.2388f, strato1 = gp < 65616.7979f;
+  const float L0 = (389.97f - 518.67f) / 36089.2388f;                               // also JSBSim's extrapolation below sea level
+  const float L2 = (411.57f - 389.97f) / (104986.8766f - 65616.7979f);
+  const float Pb1 = 472.680579f, Pb2 = 114.344890f;                                   // layer-base pressures (:460-481)
   Atmos A;
-  if (gp < 36089.2388f) {
-    const float L = (389.97f - 518.67f) / 36089.2388f;
-    A.T = 518.67f + L * gp;                     // also the extrapolation JSBSim uses below sea level
-    A.P = 2116.228f * __powf(518.67f / A.T, g0R / L);
-  } else if (gp < 65616.7979f) {
-    const float Pb = 472.680579f;                // breakpoint pressure at 36089.2388 ft from the layer formula (:460-481)
-    A.T = 389.97f;
-    A.P = Pb * __expf(-g0R * (gp - 36089.2388f) / 389.97f);
-  } else {
-    const float Pb = 114.344890f;                // breakpoint pressure at 65616.7979 ft
-    const float L = (411.57f - 389.97f) / (104986.8766f - 65616.7979f);
-    A.T = 389.97f + L * (gp - 65616.7979f);
-    A.P = Pb * __powf(389.97f / A.T, g0R / L);
-  }
+  A.T = tropo ? 518.67f + L0 * gp : (strato1 ? 389.97f : 389.97f + L2 * (gp - 65616.7979f));
+  const float base = tropo ? 518.67f : 389.97f;
+  // P = Pb * (Tb / T)^(g0R / L)  <=>  exp2(-(g0R / L) * log2(T / Tb));  isothermal layer: exp(-g0R (gp - hb) / Tb)
+  const float ex_pow = -(tropo ? g0R / L0 : g0R / L2) * __builtin_amdgcn_logf(A.T * (1.0f / base));
+  const float ex_iso = (-g0R * 1.44269504088896341f / 389.97f) * (gp - 36089.2388f);
+  const bool iso = !tropo && strato1;
+  A.P = (tropo ? 2116.228f : (strato1 ? Pb1 : Pb2)) * __builtin_amdgcn_exp2f(iso ? ex_iso : ex_pow);
   A.rho = A.P / (R * A.T);
   A.a = sqrtf(1.4f * R * A.T);
   return A;
@@ -151,17 +169,20 @@ __device__ __forceinline__ Atmos atmosphere(float h_ft) {
 // calibrated airspeed against fixed thresholds, and vc is monotonic in qc, so "vc-kts lt V" <=> "qc < qc_sl(V)". The inverse
 // (with its 10-step supersonic fixed point) runs once per env step when the observation needs vc itself.
 __device__ __forceinline__ float pitot_impact_pressure(float mach, float p) {
-  float pt;
-  if (mach < 1.0f) pt = p * __powf(1.0f + 0.2f * mach * mach, 3.5f);
-  else pt = p * 166.92158009316827f * __powf(mach, 7.0f) / __powf(7.0f * mach * mach - 1.0f, 2.5f);
-  return pt - p;
+  // subsonic (1 + 0.2 M^2)^3.5 and Rayleigh 166.92158 M^7 / (7 M^2 - 1)^2.5 with half-integer powers as products and one sqrt
+  const float m2 = mach * mach;
+  const float x = 1.0f + 0.2f * m2;
+  const float sub = x * x * x * sqrtf(x);
+  const float y = fmaxf(7.0f * m2 - 1.0f, 1.0f);
+  const float sup = 166.92158009316827f * (m2 * m2 * m2 * mach) / (y * y * sqrtf(y));
+  return p * ((mach < 1.0f) ? sub : sup) - p;
 }
 __device__ __forceinline__ float vcas_from_impact_pressure(float qc) {
   const float psl = 2116.228f, asl = 1116.448558f;  // sqrt(1.4 * R * 518.67)
   float A = qc / psl + 1.0f;
-  float M = sqrtf(fmaxf(0.0f, 5.0f * (__powf(A, 1.0f / 3.5f) - 1.0f)));
+  float M = sqrtf(fmaxf(0.0f, 5.0f * (pow_pos(A, 1.0f / 3.5f) - 1.0f)));
   if (M > 1.0f) {
-    for (int i = 0; i < 10; ++i) M = 0.8812848543473311f * sqrtf(A * __powf(1.0f - 1.0f / (7.0f * M * M), 2.5f));
+    for (int i = 0; i < 10; ++i) M = 0.8812848543473311f * sqrtf(A * pow_pos(1.0f - 1.0f / (7.0f * M * M), 2.5f));
   }
   return asl * M;
 }
@@ -436,9 +457,9 @@ __device__ __forceinline__ void tick(State& s, Derived& d, const Tab& T) {
   float alpha = 0.0f, beta = 0.0f, ca = 1.0f, sa = 0.0f, cb = 1.0f, sb = 0.0f;
   if (vt > 0.001f) {
     float suw = sqrtf(muw);
-    beta = atan2f(d.v, suw);
+    beta = atan2_fast(d.v, suw);
     cb = suw / vt; sb = d.v / vt;
-    if (muw >= 1e-6f) { alpha = atan2f(d.w, d.u); ca = d.u / suw; sa = d.w / suw; }
+    if (muw >= 1e-6f) { alpha = atan2_fast(d.w, d.u); ca = d.u / suw; sa = d.w / suw; }
   }
   float qbar = 0.5f * A.rho * vt2;
   float mach = vt / A.a;

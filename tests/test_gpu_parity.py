@@ -14,6 +14,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+VECTOR_FIELDS = (("bax", "bay", "baz"), ("aix", "aiy", "aiz"), ("ha1x", "ha1y", "ha1z"), ("wdx", "wdy", "wdz"),
+                 ("npx", "npy", "npz"), ("q0", "q1", "q2", "q3"))
+
+
 def rand_actions(rng, E, A, act_dim):
     a = np.stack([rng.integers(0, n, size=(E, A)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
     if act_dim == 5:
@@ -56,7 +60,11 @@ def test_reset_matches_oracle(pkg, oracle, task):
         for k, nm in enumerate(names):
             if not nm or nm.startswith("x_"):
                 continue
-            tol = 0.05 if nm in ("rx", "ry", "rz") else 2e-5 * max(1.0, abs(o[k])) + 1e-6
+            scale = abs(o[k])
+            for grp in VECTOR_FIELDS:          # components of one vector share the vector's scale
+                if nm in grp:
+                    scale = float(np.sqrt(sum(o[names.index(c)] ** 2 for c in grp)))
+            tol = 0.05 if nm in ("rx", "ry", "rz") else 2e-5 * max(1.0, scale) + 1e-6
             if nm in ("hv1x", "hv1y", "hv1z", "hv2x", "hv2y", "hv2z", "vx", "vy", "vz"):
                 tol = 2e-4
             assert abs(g[k] - o[k]) <= tol, (nm, g[k], o[k])
