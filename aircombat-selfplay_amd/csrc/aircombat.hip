@@ -465,13 +465,7 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) 
   // ---- substeps (env_base.py:139-154): every aircraft, then every missile against this substep's aircraft poses
   const MslParam MP = aim9l();
   bool have_pose = false;
-#ifdef AC_UNROLL
-  const int nsub = 6;
-#pragma unroll AC_UNROLL
-  for (int sub = 0; sub < nsub; ++sub) {
-#else
   for (int sub = 0; sub < c.substeps; ++sub) {
-#endif
     if (t.status == AC_ALIVE) {
       if (t.bloods <= 0.0f) t.status = AC_SHOTDOWN;  // simulatior.py:220-222: this tick still integrates
       f16::tick<false>(s, d, T);

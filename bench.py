@@ -27,17 +27,76 @@ BYTES_PER_AGENT_STEP = 593.0    # SURVEY §8(d) / BASELINE.md §3, config C2: 51
 
 
 def cpu_baseline(cfg, seconds_target=12.0):
-    """The CPU port (oracle) timed on this box's host cores, rank 0 at N=1 only: a bounded sample of the same workload."""
+    """The CPU port (oracle) timed on this box's host cores, rank 0 at N=1 only, on a bounded sample of the same workload
+    (one worker per host core, capped at the 16-core share a one-GPU box gets; the single-core rate beside it)."""
+    import threading
     from oracle import oracle as O
     ocfg = O.config_from_ac(cfg)
-    n0, s0, _ = O.bench_run(ocfg, 256, 20)                 # calibrate
-    rate = n0 / s0
-    steps = max(10, int(seconds_target * rate / (ENVS_PER_GPU * AGENTS)))
-    n, s, eps = O.bench_run(ocfg, ENVS_PER_GPU, steps)
-    return {"value": n / s, "unit": "agent-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{ENVS_PER_GPU} envs x {AGENTS} aircraft x {steps} env steps, random actions, auto-reset, "
-                      f"{s:.1f} s on 1 of {os.cpu_count()} host cores (oracle/: f64 C restatement of the JSBSim+Python path; "
-                      f"the reference's own SubprocVecEnv+jsbsim wheel cannot run here)"}
+    n0, s0, _ = O.bench_run(ocfg, 256, 20)                 # calibrate one core
+    rate1 = n0 / s0
+    threads = max(1, min(16, os.cpu_count() or 1))
+    per = ENVS_PER_GPU // threads
+    steps = max(10, int(seconds_target * rate1 / (per * AGENTS)))
+    out = [None] * threads
+
+    def work(i):
+        out[i] = O.bench_run(ocfg, per, steps, seed=20250321 + i)      # ctypes releases the GIL: real threads
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    wall = time.perf_counter() - t0
+    total = sum(o[0] for o in out)
+    return {"value": total / wall, "unit": "agent-steps/s", "cores": threads, "kind": "port",
+            "single_core_value": rate1,
+            "sample": f"{per * threads} envs x {AGENTS} aircraft x {steps} env steps split over {threads} threads (one env block each), "
+                      f"random actions, auto-reset, {wall:.1f} s wall on {threads} of {os.cpu_count()} host cores (oracle/: f64 C "
+                      f"restatement of the JSBSim+Python path; the reference's own SubprocVecEnv+jsbsim wheel cannot run here)"}
+
+
+VALU_PEAK_TINST = 256 * 4 * 32 * 2.4e9 / 1e12   # lane-instructions/s: 256 CUs x 4 SIMD-32 x 2.4 GHz (157.3 TFLOP/s fp32 = 2 flop FMA)
+VALU_PER_AGENT_STEP = 8796.0                   # SQ_INSTS_VALU per wave per launch / 64 lanes x 64 (profiles/round1_pmc_mix.txt)
+
+
+def saturating_leg(pkg, cfg, local_rank, envs=524288, steps=40, warmup=8):
+    """SURVEY 8d asks for the same path at a saturating batch (>= 2^20 aircraft) beside the BASELINE batch: 2 waves per SIMD on
+    every CU instead of one wave on an eighth of them."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    env = pkg.HipVecEnv(cfg, envs, device_id=local_rank, seed=7)
+    env.reset()
+    rng = np.random.default_rng(99)
+    pool = []
+    for _ in range(4):
+        a = np.stack([rng.integers(0, n, size=(envs, AGENTS)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
+        if env.act_dim == 5:
+            a = np.concatenate([a, (rng.random((envs, AGENTS, 1)) < 0.05).astype(np.float32)], axis=-1)
+        pool.append(torch.from_numpy(a).cuda(local_rank))
+    ptrs = [t.data_ptr() for t in pool]
+    for i in range(warmup):
+        env.step_device(ptrs[i % 4])
+    env.sync()
+    env.lib.ac_timing_begin(env._h)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        env.step_device(ptrs[i % 4])
+    env.sync()
+    wall = time.perf_counter() - t0
+    ev = C.c_float()
+    env.lib.check(env.lib.ac_timing_end(env._h, C.byref(ev)), "ac_timing_end")
+    env.close()
+    kernel_s = ev.value * 1e-3 / steps
+    rate = envs * AGENTS / kernel_s
+    return {"envs": envs, "aircraft": envs * AGENTS, "steps": steps, "value": envs * AGENTS * steps / wall, "unit": "agent-steps/s",
+            "kernel_ms": kernel_s * 1e3,
+            "hbm": {"achieved": BYTES_PER_AGENT_STEP * rate / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": BYTES_PER_AGENT_STEP * rate / 1e9 / HBM_PEAK_GBPS},
+            "valu": {"achieved": VALU_PER_AGENT_STEP * rate / 1e12, "peak": VALU_PEAK_TINST, "unit": "T lane-inst/s",
+                     "frac": VALU_PER_AGENT_STEP * rate / 1e12 / VALU_PEAK_TINST}}
 
 
 def pmc_traffic(task, envs):
@@ -64,6 +123,7 @@ def main():
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU (default: the BASELINE config)")
     ap.add_argument("--task", default="singlecombat")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-saturating", action="store_true", help="skip the extra 2^20-aircraft leg (N=1 only)")
     ap.add_argument("--checksum-calls", type=int, default=0,
                     help="after the timed region launch the read-only state digest kernel this many times (a dispatch with a known "
                          "byte count in the step kernel's access pattern, used to calibrate FETCH_SIZE under rocprofv3 --pmc)")
@@ -161,9 +221,17 @@ def main():
         hb = time.perf_counter() - t0
         result["host_boundary"] = {"value": E * AGENTS * HB / hb, "unit": "agent-steps/s", "ms_per_step": hb / HB * 1e3,
                                    "note": "VecEnv.step(numpy) incl. H2D actions, kernel, D2H obs/reward/done, info dicts"}
+        rate = E * AGENTS / (kernel_ms * 1e-3)
+        result["roofline"]["valu"] = {"achieved": VALU_PER_AGENT_STEP * rate / 1e12, "peak": VALU_PEAK_TINST, "unit": "T lane-inst/s",
+                                      "frac": VALU_PER_AGENT_STEP * rate / 1e12 / VALU_PEAK_TINST,
+                                      "note": "one wave per SIMD issues one instruction per 4 cycles; 128 waves on 1024 SIMDs at this batch"}
+        if not args.no_saturating:
+            env.close()
+            result["saturating"] = saturating_leg(pkg, cfg, local_rank)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg)
-    env.close()
+    if not env.closed:
+        env.close()
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
