@@ -415,7 +415,7 @@ __device__ __forceinline__ float altitude_raw(const Props& pr, const DevCfg& c) 
 
 template <int TASK>
 struct TaskTraits {
-  static constexpr bool HAS_MSL = (TASK == AC_TASK_SHOOT_MISSILE);
+  static constexpr bool HAS_MSL = (TASK == AC_TASK_SHOOT_MISSILE || TASK == AC_TASK_DODGE_MISSILE);
   static constexpr int MSLOTS = HAS_MSL ? AC_MAX_MISSILES_PER_AGENT : 1;
   static constexpr int OBS = (TASK == AC_TASK_SINGLECOMBAT) ? 15 : 21;
 };
@@ -506,12 +506,31 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) 
     float dmg = ealive ? of * df : 0.0f;
     t.bloods -= __shfl_xor(dmg, 1);
   }
-  if (HAS_MSL) {  // singlecombat_with_missile_task.py:194-204: learned shoot bit, previous missile must be done
-    bool prev_done = t.last_missile < 0;
+  if (HAS_MSL) {
+    bool launch;
+    if (TASK == AC_TASK_DODGE_MISSILE) {
+      // singlecombat_with_missile_task.py:108-124: rule-based launch — the enemy within max_attack_angle of the velocity vector
+      // for a full lock window (1 s of env steps), inside max_attack_distance, min_attack_interval steps after the last shot.
+      // The window is updated by every aircraft, dead ones included (their cached pose keeps being read).
+      const float dx = E.n - pr.n, dy = E.e - pr.e, dz = E.u - pr.u;
+      const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+      const float sp = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve + pr.vd * pr.vd);
+      const float ang = 57.29577951f * acosf(clampf(-1.0f, (dx * pr.vn + dy * pr.ve + dz * pr.vd) / (dist * sp + 1e-8f), 1.0f));
+      const int len = c.lock_len;                       // deque(maxlen = int(1 / time_interval))
+      const unsigned bit = 1u << (unsigned)(t.lock_pos % len);
+      t.lock_bits = (ang < c.max_attack_angle) ? (t.lock_bits | (int)bit) : (t.lock_bits & ~(int)bit);
+      t.lock_pos += 1;
+      const bool locked = __popc((unsigned)t.lock_bits & ((1u << len) - 1u)) >= len;   // np.sum(lock_duration) >= maxlen
+      launch = t.status == AC_ALIVE && locked && dist <= c.max_attack_distance && t.remaining > 0 &&
+               (t.cur_step - t.last_shoot_time) >= c.min_attack_interval;
+      if (launch) t.last_shoot_time = t.cur_step;
+    } else {  // :194-204: learned shoot bit, previous missile must be done
+      bool prev_done = t.last_missile < 0;
 #pragma unroll
-    for (int k = 0; k < MSLOTS; ++k)
-      if (k == t.last_missile) prev_done = (ms[k].status == MSL_HIT || ms[k].status == MSL_MISS);
-    bool launch = t.status == AC_ALIVE && t.shoot_action && t.remaining > 0 && prev_done;
+      for (int k = 0; k < MSLOTS; ++k)
+        if (k == t.last_missile) prev_done = (ms[k].status == MSL_HIT || ms[k].status == MSL_MISS);
+      launch = t.status == AC_ALIVE && t.shoot_action && t.remaining > 0 && prev_done;
+    }
     int k = nslots - t.remaining;  // slots are consumed in launch order
     if (launch && k >= 0 && k < nslots) {
       // MissileSimulator.launch (simulatior.py:497-514): parent's cached NEU position, (vN, vE, vDOWN), pitch, yaw
@@ -533,6 +552,7 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) 
   // ---- my first alive incoming missile (check_missile_warning, simulatior.py:321-325) is the enemy's live one
   Incoming inc{false, 0, 0, 0, 0, 0, 0};
   int my_hits = 0;
+  int inc_slot = -1;   // which of the enemy's missile slots that is
   if (HAS_MSL) {
     int best = 0x7fffffff, mine = -1;
 #pragma unroll
@@ -545,6 +565,7 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) 
     for (int k = 0; k < MSLOTS; ++k)
       if (k == mine) { a0 = ms[k].px; a1 = ms[k].py; a2 = ms[k].pz; a3 = ms[k].vx; a4 = ms[k].vy; a5 = ms[k].vz; }
     inc.any = __shfl_xor((int)(mine >= 0), 1);
+    inc_slot = __shfl_xor(mine, 1);
     inc.px = __shfl_xor(a0, 1); inc.py = __shfl_xor(a1, 1); inc.pz = __shfl_xor(a2, 1);
     inc.vx = __shfl_xor(a3, 1); inc.vy = __shfl_xor(a4, 1); inc.vz = __shfl_xor(a5, 1);
   }
@@ -580,7 +601,8 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) 
 
   // ---- rewards (after every termination ran, env_base.py:168-171; die-flag latch singlecombat_task.py:190-195)
   float reward = 0.0f;
-  if (!t.die_flag) {
+  const bool evaluates = !t.die_flag;
+  if (evaluates) {
     t.die_flag = (t.status != AC_ALIVE) ? 1 : 0;
     float r_alt = potential(altitude_raw(pr, c), c.altitude_scale, c.altitude_pot, t.pre_altitude);
     float r_pos = potential(posture_raw(pr, E), c.posture_scale, c.posture_pot, t.pre_posture);
@@ -593,9 +615,46 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) 
       reward += potential(sp, c.shoot_penalty_scale, c.shoot_pot, t.pre_shoot);
     }
   }
+  if (TASK == AC_TASK_DODGE_MISSILE) {
+    // MissilePostureReward (missile_posture_reward.py:18-46): ONE `previous_missile_v` for the whole env, an alias of the live
+    // velocity array of the first missile it saw, cleared whenever an evaluating agent has no incoming missile; agents are
+    // walked in env order. The remembered missile id (1 + launcher * MSLOTS + slot, 0 = none) lives in `shoot_action`, which this
+    // task does not otherwise use, identically in both lanes of the env.
+    float spd[MSLOTS];
+#pragma unroll
+    for (int k = 0; k < MSLOTS; ++k) spd[k] = sqrtf(ms[k].vx * ms[k].vx + ms[k].vy * ms[k].vy + ms[k].vz * ms[k].vz);
+    const int base = (threadIdx.x & 63) - slot;
+    const int my_inc_id = inc.any ? 1 + (slot ^ 1) * MSLOTS + inc_slot : 0;
+    int prev = t.shoot_action;
+    float r_mp = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ev_i = __shfl((int)evaluates, base + i), id_i = __shfl(my_inc_id, base + i);
+      if (!ev_i) continue;
+      if (id_i) {
+        if (!prev) prev = id_i;
+        float v_prev = 0.0f, v_cur = 0.0f;
+#pragma unroll
+        for (int k = 0; k < MSLOTS; ++k) {
+          float a = __shfl(spd[k], base + (prev - 1) / MSLOTS), b = __shfl(spd[k], base + (id_i - 1) / MSLOTS);
+          if (k == (prev - 1) % MSLOTS) v_prev = a;
+          if (k == (id_i - 1) % MSLOTS) v_cur = b;
+        }
+        if (slot == i) {
+          const float v_dec = (v_prev - v_cur) / 340.0f * c.missile_posture_scale;
+          const float va = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve + pr.vd * pr.vd);
+          const float ang = (inc.vx * pr.vn + inc.vy * pr.ve + inc.vz * pr.vd) / (v_cur * va);
+          r_mp = (ang < 0.0f) ? ang / (fmaxf(v_dec, 0.0f) + 1.0f) : ang * fmaxf(v_dec, 0.0f);
+        }
+      } else prev = 0;
+    }
+    t.shoot_action = prev;
+    reward += r_mp;
+  }
 
   // ---- episode end: every agent done => the env is reset and its observation replaced (env_wrappers.py:191-204)
-  bool all_done = done && (bool)__shfl_xor((int)done, 1);
+  const int other_done = __shfl_xor((int)done, 1);   // fetched outside the && (a short-circuited shuffle would read a masked-off lane)
+  bool all_done = done && (bool)other_done;
   int other_code = __shfl_xor(code, 1);
   int step_out = t.cur_step;
   if (all_done) {
@@ -771,7 +830,7 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_nvn(DevPtrs P, DevCfg c) 
   }
   bool all_done = true;
 #pragma unroll
-  for (int j = 0; j < A; ++j) all_done = all_done && (bool)__shfl((int)done, base_lane + j);
+  for (int j = 0; j < A; ++j) { const int dj = __shfl((int)done, base_lane + j); all_done = all_done && (bool)dj; }
   int step_out = t.cur_step;
   if (all_done) {
     load_state(P.tF, P.tI, P.tD, A, slot, s, t);
@@ -1014,6 +1073,8 @@ static int launch_step(ac_env* h, const float* d_actions) {
   } else if (h->cfg.task == AC_TASK_SINGLECOMBAT) {
     if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 1>), grid, block, 0, h->stream, p, h->dc);
     else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 2>), grid, block, 0, h->stream, p, h->dc);
+  } else if (h->cfg.task == AC_TASK_DODGE_MISSILE) {
+    hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_DODGE_MISSILE, 2>), grid, block, 0, h->stream, p, h->dc);
   } else {
     if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 1>), grid, block, 0, h->stream, p, h->dc);
     else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 2>), grid, block, 0, h->stream, p, h->dc);
@@ -1041,8 +1102,11 @@ const char* ac_state_field_name(int i) { return (i >= 0 && i < AC_STATE_LEN && k
 int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_t seed, ac_env_t** out) {
   if (!cfg || !out) return fail("ac_create: null argument");
   const bool scenario = cfg->task == AC_TASK_SCENARIO1 || cfg->task == AC_TASK_SCENARIO_NVN;
-  if (cfg->task != AC_TASK_SINGLECOMBAT && cfg->task != AC_TASK_SHOOT_MISSILE && cfg->task != AC_TASK_MULTICOMBAT && !scenario)
-    return fail("ac_create: task not available on the HIP path (supported: AC_TASK_SINGLECOMBAT, AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN)");
+  if (cfg->task != AC_TASK_SINGLECOMBAT && cfg->task != AC_TASK_SHOOT_MISSILE && cfg->task != AC_TASK_DODGE_MISSILE &&
+      cfg->task != AC_TASK_MULTICOMBAT && !scenario)
+    return fail("ac_create: task not available on the HIP path (supported: AC_TASK_SINGLECOMBAT, AC_TASK_DODGE_MISSILE, AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN)");
+  if (cfg->task == AC_TASK_DODGE_MISSILE && (cfg->sim_freq / cfg->agent_interaction_steps < 1 || cfg->sim_freq / cfg->agent_interaction_steps > 31))
+    return fail("ac_create: AC_TASK_DODGE_MISSILE keeps its lock window in 31 bits (needs 1 <= sim_freq / agent_interaction_steps <= 31)");
   if (cfg->task == AC_TASK_SCENARIO_NVN) {
     if ((cfg->n_agents != 4 && cfg->n_agents != 8) || cfg->n_ego * 2 != cfg->n_agents)
       return fail("ac_create: AC_TASK_SCENARIO_NVN needs n_agents in {4, 8} split into two equal teams");
@@ -1073,7 +1137,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   memset(&c, 0, sizeof c);
   c.task = cfg->task; c.A = h->A; c.n_ego = cfg->n_ego; c.substeps = cfg->agent_interaction_steps; c.max_steps = cfg->max_steps;
   c.obs_dim = h->obs_dim; c.act_dim = h->act_dim; c.N = h->N;
-  c.msl_slots = (cfg->task == AC_TASK_SHOOT_MISSILE) ? AC_MAX_MISSILES_PER_AGENT : (scenario ? 2 : 0);
+  c.msl_slots = (cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE) ? AC_MAX_MISSILES_PER_AGENT : (scenario ? 2 : 0);
   c.chaff_seed = seed;
   c.altitude_limit = (float)cfg->altitude_limit; c.acc_x = (float)cfg->acc_limit_x; c.acc_y = (float)cfg->acc_limit_y; c.acc_z = (float)cfg->acc_limit_z;
   c.posture_scale = (float)cfg->posture_scale; c.altitude_scale = (float)cfg->altitude_scale; c.event_scale = (float)cfg->event_scale;

@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_scenario(DevPtrs P, DevCf
 
   bool all_done = true;
 #pragma unroll
-  for (int j = 0; j < A; ++j) all_done = all_done && (bool)__shfl((int)done, base + j);
+  for (int j = 0; j < A; ++j) { const int dj = __shfl((int)done, base + j); all_done = all_done && (bool)dj; }
   int step_out = t.cur_step;
   if (all_done) {
     load_state(P.tF, P.tI, P.tD, A, slot, s, t);

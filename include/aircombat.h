@@ -27,7 +27,7 @@ extern "C" {
 enum {
   AC_TASK_HEADING = 0,        /* heading_task.py HeadingTask (oracle-only this round; ac_create refuses it) */
   AC_TASK_SINGLECOMBAT = 1,   /* singlecombat_task.py:16-207 SingleCombatTask: obs 15, act [41,41,41,30] */
-  AC_TASK_DODGE_MISSILE = 2,  /* singlecombat_with_missile_task.py:12-124 rule-based launch: obs 21, act 4 */
+  AC_TASK_DODGE_MISSILE = 2,  /* singlecombat_with_missile_task.py:12-124 rule-based launch from the lock window, MissilePostureReward: obs 21, act 4 */
   AC_TASK_SHOOT_MISSILE = 3,  /* singlecombat_with_missile_task.py:147-204 learned shoot bit: obs 21, act 5 */
   AC_TASK_SCENARIO1 = 5,      /* scenario1_task.py:11-145 (1v1): gun / AIM-120B / AIM-9M / chaff rules, 11 reward terms; obs 21;
                                  act 8 = [41,41,41,30] + [gun, AIM-9M, AIM-120B, chaff] (low-level control; the controller net is row N1) */

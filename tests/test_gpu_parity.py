@@ -308,3 +308,46 @@ def test_full_size_envs_are_independent_and_deterministic(pkg):
         seen.add(d)
     assert len(seen) == 40                                  # the digest does move with the state
     big.close(); one.close()
+
+
+def test_dodge_missile_rule_based_launch(pkg, oracle):
+    """SingleCombatDodgeMissileTask: launches come from the lock-window rule (enemy inside max_attack_angle for a full second,
+    inside max_attack_distance, min_attack_interval apart), rewards add MissilePostureReward with its env-wide remembered
+    missile. Flight state is re-synchronised each step; lock windows, missiles and launch bookkeeping run open-loop."""
+    cfg = pkg.default_config("singlecombat_dodge_missile")
+    cfg.init[1].lon_deg, cfg.init[1].lat_geod_deg, cfg.init[1].psi_deg = 120.02, 60.06, 171.0   # 7 km apart, closing
+    cfg.init[0].psi_deg = 9.0
+    E = 4
+    env = pkg.HipVecEnv(cfg, E)
+    ref = oracle.OracleVecEnv(oracle.config_from_ac(cfg), E)
+    obs, robs = env.reset(), ref.reset()
+    assert obs.shape == robs.shape == (E, 2, 21) and env.act_dim == 4
+    names = env.lib.state_field_names()
+    ix = {nm: k for k, nm in enumerate(names) if nm}
+    task_fields = ("bloods", "pre_posture", "pre_altitude", "pre_event", "pre_shoot", "status", "die_flag", "remaining", "pre_remaining",
+                   "shoot_action", "last_missile", "last_shoot_time", "lock_bits", "lock_pos", "cur_step")
+    fdm_fields = np.array([k for k, nm in enumerate(names) if nm and not nm.startswith("x_") and nm not in task_fields])
+    rng = np.random.default_rng(17)
+    launches = shotdowns = 0
+    for step in range(260):
+        for e in range(E):
+            for a in range(2):
+                v = env.get_state(e, a)
+                v[fdm_fields] = ref.envs[e].export_state(a)[fdm_fields]
+                env.set_state(e, a, v)
+        act = np.array([20, 18.6, 20, 15], dtype=np.float32) + rng.integers(-2, 3, size=(E, 2, 4)).astype(np.float32)
+        obs, rew, done, info = env.step(act)
+        robs, rrew, rdone, rinfo = ref.step(act)
+        assert (done == rdone).all(), (step, done[..., 0], rdone[..., 0])
+        ok = obs_close(obs, robs, 10.0)
+        assert ok.all(), (step, np.argwhere(~ok)[:5], obs[~ok][:5], robs[~ok][:5])
+        assert (np.abs(rew - rrew) <= 10 * (5e-3 + 1e-3 * np.abs(rrew))).all(), (step, rew.ravel(), rrew.ravel())
+        for e in range(E):
+            shotdowns += int(rinfo[e][1]) == 4 and int(rinfo[e][3]) == 1
+            if not rinfo[e][3]:
+                for a in range(2):
+                    g, o = env.get_state(e, a), ref.envs[e].export_state(a)
+                    assert g[ix["remaining"]] == o[ix["remaining"]] and g[ix["last_shoot_time"]] == o[ix["last_shoot_time"]], (step, e, a)
+                    launches = max(launches, int(2 - o[ix["remaining"]]))
+    assert launches >= 1 and shotdowns >= 1, (launches, shotdowns)
+    env.close()

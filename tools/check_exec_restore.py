@@ -57,8 +57,8 @@ def scan(path):
                     break
                 if re.match(r"^\s+s_\w*saveexec|^\s+s_\w+ exec,", t):
                     break            # an else-flip or another region begins: what follows is predicated on purpose
-                if VEC.match(t):
-                    vecs.append((j + 1, t.strip()))
+                if VEC.match(t) and not re.match(r"^\s+v_(writelane|readlane|readfirstlane)_b32", t):
+                    vecs.append((j + 1, t.strip()))      # (lane-indexed SGPR spill moves ignore EXEC)
                 j += 1
         i += 1
     return bad
