@@ -40,6 +40,7 @@ class AcConfig(C.Structure):
         ("alt_safe", C.c_double), ("alt_danger", C.c_double), ("alt_kv", C.c_double),
         ("max_attack_angle", C.c_double), ("max_attack_distance", C.c_double), ("min_attack_interval", C.c_int32),
         ("use_artillery", C.c_int32),
+        ("hierarchical", C.c_int32),
     ]
 
 
@@ -67,6 +68,9 @@ SIGNATURES = {
     "ac_timing_begin": (C.c_int, [_p]),
     "ac_timing_end": (C.c_int, [_p, C.POINTER(C.c_float)]),
     "ac_state_checksum": (C.c_int, [_p, C.POINTER(C.c_uint64)]),
+    "ac_load_controller": (C.c_int, [_p, _p, C.c_int64]),
+    "ac_get_controller_state": (C.c_int, [_p, C.c_int32, C.c_int32, _p, _p]),
+    "ac_set_controller_state": (C.c_int, [_p, C.c_int32, C.c_int32, _p]),
     "ac_last_error": (C.c_char_p, []),
     "ac_version": (C.c_char_p, []),
 }

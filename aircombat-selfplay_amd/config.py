@@ -19,7 +19,14 @@ TASK_IDS = {
     "scenario_nvn": AC_TASK_SCENARIO_NVN,            # Scenario2_NvN / Scenario3_NvN, low-level control
     "scenario2_nvn": AC_TASK_SCENARIO_NVN,
     "scenario3_nvn": AC_TASK_SCENARIO_NVN,
+    "hierarchical_singlecombat": AC_TASK_SINGLECOMBAT,        # HierarchicalSingleCombatTask: [3,5,3] through the low-level controller
+    "hierarchical_multiplecombat": AC_TASK_MULTICOMBAT,       # HierarchicalMultipleCombatTask
 }
+# task names whose reference class takes the [3,5,3] (+ weapon bits) action through the low-level controller. The scenario tasks
+# are hierarchical in the reference (scenario1_task.py:11, scenario2_task.py:14); config_from_yaml follows that, while
+# default_config() keeps the control-index form unless asked (tests drive the weapon rules with explicit controls).
+ALWAYS_HIERARCHICAL = ("hierarchical_singlecombat", "hierarchical_multiplecombat")
+HIERARCHICAL_IN_REFERENCE = ALWAYS_HIERARCHICAL + ("scenario1", "scenario2_nvn", "scenario3_nvn")
 
 # defaults of AircraftSimulator.clear_defalut_condition (simulatior.py:192-208)
 _IC_DEFAULT = dict(lon_deg=120.0, lat_geod_deg=60.0, h_sl_ft=20000.0, psi_deg=0.0, u_fps=800.0, v_fps=0.0, w_fps=0.0,
@@ -33,13 +40,15 @@ def _clip(v, lo, hi):
     return min(max(v, lo), hi)
 
 
-def config_from_dict(data, task=None):
-    """Build an AcConfig from a parsed scenario dict; ``task`` overrides the YAML's task name with one of TASK_IDS."""
+def config_from_dict(data, task=None, hierarchical=None):
+    """Build an AcConfig from a parsed scenario dict; ``task`` overrides the YAML's task name with one of TASK_IDS;
+    ``hierarchical`` (None = what the task name implies) selects the [3,5,3] action through the low-level controller."""
     cfg = AcConfig()
     name = task or data.get("task")
     if name not in TASK_IDS:
         raise NotImplementedError(f"Unknown taskname: {name} (available: {sorted(TASK_IDS)})")
     cfg.task = TASK_IDS[name]
+    cfg.hierarchical = int(name in ALWAYS_HIERARCHICAL if hierarchical is None else bool(hierarchical))
     acs = data["aircraft_configs"]
     uids = list(acs.keys())
     if len(uids) > AC_MAX_AGENTS:
@@ -90,13 +99,15 @@ def config_from_dict(data, task=None):
     return cfg
 
 
-def config_from_yaml(path, task=None):
+def config_from_yaml(path, task=None, hierarchical=None):
     with open(path, "r", encoding="utf-8") as f:
         data = yaml.load(f, Loader=yaml.FullLoader)
-    return config_from_dict(data, task=task)
+    if hierarchical is None:   # a shipped YAML means the reference's own task class
+        hierarchical = (task or data.get("task")) in HIERARCHICAL_IN_REFERENCE
+    return config_from_dict(data, task=task, hierarchical=hierarchical)
 
 
-def default_nvn_config(n_per_side=2, task="multiplecombat"):
+def default_nvn_config(n_per_side=2, task="multiplecombat", hierarchical=False):
     """The aircraft block of reference configs/scenario2/scenario2_nvn.yaml (2v2) or scenario3/scenario3_nvn.yaml (4v4)
     with the MultipleCombatTask semantics (BASELINE configs C4 / C5 without the weapon rules)."""
     acs = {}
@@ -111,17 +122,19 @@ def default_nvn_config(n_per_side=2, task="multiplecombat"):
             "PostureReward_scale": 15.0, "PostureReward_potential": True, "PostureReward_orientation_version": "v2",
             "PostureReward_range_version": "v3", "AltitudeReward_safe_altitude": 4.0, "AltitudeReward_danger_altitude": 3.5,
             "AltitudeReward_Kv": 0.2}
-    return config_from_dict(data)
+    return config_from_dict(data, hierarchical=hierarchical)
 
 
-def default_config(task="singlecombat"):
+def default_config(task="singlecombat", hierarchical=False):
     """The 1v1 block of reference configs/scenario1/WVR_selfplay.yaml (BASELINE configs C2 / C3)."""
-    if task == "multiplecombat":
-        return default_nvn_config(2)
+    if task in ALWAYS_HIERARCHICAL:
+        hierarchical = True
+    if task in ("multiplecombat", "hierarchical_multiplecombat"):
+        return default_nvn_config(2, hierarchical=hierarchical)
     if task in ("scenario_nvn", "scenario2_nvn"):
-        return default_nvn_config(2, task="scenario_nvn")
+        return default_nvn_config(2, task="scenario_nvn", hierarchical=hierarchical)
     if task == "scenario3_nvn":
-        return default_nvn_config(4, task="scenario_nvn")
+        return default_nvn_config(4, task="scenario_nvn", hierarchical=hierarchical)
     data = {
         "task": task, "sim_freq": 60, "agent_interaction_steps": 6, "max_steps": 9000, "altitude_limit": 2500,
         "acceleration_limit_x": 10.0, "acceleration_limit_y": 10.0, "acceleration_limit_z": 10.0,
@@ -140,4 +153,4 @@ def default_config(task="singlecombat"):
         "AltitudeReward_safe_altitude": 4.0, "AltitudeReward_danger_altitude": 3.5, "AltitudeReward_Kv": 0.2,
         "EventDrivenReward_scale": 1, "EventDrivenReward_potential": True,
     }
-    return config_from_dict(data)
+    return config_from_dict(data, hierarchical=hierarchical)

@@ -106,6 +106,7 @@ struct DevPtrs {
   float* F; int* I; double* D;           // live state, SoA [field][N]
   float* MF; int* MI;                    // missiles, SoA [slot][field][N]
   double* MD;                            // scenario tasks: the same layout in fp64 instead of MF
+  float* H;                              // hierarchical tasks: GRU state of the low-level controller, [128][N] (else null)
   const float* tF; const int* tI; const double* tD;  // reset template, [field][A]
   const float* tab;                      // F16_PACK as fp32 in HBM (staged to LDS per workgroup)
   const float* actions;                  // [N][act_dim]
@@ -158,6 +159,12 @@ __device__ __forceinline__ void store_msl(R* MF, int* MI, int N, int n, int slot
   f[MF_theta * N + n] = m.theta; f[MF_psi * N + n] = m.psi; f[MF_t * N + n] = m.t; f[MF_m * N + n] = m.m;
   f[MF_dth * N + n] = m.dth; f[MF_dph * N + n] = m.dph; f[MF_dprev * N + n] = m.dprev;
   i[MI_status * N + n] = m.status; i[MI_recede * N + n] = m.recede; i[MI_order * N + n] = m.order;
+}
+
+// task.reset() of the hierarchical tasks clears _inner_rnn_states (singlecombat_task.py:258-262)
+__device__ __forceinline__ void zero_controller_state(const DevPtrs& P, int N, int n, bool live) {
+  if (P.H && live)
+    for (int k = 0; k < 128; ++k) P.H[(size_t)k * N + n] = 0.0f;
 }
 
 // What the Python wrapper caches after every JSBSim run (simulatior.py:238-258) plus the clipped unit
@@ -659,6 +666,7 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) 
   int step_out = t.cur_step;
   if (all_done) {
     load_state(P.tF, P.tI, P.tD, 2, slot, s, t);
+    zero_controller_state(P, N, n, live);
 #pragma unroll
     for (int k = 0; k < MSLOTS; ++k) { ms[k] = Msl{}; ms[k].status = MSL_INACTIVE; }
     const float* tobs = (const float*)(P.tF + (size_t)NF * 2) + slot * OBS;  // template observation follows the template fields
@@ -834,6 +842,7 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_nvn(DevPtrs P, DevCfg c) 
   int step_out = t.cur_step;
   if (all_done) {
     load_state(P.tF, P.tI, P.tD, A, slot, s, t);
+    zero_controller_state(P, N, n, live);
     const float* tobs = P.tF + (size_t)NF * A + slot * OBS;
 #pragma unroll
     for (int k = 0; k < OBS; ++k) ob[k] = tobs[k];
@@ -996,6 +1005,7 @@ __global__ void init_kernel_nvn(InitArgs ia, DevCfg c, const float* tab, float* 
 }
 
 #include "scenario_kernel.hpp"
+#include "controller_kernel.hpp"
 
 // reset(): every env takes the template (SubprocVecEnv.reset -> env.reset(), env_base.py:98-113)
 __global__ void reset_all_kernel(DevPtrs P, DevCfg c) {
@@ -1013,6 +1023,7 @@ __global__ void reset_all_kernel(DevPtrs P, DevCfg c) {
   }
   const float* tobs = P.tF + (size_t)NF * c.A + slot * OBS;
   for (int k = 0; k < OBS; ++k) P.obs[(size_t)n * OBS + k] = tobs[k];
+  zero_controller_state(P, N, n, true);
   P.rew[n] = 0.0f; P.done[n] = 0;
   if (slot == 0) { int* inf = P.info + (size_t)(n / c.A) * 4; inf[0] = 0; inf[1] = 0; inf[2] = 0; inf[3] = 0; }
 }
@@ -1036,6 +1047,8 @@ struct ac_env {
   float* d_tab;
   float* d_tF; int* d_tI; double* d_tD;
   float* d_XF; int* d_XI;                // scenario-task extension state
+  float* d_ctlW; float* d_low;           // hierarchical tasks: controller weights (device layout), low-level action buffer
+  int act_low;                           // width of the low-level action the step kernels decode
   hipEvent_t ev0, ev1;
   bool timing;
 };
@@ -1053,6 +1066,13 @@ static int launch_step(ac_env* h, const float* d_actions) {
   DevPtrs p = h->dp;
   p.actions = d_actions ? d_actions : h->d_actions;
   dim3 block(64), grid((h->N + 63) / 64);
+  if (h->cfg.hierarchical) {   // [3,5,3] (+ weapon bits) -> control indices, then the ordinary step on those
+    if (!h->d_ctlW) return fail("hierarchical task: ac_load_controller has not been called");
+    ctl::Args a{h->d_ctlW, p.actions, p.obs, p.H, h->d_low, h->N, h->obs_dim, h->act_dim, h->act_low};
+    hipLaunchKernelGGL(controller_kernel, grid, dim3(512), 0, h->stream, a);
+    HIP_OK(hipGetLastError());
+    p.actions = h->d_low;
+  }
   const bool one_wave_per_simd = grid.x <= 1024;  // 256 CUs x 4 SIMDs
   if (h->cfg.task == AC_TASK_SCENARIO1 || h->cfg.task == AC_TASK_SCENARIO_NVN) {
 #define AC_LAUNCH_SCN(AA)                                                                                                        \
@@ -1119,6 +1139,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     if ((cfg->n_agents != 4 && cfg->n_agents != 8) || cfg->n_ego <= 0 || cfg->n_ego >= cfg->n_agents)
       return fail("ac_create: AC_TASK_MULTICOMBAT needs n_agents in {4, 8} and 0 < n_ego < n_agents");
   } else if (cfg->n_agents != 2 || cfg->n_ego != 1) return fail("ac_create: 1v1 tasks need n_agents == 2 and n_ego == 1");
+  if (cfg->hierarchical && (cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE))
+    return fail("ac_create: the hierarchical form is available for AC_TASK_SINGLECOMBAT, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN");
   if (n_envs <= 0) return fail("ac_create: n_envs must be positive");
   if (cfg->sim_freq != 60) return fail("ac_create: sim_freq must be 60 (the FDM tick is compiled for 1/60 s)");
   for (int i = 0; i < cfg->n_agents; ++i)
@@ -1132,11 +1154,13 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   h->cfg = *cfg; h->E = n_envs; h->A = cfg->n_agents; h->N = n_envs * cfg->n_agents; h->device = device_id;
   h->obs_dim = (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
-  h->act_dim = scenario ? 8 : ((cfg->task == AC_TASK_SHOOT_MISSILE) ? 5 : 4);
+  h->act_low = scenario ? 8 : ((cfg->task == AC_TASK_SHOOT_MISSILE) ? 5 : 4);
+  // hierarchical tasks (HierarchicalSingleCombatTask and everything built on it): [3,5,3] (+ the four weapon bits)
+  h->act_dim = cfg->hierarchical ? (scenario ? 7 : 3) : h->act_low;
   DevCfg& c = h->dc;
   memset(&c, 0, sizeof c);
   c.task = cfg->task; c.A = h->A; c.n_ego = cfg->n_ego; c.substeps = cfg->agent_interaction_steps; c.max_steps = cfg->max_steps;
-  c.obs_dim = h->obs_dim; c.act_dim = h->act_dim; c.N = h->N;
+  c.obs_dim = h->obs_dim; c.act_dim = h->act_low; c.N = h->N;
   c.msl_slots = (cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE) ? AC_MAX_MISSILES_PER_AGENT : (scenario ? 2 : 0);
   c.chaff_seed = seed;
   c.altitude_limit = (float)cfg->altitude_limit; c.acc_x = (float)cfg->acc_limit_x; c.acc_y = (float)cfg->acc_limit_y; c.acc_z = (float)cfg->acc_limit_z;
@@ -1182,6 +1206,13 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     HIP_OK(hipMalloc(&h->d_XF, sizeof(float) * NXF * N));
     HIP_OK(hipMalloc(&h->d_XI, sizeof(int) * NXI * N));
   }
+  p.H = nullptr;
+  if (cfg->hierarchical) {
+    HIP_OK(hipMalloc(&p.H, sizeof(float) * 128 * N));
+    HIP_OK(hipMemset(p.H, 0, sizeof(float) * 128 * N));
+    HIP_OK(hipMalloc(&h->d_low, sizeof(float) * N * h->act_low));
+    HIP_OK(hipMemset(h->d_low, 0, sizeof(float) * N * h->act_low));
+  }
   p.tF = h->d_tF; p.tI = h->d_tI; p.tD = h->d_tD; p.tab = h->d_tab; p.actions = h->d_actions;
   InitArgs ia;
   for (int i = 0; i < AC_MAX_AGENTS; ++i) ia.ic[i] = cfg->init[i];
@@ -1211,7 +1242,7 @@ int ac_destroy(ac_env_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->dp.F, h->dp.I, h->dp.D, h->dp.MF, h->dp.MD, h->dp.MI, h->dp.obs, h->dp.rew, h->dp.done, h->dp.info,
-                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI};
+                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->d_ctlW, h->d_low};
   for (void* b : bufs) (void)hipFree(b);
   (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
   (void)hipStreamDestroy(h->stream);
@@ -1382,6 +1413,46 @@ int ac_state_checksum(ac_env_t* h, uint64_t* out) {
   HIP_OK(hipMemcpy(&v, d_out, sizeof v, hipMemcpyDeviceToHost));
   HIP_OK(hipFree(d_out));
   *out = (uint64_t)v;
+  return 0;
+}
+int ac_load_controller(ac_env_t* h, const float* weights, int64_t n) {
+  using namespace ctl;
+  if (!h || !weights) return fail("ac_load_controller: null argument");
+  if (!h->cfg.hierarchical) return fail("ac_load_controller: the handle was not created with cfg.hierarchical");
+  if (n != S_END) return fail("ac_load_controller: expected 137753 floats (layout of tools/export_baseline_actor.py)");
+  HIP_OK(hipSetDevice(h->device));
+  std::vector<float> d(D_END, 0.0f);
+  auto transpose = [&](int src, int dst, int rows_out, int cols_in, int ld_dst) {   // src [out][in] -> dst [in][ld_dst]
+    for (int j = 0; j < rows_out; ++j)
+      for (int k = 0; k < cols_in; ++k) d[dst + k * ld_dst + j] = weights[src + j * cols_in + k];
+  };
+  auto copy = [&](int src, int dst, int cnt) { for (int i = 0; i < cnt; ++i) d[dst + i] = weights[src + i]; };
+  transpose(S_W1, D_W1T, 128, 12, 128); copy(S_B1, D_B1, 128); copy(S_G1, D_G1, 128); copy(S_BE1, D_BE1, 128);
+  transpose(S_W2, D_W2T, 128, 128, 128); copy(S_B2, D_B2, 128); copy(S_G2, D_G2, 128); copy(S_BE2, D_BE2, 128);
+  transpose(S_WIH, D_WIHT, 384, 128, 384); transpose(S_WHH, D_WHHT, 384, 128, 384); copy(S_BIH, D_BIH, 384); copy(S_BHH, D_BHH, 384);
+  copy(S_G3, D_G3, 128); copy(S_BE3, D_BE3, 128);
+  transpose(S_WA, D_WAT, NH, 128, NHP); copy(S_BA, D_BA, NH);
+  if (!h->d_ctlW) HIP_OK(hipMalloc(&h->d_ctlW, sizeof(float) * D_END));
+  HIP_OK(hipMemcpy(h->d_ctlW, d.data(), sizeof(float) * D_END, hipMemcpyHostToDevice));
+  return 0;
+}
+int ac_get_controller_state(ac_env_t* h, int32_t env, int32_t agent, float* hidden, float* low_action) {
+  if (check_idx(h, env, agent)) return fail("ac_get_controller_state: bad argument");
+  if (!h->cfg.hierarchical) return fail("ac_get_controller_state: not a hierarchical handle");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  const size_t N = h->N, n = (size_t)env * h->A + agent;
+  if (hidden) HIP_OK(hipMemcpy2D(hidden, sizeof(float), h->dp.H + n, sizeof(float) * N, sizeof(float), 128, hipMemcpyDeviceToHost));
+  if (low_action) HIP_OK(hipMemcpy(low_action, h->d_low + n * h->act_low, sizeof(float) * h->act_low, hipMemcpyDeviceToHost));
+  return 0;
+}
+int ac_set_controller_state(ac_env_t* h, int32_t env, int32_t agent, const float* hidden) {
+  if (check_idx(h, env, agent) || !hidden) return fail("ac_set_controller_state: bad argument");
+  if (!h->cfg.hierarchical) return fail("ac_set_controller_state: not a hierarchical handle");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  const size_t N = h->N, n = (size_t)env * h->A + agent;
+  HIP_OK(hipMemcpy2D(h->dp.H + n, sizeof(float) * N, hidden, sizeof(float), sizeof(float), 128, hipMemcpyHostToDevice));
   return 0;
 }
 int ac_get_missile(ac_env_t* h, int32_t env, int32_t agent, int32_t k, double out[12]) {

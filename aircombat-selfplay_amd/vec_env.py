@@ -7,6 +7,7 @@ Mirrors ``SubprocVecEnv`` / ``DummyVecEnv`` of the reference (envs/env_wrappers.
 (the buffers cast to float32 on insert, algorithms/utils/buffer.py:52-58).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -62,6 +63,9 @@ def _spaces():
         return (lambda low, high, shape: _Box(low, high, shape)), _MultiDiscrete, _Discrete, (lambda xs: _Tuple(xs))
 
 
+CONTROLLER_WEIGHTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "baseline_actor.f32")
+
+
 class HipVecEnv:
     """E parallel 1v1 air-combat envs advanced by one HIP kernel launch per ``step``."""
 
@@ -81,7 +85,17 @@ class HipVecEnv:
         self.act_dim = self.lib.ac_act_dim(self._h)
         Box, MultiDiscrete, Discrete, Tuple = _spaces()
         self.observation_space = Box(low=-10, high=10.0, shape=(self.obs_dim,))
-        if config.task == AC_TASK_SHOOT_MISSILE:
+        self.hierarchical = bool(config.hierarchical)
+        if self.hierarchical:
+            # BaselineActor() + load_state_dict(model/baseline_model.pt) of HierarchicalSingleCombatTask.__init__
+            # (singlecombat_task.py:211-219): the exported weights go to the device once
+            w = np.fromfile(CONTROLLER_WEIGHTS, dtype=np.float32)
+            self.lib.check(self.lib.ac_load_controller(self._h, w.ctypes.data, int(w.size)), "ac_load_controller")
+        if self.hierarchical and config.task in (AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN):
+            self.action_space = Tuple([MultiDiscrete([3, 5, 3]), MultiDiscrete([2, 2, 2, 2])])     # scenario1_task.py:29-31
+        elif self.hierarchical:
+            self.action_space = MultiDiscrete([3, 5, 3])                                           # singlecombat_task.py:221-222
+        elif config.task == AC_TASK_SHOOT_MISSILE:
             self.action_space = Tuple([MultiDiscrete([41, 41, 41, 30]), Discrete(2)])
         elif config.task in (AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN):
             # low-level controls + [gun, AIM-9M, AIM-120B, chaff] (scenario1_task.py:29-31 with the controller net bypassed)
@@ -192,6 +206,18 @@ class HipVecEnv:
         out = (C.c_double * 12)()
         self.lib.check(self.lib.ac_get_entity(self._h, env, agent, out), "ac_get_entity")
         return np.array(out[:], dtype=np.float64)
+
+    def get_controller_state(self, env, agent):
+        """(hidden[128], low_action[act_low]) of the low-level controller for one aircraft (hierarchical tasks)."""
+        hid = np.zeros(128, dtype=np.float32)
+        low = np.zeros(8, dtype=np.float32)
+        self.lib.check(self.lib.ac_get_controller_state(self._h, env, agent, hid.ctypes.data, low.ctypes.data), "ac_get_controller_state")
+        return hid, low
+
+    def set_controller_state(self, env, agent, hidden):
+        hid = np.ascontiguousarray(hidden, dtype=np.float32)
+        assert hid.size == 128
+        self.lib.check(self.lib.ac_set_controller_state(self._h, env, agent, hid.ctypes.data), "ac_set_controller_state")
 
     def state_checksum(self):
         """64-bit order-independent digest of every aircraft's state (ac_state_checksum)."""

@@ -24,6 +24,11 @@ int or_env_obs_dim_n(int task, int n_aircraft) {
   if (task == OR_TASK_WVR) return 15; /* HierarchicalSingleCombatTask keeps SingleCombatTask's 15-value observation */
   return or_env_obs_dim(task);
 }
+/* hierarchical action spaces: MultiDiscrete [3,5,3] (singlecombat_task.py:221-222), + [2,2,2,2] weapon bits for the scenario tasks */
+int or_env_act_dim_h(int task, int hierarchical) {
+  if (!hierarchical) return or_env_act_dim(task);
+  return (task == OR_TASK_SCENARIO1 || task == OR_TASK_SCENARIO_NVN) ? 7 : 3;
+}
 int or_env_act_dim(int task) {
   if (task == OR_TASK_SCENARIO1 || task == OR_TASK_SCENARIO_NVN) return 8; /* 4 low-level controls + [gun, AIM-9M, AIM-120B, chaff] */
   return task == OR_TASK_SHOOT_MISSILE ? 5 : 4;
@@ -262,7 +267,7 @@ void or_env_init(OrEnv* e, const OrEnvConfig* c) {
   memset(e, 0, sizeof *e);
   e->cfg = *c;
   e->obs_dim = or_env_obs_dim_n(c->task, c->n_aircraft);
-  e->act_dim = or_env_act_dim(c->task);
+  e->act_dim = or_env_act_dim_h(c->task, c->hierarchical);
   for (int i = 0; i < c->n_aircraft; i++) e->ac[i].team = (i < c->n_ego) ? 0 : 1;
   e->mp_prev_missile = -1;
 }
@@ -871,6 +876,8 @@ void or_env_task_reset(OrEnv* e) {
     a->last_chaff = -1;
     a->rem_gun = a->rem_9m = a->rem_120b = a->rem_chaff = c->num_missiles[i];
     for (int k = 0; k < 4; k++) a->shoot4[k] = 0;
+    for (int k = 0; k < 128; k++) a->rnn[k] = 0;   /* singlecombat_task.py:258-262 */
+    for (int k = 0; k < 4; k++) a->low_action[k] = 0;
   }
   reward_reset(e);
 }
@@ -888,9 +895,28 @@ static void decode_action(const OrEnv* e, int i, const double* act, double out[4
 void or_env_step(OrEnv* e, const double* actions, double* obs, double* rew, uint8_t* done, int32_t* info) {
   const OrEnvConfig* c = &e->cfg;
   e->current_step += 1;
+  double pre_obs[OR_MAX_AC * 64];
+  if (c->hierarchical) get_obs(e, pre_obs);   /* normalize_action reads get_obs of the state BEFORE the step (singlecombat_task.py:231) */
   for (int i = 0; i < c->n_aircraft; i++) {
     const double* act = actions + i * e->act_dim;
     double u[4];
+    if (c->hierarchical) {
+      /* HierarchicalSingleCombatTask.normalize_action (singlecombat_task.py:223-256): [3,5,3] -> 12 controller inputs -> 4 indices */
+      static const double d_alt[3] = {0.1, 0, -0.1}, d_vel[3] = {0.05, 0, -0.05};
+      static const double d_hdg[5] = {-M_PI / 6, -M_PI / 12, 0, M_PI / 12, M_PI / 6};
+      double x[12], low[4];
+      x[0] = (e->ac[i].geodetic[2] < 3500) ? d_alt[0] : d_alt[(int)act[0]];   /* :235-239: below 3500 m always climb */
+      x[1] = d_hdg[(int)act[1]];
+      x[2] = d_vel[(int)act[2]];
+      for (int k = 0; k < 9; k++) x[3 + k] = pre_obs[i * e->obs_dim + k];
+      or_actor_forward(x, e->ac[i].rnn, e->ac[i].low_action, NULL);
+      for (int k = 0; k < 4; k++) low[k] = e->ac[i].low_action[k];
+      if (c->task == OR_TASK_SCENARIO_NVN || (c->task == OR_TASK_SCENARIO1 && e->ac[i].team == 0))
+        for (int k = 0; k < 4; k++) e->ac[i].shoot4[k] = act[3 + k] != 0;
+      decode_action(e, i, low, u);
+      f16_set_controls(&e->ac[i].fdm, u[0], u[1], u[2], u[3]);
+      continue;
+    }
     if (c->task == OR_TASK_SHOOT_MISSILE) e->ac[i].shoot_action = act[4] != 0; /* :182-184 */
     /* Scenario1 only refreshes the ego team's weapon bits (scenario1_task.py:44-45); the NvN tasks refresh both (scenario2_task.py:58-61) */
     if (c->task == OR_TASK_SCENARIO_NVN || (c->task == OR_TASK_SCENARIO1 && e->ac[i].team == 0))

@@ -59,6 +59,7 @@ typedef struct {
   double relative_altitude_scale, relative_altitude_KH;   /* RelativeAltitudeReward_scale / _KH */
   double gun_scale;                                       /* common scale of the CombatGeometry / Gun* terms (all default 1) */
   uint64_t chaff_seed;                                    /* counter-based stand-in for the global np.random of env_base.py:153 */
+  int hierarchical;   /* Hierarchical* / Scenario* tasks as shipped: action = [3,5,3] (+4 weapon bits) through the low-level controller */
 } OrEnvConfig;
 
 typedef struct {
@@ -85,6 +86,8 @@ typedef struct {
   /* reward memory */
   double pre_posture, pre_altitude, pre_event, pre_heading, pre_shoot;
   int pre_remaining_missiles;
+  double rnn[128];      /* _inner_rnn_states[agent_id] of the hierarchical tasks (singlecombat_task.py:258-262) */
+  int low_action[4];    /* last output of the low-level controller */
 } OrAircraft;
 
 typedef struct {
@@ -125,6 +128,7 @@ typedef struct {
 int or_env_obs_dim(int task);   /* for OR_TASK_MULTICOMBAT use or_env_obs_dim_n */
 int or_env_obs_dim_n(int task, int n_aircraft);
 int or_env_act_dim(int task);
+int or_env_act_dim_h(int task, int hierarchical);
 void or_env_default_config(OrEnvConfig* c, int task);
 void or_env_init(OrEnv* e, const OrEnvConfig* c);
 /* seed with the raw PCG64 state/inc as numpy reports them (np.random.PCG64(seed).state['state']) */
@@ -135,6 +139,10 @@ void or_env_step(OrEnv* e, const double* actions /* [n_aircraft][act_dim] */, do
                  int32_t* info /* [4]: current_step, done_code, heading_turn_counts, all_done */);
 
 void or_env_task_reset(OrEnv* e);
+/* low-level controller (lowlevel_actor.c) */
+int or_actor_load(const char* path);
+int or_actor_loaded(void);
+void or_actor_forward(const double* x, double* h, int* act, double* logits);
 void or_env_refresh_cache(OrEnv* e, int i);   /* AircraftSimulator._update_properties from the current FDM outputs */
 void or_env_evaluate(OrEnv* e, double* obs, double* rew, uint8_t* done, int32_t* info);
 

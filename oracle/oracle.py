@@ -42,6 +42,7 @@ class OrEnvConfig(C.Structure):
         ("use_artillery", C.c_int),
         ("relative_altitude_scale", C.c_double), ("relative_altitude_KH", C.c_double), ("gun_scale", C.c_double),
         ("chaff_seed", C.c_uint64),
+        ("hierarchical", C.c_int),
     ]
 
 
@@ -71,6 +72,7 @@ def lib():
         L.or_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.or_env_obs_dim.argtypes = [C.c_int]
         L.or_env_act_dim.argtypes = [C.c_int]
+        L.or_env_act_dim_h.argtypes = [C.c_int, C.c_int]
         L.or_env_obs_dim_n.argtypes = [C.c_int, C.c_int]
         L.or_state_export.argtypes = [C.c_void_p, C.c_int, dp, C.c_int]
         L.or_state_import.argtypes = [C.c_void_p, C.c_int, dp]
@@ -119,6 +121,11 @@ def lib():
         L.or_env_get_misc.argtypes = [C.c_void_p, dp]
         L.or_bench_run.argtypes = [C.POINTER(OrEnvConfig), C.c_int, C.c_int, C.c_uint64, dp, C.POINTER(C.c_long)]
         L.or_bench_run.restype = C.c_long
+        L.or_actor_load.argtypes = [C.c_char_p]
+        L.or_actor_forward.argtypes = [dp, dp, C.POINTER(C.c_int), dp]
+        L.or_actor_forward.restype = None
+        L.or_env_get_rnn.argtypes = [C.c_void_p, C.c_int, dp, C.POINTER(C.c_int)]
+        L.or_env_set_rnn.argtypes = [C.c_void_p, C.c_int, dp]
         assert L.or_env_config_sizeof() == C.sizeof(OrEnvConfig), "OrEnvConfig layout mismatch"
         _lib = L
     return _lib
@@ -144,7 +151,7 @@ def config_from_ac(ac_cfg):
                  "altitude_limit", "acc_limit_x", "acc_limit_y", "acc_limit_z", "posture_scale", "posture_potential",
                  "altitude_scale", "altitude_potential", "event_scale", "event_potential", "missile_posture_scale",
                  "shoot_penalty_scale", "shoot_penalty_potential", "alt_safe", "alt_danger", "alt_kv", "max_attack_angle",
-                 "max_attack_distance", "min_attack_interval", "use_artillery"):
+                 "max_attack_distance", "min_attack_interval", "use_artillery", "hierarchical"):
         setattr(c, name, getattr(ac_cfg, name))
     for i in range(OR_MAX_AC):
         src, dst = ac_cfg.init[i], c.init[i]
@@ -167,7 +174,9 @@ class OracleEnv:
         L.or_env_init(self.p, C.byref(cfg))
         self.A = cfg.n_aircraft
         self.obs_dim = L.or_env_obs_dim_n(cfg.task, cfg.n_aircraft)
-        self.act_dim = L.or_env_act_dim(cfg.task)
+        self.act_dim = L.or_env_act_dim_h(cfg.task, cfg.hierarchical)
+        if cfg.hierarchical:
+            actor_load()
         if pcg64_state is not None:
             self.seed_from_numpy(pcg64_state)
 
@@ -234,6 +243,17 @@ class OracleEnv:
             res.append(np.array(out[:]))
         return res
 
+    def get_rnn(self, i):
+        """(hidden[128], low_action[4]) of the low-level controller for aircraft i (hierarchical tasks)."""
+        h = np.zeros(128)
+        low = (C.c_int * 4)()
+        self.L.or_env_get_rnn(self.p, i, h.ctypes.data_as(C.POINTER(C.c_double)), low)
+        return h, np.array(low[:])
+
+    def set_rnn(self, i, h):
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        self.L.or_env_set_rnn(self.p, i, h.ctypes.data_as(C.POINTER(C.c_double)))
+
     def status(self, i):
         return self.L.or_env_status(self.p, i)
 
@@ -269,6 +289,26 @@ class OracleVecEnv:
                 o = e.reset()
             obs.append(o); rew.append(r); done.append(d); info.append(i)
         return np.stack(obs), np.stack(rew)[..., None], np.stack(done)[..., None], np.stack(info)
+
+
+ACTOR_WEIGHTS = os.path.join(os.path.dirname(HERE), "aircombat-selfplay_amd", "data", "baseline_actor.f32")
+
+
+def actor_load(path=ACTOR_WEIGHTS):
+    rc = lib().or_actor_load(path.encode())
+    if rc != 0:
+        raise RuntimeError(f"or_actor_load({path}) -> {rc}")
+
+
+def actor_forward(x, h):
+    """One call of the low-level controller: x[12], h[128] -> (action[4], new h[128], logits[153])."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    h = np.array(h, dtype=np.float64).ravel().copy()
+    act = (C.c_int * 4)()
+    logits = np.zeros(153)
+    dp = C.POINTER(C.c_double)
+    lib().or_actor_forward(x.ctypes.data_as(dp), h.ctypes.data_as(dp), act, logits.ctypes.data_as(dp))
+    return np.array(act[:]), h, logits
 
 
 def bench_run(cfg, n_envs, steps, seed=20250321):

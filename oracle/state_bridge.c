@@ -179,3 +179,10 @@ void or_env_get_counters(const OrEnv* e, int i, double out[6]) {
   out[0] = a->rem_gun; out[1] = a->rem_9m; out[2] = a->rem_120b; out[3] = a->rem_chaff; out[4] = a->bloods; out[5] = a->status;
 }
 void or_env_get_misc(const OrEnv* e, double out[3]) { out[0] = e->n_chaff; out[1] = (double)e->chaff_draws; out[2] = e->current_step; }
+
+/* hierarchical tasks: the controller's GRU state and its last output for aircraft i */
+void or_env_get_rnn(const OrEnv* e, int i, double* h, int* low_action) {
+  for (int k = 0; k < 128; k++) h[k] = e->ac[i].rnn[k];
+  if (low_action) for (int k = 0; k < 4; k++) low_action[k] = e->ac[i].low_action[k];
+}
+void or_env_set_rnn(OrEnv* e, int i, const double* h) { for (int k = 0; k < 128; k++) e->ac[i].rnn[k] = h[k]; }

@@ -762,6 +762,42 @@ def gen_curriculum_table():
     np.savez_compressed(os.path.join(OUT, "curriculum_spawn.npz"), table=np.array(res, dtype=float))
 
 
+def gen_baseline_actor(rng):
+    """The low-level controller (envs/JSBSim/model/baseline_actor.py BaselineActor + model/baseline_model.pt) driven like
+    HierarchicalSingleCombatTask.normalize_action does (singlecombat_task.py:223-256): 12 inputs -> 4 argmax indices, GRU
+    state carried over a sequence. Logits are read from the reference module's own head layers."""
+    import torch
+    from envs.JSBSim.model.baseline_actor import BaselineActor
+    actor = BaselineActor()
+    actor.load_state_dict(torch.load(os.path.join(REF, "envs/JSBSim/model/baseline_model.pt"), map_location=torch.device("cpu")))
+    actor.eval()
+    S, T = 16, 24
+    d_alt, d_hdg, d_vel = np.array([0.1, 0, -0.1]), np.array([-np.pi / 6, -np.pi / 12, 0, np.pi / 12, np.pi / 6]), np.array([0.05, 0, -0.05])
+    X = np.zeros((S, T, 12)); ACT = np.zeros((S, T, 4), dtype=np.int64); H = np.zeros((S, T, 128)); LOG = np.zeros((S, T, 153))
+    with torch.no_grad():
+        for s_ in range(S):
+            h = np.zeros((1, 1, 128))
+            roll, pitch = rng.uniform(-0.5, 0.5), rng.uniform(-0.2, 0.2)
+            alt, u = rng.uniform(3000, 9000), rng.uniform(180, 330)
+            for t_ in range(T):
+                roll += rng.normal(0, 0.15); pitch = np.clip(pitch + rng.normal(0, 0.05), -1.2, 1.2)
+                alt += rng.normal(0, 40); u = np.clip(u + rng.normal(0, 4), 120, 400)
+                x = np.array([d_alt[rng.integers(3)], d_hdg[rng.integers(5)], d_vel[rng.integers(3)], alt / 5000,
+                              np.sin(roll), np.cos(roll), np.sin(pitch), np.cos(pitch), u / 340, rng.normal(0, 0.02),
+                              rng.normal(0, 0.05), (u * rng.uniform(0.75, 1.0)) / 340])
+                if s_ >= S - 4:                       # a few wild inputs: large magnitudes exercise the LayerNorms
+                    x = x * rng.uniform(0.2, 4.0, size=12)
+                X[s_, t_] = x
+                a, h2 = actor(x[None, :], h)
+                xt = torch.from_numpy(x[None, :]).float()
+                feat = actor.base(xt)
+                feat, _ = actor.rnn(feat, torch.from_numpy(h).float())
+                LOG[s_, t_] = np.concatenate([m.logits_net(feat).numpy().ravel() for m in actor.act.action_outs])
+                h = h2.numpy()
+                ACT[s_, t_] = a.numpy().ravel(); H[s_, t_] = h.ravel()
+    np.savez_compressed(os.path.join(OUT, "baseline_actor.npz"), x=X, action=ACT, hidden=H.astype(np.float32), logits=LOG.astype(np.float32))
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit(f"{REF} not present: golden vectors are generated in the build container only")
@@ -776,6 +812,7 @@ def main():
     gen_curriculum_table()
     gen_multicombat_sequences(np.random.default_rng(77))
     gen_scenario_sequences(np.random.default_rng(78))
+    gen_baseline_actor(np.random.default_rng(79))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -351,3 +351,62 @@ def test_dodge_missile_rule_based_launch(pkg, oracle):
                     launches = max(launches, int(2 - o[ix["remaining"]]))
     assert launches >= 1 and shotdowns >= 1, (launches, shotdowns)
     env.close()
+
+
+@pytest.mark.parametrize("task", ["hierarchical_singlecombat", "scenario1", "scenario_nvn"])
+def test_hierarchical_tasks_lowlevel_controller(pkg, oracle, task):
+    """The as-shipped action space: MultiDiscrete [3,5,3] (+ four weapon bits) -> BaselineActor (MLP + GRU + four argmax
+    heads) -> control indices -> step. Each step both sides start from the oracle's flight state and GRU state; compared are the
+    controller's argmax indices (identical except where the oracle's own top-two logits tie to fp32 accuracy: < 0.2 % of
+    calls), the new GRU state (fp32 GEMV accuracy) and, where the indices agree, everything the step returns."""
+    cfg = pkg.default_config(task, hierarchical=True)
+    if task == "scenario1":
+        cfg.init[1].lon_deg, cfg.init[1].lat_geod_deg, cfg.init[1].psi_deg = 120.02, 60.06, 171.0
+        cfg.init[0].psi_deg = 9.0
+    A = cfg.n_agents
+    E = 6
+    cls = pkg.HipShareVecEnv if A > 2 else pkg.HipVecEnv
+    env = cls(cfg, E, seed=5)
+    ref = oracle.OracleVecEnv(oracle.config_from_ac(cfg), E, chaff_seed=5)
+    out = env.reset()
+    obs = out[0] if A > 2 else out
+    robs = ref.reset()
+    assert obs.shape == robs.shape
+    assert env.act_dim == (3 if task == "hierarchical_singlecombat" else 7)
+    names = env.lib.state_field_names()
+    task_fields = ("bloods", "pre_posture", "pre_altitude", "pre_event", "pre_shoot", "status", "die_flag", "remaining", "pre_remaining",
+                   "shoot_action", "last_missile", "last_shoot_time", "lock_bits", "lock_pos", "cur_step")
+    fdm_fields = np.array([k for k, nm in enumerate(names) if nm and not nm.startswith("x_") and nm not in task_fields])
+    rng = np.random.default_rng(23)
+    calls = flips = 0
+    hi = np.stack([rng.integers(0, n, size=(E, A)) for n in (3, 5, 3)], axis=-1).astype(np.float32)
+    for step in range(120):
+        if step % 7 == 0:   # hold a high-level choice for a while, like a policy acting at 10 Hz
+            hi = np.stack([rng.integers(0, n, size=(E, A)) for n in (3, 5, 3)], axis=-1).astype(np.float32)
+        act = hi if env.act_dim == 3 else np.concatenate([hi, (rng.random((E, A, 4)) < 0.3).astype(np.float32)], axis=-1)
+        for e in range(E):
+            for a in range(A):
+                v = env.get_state(e, a)
+                v[fdm_fields] = ref.envs[e].export_state(a)[fdm_fields]
+                env.set_state(e, a, v)
+                env.set_controller_state(e, a, ref.envs[e].get_rnn(a)[0])
+        res = env.step(act)
+        obs, rew, done = (res[0], res[2], res[3]) if A > 2 else (res[0], res[1], res[2])
+        robs, rrew, rdone, rinfo = ref.step(act)
+        same_env = np.ones(E, dtype=bool)
+        for e in range(E):
+            for a in range(A):
+                hid, low = env.get_controller_state(e, a)
+                rh, rlow = ref.envs[e].get_rnn(a)
+                calls += 4
+                bad = int((low[:4].astype(int) != rlow).sum())
+                flips += bad
+                same_env[e] &= bad == 0
+                if not rinfo[e][3]:
+                    assert np.abs(hid - rh).max() < 5e-5, (step, e, a, np.abs(hid - rh).max())
+        ok = (done == rdone).all(axis=(1, 2)) | ~same_env
+        assert ok.all(), (step, done[..., 0], rdone[..., 0])
+        good = same_env & (done == rdone).all(axis=(1, 2))
+        assert (np.abs(obs[good] - robs[good]) <= 10 * (2e-4 + 2e-4 * np.abs(robs[good]))).mean() > 0.995, step
+    assert flips <= max(2, calls // 500), (flips, calls)
+    env.close()

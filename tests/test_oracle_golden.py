@@ -249,3 +249,27 @@ def test_scenario_weapon_sequences(oracle):
                 assert close(r, rew[t], rtol=1e-7, atol=1e-6).all(), (ep, t, r, rew[t])
             launched = max(launched, len(ms)); chaffs = max(chaffs, int(gm[0])); hits += int(sum(1 for m in ms if int(m[0]) == 1))
     assert launched >= 4 and chaffs >= 2
+
+
+def test_lowlevel_controller_matches_reference_module(oracle):
+    """BaselineActor restatement (oracle/lowlevel_actor.c) against outputs of the reference's own module over GRU sequences:
+    logits and hidden state to fp32-summation accuracy (the reference computes in float32), argmax indices identical wherever
+    the reference's top-two logits are further apart than that accuracy."""
+    g = load("baseline_actor.npz")
+    oracle.actor_load()
+    S, T = g["x"].shape[:2]
+    flips = total = 0
+    for s in range(S):
+        h = np.zeros(128)
+        for t in range(T):
+            act, h, logits = oracle.actor_forward(g["x"][s, t], h)
+            assert np.abs(h - g["hidden"][s, t]).max() < 2e-5, (s, t, np.abs(h - g["hidden"][s, t]).max())
+            assert np.abs(logits - g["logits"][s, t]).max() < 2e-4 * max(1.0, np.abs(g["logits"][s, t]).max()), (s, t)
+            for hd, (a, b) in enumerate(((0, 41), (41, 82), (82, 123), (123, 153))):
+                top2 = np.sort(g["logits"][s, t, a:b])[-2:]
+                total += 1
+                if act[hd] != g["action"][s, t, hd]:
+                    assert top2[1] - top2[0] < 1e-4, (s, t, hd, act[hd], g["action"][s, t, hd], top2)
+                    flips += 1
+            h = g["hidden"][s, t].astype(np.float64)      # follow the reference's trajectory
+    assert flips <= total // 200, (flips, total)
