@@ -1069,7 +1069,7 @@ static int launch_step(ac_env* h, const float* d_actions) {
   if (h->cfg.hierarchical) {   // [3,5,3] (+ weapon bits) -> control indices, then the ordinary step on those
     if (!h->d_ctlW) return fail("hierarchical task: ac_load_controller has not been called");
     ctl::Args a{h->d_ctlW, p.actions, p.obs, p.H, h->d_low, h->N, h->obs_dim, h->act_dim, h->act_low};
-    hipLaunchKernelGGL(controller_kernel, grid, dim3(512), 0, h->stream, a);
+    hipLaunchKernelGGL(controller_kernel, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
     HIP_OK(hipGetLastError());
     p.actions = h->d_low;
   }
@@ -1422,16 +1422,22 @@ int ac_load_controller(ac_env_t* h, const float* weights, int64_t n) {
   if (n != S_END) return fail("ac_load_controller: expected 137753 floats (layout of tools/export_baseline_actor.py)");
   HIP_OK(hipSetDevice(h->device));
   std::vector<float> d(D_END, 0.0f);
-  auto transpose = [&](int src, int dst, int rows_out, int cols_in, int ld_dst) {   // src [out][in] -> dst [in][ld_dst]
-    for (int j = 0; j < rows_out; ++j)
-      for (int k = 0; k < cols_in; ++k) d[dst + k * ld_dst + j] = weights[src + j * cols_in + k];
+  // B-operand tiles of v_mfma_f32_32x32x2_f32: element (group g, lane, q) of column tile c is W[j = 32 c + lane % 32][k = 2 (4 g + q) + lane / 32]
+  auto tiles = [&](int src, int dst, int J, int K, int Kpad, int ntiles) {
+    for (int c = 0; c < ntiles; ++c)
+      for (int g = 0; g < Kpad / 8; ++g)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int q = 0; q < 4; ++q) {
+            const int k = 2 * (4 * g + q) + lane / 32, j = 32 * c + lane % 32;
+            d[dst + ((size_t)(c * (Kpad / 8) + g) * 64 + lane) * 4 + q] = (j < J && k < K) ? weights[src + j * K + k] : 0.0f;
+          }
   };
   auto copy = [&](int src, int dst, int cnt) { for (int i = 0; i < cnt; ++i) d[dst + i] = weights[src + i]; };
-  transpose(S_W1, D_W1T, 128, 12, 128); copy(S_B1, D_B1, 128); copy(S_G1, D_G1, 128); copy(S_BE1, D_BE1, 128);
-  transpose(S_W2, D_W2T, 128, 128, 128); copy(S_B2, D_B2, 128); copy(S_G2, D_G2, 128); copy(S_BE2, D_BE2, 128);
-  transpose(S_WIH, D_WIHT, 384, 128, 384); transpose(S_WHH, D_WHHT, 384, 128, 384); copy(S_BIH, D_BIH, 384); copy(S_BHH, D_BHH, 384);
+  tiles(S_W1, D_W1, 128, 12, 16, 4); copy(S_B1, D_B1, 128); copy(S_G1, D_G1, 128); copy(S_BE1, D_BE1, 128);
+  tiles(S_W2, D_W2, 128, 128, 128, 4); copy(S_B2, D_B2, 128); copy(S_G2, D_G2, 128); copy(S_BE2, D_BE2, 128);
+  tiles(S_WIH, D_WIH, 384, 128, 128, 12); tiles(S_WHH, D_WHH, 384, 128, 128, 12); copy(S_BIH, D_BIH, 384); copy(S_BHH, D_BHH, 384);
   copy(S_G3, D_G3, 128); copy(S_BE3, D_BE3, 128);
-  transpose(S_WA, D_WAT, NH, 128, NHP); copy(S_BA, D_BA, NH);
+  tiles(S_WA, D_WA, NH, 128, 128, 5); copy(S_BA, D_BA, NH);
   if (!h->d_ctlW) HIP_OK(hipMalloc(&h->d_ctlW, sizeof(float) * D_END));
   HIP_OK(hipMemcpy(h->d_ctlW, d.data(), sizeof(float) * D_END, hipMemcpyHostToDevice));
   return 0;

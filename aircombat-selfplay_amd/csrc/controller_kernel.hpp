@@ -5,27 +5,33 @@
 // (delta altitude, delta heading, delta speed) + the first nine values of the aircraft's current observation; the four argmax
 // indices become the control indices the step kernel decodes. Included by aircombat.hip.
 //
-// Mapping: one workgroup = 64 aircraft x 8 waves. In every wave lane l is aircraft l, so LayerNorm, the GRU gate algebra and
-// argmax are lane-local; the waves split the OUTPUT neurons of each layer (16 of 128, 3 x 16 of 384, 20 of 153). A wave's
-// weights are wave-uniform: they arrive through the scalar cache (s_load_dwordx16 of a transposed [k][j] matrix) and feed
-// v_fmac_f32 as SGPR operands; the 128 inputs of a layer sit in VGPRs, activations cross waves through LDS as [feature][lane]
-// (bank-conflict free). fp32 FMA chains in k order: same arithmetic as an fp32 GEMV, deterministic.
+// This is the one GEMM-shaped piece of the path, so it runs on the matrix cores in full fp32
+// (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation in k order). One workgroup = 32 aircraft (the M of the tile)
+// x 4 waves; each wave owns 32-column tiles of a layer's outputs (one tile of the 128-wide layers, the six gate tiles of its 32
+// GRU units, one or two of the five head tiles). Activations live in LDS feature-major [k][32] — exactly the A-operand order
+// (lane = (row, k parity)) — and weights are pre-tiled on the host so that one coalesced 16-byte load per lane feeds four
+// MFMAs. LayerNorm / gate algebra / argmax are a few hundred VALU instructions around ~580 MFMAs per wave.
+// (A first version kept lane = aircraft with wave-uniform weights through the scalar cache: every s_load missed and stalled
+// its wave for ~600 cycles, 257 us per call.)
 #pragma once
 
 namespace ctl {
-constexpr int HID = 128, NH = 153, NHP = 160;   // hidden width, stacked head outputs, padded to 8 waves x 20
-// device blob (floats): every matrix transposed to [k][j] so that 16 consecutive outputs of one input are one 64-byte scalar load
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr int HID = 128, NH = 153, NHP = 160;   // hidden width, stacked head outputs, padded to 5 column tiles
+constexpr int MT = 32;                          // aircraft per workgroup
+constexpr int LS = 33;                          // LDS row stride of the [feature][aircraft] buffers (odd: column writes hit 32 banks)
+// B-operand tiles: tile(c, K) = K/8 groups x 64 lanes x 4 floats; element (t4, lane, q) = W[j = 32c + lane%32][k = 2(4 t4 + q) + lane/32]
+constexpr int tile_floats(int K) { return (K / 8) * 64 * 4; }
 enum : int {
-  D_W1T = 0,                        // [12][128]
-  D_B1 = D_W1T + 12 * 128, D_G1 = D_B1 + 128, D_BE1 = D_G1 + 128,
-  D_W2T = D_BE1 + 128,              // [128][128]
-  D_B2 = D_W2T + 128 * 128, D_G2 = D_B2 + 128, D_BE2 = D_G2 + 128,
-  D_WIHT = D_BE2 + 128,             // [128][384]
-  D_WHHT = D_WIHT + 128 * 384,      // [128][384]
-  D_BIH = D_WHHT + 128 * 384, D_BHH = D_BIH + 384,
-  D_G3 = D_BHH + 384, D_BE3 = D_G3 + 128,
-  D_WAT = D_BE3 + 128,              // [128][160] (columns 153..159 zero)
-  D_BA = D_WAT + 128 * NHP,         // [160]
+  D_W1 = 0,                                  // K = 16 (12 padded), 4 tiles
+  D_W2 = D_W1 + 4 * tile_floats(16),         // K = 128, 4 tiles
+  D_WIH = D_W2 + 4 * tile_floats(128),       // 12 tiles (r0..3, z0..3, n0..3)
+  D_WHH = D_WIH + 12 * tile_floats(128),     // 12 tiles
+  D_WA = D_WHH + 12 * tile_floats(128),      // 5 tiles (columns 153..159 zero)
+  D_B1 = D_WA + 5 * tile_floats(128), D_G1 = D_B1 + 128, D_BE1 = D_G1 + 128,
+  D_B2 = D_BE1 + 128, D_G2 = D_B2 + 128, D_BE2 = D_G2 + 128,
+  D_BIH = D_BE2 + 128, D_BHH = D_BIH + 384, D_G3 = D_BHH + 384, D_BE3 = D_G3 + 128,
+  D_BA = D_BE3 + 128,                        // [160]
   D_END = D_BA + NHP
 };
 // source blob of tools/export_baseline_actor.py ([out][in] like torch)
@@ -37,7 +43,7 @@ enum : int {
 };
 
 struct Args {
-  const float* W;          // device blob
+  const float* W;          // device blob (layout above)
   const float* hi;         // [N][act_hi]: 3 high-level choices (+ weapon bits passed through)
   const float* obs;        // [N][obs_dim]: observation of the CURRENT state (last step's / the reset's output)
   float* H;                // [128][N] GRU state
@@ -45,171 +51,186 @@ struct Args {
   int N, obs_dim, act_hi, act_low;
 };
 
-struct W16 { float v[16]; };
-struct W4 { float v[4]; };
-
-// acc[0..NJ) += sum_k WT[k][j0 + j] * x[k]; WT row length J. Wave-uniform addresses: scalar loads.
-template <int K, int NJ>
-__device__ __forceinline__ void gemv_slice(const float* __restrict__ WT, int J, int j0, const float (&x)[K], float (&acc)[NJ]) {
-  static_assert(NJ % 4 == 0, "slices are multiples of 4 outputs");
+// A operands of one layer for this lane: A[t] = act[k = 2t + lane/32][row = lane%32]
+template <int K>
+__device__ __forceinline__ void load_a(const float* act, int lane, float (&A)[K / 2]) {
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const float* row = WT + k * J + j0;
+  for (int t = 0; t < K / 2; ++t) A[t] = act[(2 * t + (lane >> 5)) * LS + (lane & 31)];
+}
+// acc += A(32 x K) * tile(K x 32)
+template <int K>
+__device__ __forceinline__ void mma_tile(const float* __restrict__ tile, int lane, const float (&A)[K / 2], floatx16& acc) {
+  const float4* t4 = reinterpret_cast<const float4*>(tile) + lane;
 #pragma unroll
-    for (int b = 0; b < NJ; b += 16) {
-      if (b + 16 <= NJ) {
-        const W16 w = *reinterpret_cast<const W16*>(row + b);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[b + j] = fmaf(w.v[j], x[k], acc[b + j]);
-      } else {
-#pragma unroll
-        for (int q = b; q < NJ; q += 4) {
-          const W4 w = *reinterpret_cast<const W4*>(row + q);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[q + j] = fmaf(w.v[j], x[k], acc[q + j]);
-        }
-      }
-    }
+  for (int g = 0; g < K / 8; ++g) {
+    const float4 b = t4[g * 64];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 0], b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 1], b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 2], b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 3], b.w, acc, 0, 0, 0);
   }
 }
+__device__ __forceinline__ floatx16 splat(float v) {
+  floatx16 a;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = v;
+  return a;
+}
+// result layout of the 32x32 tile: acc[r] is (row = 8 (r / 4) + 4 (lane / 32) + r % 4, column = lane % 32)
+__device__ __forceinline__ int c_row(int r, int lane) { return (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3); }
 
-// torch.nn.LayerNorm(128), eps 1e-5, biased variance; g / b wave-uniform
-__device__ __forceinline__ void layer_norm(float (&x)[HID], const float* __restrict__ g, const float* __restrict__ b) {
+// torch.nn.LayerNorm(128) (eps 1e-5, biased variance) of buf[feature][row] in place; 256 threads: thread = (row, 16-feature part)
+__device__ __forceinline__ void layer_norm(float* buf, float* red, const float* __restrict__ g, const float* __restrict__ b, int tid) {
+  const int row = tid & 31, part = tid >> 5;
+  float x[16];
+  float s = 0.0f;
+#pragma unroll
+  for (int f = 0; f < 16; ++f) { x[f] = buf[(part * 16 + f) * LS + row]; s += x[f]; }
+  red[part * LS + row] = s;
+  __syncthreads();
   float m = 0.0f;
 #pragma unroll
-  for (int i = 0; i < HID; ++i) m += x[i];
+  for (int p = 0; p < 8; ++p) m += red[p * LS + row];
   m *= (1.0f / HID);
   float v = 0.0f;
 #pragma unroll
-  for (int i = 0; i < HID; ++i) { const float d = x[i] - m; v = fmaf(d, d, v); }
-  const float is = rsqrtf(v * (1.0f / HID) + 1e-5f);
+  for (int f = 0; f < 16; ++f) { const float d = x[f] - m; v = fmaf(d, d, v); }
+  red[(8 + part) * LS + row] = v;
+  __syncthreads();
+  float var = 0.0f;
 #pragma unroll
-  for (int i = 0; i < HID; ++i) x[i] = fmaf((x[i] - m) * is, g[i], b[i]);
+  for (int p = 0; p < 8; ++p) var += red[(8 + p) * LS + row];
+  const float is = rsqrtf(var * (1.0f / HID) + 1e-5f);
+#pragma unroll
+  for (int f = 0; f < 16; ++f) buf[(part * 16 + f) * LS + row] = fmaf((x[f] - m) * is, g[part * 16 + f], b[part * 16 + f]);
+  __syncthreads();
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f); }
-
-__device__ __forceinline__ void lds_get(const float* buf, int lane, float (&x)[HID]) {
-#pragma unroll
-  for (int k = 0; k < HID; ++k) x[k] = buf[k * 64 + lane];
-}
 }  // namespace ctl
 
-__global__ __launch_bounds__(512) void controller_kernel(ctl::Args a) {
+__global__ __launch_bounds__(256) void controller_kernel(ctl::Args a) {
   using namespace ctl;
-  __shared__ float bufA[NHP * 64];   // activations / head logits, [feature][lane]
-  __shared__ float bufB[HID * 64];
-  __shared__ float bufH[HID * 64];   // GRU state of the 64 aircraft
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave index, kept scalar so that weight addresses are uniform
-  const int n = blockIdx.x * 64 + lane;
-  const bool live = n < a.N;
-  const int nn = live ? n : a.N - 1;
+  __shared__ float act0[HID * LS];   // activations, feature-major [k][row]
+  __shared__ float act1[HID * LS];
+  __shared__ float hbuf[HID * LS];   // GRU state of the 32 aircraft
+  __shared__ float lg[NHP * LS];     // head logits
+  __shared__ float red[16 * LS];     // LayerNorm partial sums
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i0 = blockIdx.x * MT;
   const float* __restrict__ W = a.W;
+  const int col = lane & 31;
 
-  // ---- inputs: wave 0 builds the 12 controller inputs, every wave loads 16 features of the GRU state
-  if (w == 0) {
-    const float* hi = a.hi + (size_t)nn * a.act_hi;
-    const float* ob = a.obs + (size_t)nn * a.obs_dim;
-    const int c0 = (int)hi[0], c1 = (int)hi[1], c2 = (int)hi[2];
-    // singlecombat_task.py:217-219, 235-241: below 3500 m the altitude choice is overridden by "climb"
-    const float d_alt = (ob[0] * 5000.0f < 3500.0f) ? 0.1f : (c0 == 0 ? 0.1f : (c0 == 1 ? 0.0f : -0.1f));
-    const float d_hdg = (float)(c1 - 2) * 0.26179938779914943f;   // {-pi/6, -pi/12, 0, pi/12, pi/6}
-    const float d_vel = c2 == 0 ? 0.05f : (c2 == 1 ? 0.0f : -0.05f);
-    bufA[0 * 64 + lane] = d_alt; bufA[1 * 64 + lane] = d_hdg; bufA[2 * 64 + lane] = d_vel;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) bufA[(3 + k) * 64 + lane] = ob[k];
-  }
-#pragma unroll
-  for (int k = 0; k < 16; ++k) bufH[(w * 16 + k) * 64 + lane] = a.H[(size_t)(w * 16 + k) * a.N + nn];
-  __syncthreads();
-
-  float x[HID];
-  // ---- MLP layer 1: Linear(12, 128) + ReLU, then LayerNorm
+  // ---- stage: 12 controller inputs (rows 12..15 of the K = 16 pad are zero) and the GRU state
   {
-    float x12[12];
+    const int row = tid & 31, part = tid >> 5;   // 8 parts
+    const int n = min(i0 + row, a.N - 1);
+    if (part < 2) {   // two threads per aircraft build 8 of the 16 input rows each
+      const float* hi = a.hi + (size_t)n * a.act_hi;
+      const float* ob = a.obs + (size_t)n * a.obs_dim;
+      if (part == 0) {
+        const int c0 = (int)hi[0], c1 = (int)hi[1], c2 = (int)hi[2];
+        // singlecombat_task.py:217-219, 235-241: below 3500 m the altitude choice is overridden by "climb"
+        act0[0 * LS + row] = (ob[0] * 5000.0f < 3500.0f) ? 0.1f : (c0 == 0 ? 0.1f : (c0 == 1 ? 0.0f : -0.1f));
+        act0[1 * LS + row] = (float)(c1 - 2) * 0.26179938779914943f;   // {-pi/6, -pi/12, 0, pi/12, pi/6}
+        act0[2 * LS + row] = c2 == 0 ? 0.05f : (c2 == 1 ? 0.0f : -0.05f);
 #pragma unroll
-    for (int k = 0; k < 12; ++k) x12[k] = bufA[k * 64 + lane];
-    float acc[16];
+        for (int k = 0; k < 5; ++k) act0[(3 + k) * LS + row] = ob[k];
+      } else {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = W[D_B1 + w * 16 + j];
-    gemv_slice<12, 16>(W + D_W1T, 128, w * 16, x12, acc);
+        for (int k = 5; k < 9; ++k) act0[(3 + k) * LS + row] = ob[k];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) bufB[(w * 16 + j) * 64 + lane] = fmaxf(acc[j], 0.0f);
+        for (int k = 12; k < 16; ++k) act0[k * LS + row] = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < 16; ++f) hbuf[(part * 16 + f) * LS + row] = a.H[(size_t)(part * 16 + f) * a.N + n];
   }
   __syncthreads();
-  lds_get(bufB, lane, x);
-  layer_norm(x, W + D_G1, W + D_BE1);
+
+  // ---- MLP layer 1: Linear(12, 128) + ReLU + LayerNorm; wave w owns output columns 32 w .. 32 w + 31
+  {
+    float A[8];
+    load_a<16>(act0, lane, A);
+    floatx16 acc = splat(W[D_B1 + w * 32 + col]);
+    mma_tile<16>(W + D_W1 + w * tile_floats(16), lane, A, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) act1[(w * 32 + col) * LS + c_row(r, lane)] = fmaxf(acc[r], 0.0f);
+  }
+  __syncthreads();
+  layer_norm(act1, red, W + D_G1, W + D_BE1, tid);
   // ---- MLP layer 2
   {
-    float acc[16];
+    float A[64];
+    load_a<HID>(act1, lane, A);
+    floatx16 acc = splat(W[D_B2 + w * 32 + col]);
+    mma_tile<HID>(W + D_W2 + w * tile_floats(HID), lane, A, acc);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = W[D_B2 + w * 16 + j];
-    gemv_slice<HID, 16>(W + D_W2T, 128, w * 16, x, acc);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) bufA[(w * 16 + j) * 64 + lane] = fmaxf(acc[j], 0.0f);
+    for (int r = 0; r < 16; ++r) act0[(w * 32 + col) * LS + c_row(r, lane)] = fmaxf(acc[r], 0.0f);   // act0's inputs were consumed before the last barriers
   }
   __syncthreads();
-  lds_get(bufA, lane, x);
-  layer_norm(x, W + D_G2, W + D_BE2);
-  // ---- GRU cell (torch gate order r, z, n): this wave owns hidden units w*16 .. w*16+15
-  float hnew[16];
+  layer_norm(act0, red, W + D_G2, W + D_BE2, tid);
+  // ---- GRU cell (torch gate order r, z, n): wave w owns hidden units 32 w .. 32 w + 31, i.e. gate tiles w, 4 + w, 8 + w
   {
-    float gi[48], gh[48];
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) { gi[g * 16 + j] = W[D_BIH + g * 128 + w * 16 + j]; gh[g * 16 + j] = W[D_BHH + g * 128 + w * 16 + j]; }
-    // three 16-wide slices of the 384 gate rows: columns g*128 + w*16 + j
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      float (&acc)[16] = *reinterpret_cast<float (*)[16]>(&gi[g * 16]);
-      gemv_slice<HID, 16>(W + D_WIHT, 384, g * 128 + w * 16, x, acc);
+    floatx16 ir = splat(W[D_BIH + 0 * 128 + w * 32 + col]), iz = splat(W[D_BIH + 1 * 128 + w * 32 + col]), in_ = splat(W[D_BIH + 2 * 128 + w * 32 + col]);
+    floatx16 hr = splat(W[D_BHH + 0 * 128 + w * 32 + col]), hz = splat(W[D_BHH + 1 * 128 + w * 32 + col]), hn = splat(W[D_BHH + 2 * 128 + w * 32 + col]);
+    {
+      float A[64];
+      load_a<HID>(act0, lane, A);
+      mma_tile<HID>(W + D_WIH + (0 + w) * tile_floats(HID), lane, A, ir);
+      mma_tile<HID>(W + D_WIH + (4 + w) * tile_floats(HID), lane, A, iz);
+      mma_tile<HID>(W + D_WIH + (8 + w) * tile_floats(HID), lane, A, in_);
     }
-    float h[HID];
-    lds_get(bufH, lane, h);
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      float (&acc)[16] = *reinterpret_cast<float (*)[16]>(&gh[g * 16]);
-      gemv_slice<HID, 16>(W + D_WHHT, 384, g * 128 + w * 16, h, acc);
+    {
+      float A[64];
+      load_a<HID>(hbuf, lane, A);
+      mma_tile<HID>(W + D_WHH + (0 + w) * tile_floats(HID), lane, A, hr);
+      mma_tile<HID>(W + D_WHH + (4 + w) * tile_floats(HID), lane, A, hz);
+      mma_tile<HID>(W + D_WHH + (8 + w) * tile_floats(HID), lane, A, hn);
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float r = sigmoid_f(gi[j] + gh[j]);
-      const float z = sigmoid_f(gi[16 + j] + gh[16 + j]);
-      const float nn_ = tanh_f(gi[32 + j] + r * gh[32 + j]);
-      const float hold = bufH[(w * 16 + j) * 64 + lane];
-      hnew[j] = (1.0f - z) * nn_ + z * hold;
+    for (int r = 0; r < 16; ++r) {
+      const int row = c_row(r, lane), unit = w * 32 + col;
+      const float rg = sigmoid_f(ir[r] + hr[r]);
+      const float zg = sigmoid_f(iz[r] + hz[r]);
+      const float ng = tanh_f(in_[r] + rg * hn[r]);
+      const float hnew = (1.0f - zg) * ng + zg * hbuf[unit * LS + row];
+      act1[unit * LS + row] = hnew;
+      if (i0 + row < a.N) a.H[(size_t)unit * a.N + i0 + row] = hnew;
     }
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    bufB[(w * 16 + j) * 64 + lane] = hnew[j];
-    if (live) a.H[(size_t)(w * 16 + j) * a.N + n] = hnew[j];
   }
   __syncthreads();
-  lds_get(bufB, lane, x);
-  layer_norm(x, W + D_G3, W + D_BE3);
-  // ---- heads: 153 logits split 8 x 20 (padded columns are zero weights)
+  layer_norm(act1, red, W + D_G3, W + D_BE3, tid);
+  // ---- heads: 153 logits = five column tiles; wave w takes tile w, wave 0 also the fifth
   {
-    float acc[20];
+    float A[64];
+    load_a<HID>(act1, lane, A);
+    floatx16 acc = splat(W[D_BA + w * 32 + col]);
+    mma_tile<HID>(W + D_WA + w * tile_floats(HID), lane, A, acc);
 #pragma unroll
-    for (int j = 0; j < 20; ++j) acc[j] = W[D_BA + w * 20 + j];
-    gemv_slice<HID, 20>(W + D_WAT, NHP, w * 20, x, acc);
+    for (int r = 0; r < 16; ++r) lg[(w * 32 + col) * LS + c_row(r, lane)] = acc[r];
+    if (w == 0) {
+      floatx16 acc4 = splat(W[D_BA + 128 + col]);
+      mma_tile<HID>(W + D_WA + 4 * tile_floats(HID), lane, A, acc4);
 #pragma unroll
-    for (int j = 0; j < 20; ++j) bufA[(w * 20 + j) * 64 + lane] = acc[j];
+      for (int r = 0; r < 16; ++r) lg[(128 + col) * LS + c_row(r, lane)] = acc4[r];
+    }
   }
   __syncthreads();
-  if (w < 4) {   // wave hd scans head hd of its 64 aircraft: first maximum, like torch argmax
-    const int off = w * 41, cnt = (w == 3) ? 30 : 41;
-    float best = bufA[off * 64 + lane];
+  if (tid < 128) {   // thread = (head, aircraft): first maximum, like torch argmax
+    const int head = tid >> 5, row = tid & 31;
+    const int off = head * 41, cnt = (head == 3) ? 30 : 41;
+    float best = lg[off * LS + row];
     int bi = 0;
     for (int j = 1; j < cnt; ++j) {
-      const float v = bufA[(off + j) * 64 + lane];
+      const float v = lg[(off + j) * LS + row];
       if (v > best) { best = v; bi = j; }
     }
-    if (live) a.low[(size_t)n * a.act_low + w] = (float)bi;
-  } else if (w == 4 && live) {   // weapon bits ride along unchanged
-    for (int k = 4; k < a.act_low; ++k) a.low[(size_t)n * a.act_low + k] = a.hi[(size_t)n * a.act_hi + (k - 1)];
+    if (i0 + row < a.N) a.low[(size_t)(i0 + row) * a.act_low + head] = (float)bi;
+  } else if (tid < 160) {   // weapon bits ride along unchanged
+    const int row = tid & 31;
+    if (i0 + row < a.N)
+      for (int k = 4; k < a.act_low; ++k) a.low[(size_t)(i0 + row) * a.act_low + k] = a.hi[(size_t)(i0 + row) * a.act_hi + (k - 1)];
   }
 }

@@ -142,6 +142,7 @@ def main():
     E = args.envs
     cfg = pkg.default_config(args.task)
     env = pkg.HipVecEnv(cfg, E, device_id=local_rank, seed=1 + 1000 * rank)
+    nvec = (3, 5, 3) if env.hierarchical else (41, 41, 41, 30)
     env.reset()
     act_dim = env.act_dim
 
@@ -150,7 +151,7 @@ def main():
     POOL = 64
     pool = []
     for _ in range(POOL):
-        a = np.stack([rng.integers(0, n, size=(E, AGENTS)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
+        a = np.stack([rng.integers(0, n, size=(E, AGENTS)) for n in nvec], axis=-1).astype(np.float32)
         if act_dim == 5:
             a = np.concatenate([a, (rng.random((E, AGENTS, 1)) < 0.05).astype(np.float32)], axis=-1)
         pool.append(torch.from_numpy(a).cuda(local_rank))
