@@ -68,6 +68,8 @@ SIGNATURES = {
     "ac_timing_begin": (C.c_int, [_p]),
     "ac_timing_end": (C.c_int, [_p, C.POINTER(C.c_float)]),
     "ac_state_checksum": (C.c_int, [_p, C.POINTER(C.c_uint64)]),
+    "ac_pin_host_buffer": (C.c_int, [_p, _p, C.c_int64]),
+    "ac_unpin_host_buffer": (C.c_int, [_p, _p]),
     "ac_load_controller": (C.c_int, [_p, _p, C.c_int64]),
     "ac_get_controller_state": (C.c_int, [_p, C.c_int32, C.c_int32, _p, _p]),
     "ac_set_controller_state": (C.c_int, [_p, C.c_int32, C.c_int32, _p]),

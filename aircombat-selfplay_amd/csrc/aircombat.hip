@@ -1415,6 +1415,18 @@ int ac_state_checksum(ac_env_t* h, uint64_t* out) {
   *out = (uint64_t)v;
   return 0;
 }
+int ac_pin_host_buffer(ac_env_t* h, void* ptr, int64_t bytes) {
+  if (!h || !ptr || bytes <= 0) return fail("ac_pin_host_buffer: bad argument");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+  return 0;
+}
+int ac_unpin_host_buffer(ac_env_t* h, void* ptr) {
+  if (!h || !ptr) return fail("ac_unpin_host_buffer: bad argument");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipHostUnregister(ptr));
+  return 0;
+}
 int ac_load_controller(ac_env_t* h, const float* weights, int64_t n) {
   using namespace ctl;
   if (!h || !weights) return fail("ac_load_controller: null argument");

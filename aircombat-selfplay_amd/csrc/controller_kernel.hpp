@@ -57,17 +57,24 @@ __device__ __forceinline__ void load_a(const float* act, int lane, float (&A)[K 
 #pragma unroll
   for (int t = 0; t < K / 2; ++t) A[t] = act[(2 * t + (lane >> 5)) * LS + (lane & 31)];
 }
-// acc += A(32 x K) * tile(K x 32)
+// B operands of one column tile for this lane: K/8 coalesced 16-byte loads (4 MFMAs each). Kept separate from the MFMA loop so
+// that the NEXT tile's loads are in flight while the current tile multiplies (an L2 round trip is ~10 MFMAs long).
 template <int K>
-__device__ __forceinline__ void mma_tile(const float* __restrict__ tile, int lane, const float (&A)[K / 2], floatx16& acc) {
+__device__ __forceinline__ void load_b(const float* __restrict__ tile, int lane, float4 (&B)[K / 8]) {
   const float4* t4 = reinterpret_cast<const float4*>(tile) + lane;
 #pragma unroll
+  for (int g = 0; g < K / 8; ++g) B[g] = t4[g * 64];
+  __builtin_amdgcn_sched_barrier(0);   // keep these loads ahead of the MFMA chain that follows (the scheduler would sink them)
+}
+// acc += A(32 x K) * tile(K x 32)
+template <int K>
+__device__ __forceinline__ void mma_tile(const float (&A)[K / 2], const float4 (&B)[K / 8], floatx16& acc) {
+#pragma unroll
   for (int g = 0; g < K / 8; ++g) {
-    const float4 b = t4[g * 64];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 0], b.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 1], b.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 2], b.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 3], b.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 0], B[g].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 1], B[g].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 2], B[g].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 3], B[g].w, acc, 0, 0, 0);
   }
 }
 __device__ __forceinline__ floatx16 splat(float v) {
@@ -152,20 +159,25 @@ __global__ __launch_bounds__(256) void controller_kernel(ctl::Args a) {
   // ---- MLP layer 1: Linear(12, 128) + ReLU + LayerNorm; wave w owns output columns 32 w .. 32 w + 31
   {
     float A[8];
+    float4 B[2];
+    load_b<16>(W + D_W1 + w * tile_floats(16), lane, B);
     load_a<16>(act0, lane, A);
     floatx16 acc = splat(W[D_B1 + w * 32 + col]);
-    mma_tile<16>(W + D_W1 + w * tile_floats(16), lane, A, acc);
+    mma_tile<16>(A, B, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) act1[(w * 32 + col) * LS + c_row(r, lane)] = fmaxf(acc[r], 0.0f);
   }
   __syncthreads();
+  float4 Bq[16], Bn[16];   // current / next weight tile
+  load_b<HID>(W + D_W2 + w * tile_floats(HID), lane, Bq);            // in flight across the LayerNorm
   layer_norm(act1, red, W + D_G1, W + D_BE1, tid);
   // ---- MLP layer 2
   {
     float A[64];
     load_a<HID>(act1, lane, A);
+    load_b<HID>(W + D_WIH + (0 + w) * tile_floats(HID), lane, Bn);   // first GRU tile
     floatx16 acc = splat(W[D_B2 + w * 32 + col]);
-    mma_tile<HID>(W + D_W2 + w * tile_floats(HID), lane, A, acc);
+    mma_tile<HID>(A, Bq, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) act0[(w * 32 + col) * LS + c_row(r, lane)] = fmaxf(acc[r], 0.0f);   // act0's inputs were consumed before the last barriers
   }
@@ -178,16 +190,16 @@ __global__ __launch_bounds__(256) void controller_kernel(ctl::Args a) {
     {
       float A[64];
       load_a<HID>(act0, lane, A);
-      mma_tile<HID>(W + D_WIH + (0 + w) * tile_floats(HID), lane, A, ir);
-      mma_tile<HID>(W + D_WIH + (4 + w) * tile_floats(HID), lane, A, iz);
-      mma_tile<HID>(W + D_WIH + (8 + w) * tile_floats(HID), lane, A, in_);
+      load_b<HID>(W + D_WIH + (4 + w) * tile_floats(HID), lane, Bq); mma_tile<HID>(A, Bn, ir);
+      load_b<HID>(W + D_WIH + (8 + w) * tile_floats(HID), lane, Bn); mma_tile<HID>(A, Bq, iz);
+      load_b<HID>(W + D_WHH + (0 + w) * tile_floats(HID), lane, Bq); mma_tile<HID>(A, Bn, in_);
     }
     {
       float A[64];
       load_a<HID>(hbuf, lane, A);
-      mma_tile<HID>(W + D_WHH + (0 + w) * tile_floats(HID), lane, A, hr);
-      mma_tile<HID>(W + D_WHH + (4 + w) * tile_floats(HID), lane, A, hz);
-      mma_tile<HID>(W + D_WHH + (8 + w) * tile_floats(HID), lane, A, hn);
+      load_b<HID>(W + D_WHH + (4 + w) * tile_floats(HID), lane, Bn); mma_tile<HID>(A, Bq, hr);
+      load_b<HID>(W + D_WHH + (8 + w) * tile_floats(HID), lane, Bq); mma_tile<HID>(A, Bn, hz);
+      load_b<HID>(W + D_WA + w * tile_floats(HID), lane, Bn);        mma_tile<HID>(A, Bq, hn);   // Bn: this wave's head tile
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -206,13 +218,14 @@ __global__ __launch_bounds__(256) void controller_kernel(ctl::Args a) {
   {
     float A[64];
     load_a<HID>(act1, lane, A);
+    if (w == 0) load_b<HID>(W + D_WA + 4 * tile_floats(HID), lane, Bq);
     floatx16 acc = splat(W[D_BA + w * 32 + col]);
-    mma_tile<HID>(W + D_WA + w * tile_floats(HID), lane, A, acc);
+    mma_tile<HID>(A, Bn, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) lg[(w * 32 + col) * LS + c_row(r, lane)] = acc[r];
     if (w == 0) {
       floatx16 acc4 = splat(W[D_BA + 128 + col]);
-      mma_tile<HID>(W + D_WA + 4 * tile_floats(HID), lane, A, acc4);
+      mma_tile<HID>(A, Bq, acc4);
 #pragma unroll
       for (int r = 0; r < 16; ++r) lg[(128 + col) * LS + c_row(r, lane)] = acc4[r];
     }

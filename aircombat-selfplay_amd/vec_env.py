@@ -109,6 +109,11 @@ class HipVecEnv:
         self._rew = np.zeros((E, A, 1), dtype=np.float32)
         self._done = np.zeros((E, A, 1), dtype=np.uint8)
         self._info = np.zeros((E, 4), dtype=np.int32)
+        # page-lock the reusable buffers: H2D / D2H then run as direct DMA
+        self._pinned = []
+        for buf in (self._actions, self._obs, self._rew, self._done, self._info):
+            if self.lib.ac_pin_host_buffer(self._h, buf.ctypes.data, buf.nbytes) == 0:
+                self._pinned.append(buf)
 
     # ---- reference surface
     def reset(self):
@@ -129,14 +134,16 @@ class HipVecEnv:
         self.lib.check(self.lib.ac_step(self._h, self._actions.ctypes.data, self._obs.ctypes.data, self._rew.ctypes.data,
                                         self._done.ctypes.data, self._info.ctypes.data), "ac_step")
         self.waiting = False
+        return self._obs.copy(), self._rew.copy(), self._done.astype(bool), self._infos()
+
+    def _infos(self):
+        """ndarray of one fresh dict per env, like np.stack of the workers' info dicts (env_wrappers.py:276-282)."""
         infos = np.empty(self.num_envs, dtype=object)
-        cur, code = self._info[:, 0], self._info[:, 1]
-        for i in range(self.num_envs):
-            d = {"current_step": int(cur[i])}
-            if code[i]:
-                d["done_condition"] = DONE_MESSAGES.get(int(code[i]), "")
-            infos[i] = d
-        return self._obs.copy(), self._rew.copy(), self._done.astype(bool), infos
+        infos[:] = [{"current_step": c} for c in self._info[:, 0].tolist()]
+        code = self._info[:, 1]
+        for i in np.flatnonzero(code).tolist():
+            infos[i]["done_condition"] = DONE_MESSAGES.get(int(code[i]), "")
+        return infos
 
     def step(self, actions):
         self.step_async(actions)
@@ -148,6 +155,9 @@ class HipVecEnv:
     def close(self):
         if self.closed:
             return
+        for buf in self._pinned:
+            self.lib.ac_unpin_host_buffer(self._h, buf.ctypes.data)
+        self._pinned = []
         self.lib.ac_destroy(self._h)
         self._h = None
         self.closed = True

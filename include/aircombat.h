@@ -116,6 +116,12 @@ int ac_get_missile(ac_env_t* h, int32_t env, int32_t agent, int32_t k, double ou
  * the step kernel's access pattern, (4*63 + 4*12 + 8*3) bytes per aircraft; no reference counterpart. */
 int ac_state_checksum(ac_env_t* h, uint64_t* out);
 
+/* Optional: page-lock a caller-owned host buffer that is handed to ac_step / ac_reset repeatedly, so that the copies run as
+ * direct DMA instead of through a staging buffer (the caller still owns the memory; unpin before freeing it). The reference has
+ * no counterpart: its workers pickle arrays through pipes (env_wrappers.py:182-229). */
+int ac_pin_host_buffer(ac_env_t* h, void* ptr, int64_t bytes);
+int ac_unpin_host_buffer(ac_env_t* h, void* ptr);
+
 /* Low-level controller of the hierarchical tasks: replaces BaselineActor() + load_state_dict(baseline_model.pt) of
  * HierarchicalSingleCombatTask.__init__ (R/envs/JSBSim/tasks/singlecombat_task.py:211-219). `weights` = the 137753 float32 of
  * aircombat-selfplay_amd/data/baseline_actor.f32 (layout in tools/export_baseline_actor.py). Must be called once before the first
