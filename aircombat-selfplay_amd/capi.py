@@ -40,6 +40,9 @@ class AcConfig(C.Structure):
         ("alt_safe", C.c_double), ("alt_danger", C.c_double), ("alt_kv", C.c_double),
         ("max_attack_angle", C.c_double), ("max_attack_distance", C.c_double), ("min_attack_interval", C.c_int32),
         ("use_artillery", C.c_int32),
+        ("heading_scale", C.c_double), ("heading_potential", C.c_int32),
+        ("max_heading_increment", C.c_double), ("max_altitude_increment", C.c_double),
+        ("max_velocities_u_increment", C.c_double), ("check_interval", C.c_double),
         ("hierarchical", C.c_int32),
     ]
 
@@ -68,6 +71,8 @@ SIGNATURES = {
     "ac_timing_begin": (C.c_int, [_p]),
     "ac_timing_end": (C.c_int, [_p, C.POINTER(C.c_float)]),
     "ac_state_checksum": (C.c_int, [_p, C.POINTER(C.c_uint64)]),
+    "ac_seed_envs": (C.c_int, [_p, _p]),
+    "ac_get_heading_state": (C.c_int, [_p, C.c_int32, _p]),
     "ac_pin_host_buffer": (C.c_int, [_p, _p, C.c_int64]),
     "ac_unpin_host_buffer": (C.c_int, [_p, _p]),
     "ac_load_controller": (C.c_int, [_p, _p, C.c_int64]),

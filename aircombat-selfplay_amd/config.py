@@ -96,6 +96,14 @@ def config_from_dict(data, task=None, hierarchical=None):
     cfg.max_attack_distance = float(g("max_attack_distance", float("inf")))
     cfg.min_attack_interval = int(g("min_attack_interval", 125))
     cfg.use_artillery = int(bool(g("use_artillery", False)))
+    # HeadingTask: HeadingReward scale / potential; UnreachHeading reads its limits from the first aircraft's block
+    # (unreach_heading.py:14-19)
+    cfg.heading_scale = float(g("HeadingReward_scale", 1.0)); cfg.heading_potential = int(bool(g("HeadingReward_potential", False)))
+    first = acs[uids[0]]
+    cfg.max_heading_increment = float(first.get("max_heading_increment", 180))
+    cfg.max_altitude_increment = float(first.get("max_altitude_increment", 7000))
+    cfg.max_velocities_u_increment = float(first.get("max_velocities_u_increment", 100))
+    cfg.check_interval = float(first.get("check_interval", 30))
     return cfg
 
 
@@ -125,8 +133,23 @@ def default_nvn_config(n_per_side=2, task="multiplecombat", hierarchical=False):
     return config_from_dict(data, hierarchical=hierarchical)
 
 
+def default_heading_config():
+    """reference configs/singlecontrol/heading.yaml (BASELINE config C1)."""
+    data = {"task": "heading", "sim_freq": 60, "agent_interaction_steps": 6, "max_steps": 10000, "altitude_limit": 2500,
+            "acceleration_limit_x": 10.0, "acceleration_limit_y": 10.0, "acceleration_limit_z": 10.0,
+            "aircraft_configs": {"A0100": {"color": "Blue", "model": "f16", "max_heading_increment": 180, "max_altitude_increment": 7000,
+                                           "max_velocities_u_increment": 100, "check_interval": 30,
+                                           "init_state": {"ic_long_gc_deg": 120.0, "ic_lat_geod_deg": 60.0, "ic_h_sl_ft": 20000,
+                                                          "ic_psi_true_deg": 0.0, "ic_u_fps": 800.0}}},
+            "battle_field_center": [120.0, 60.0, 0.0],
+            "AltitudeReward_safe_altitude": 4.0, "AltitudeReward_danger_altitude": 3.5, "AltitudeReward_Kv": 0.2}
+    return config_from_dict(data, hierarchical=False)
+
+
 def default_config(task="singlecombat", hierarchical=False):
     """The 1v1 block of reference configs/scenario1/WVR_selfplay.yaml (BASELINE configs C2 / C3)."""
+    if task == "heading":
+        return default_heading_config()
     if task in ALWAYS_HIERARCHICAL:
         hierarchical = True
     if task in ("multiplecombat", "hierarchical_multiplecombat"):

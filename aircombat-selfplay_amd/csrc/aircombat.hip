@@ -270,6 +270,9 @@ constexpr int first_tick_above(double limit) {       // smallest k with t_k > li
   do { t += 1.0 / 60.0; ++k; } while (!(t > limit));
   return k;
 }
+// Overload only counts after "simulation/sim-time-sec > 10" (overload.py:30): JSBSim's clock is the fp64 running sum of dT
+// (FGFDMExec.cpp:196-203), and 600 additions of 1/60 already exceed 10, so the rule switches on at tick 600, not 601.
+constexpr int kTickOverload = first_tick_above(10.0);
 struct MslParam { float g, t_max, t_thrust, Isp, Length, Diameter, cD, m0, dm, K, nyz_max, Rc, v_min; int recede_max, k_burnout, k_timeout; };
 __device__ __forceinline__ MslParam aim9l() {  // simulatior.py:421-433
   constexpr int kb = first_tick_not_below(3.0), kt = first_tick_above(60.0);
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) 
     float np_max = fmaxf(fabsf(s.npx), fmaxf(fabsf(s.npy), fabsf(s.npz)));
     float pqr = sqrtf(d.p * d.p + d.q * d.q + d.r * d.r);
     bool extreme = (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);  // catalog.py:386-416
-    bool overload = ((float)s.ticks * (1.0f / 60.0f) > 10.0f) &&
+    bool overload = (s.ticks >= kTickOverload) &&
                     (fabsf(s.npx) > c.acc_x || fabsf(s.npy) > c.acc_y || fabsf(s.npz + 1.0f) > c.acc_z);  // overload.py:38-46
     if (pr.alt_m <= c.altitude_limit) { t.status = AC_CRASH; code = AC_DONE_LOW_ALTITUDE; done = true; }
     else if (extreme) { t.status = AC_CRASH; code = AC_DONE_EXTREME_STATE; done = true; }
@@ -812,7 +815,7 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_nvn(DevPtrs P, DevCfg c) 
   float np_max = fmaxf(fabsf(s.npx), fmaxf(fabsf(s.npy), fabsf(s.npz)));
   float pqr = sqrtf(d.p * d.p + d.q * d.q + d.r * d.r);
   const bool extreme = (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);
-  const bool overload = ((float)s.ticks * (1.0f / 60.0f) > 10.0f) &&
+  const bool overload = (s.ticks >= kTickOverload) &&
                         (fabsf(s.npx) > c.acc_x || fabsf(s.npy) > c.acc_y || fabsf(s.npz + 1.0f) > c.acc_z);
   const bool low = pr.alt_m <= c.altitude_limit;
 #pragma unroll
@@ -1006,6 +1009,7 @@ __global__ void init_kernel_nvn(InitArgs ia, DevCfg c, const float* tab, float* 
 
 #include "scenario_kernel.hpp"
 #include "controller_kernel.hpp"
+#include "heading_kernel.hpp"
 
 // reset(): every env takes the template (SubprocVecEnv.reset -> env.reset(), env_base.py:98-113)
 __global__ void reset_all_kernel(DevPtrs P, DevCfg c) {
@@ -1048,6 +1052,7 @@ struct ac_env {
   float* d_tF; int* d_tI; double* d_tD;
   float* d_XF; int* d_XI;                // scenario-task extension state
   float* d_ctlW; float* d_low;           // hierarchical tasks: controller weights (device layout), low-level action buffer
+  HeadingPtrs hp; HeadingCfg hc;         // HeadingTask: targets, check clock, numpy-PCG64 state per env
   int act_low;                           // width of the low-level action the step kernels decode
   hipEvent_t ev0, ev1;
   bool timing;
@@ -1074,6 +1079,11 @@ static int launch_step(ac_env* h, const float* d_actions) {
     p.actions = h->d_low;
   }
   const bool one_wave_per_simd = grid.x <= 1024;  // 256 CUs x 4 SIMDs
+  if (h->cfg.task == AC_TASK_HEADING) {
+    hipLaunchKernelGGL(step_kernel_heading, grid, block, 0, h->stream, p, h->dc, h->hp, h->hc, 0);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
   if (h->cfg.task == AC_TASK_SCENARIO1 || h->cfg.task == AC_TASK_SCENARIO_NVN) {
 #define AC_LAUNCH_SCN(AA)                                                                                                        \
   do {                                                                                                                           \
@@ -1104,6 +1114,11 @@ static int launch_step(ac_env* h, const float* d_actions) {
 }
 static int launch_reset(ac_env* h) {
   dim3 block(64), grid((h->N + 63) / 64);
+  if (h->cfg.task == AC_TASK_HEADING) {   // every env draws a new episode from its own generator
+    hipLaunchKernelGGL(step_kernel_heading, grid, block, 0, h->stream, h->dp, h->dc, h->hp, h->hc, 1);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(reset_all_kernel, grid, block, 0, h->stream, h->dp, h->dc);
   HIP_OK(hipGetLastError());
   if (h->d_XF) {
@@ -1122,9 +1137,12 @@ const char* ac_state_field_name(int i) { return (i >= 0 && i < AC_STATE_LEN && k
 int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_t seed, ac_env_t** out) {
   if (!cfg || !out) return fail("ac_create: null argument");
   const bool scenario = cfg->task == AC_TASK_SCENARIO1 || cfg->task == AC_TASK_SCENARIO_NVN;
+  const bool heading = cfg->task == AC_TASK_HEADING;
   if (cfg->task != AC_TASK_SINGLECOMBAT && cfg->task != AC_TASK_SHOOT_MISSILE && cfg->task != AC_TASK_DODGE_MISSILE &&
-      cfg->task != AC_TASK_MULTICOMBAT && !scenario)
-    return fail("ac_create: task not available on the HIP path (supported: AC_TASK_SINGLECOMBAT, AC_TASK_DODGE_MISSILE, AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN)");
+      cfg->task != AC_TASK_MULTICOMBAT && !scenario && !heading)
+    return fail("ac_create: unknown task (supported: AC_TASK_HEADING, AC_TASK_SINGLECOMBAT, AC_TASK_DODGE_MISSILE, AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN)");
+  if (heading && (cfg->n_agents != 1 || cfg->n_ego != 1 || cfg->hierarchical))
+    return fail("ac_create: AC_TASK_HEADING is a single-aircraft task with control-index actions (n_agents == n_ego == 1)");
   if (cfg->task == AC_TASK_DODGE_MISSILE && (cfg->sim_freq / cfg->agent_interaction_steps < 1 || cfg->sim_freq / cfg->agent_interaction_steps > 31))
     return fail("ac_create: AC_TASK_DODGE_MISSILE keeps its lock window in 31 bits (needs 1 <= sim_freq / agent_interaction_steps <= 31)");
   if (cfg->task == AC_TASK_SCENARIO_NVN) {
@@ -1138,7 +1156,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   } else if (cfg->task == AC_TASK_MULTICOMBAT) {
     if ((cfg->n_agents != 4 && cfg->n_agents != 8) || cfg->n_ego <= 0 || cfg->n_ego >= cfg->n_agents)
       return fail("ac_create: AC_TASK_MULTICOMBAT needs n_agents in {4, 8} and 0 < n_ego < n_agents");
-  } else if (cfg->n_agents != 2 || cfg->n_ego != 1) return fail("ac_create: 1v1 tasks need n_agents == 2 and n_ego == 1");
+  } else if (!heading && (cfg->n_agents != 2 || cfg->n_ego != 1)) return fail("ac_create: 1v1 tasks need n_agents == 2 and n_ego == 1");
   if (cfg->hierarchical && (cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE))
     return fail("ac_create: the hierarchical form is available for AC_TASK_SINGLECOMBAT, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN");
   if (n_envs <= 0) return fail("ac_create: n_envs must be positive");
@@ -1152,7 +1170,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   ac_env* h = new ac_env();
   memset(h, 0, sizeof *h);
   h->cfg = *cfg; h->E = n_envs; h->A = cfg->n_agents; h->N = n_envs * cfg->n_agents; h->device = device_id;
-  h->obs_dim = (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
+  h->obs_dim = heading ? 12 : (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
   h->act_low = scenario ? 8 : ((cfg->task == AC_TASK_SHOOT_MISSILE) ? 5 : 4);
   // hierarchical tasks (HierarchicalSingleCombatTask and everything built on it): [3,5,3] (+ the four weapon bits)
@@ -1206,6 +1224,25 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     HIP_OK(hipMalloc(&h->d_XF, sizeof(float) * NXF * N));
     HIP_OK(hipMalloc(&h->d_XI, sizeof(int) * NXI * N));
   }
+  if (heading) {
+    HIP_OK(hipMalloc(&h->hp.HD, sizeof(double) * NHD * N));
+    HIP_OK(hipMalloc(&h->hp.HF, sizeof(float) * NHF * N));
+    HIP_OK(hipMalloc(&h->hp.HI, sizeof(int) * N));
+    HIP_OK(hipMalloc(&h->hp.HR, sizeof(unsigned long long) * 4 * N));
+    HIP_OK(hipMemset(h->hp.HD, 0, sizeof(double) * NHD * N));
+    HIP_OK(hipMemset(h->hp.HF, 0, sizeof(float) * NHF * N));
+    HIP_OK(hipMemset(h->hp.HI, 0, sizeof(int) * N));
+    // stand-in seeding until ac_seed_envs supplies numpy's PCG64 states: splitmix64 of (seed, env), increment forced odd
+    std::vector<unsigned long long> r(4 * N);
+    unsigned long long z = seed;
+    auto sm = [&z]() { z += 0x9E3779B97F4A7C15ULL; unsigned long long v = z; v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ULL; v = (v ^ (v >> 27)) * 0x94D049BB133111EBULL; return v ^ (v >> 31); };
+    for (size_t e = 0; e < N; ++e) { r[0 * N + e] = sm(); r[1 * N + e] = sm(); r[2 * N + e] = sm(); r[3 * N + e] = sm() | 1ULL; }
+    HIP_OK(hipMemcpy(h->hp.HR, r.data(), sizeof(unsigned long long) * 4 * N, hipMemcpyHostToDevice));
+    h->hc.ic = cfg->init[0];
+    h->hc.max_heading_increment = cfg->max_heading_increment; h->hc.max_altitude_increment = cfg->max_altitude_increment;
+    h->hc.max_velocities_u_increment = cfg->max_velocities_u_increment; h->hc.check_interval = cfg->check_interval;
+    h->hc.heading_scale = (float)cfg->heading_scale; h->hc.heading_pot = cfg->heading_potential;
+  }
   p.H = nullptr;
   if (cfg->hierarchical) {
     HIP_OK(hipMalloc(&p.H, sizeof(float) * 128 * N));
@@ -1216,7 +1253,9 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   p.tF = h->d_tF; p.tI = h->d_tI; p.tD = h->d_tD; p.tab = h->d_tab; p.actions = h->d_actions;
   InitArgs ia;
   for (int i = 0; i < AC_MAX_AGENTS; ++i) ia.ic[i] = cfg->init[i];
-  if (scenario && h->A == 2)
+  if (heading) {
+    // no reset template: every reset runs the initial-condition procedure on fresh draws inside the kernel
+  } else if (scenario && h->A == 2)
     hipLaunchKernelGGL(init_kernel_scenario<2>, dim3(1), dim3(64), 0, h->stream, ia, h->dc, h->d_tab, h->d_tF, h->d_tI, h->d_tD);
   else if (scenario && h->A == 4)
     hipLaunchKernelGGL(init_kernel_scenario<4>, dim3(1), dim3(64), 0, h->stream, ia, h->dc, h->d_tab, h->d_tF, h->d_tI, h->d_tD);
@@ -1242,7 +1281,7 @@ int ac_destroy(ac_env_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->dp.F, h->dp.I, h->dp.D, h->dp.MF, h->dp.MD, h->dp.MI, h->dp.obs, h->dp.rew, h->dp.done, h->dp.info,
-                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->d_ctlW, h->d_low};
+                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->d_ctlW, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
   for (void* b : bufs) (void)hipFree(b);
   (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
   (void)hipStreamDestroy(h->stream);
@@ -1413,6 +1452,33 @@ int ac_state_checksum(ac_env_t* h, uint64_t* out) {
   HIP_OK(hipMemcpy(&v, d_out, sizeof v, hipMemcpyDeviceToHost));
   HIP_OK(hipFree(d_out));
   *out = (uint64_t)v;
+  return 0;
+}
+int ac_seed_envs(ac_env_t* h, const uint64_t* states) {
+  if (!h || !states) return fail("ac_seed_envs: null argument");
+  if (h->cfg.task != AC_TASK_HEADING) return fail("ac_seed_envs: only AC_TASK_HEADING draws from env.np_random");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  const size_t N = h->N;
+  std::vector<unsigned long long> r(4 * N);
+  for (size_t e = 0; e < N; ++e)
+    for (int k = 0; k < 4; ++k) r[k * N + e] = states[e * 4 + k];
+  HIP_OK(hipMemcpy(h->hp.HR, r.data(), sizeof(unsigned long long) * 4 * N, hipMemcpyHostToDevice));
+  return 0;
+}
+int ac_get_heading_state(ac_env_t* h, int32_t env, double out[8]) {
+  if (check_idx(h, env, 0) || !out) return fail("ac_get_heading_state: bad argument");
+  if (h->cfg.task != AC_TASK_HEADING) return fail("ac_get_heading_state: not an AC_TASK_HEADING handle");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  const size_t N = h->N, n = env;
+  for (int f = 0; f < NHD; ++f) HIP_OK(hipMemcpy(&out[f], h->hp.HD + f * N + n, sizeof(double), hipMemcpyDeviceToHost));
+  int tc; HIP_OK(hipMemcpy(&tc, h->hp.HI + n, sizeof tc, hipMemcpyDeviceToHost));
+  out[5] = tc;
+  float lp, lq;
+  HIP_OK(hipMemcpy(&lp, h->hp.HF + HF_last_p * N + n, sizeof lp, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(&lq, h->hp.HF + HF_last_q * N + n, sizeof lq, hipMemcpyDeviceToHost));
+  out[6] = lp; out[7] = lq;
   return 0;
 }
 int ac_pin_host_buffer(ac_env_t* h, void* ptr, int64_t bytes) {

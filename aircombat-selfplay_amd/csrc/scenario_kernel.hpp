@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_scenario(DevPtrs P, DevCf
   float np_max = fmaxf(fabsf(s.npx), fmaxf(fabsf(s.npy), fabsf(s.npz)));
   float pqr = sqrtf(d.p * d.p + d.q * d.q + d.r * d.r);
   const bool extreme = (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);
-  const bool overload = ((float)s.ticks * (1.0f / 60.0f) > 10.0f) &&
+  const bool overload = (s.ticks >= kTickOverload) &&
                         (fabsf(s.npx) > c.acc_x || fabsf(s.npy) > c.acc_y || fabsf(s.npz + 1.0f) > c.acc_z);
   const bool low = pr.alt_m <= c.altitude_limit;
   auto terminations = [&]() {

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-from .capi import (AcConfig, AC_STATE_LEN, AC_TASK_SINGLECOMBAT, AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1,
+from .capi import (AcConfig, AC_STATE_LEN, AC_TASK_HEADING, AC_TASK_SINGLECOMBAT, AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1,
                    AC_TASK_SCENARIO_NVN, load_library)
 from .config import config_from_yaml, default_config
 
@@ -86,6 +86,15 @@ class HipVecEnv:
         Box, MultiDiscrete, Discrete, Tuple = _spaces()
         self.observation_space = Box(low=-10, high=10.0, shape=(self.obs_dim,))
         self.hierarchical = bool(config.hierarchical)
+        if config.task == AC_TASK_HEADING:
+            # env.seed(seed + 1000 i) -> seeding.np_random (env_base.py:252-258, train_jsbsim.py:33): hand numpy's own PCG64
+            # state of every env to the device, so resets and UnreachHeading draw exactly numpy's stream
+            st = np.zeros((self.num_envs, 4), dtype=np.uint64)
+            m = (1 << 64) - 1
+            for i in range(self.num_envs):
+                b = np.random.PCG64(int(seed) + 1000 * i).state["state"]
+                st[i] = (b["state"] >> 64, b["state"] & m, b["inc"] >> 64, b["inc"] & m)
+            self.lib.check(self.lib.ac_seed_envs(self._h, st.ctypes.data), "ac_seed_envs")
         if self.hierarchical:
             # BaselineActor() + load_state_dict(model/baseline_model.pt) of HierarchicalSingleCombatTask.__init__
             # (singlecombat_task.py:211-219): the exported weights go to the device once
@@ -143,6 +152,8 @@ class HipVecEnv:
         code = self._info[:, 1]
         for i in np.flatnonzero(code).tolist():
             infos[i]["done_condition"] = DONE_MESSAGES.get(int(code[i]), "")
+            if code[i] == 8:   # UnreachHeading reports its curriculum stage when it ends the episode (unreach_heading.py:60-63)
+                infos[i]["heading_turn_counts"] = int(self._info[i, 2])
         return infos
 
     def step(self, actions):
@@ -216,6 +227,12 @@ class HipVecEnv:
         out = (C.c_double * 12)()
         self.lib.check(self.lib.ac_get_entity(self._h, env, agent, out), "ac_get_entity")
         return np.array(out[:], dtype=np.float64)
+
+    def get_heading_state(self, env):
+        """HeadingTask bookkeeping of one env: sim_time, target heading / altitude / speed, next check time, turn count, last p, q."""
+        out = (C.c_double * 8)()
+        self.lib.check(self.lib.ac_get_heading_state(self._h, env, out), "ac_get_heading_state")
+        return np.array(out[:])
 
     def get_controller_state(self, env, agent):
         """(hidden[128], low_action[act_low]) of the low-level controller for one aircraft (hierarchical tasks)."""

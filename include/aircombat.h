@@ -26,7 +26,8 @@ extern "C" {
 
 /* task semantics, R/envs/JSBSim/tasks/ */
 enum {
-  AC_TASK_HEADING = 0,        /* heading_task.py HeadingTask (oracle-only this round; ac_create refuses it) */
+  AC_TASK_HEADING = 0,        /* heading_task.py:9-110 HeadingTask under SingleControlEnv (BASELINE C1): 1 aircraft, obs 12, act [41,41,41,30],
+                                 randomised reset and UnreachHeading draws from the env's numpy Generator(PCG64), see ac_seed_envs */
   AC_TASK_SINGLECOMBAT = 1,   /* singlecombat_task.py:16-207 SingleCombatTask: obs 15, act [41,41,41,30] */
   AC_TASK_DODGE_MISSILE = 2,  /* singlecombat_with_missile_task.py:12-124 rule-based launch from the lock window, MissilePostureReward: obs 21, act 4 */
   AC_TASK_SHOOT_MISSILE = 3,  /* singlecombat_with_missile_task.py:147-204 learned shoot bit: obs 21, act 5 */
@@ -68,6 +69,9 @@ typedef struct ac_config {
   double alt_safe, alt_danger, alt_kv;
   double max_attack_angle, max_attack_distance; int32_t min_attack_interval;
   int32_t use_artillery;
+  /* HeadingTask only: HeadingReward_scale / _potential (reward_function_base.py:14-15), UnreachHeading limits (unreach_heading.py:27-31) */
+  double heading_scale; int32_t heading_potential;
+  double max_heading_increment, max_altitude_increment, max_velocities_u_increment, check_interval;
   int32_t hierarchical;             /* Hierarchical* / Scenario* tasks as shipped: actions are MultiDiscrete [3,5,3] (+ the four weapon
                                        bits) and go through the low-level controller (singlecombat_task.py:209-262); 0 = control indices */
 } ac_config_t;
@@ -115,6 +119,13 @@ int ac_get_missile(ac_env_t* h, int32_t env, int32_t agent, int32_t k, double ou
  * same state give E times the digest of one env (mod 2^64). Test / profiling aid: one read-only pass over the state arrays with
  * the step kernel's access pattern, (4*63 + 4*12 + 8*3) bytes per aircraft; no reference counterpart. */
 int ac_state_checksum(ac_env_t* h, uint64_t* out);
+
+/* AC_TASK_HEADING: replaces env.seed(seed) -> gymnasium seeding.np_random(seed) (R/envs/JSBSim/envs/env_base.py:252-258): the four
+ * 64-bit words (state_hi, state_lo, inc_hi, inc_lo) of numpy's PCG64 bit generator for every env, [E][4]. The reference seeds env i
+ * with seed + 1000 i (scripts/train/train_jsbsim.py:33); resets and UnreachHeading then draw exactly numpy's stream on the device. */
+int ac_seed_envs(ac_env_t* h, const uint64_t* states);
+/* test access: sim_time, target heading deg / altitude ft / speed m/s, next check time, heading_turn_counts, last p, last q */
+int ac_get_heading_state(ac_env_t* h, int32_t env, double out[8]);
 
 /* Optional: page-lock a caller-owned host buffer that is handed to ac_step / ac_reset repeatedly, so that the copies run as
  * direct DMA instead of through a staging buffer (the caller still owns the memory; unpin before freeing it). The reference has

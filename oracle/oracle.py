@@ -151,7 +151,8 @@ def config_from_ac(ac_cfg):
                  "altitude_limit", "acc_limit_x", "acc_limit_y", "acc_limit_z", "posture_scale", "posture_potential",
                  "altitude_scale", "altitude_potential", "event_scale", "event_potential", "missile_posture_scale",
                  "shoot_penalty_scale", "shoot_penalty_potential", "alt_safe", "alt_danger", "alt_kv", "max_attack_angle",
-                 "max_attack_distance", "min_attack_interval", "use_artillery", "hierarchical"):
+                 "max_attack_distance", "min_attack_interval", "use_artillery", "hierarchical", "heading_scale", "heading_potential",
+                 "max_heading_increment", "max_altitude_increment", "max_velocities_u_increment", "check_interval"):
         setattr(c, name, getattr(ac_cfg, name))
     for i in range(OR_MAX_AC):
         src, dst = ac_cfg.init[i], c.init[i]

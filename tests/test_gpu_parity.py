@@ -410,3 +410,50 @@ def test_hierarchical_tasks_lowlevel_controller(pkg, oracle, task):
         assert (np.abs(obs[good] - robs[good]) <= 10 * (2e-4 + 2e-4 * np.abs(robs[good]))).mean() > 0.995, step
     assert flips <= max(2, calls // 500), (flips, calls)
     env.close()
+
+
+def test_heading_task_numpy_stream_on_device(pkg, oracle):
+    """BASELINE config C1 on the device: SingleControlEnv / HeadingTask. Every env owns numpy's PCG64 stream of seed + 1000 i:
+    the reset draws (heading, altitude, speed), the UnreachHeading target draws at each check time and the draws of the next
+    auto-reset must be the very numbers the oracle's numpy mirror produces. Flight state re-synchronised each step."""
+    cfg = pkg.default_config("heading")
+    E, seed = 6, 11
+    env = pkg.HipVecEnv(cfg, E, seed=seed)
+    ocfg = oracle.config_from_ac(cfg)
+    refs = [oracle.OracleEnv(ocfg, pcg64_state=np.random.PCG64(seed + 1000 * i).state) for i in range(E)]
+    obs = env.reset()
+    robs = np.stack([r.reset() for r in refs])
+    assert obs.shape == robs.shape == (E, 1, 12) and env.act_dim == 4
+    assert obs_close(obs, robs).all(), np.abs(obs - robs).max()
+    names = env.lib.state_field_names()
+    task_fields = ("bloods", "pre_posture", "pre_altitude", "pre_event", "pre_shoot", "status", "die_flag", "remaining", "pre_remaining",
+                   "shoot_action", "last_missile", "last_shoot_time", "lock_bits", "lock_pos", "cur_step")
+    fdm_fields = np.array([k for k, nm in enumerate(names) if nm and not nm.startswith("x_") and nm not in task_fields])
+    rng = np.random.default_rng(4)
+    resets = turns = 0
+    for step in range(340):
+        for e in range(E):
+            v = env.get_state(e, 0)
+            v[fdm_fields] = refs[e].export_state(0)[fdm_fields]
+            env.set_state(e, 0, v)
+        act = np.array([20, 18.6, 20, 15], dtype=np.float32) + rng.integers(-3, 4, size=(E, 1, 4)).astype(np.float32)
+        obs, rew, done, info = env.step(act)
+        for e in range(E):
+            o, r, d, i = refs[e].step(act[e])
+            if i[3]:
+                o = refs[e].reset()
+                resets += 1
+            assert bool(done[e, 0, 0]) == bool(d[0]), (step, e)
+            assert obs_close(obs[e], o, 10.0).all(), (step, e, obs[e], o)
+            assert abs(rew[e, 0, 0] - r[0]) <= 10 * (5e-3 + 1e-3 * abs(r[0])), (step, e, rew[e, 0, 0], r[0])
+            hs = env.get_heading_state(e)
+            out = np.zeros(8)
+            refs[e].L.or_env_heading_get(refs[e].p, out.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double)))
+            # or_env_heading_get: target heading deg, altitude ft, speed m/s, check time, turn counts, ...
+            assert np.allclose(hs[1:5], out[0:4], rtol=1e-12, atol=1e-9), (step, e, hs, out)
+            assert int(hs[5]) == int(out[4]), (step, e)
+            turns = max(turns, int(hs[5]))
+            if i[1] == 8:
+                assert info[e].get("heading_turn_counts") == int(i[2])
+    assert resets >= 3 and turns >= 1, (resets, turns)
+    env.close()
