@@ -96,6 +96,14 @@ def config_from_dict(data, task=None, hierarchical=None):
     cfg.max_attack_distance = float(g("max_attack_distance", float("inf")))
     cfg.min_attack_interval = int(g("min_attack_interval", 125))
     cfg.use_artillery = int(bool(g("use_artillery", False)))
+    # scripted opponents (singlecombat_task.py:19-27, load_agent :197-207): 'pursue' and 'maneuver' feed the low-level controller;
+    # 'loiter' is named by some shipped YAMLs but the reference has no such agent (load_agent raises NotImplementedError)
+    cfg.use_baseline = 0
+    if g("use_baseline", False):
+        kind = g("baseline_type", "pursue")
+        if kind not in ("pursue", "maneuver"):
+            raise NotImplementedError(f"baseline_type={kind}: the reference's load_agent only knows the controller-driven 'pursue' and 'maneuver' here")
+        cfg.use_baseline = 1 if kind == "pursue" else 2
     # HeadingTask: HeadingReward scale / potential; UnreachHeading reads its limits from the first aircraft's block
     # (unreach_heading.py:14-19)
     cfg.heading_scale = float(g("HeadingReward_scale", 1.0)); cfg.heading_potential = int(bool(g("HeadingReward_potential", False)))

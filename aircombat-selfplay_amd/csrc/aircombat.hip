@@ -107,6 +107,7 @@ struct DevPtrs {
   float* MF; int* MI;                    // missiles, SoA [slot][field][N]
   double* MD;                            // scenario tasks: the same layout in fp64 instead of MF
   float* H;                              // hierarchical tasks: GRU state of the low-level controller, [128][N] (else null)
+  int* man_step; float* man_h0;          // scripted ManeuverAgent opponents: step counter and latched heading, [N]
   const float* tF; const int* tI; const double* tD;  // reset template, [field][A]
   const float* tab;                      // F16_PACK as fp32 in HBM (staged to LDS per workgroup)
   const float* actions;                  // [N][act_dim]
@@ -163,8 +164,10 @@ __device__ __forceinline__ void store_msl(R* MF, int* MI, int N, int n, int slot
 
 // task.reset() of the hierarchical tasks clears _inner_rnn_states (singlecombat_task.py:258-262)
 __device__ __forceinline__ void zero_controller_state(const DevPtrs& P, int N, int n, bool live) {
-  if (P.H && live)
+  if (P.H && live) {
     for (int k = 0; k < 128; ++k) P.H[(size_t)k * N + n] = 0.0f;
+    P.man_step[n] = 0; P.man_h0[n] = 0.0f;   // BaselineAgent.reset (baseline.py:37-38,133-136)
+  }
 }
 
 // What the Python wrapper caches after every JSBSim run (simulatior.py:238-258) plus the clipped unit
@@ -1073,7 +1076,9 @@ static int launch_step(ac_env* h, const float* d_actions) {
   dim3 block(64), grid((h->N + 63) / 64);
   if (h->cfg.hierarchical) {   // [3,5,3] (+ weapon bits) -> control indices, then the ordinary step on those
     if (!h->d_ctlW) return fail("hierarchical task: ac_load_controller has not been called");
-    ctl::Args a{h->d_ctlW, p.actions, p.obs, p.H, h->d_low, h->N, h->obs_dim, h->act_dim, h->act_low};
+    ctl::Args a{h->d_ctlW, p.actions, p.obs, p.H, h->d_low, h->N, h->obs_dim, h->act_dim, h->act_low,
+                h->cfg.use_baseline, h->A, h->cfg.n_ego, h->cfg.use_artillery,
+                (float)h->cfg.agent_interaction_steps / (float)h->cfg.sim_freq, p.man_step, p.man_h0, p, h->dc};
     hipLaunchKernelGGL(controller_kernel, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
     HIP_OK(hipGetLastError());
     p.actions = h->d_low;
@@ -1157,6 +1162,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     if ((cfg->n_agents != 4 && cfg->n_agents != 8) || cfg->n_ego <= 0 || cfg->n_ego >= cfg->n_agents)
       return fail("ac_create: AC_TASK_MULTICOMBAT needs n_agents in {4, 8} and 0 < n_ego < n_agents");
   } else if (!heading && (cfg->n_agents != 2 || cfg->n_ego != 1)) return fail("ac_create: 1v1 tasks need n_agents == 2 and n_ego == 1");
+  if (cfg->use_baseline && (!cfg->hierarchical || cfg->use_baseline < 0 || cfg->use_baseline > 2 || cfg->n_ego * 2 != cfg->n_agents))
+    return fail("ac_create: use_baseline (1 pursue, 2 maneuver) needs the hierarchical form and equal teams (enemy k is flown by scripted agent k)");
   if (cfg->hierarchical && (cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE))
     return fail("ac_create: the hierarchical form is available for AC_TASK_SINGLECOMBAT, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN");
   if (n_envs <= 0) return fail("ac_create: n_envs must be positive");
@@ -1243,12 +1250,16 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     h->hc.max_velocities_u_increment = cfg->max_velocities_u_increment; h->hc.check_interval = cfg->check_interval;
     h->hc.heading_scale = (float)cfg->heading_scale; h->hc.heading_pot = cfg->heading_potential;
   }
-  p.H = nullptr;
+  p.H = nullptr; p.man_step = nullptr; p.man_h0 = nullptr;
   if (cfg->hierarchical) {
     HIP_OK(hipMalloc(&p.H, sizeof(float) * 128 * N));
     HIP_OK(hipMemset(p.H, 0, sizeof(float) * 128 * N));
     HIP_OK(hipMalloc(&h->d_low, sizeof(float) * N * h->act_low));
     HIP_OK(hipMemset(h->d_low, 0, sizeof(float) * N * h->act_low));
+    HIP_OK(hipMalloc(&p.man_step, sizeof(int) * N));
+    HIP_OK(hipMemset(p.man_step, 0, sizeof(int) * N));
+    HIP_OK(hipMalloc(&p.man_h0, sizeof(float) * N));
+    HIP_OK(hipMemset(p.man_h0, 0, sizeof(float) * N));
   }
   p.tF = h->d_tF; p.tI = h->d_tI; p.tD = h->d_tD; p.tab = h->d_tab; p.actions = h->d_actions;
   InitArgs ia;
@@ -1281,7 +1292,7 @@ int ac_destroy(ac_env_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->dp.F, h->dp.I, h->dp.D, h->dp.MF, h->dp.MD, h->dp.MI, h->dp.obs, h->dp.rew, h->dp.done, h->dp.info,
-                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->d_ctlW, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
+                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_ctlW, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
   for (void* b : bufs) (void)hipFree(b);
   (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
   (void)hipStreamDestroy(h->stream);

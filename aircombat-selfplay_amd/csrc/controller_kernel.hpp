@@ -49,7 +49,28 @@ struct Args {
   float* H;                // [128][N] GRU state
   float* low;              // [N][act_low] out: 4 control indices (+ the weapon bits)
   int N, obs_dim, act_hi, act_low;
+  // scripted opponents (use_baseline, model/baseline.py): the enemy team's inputs come from geometry instead of `hi`
+  int use_baseline;        // 0 none, 1 PursueAgent, 2 ManeuverAgent('triangle')
+  int A, n_ego, use_artillery;
+  float time_interval;     // env.time_interval = agent_interaction_steps / sim_freq
+  int* man_step;           // [N] ManeuverAgent.step
+  float* man_h0;           // [N] ManeuverAgent.init_heading (latched when step == 0)
+  DevPtrs P; DevCfg c;     // aircraft state (scripted inputs are computed from it)
 };
+__device__ __forceinline__ float in_range_rad_f(float a) {   // utils.py:114-119 with Python's % semantics
+  a = fmodf(a, 6.283185307179586f);
+  if (a < 0.0f) a += 6.283185307179586f;
+  if (a > 3.14159265358979f) a -= 6.283185307179586f;
+  return a;
+}
+__device__ __noinline__ void aircraft_props(const DevPtrs& P, const DevCfg& c, int n, Props& pr, float& psi) {
+  State s; Task t; Derived d;
+  load_state(P.F, P.I, P.D, c.N, n, s, t);
+  f16::locate(s, d); f16::body_frame(s, d);
+  make_props(s, d, c, pr);
+  psi = atan2f(pr.m12, pr.m11);
+  if (psi < 0.0f) psi += 6.283185307179586f;
+}
 
 // A operands of one layer for this lane: A[t] = act[k = 2t + lane/32][row = lane%32]
 template <int K>
@@ -133,23 +154,54 @@ __global__ __launch_bounds__(256) void controller_kernel(ctl::Args a) {
   {
     const int row = tid & 31, part = tid >> 5;   // 8 parts
     const int n = min(i0 + row, a.N - 1);
-    if (part < 2) {   // two threads per aircraft build 8 of the 16 input rows each
+    if (part == 0) {
       const float* hi = a.hi + (size_t)n * a.act_hi;
       const float* ob = a.obs + (size_t)n * a.obs_dim;
-      if (part == 0) {
+      const int slot = n % a.A;
+      float x[12];
+      if (a.use_baseline && slot >= a.n_ego) {
+        // the enemy team is flown by BaselineAgent k (singlecombat_task.py:224-228, scenario1_task.py:41-49, scenario2_task.py:49-58)
+        Props pr; float psi;
+        aircraft_props(a.P, a.c, n, pr, psi);
+        float dv0, dv1, dv2;
+        if (a.use_baseline == 2) {   // ManeuverAgent('triangle').set_delta_value (baseline.py:137-155)
+          int st = a.man_step[n];
+          float h0 = (st == 0) ? psi : a.man_h0[n];
+          int i = 0;
+          for (i = 0; i < 300; ++i) if ((float)st <= (float)(i + 1) * 30.0f / a.time_interval) break;
+          i = min(i, 299) % 3;
+          dv1 = h0 + (i == 0 ? 1.0471975511965976f : (i == 1 ? 3.14159265358979f : -1.0471975511965976f)) - psi;
+          dv0 = 6000.0f - pr.alt_m; dv2 = 243.0f - pr.ub;
+          if (i0 + row < a.N) { a.man_step[n] = st + 1; a.man_h0[n] = h0; }
+        } else {                      // PursueAgent.set_delta_value(env, task, k) (baseline.py:85-104): chase aircraft k of the list
+          Props pt; float psit;
+          aircraft_props(a.P, a.c, n - a.n_ego, pt, psit);
+          dv0 = pt.u - pr.u;
+          const float ev = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve), dx = pt.n - pr.n, dy = pt.e - pr.e;
+          const float R = sqrtf(dx * dx + dy * dy);
+          const float ao = acosf(clampf(-1.0f, (dx * pr.vn + dy * pr.ve) / (R * ev + 1e-8f), 1.0f));
+          const float cr = pr.vn * dy - pr.ve * dx;
+          dv1 = ao * (float)((cr > 0.0f) - (cr < 0.0f));
+          dv2 = pt.ub - pr.ub;
+        }
+        // BaselineAgent.get_observation (baseline.py:45-63)
+        x[0] = dv0 / 1000.0f; x[1] = in_range_rad_f(dv1); x[2] = dv2 / 340.0f; x[3] = pr.alt_m / 5000.0f;
+        x[4] = pr.sphi; x[5] = pr.cphi; x[6] = pr.stht; x[7] = pr.ctht;
+        x[8] = pr.ub / 340.0f; x[9] = pr.vb / 340.0f; x[10] = pr.wb / 340.0f; x[11] = pr.vc / 340.0f;
+      } else {
         const int c0 = (int)hi[0], c1 = (int)hi[1], c2 = (int)hi[2];
         // singlecombat_task.py:217-219, 235-241: below 3500 m the altitude choice is overridden by "climb"
-        act0[0 * LS + row] = (ob[0] * 5000.0f < 3500.0f) ? 0.1f : (c0 == 0 ? 0.1f : (c0 == 1 ? 0.0f : -0.1f));
-        act0[1 * LS + row] = (float)(c1 - 2) * 0.26179938779914943f;   // {-pi/6, -pi/12, 0, pi/12, pi/6}
-        act0[2 * LS + row] = c2 == 0 ? 0.05f : (c2 == 1 ? 0.0f : -0.05f);
+        x[0] = (ob[0] * 5000.0f < 3500.0f) ? 0.1f : (c0 == 0 ? 0.1f : (c0 == 1 ? 0.0f : -0.1f));
+        x[1] = (float)(c1 - 2) * 0.26179938779914943f;   // {-pi/6, -pi/12, 0, pi/12, pi/6}
+        x[2] = c2 == 0 ? 0.05f : (c2 == 1 ? 0.0f : -0.05f);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) act0[(3 + k) * LS + row] = ob[k];
-      } else {
-#pragma unroll
-        for (int k = 5; k < 9; ++k) act0[(3 + k) * LS + row] = ob[k];
-#pragma unroll
-        for (int k = 12; k < 16; ++k) act0[k * LS + row] = 0.0f;
+        for (int k = 0; k < 9; ++k) x[3 + k] = ob[k];
       }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) act0[k * LS + row] = x[k];
+    } else if (part == 1) {
+#pragma unroll
+      for (int k = 12; k < 16; ++k) act0[k * LS + row] = 0.0f;
     }
 #pragma unroll
     for (int f = 0; f < 16; ++f) hbuf[(part * 16 + f) * LS + row] = a.H[(size_t)(part * 16 + f) * a.N + n];
@@ -243,7 +295,11 @@ __global__ __launch_bounds__(256) void controller_kernel(ctl::Args a) {
     if (i0 + row < a.N) a.low[(size_t)(i0 + row) * a.act_low + head] = (float)bi;
   } else if (tid < 160) {   // weapon bits ride along unchanged
     const int row = tid & 31;
-    if (i0 + row < a.N)
-      for (int k = 4; k < a.act_low; ++k) a.low[(size_t)(i0 + row) * a.act_low + k] = a.hi[(size_t)(i0 + row) * a.act_hi + (k - 1)];
+    if (i0 + row < a.N) {
+      const int nn = i0 + row;
+      const bool scripted = a.use_baseline && (nn % a.A) >= a.n_ego;   // scenario1_task.py:42-48: bits [0,0,0,0], or all ones with artillery
+      for (int k = 4; k < a.act_low; ++k)
+        a.low[(size_t)nn * a.act_low + k] = scripted ? (a.use_artillery ? 1.0f : 0.0f) : a.hi[(size_t)nn * a.act_hi + (k - 1)];
+    }
   }
 }

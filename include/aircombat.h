@@ -72,6 +72,8 @@ typedef struct ac_config {
   /* HeadingTask only: HeadingReward_scale / _potential (reward_function_base.py:14-15), UnreachHeading limits (unreach_heading.py:27-31) */
   double heading_scale; int32_t heading_potential;
   double max_heading_increment, max_altitude_increment, max_velocities_u_increment, check_interval;
+  int32_t use_baseline;             /* scripted enemy team (`use_baseline: true`, `baseline_type`, singlecombat_task.py:19-27, model/baseline.py):
+                                       0 none, 1 PursueAgent, 2 ManeuverAgent('triangle'); the enemy rows of `actions` are ignored */
   int32_t hierarchical;             /* Hierarchical* / Scenario* tasks as shipped: actions are MultiDiscrete [3,5,3] (+ the four weapon
                                        bits) and go through the low-level controller (singlecombat_task.py:209-262); 0 = control indices */
 } ac_config_t;

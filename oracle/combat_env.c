@@ -24,6 +24,48 @@ int or_env_obs_dim_n(int task, int n_aircraft) {
   if (task == OR_TASK_WVR) return 15; /* HierarchicalSingleCombatTask keeps SingleCombatTask's 15-value observation */
   return or_env_obs_dim(task);
 }
+/* ------------------------------------------------------------------ scripted opponents (model/baseline.py) */
+static double in_range_rad(double a) { /* utils.py:114-119, Python % semantics */
+  a = fmod(a, 2 * M_PI);
+  if (a < 0) a += 2 * M_PI;
+  if (a > M_PI) a -= 2 * M_PI;
+  return a;
+}
+/* BaselineAgent.get_observation (baseline.py:45-63): delta values + own attitude / speeds */
+static void baseline_observation(const OrAircraft* a, const double dv[3], double x[12]) {
+  x[0] = dv[0] / 1000; x[1] = in_range_rad(dv[1]); x[2] = dv[2] / 340;
+  x[3] = clampd(-500, a->fdm.h_sl * 0.3048, 26000) / 5000;
+  x[4] = sin(a->fdm.phi); x[5] = cos(a->fdm.phi); x[6] = sin(a->fdm.tht); x[7] = cos(a->fdm.tht);
+  x[8] = clampd(-700, a->fdm.uvw[0] * 0.3048, 700) / 340; x[9] = clampd(-700, a->fdm.uvw[1] * 0.3048, 700) / 340;
+  x[10] = clampd(-700, a->fdm.uvw[2] * 0.3048, 700) / 340; x[11] = clampd(0, a->fdm.vc_fps * 0.3048, 1400) / 340;
+}
+/* PursueAgent.set_delta_value (baseline.py:85-104): climb to the target's height, turn onto it (2-D AO with side), match its speed */
+void or_pursue_delta(const OrAircraft* ego, const OrAircraft* tgt, double dv[3]) {
+  dv[0] = tgt->position[2] - ego->position[2];
+  double vx = ego->velocity[0], vy = ego->velocity[1];
+  double ev = hypot(vx, vy), dx = tgt->position[0] - ego->position[0], dy = tgt->position[1] - ego->position[1];
+  double R = hypot(dx, dy), proj = dx * vx + dy * vy;
+  double ao = acos(clampd(-1, proj / (R * ev + 1e-8), 1));
+  double cr = vx * dy - vy * dx;
+  dv[1] = ao * ((cr > 0) - (cr < 0));
+  dv[2] = clampd(-700, tgt->fdm.uvw[0] * 0.3048, 700) - clampd(-700, ego->fdm.uvw[0] * 0.3048, 700);
+}
+/* ManeuverAgent('triangle').set_delta_value (baseline.py:114-155): heading schedule [pi/3, pi, -pi/3] x 100 every turn_interval
+ * seconds relative to the heading latched at the first call; 6000 m, 243 m/s */
+void or_maneuver_delta(OrAircraft* a, double turn_interval, double time_interval, double dv[3]) {
+  static const double hl[3] = {M_PI / 3, M_PI, -M_PI / 3};
+  double cur = a->fdm.psi;
+  if (!a->man_init_set) { a->man_init_heading = cur; a->man_init_set = 1; }
+  int i = 0;
+  for (i = 0; i < 300; i++) if (a->man_step <= (i + 1) * turn_interval / time_interval) break;
+  if (i >= 300) i = 299;
+  dv[1] = a->man_init_heading + hl[i % 3] - cur;
+  dv[0] = 6000 - clampd(-500, a->fdm.h_sl * 0.3048, 26000);
+  dv[2] = 243 - clampd(-700, a->fdm.uvw[0] * 0.3048, 700);
+  a->man_step += 1;
+}
+void or_baseline_observation(const OrAircraft* a, const double dv[3], double x[12]) { baseline_observation(a, dv, x); }
+
 /* hierarchical action spaces: MultiDiscrete [3,5,3] (singlecombat_task.py:221-222), + [2,2,2,2] weapon bits for the scenario tasks */
 int or_env_act_dim_h(int task, int hierarchical) {
   if (!hierarchical) return or_env_act_dim(task);
@@ -876,7 +918,8 @@ void or_env_task_reset(OrEnv* e) {
     a->last_chaff = -1;
     a->rem_gun = a->rem_9m = a->rem_120b = a->rem_chaff = c->num_missiles[i];
     for (int k = 0; k < 4; k++) a->shoot4[k] = 0;
-    for (int k = 0; k < 128; k++) a->rnn[k] = 0;   /* singlecombat_task.py:258-262 */
+    for (int k = 0; k < 128; k++) a->rnn[k] = 0;   /* singlecombat_task.py:258-262; BaselineAgent.reset (baseline.py:37-38,133-136) */
+    a->man_step = 0; a->man_init_set = 0; a->man_init_heading = 0;
     for (int k = 0; k < 4; k++) a->low_action[k] = 0;
   }
   reward_reset(e);
@@ -905,13 +948,25 @@ void or_env_step(OrEnv* e, const double* actions, double* obs, double* rew, uint
       static const double d_alt[3] = {0.1, 0, -0.1}, d_vel[3] = {0.05, 0, -0.05};
       static const double d_hdg[5] = {-M_PI / 6, -M_PI / 12, 0, M_PI / 12, M_PI / 6};
       double x[12], low[4];
-      x[0] = (e->ac[i].geodetic[2] < 3500) ? d_alt[0] : d_alt[(int)act[0]];   /* :235-239: below 3500 m always climb */
-      x[1] = d_hdg[(int)act[1]];
-      x[2] = d_vel[(int)act[2]];
-      for (int k = 0; k < 9; k++) x[3 + k] = pre_obs[i * e->obs_dim + k];
+      const int scripted = c->use_baseline && e->ac[i].team == 1;
+      if (scripted) {
+        /* singlecombat_task.py:224-228 / scenario1_task.py:41-49 / scenario2_task.py:49-58: enemy k is flown by baseline agent k,
+         * which chases aircraft k of the whole list (PursueAgent.get_action(env, task, idx)) */
+        double dv[3];
+        if (c->use_baseline == 2) or_maneuver_delta(&e->ac[i], 30.0, (double)c->agent_interaction_steps / c->sim_freq, dv);
+        else or_pursue_delta(&e->ac[i], &e->ac[i - c->n_ego], dv);
+        baseline_observation(&e->ac[i], dv, x);
+      } else {
+        x[0] = (e->ac[i].geodetic[2] < 3500) ? d_alt[0] : d_alt[(int)act[0]];   /* :235-239: below 3500 m always climb */
+        x[1] = d_hdg[(int)act[1]];
+        x[2] = d_vel[(int)act[2]];
+        for (int k = 0; k < 9; k++) x[3 + k] = pre_obs[i * e->obs_dim + k];
+      }
+      for (int k = 0; k < 12; k++) e->ac[i].ctl_in[k] = x[k];
       or_actor_forward(x, e->ac[i].rnn, e->ac[i].low_action, NULL);
       for (int k = 0; k < 4; k++) low[k] = e->ac[i].low_action[k];
-      if (c->task == OR_TASK_SCENARIO_NVN || (c->task == OR_TASK_SCENARIO1 && e->ac[i].team == 0))
+      if (scripted) { for (int k = 0; k < 4; k++) e->ac[i].shoot4[k] = c->use_artillery ? 1 : 0; }
+      else if (c->task == OR_TASK_SCENARIO_NVN || (c->task == OR_TASK_SCENARIO1 && e->ac[i].team == 0))
         for (int k = 0; k < 4; k++) e->ac[i].shoot4[k] = act[3 + k] != 0;
       decode_action(e, i, low, u);
       f16_set_controls(&e->ac[i].fdm, u[0], u[1], u[2], u[3]);

@@ -59,6 +59,7 @@ typedef struct {
   double relative_altitude_scale, relative_altitude_KH;   /* RelativeAltitudeReward_scale / _KH */
   double gun_scale;                                       /* common scale of the CombatGeometry / Gun* terms (all default 1) */
   uint64_t chaff_seed;                                    /* counter-based stand-in for the global np.random of env_base.py:153 */
+  int use_baseline;   /* the enemy team is flown by a scripted BaselineAgent (singlecombat_task.py:19-27): 0 none, 1 pursue, 2 maneuver('triangle') */
   int hierarchical;   /* Hierarchical* / Scenario* tasks as shipped: action = [3,5,3] (+4 weapon bits) through the low-level controller */
 } OrEnvConfig;
 
@@ -88,6 +89,8 @@ typedef struct {
   int pre_remaining_missiles;
   double rnn[128];      /* _inner_rnn_states[agent_id] of the hierarchical tasks (singlecombat_task.py:258-262) */
   int low_action[4];    /* last output of the low-level controller */
+  int man_step, man_init_set; double man_init_heading;   /* ManeuverAgent.step / init_heading (baseline.py:133-136) */
+  double ctl_in[12];    /* last controller input vector (test hook) */
 } OrAircraft;
 
 typedef struct {

@@ -42,6 +42,7 @@ class OrEnvConfig(C.Structure):
         ("use_artillery", C.c_int),
         ("relative_altitude_scale", C.c_double), ("relative_altitude_KH", C.c_double), ("gun_scale", C.c_double),
         ("chaff_seed", C.c_uint64),
+        ("use_baseline", C.c_int),
         ("hierarchical", C.c_int),
     ]
 
@@ -152,7 +153,7 @@ def config_from_ac(ac_cfg):
                  "altitude_scale", "altitude_potential", "event_scale", "event_potential", "missile_posture_scale",
                  "shoot_penalty_scale", "shoot_penalty_potential", "alt_safe", "alt_danger", "alt_kv", "max_attack_angle",
                  "max_attack_distance", "min_attack_interval", "use_artillery", "hierarchical", "heading_scale", "heading_potential",
-                 "max_heading_increment", "max_altitude_increment", "max_velocities_u_increment", "check_interval"):
+                 "max_heading_increment", "max_altitude_increment", "max_velocities_u_increment", "check_interval", "use_baseline"):
         setattr(c, name, getattr(ac_cfg, name))
     for i in range(OR_MAX_AC):
         src, dst = ac_cfg.init[i], c.init[i]

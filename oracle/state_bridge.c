@@ -186,3 +186,13 @@ void or_env_get_rnn(const OrEnv* e, int i, double* h, int* low_action) {
   if (low_action) for (int k = 0; k < 4; k++) low_action[k] = e->ac[i].low_action[k];
 }
 void or_env_set_rnn(OrEnv* e, int i, const double* h) { for (int k = 0; k < 128; k++) e->ac[i].rnn[k] = h[k]; }
+
+/* scripted-opponent golden hooks: delta values and the 12 controller inputs of aircraft i chasing aircraft j / flying the schedule */
+void or_pursue_delta(const OrAircraft* ego, const OrAircraft* tgt, double dv[3]);
+void or_maneuver_delta(OrAircraft* a, double turn_interval, double time_interval, double dv[3]);
+void or_baseline_observation(const OrAircraft* a, const double dv[3], double x[12]);
+void or_env_pursue(OrEnv* e, int i, int j, double* dv, double* x) { or_pursue_delta(&e->ac[i], &e->ac[j], dv); or_baseline_observation(&e->ac[i], dv, x); }
+void or_env_maneuver(OrEnv* e, int i, double turn_interval, double time_interval, double* dv, double* x) {
+  or_maneuver_delta(&e->ac[i], turn_interval, time_interval, dv); or_baseline_observation(&e->ac[i], dv, x);
+}
+void or_env_get_ctl_in(const OrEnv* e, int i, double* x) { for (int k = 0; k < 12; k++) x[k] = e->ac[i].ctl_in[k]; }

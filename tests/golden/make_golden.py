@@ -798,6 +798,48 @@ def gen_baseline_actor(rng):
     np.savez_compressed(os.path.join(OUT, "baseline_actor.npz"), x=X, action=ACT, hidden=H.astype(np.float32), logits=LOG.astype(np.float32))
 
 
+def gen_baseline_agents(rng):
+    """Scripted opponents of the `use_baseline` YAMLs (envs/JSBSim/model/baseline.py): PursueAgent.set_delta_value /
+    BaselineAgent.get_observation on random two-aircraft poses, and a ManeuverAgent('triangle') sequence (turn schedule + latched
+    initial heading). Outputs are the 12 controller inputs; the controller itself is pinned by baseline_actor.npz."""
+    import torch
+    from envs.JSBSim.model.baseline import PursueAgent, ManeuverAgent
+    orig = torch.load
+    torch.load = lambda f, map_location=None, **kw: orig(f, map_location="cpu", **kw)   # the reference asks for 'cuda'
+    try:
+        pursue, man = PursueAgent(agent_id=1), ManeuverAgent(agent_id=1, maneuver="triangle")
+    finally:
+        torch.load = orig
+    a, b = FakeAircraft("A0100", "Blue"), FakeAircraft("B0100", "Red")
+    link([a, b])
+    env = FakeEnv([a, b])
+    # the three delta properties are read (and ignored) by get_observation's state_var
+    for k, prop in enumerate(pursue.state_var[:3]):
+        for ac in (a, b):
+            ac.props[prop.name_jsbsim] = 0.0
+    P = 160
+    poses = np.zeros((P, 2, 20)); delta = np.zeros((P, 3)); obs = np.zeros((P, 12))
+    for k in range(P):
+        random_pose(rng, a); random_pose(rng, b, spread_km=12.0 if k % 3 else 2.0)
+        poses[k, 0], poses[k, 1] = pose_vector(a), pose_vector(b)
+        dv = pursue.set_delta_value(env, None, 0)
+        delta[k] = dv
+        obs[k] = pursue.get_observation(env, None, dv)[0]
+    # maneuver: 70 steps with a 1.5 s turn interval so that several schedule entries are crossed
+    man.turn_interval = 1.5
+    man.reset()
+    T = 70
+    mposes = np.zeros((T, 20)); mdelta = np.zeros((T, 3)); mobs = np.zeros((T, 12))
+    for t_ in range(T):
+        random_pose(rng, b)
+        mposes[t_] = pose_vector(b)
+        dv = man.set_delta_value(env, None)
+        mdelta[t_] = dv
+        mobs[t_] = man.get_observation(env, None, dv)[0]
+    np.savez_compressed(os.path.join(OUT, "baseline_agents.npz"), poses=poses, pursue_delta=delta, pursue_obs=obs,
+                        man_poses=mposes, man_delta=mdelta, man_obs=mobs, man_turn_interval=1.5, time_interval=env.time_interval)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit(f"{REF} not present: golden vectors are generated in the build container only")
@@ -813,6 +855,7 @@ def main():
     gen_multicombat_sequences(np.random.default_rng(77))
     gen_scenario_sequences(np.random.default_rng(78))
     gen_baseline_actor(np.random.default_rng(79))
+    gen_baseline_agents(np.random.default_rng(80))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

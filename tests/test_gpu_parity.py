@@ -353,8 +353,9 @@ def test_dodge_missile_rule_based_launch(pkg, oracle):
     env.close()
 
 
-@pytest.mark.parametrize("task", ["hierarchical_singlecombat", "scenario1", "scenario_nvn"])
-def test_hierarchical_tasks_lowlevel_controller(pkg, oracle, task):
+@pytest.mark.parametrize("task,baseline", [("hierarchical_singlecombat", 0), ("scenario1", 0), ("scenario_nvn", 0),
+                                           ("scenario1", 1), ("scenario_nvn", 1), ("hierarchical_singlecombat", 2)])
+def test_hierarchical_tasks_lowlevel_controller(pkg, oracle, task, baseline):
     """The as-shipped action space: MultiDiscrete [3,5,3] (+ four weapon bits) -> BaselineActor (MLP + GRU + four argmax
     heads) -> control indices -> step. Each step both sides start from the oracle's flight state and GRU state; compared are the
     controller's argmax indices (identical except where the oracle's own top-two logits tie to fp32 accuracy: < 0.2 % of

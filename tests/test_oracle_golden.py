@@ -273,3 +273,29 @@ def test_lowlevel_controller_matches_reference_module(oracle):
                     flips += 1
             h = g["hidden"][s, t].astype(np.float64)      # follow the reference's trajectory
     assert flips <= total // 200, (flips, total)
+
+
+def test_scripted_opponents_match_reference(oracle):
+    """PursueAgent / ManeuverAgent('triangle') of the use_baseline YAMLs: delta values and the 12 controller inputs from the
+    reference's own classes on random poses; the maneuver sequence crosses several schedule entries with its latched heading."""
+    g = load("baseline_agents.npz")
+    cfg = oracle.default_config(oracle.TASK_SINGLECOMBAT)
+    env = oracle.OracleEnv(cfg)
+    env.reset()
+    dp = C.POINTER(C.c_double)
+    L = env.L
+    L.or_env_pursue.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp]
+    L.or_env_maneuver.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, dp, dp]
+    for k in range(g["poses"].shape[0]):
+        env.set_pose(0, g["poses"][k, 0]); env.set_pose(1, g["poses"][k, 1])
+        dv, x = np.zeros(3), np.zeros(12)
+        L.or_env_pursue(env.p, 1, 0, dv.ctypes.data_as(dp), x.ctypes.data_as(dp))
+        assert np.allclose(dv, g["pursue_delta"][k], rtol=1e-9, atol=5e-8), (k, dv, g["pursue_delta"][k])
+        assert np.allclose(x, g["pursue_obs"][k], rtol=1e-9, atol=5e-8), (k, x, g["pursue_obs"][k])
+    env.task_reset()
+    for t in range(g["man_poses"].shape[0]):
+        env.set_pose(1, g["man_poses"][t])
+        dv, x = np.zeros(3), np.zeros(12)
+        L.or_env_maneuver(env.p, 1, float(g["man_turn_interval"]), float(g["time_interval"]), dv.ctypes.data_as(dp), x.ctypes.data_as(dp))
+        assert np.allclose(dv, g["man_delta"][t], rtol=1e-9, atol=1e-9), (t, dv, g["man_delta"][t])
+        assert np.allclose(x, g["man_obs"][t], rtol=1e-9, atol=1e-9), (t, x, g["man_obs"][t])
