@@ -26,7 +26,45 @@ TASK_IDS = {
 # are hierarchical in the reference (scenario1_task.py:11, scenario2_task.py:14); config_from_yaml follows that, while
 # default_config() keeps the control-index form unless asked (tests drive the weapon rules with explicit controls).
 ALWAYS_HIERARCHICAL = ("hierarchical_singlecombat", "hierarchical_multiplecombat")
-HIERARCHICAL_IN_REFERENCE = ALWAYS_HIERARCHICAL + ("scenario1", "scenario2_nvn", "scenario3_nvn")
+HIERARCHICAL_IN_REFERENCE = ALWAYS_HIERARCHICAL + ("scenario1", "scenario2_nvn", "scenario3_nvn", "scenario1_curriculum",
+                                                   "scenario2_nvn_curriculum", "scenario3_nvn_curriculum")
+# The *_curriculum tasks (scenario1_task.py:147-195, scenario2_task.py:318-383) respawn the aircraft from
+# env.reset_simulators_curriculum(curriculum_angle) at every reset. The angle is meant to grow with the ego win rate, but it never
+# does in the reference: the 1v1 tasks AND `success` over conditions that start with LowAltitude (always False), and every task
+# pops its record back to 20 entries while the advance needs len(record) > 20. So these tasks are the base task with the
+# angle-0 spawn; `curriculum_angle` in the scenario dict selects another fixed angle for users who want one.
+CURRICULUM_BASE = {"scenario1_curriculum": "scenario1", "scenario2_nvn_curriculum": "scenario2_nvn",
+                   "scenario3_nvn_curriculum": "scenario3_nvn"}
+
+
+def curriculum_spawn(center_lat, center_lon, radius_km, angle_deg):
+    """calculate_coordinates_heading_by_curriculum (utils/utils.py:126-156) for one angle: a point on a circle about the centre
+    (0 deg = due south, counter-clockwise) and the heading to fly there; spherical Earth of 6371 km."""
+    import math
+    d = radius_km / 6371.0
+    la, lo = math.radians(center_lat), math.radians(center_lon)
+    th = math.radians(180 - angle_deg)
+    nla = math.asin(math.sin(la) * math.cos(d) + math.cos(la) * math.sin(d) * math.cos(th))
+    nlo = lo + math.atan2(math.sin(th) * math.sin(d) * math.cos(la), math.cos(d) - math.sin(la) * math.sin(nla))
+    hdg = 2 * angle_deg if 0 <= angle_deg < 90 else 360 - 2 * angle_deg
+    return math.degrees(nla), math.degrees(nlo), hdg
+
+
+def apply_curriculum_spawn(cfg, angle=0):
+    """reset_simulators_curriculum (singlecombat_env.py:87-122 for two aircraft, multiplecombat_env.py:185-248 otherwise, which
+    rewrites list entries 0..3 whatever the team sizes): 20 000 ft, 800 ft/s."""
+    def put(i, lat, lon, psi):
+        ic = cfg.init[i]
+        ic.lat_geod_deg, ic.lon_deg, ic.psi_deg, ic.h_sl_ft, ic.u_fps = lat, lon, float(psi), 20000.0, 800.0
+    if cfg.n_agents == 2:
+        put(0, *curriculum_spawn(60.1, 120.0, 11.119, angle))
+        put(1, 60.1, 120.0, 0)
+    else:
+        put(0, *curriculum_spawn(60.1, 120.0, 11.119, angle))
+        put(1, *curriculum_spawn(60.1, 120.01, 11.119, angle))
+        put(2, 60.1, 120.0, 0)
+        put(3, 60.1, 120.01, 0)
+    return cfg
 
 # defaults of AircraftSimulator.clear_defalut_condition (simulatior.py:192-208)
 _IC_DEFAULT = dict(lon_deg=120.0, lat_geod_deg=60.0, h_sl_ft=20000.0, psi_deg=0.0, u_fps=800.0, v_fps=0.0, w_fps=0.0,
@@ -45,6 +83,11 @@ def config_from_dict(data, task=None, hierarchical=None):
     ``hierarchical`` (None = what the task name implies) selects the [3,5,3] action through the low-level controller."""
     cfg = AcConfig()
     name = task or data.get("task")
+    curriculum = name in CURRICULUM_BASE
+    if curriculum:
+        if hierarchical is None:
+            hierarchical = False
+        name = CURRICULUM_BASE[name]
     if name not in TASK_IDS:
         raise NotImplementedError(f"Unknown taskname: {name} (available: {sorted(TASK_IDS)})")
     cfg.task = TASK_IDS[name]
@@ -112,6 +155,8 @@ def config_from_dict(data, task=None, hierarchical=None):
     cfg.max_altitude_increment = float(first.get("max_altitude_increment", 7000))
     cfg.max_velocities_u_increment = float(first.get("max_velocities_u_increment", 100))
     cfg.check_interval = float(first.get("check_interval", 30))
+    if curriculum:
+        apply_curriculum_spawn(cfg, int(data.get("curriculum_angle", 0)))
     return cfg
 
 

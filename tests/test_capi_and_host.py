@@ -95,3 +95,23 @@ def test_generated_table_copies_are_in_sync():
     a = open(os.path.join(ROOT, "oracle", "f16_tables.h")).read()
     b = open(os.path.join(ROOT, "aircombat-selfplay_amd", "csrc", "f16_tables.h")).read()
     assert a == b
+
+
+def test_curriculum_spawn_matches_reference_table():
+    """Host-side restatement of calculate_coordinates_heading_by_curriculum against the fixture generated from the reference,
+    and the *_curriculum task names resolving to their base task with the angle-0 spawn."""
+    import numpy as np
+    import aircombat_selfplay_amd as pkg
+    from aircombat_selfplay_amd.config import curriculum_spawn, config_from_dict
+    t = np.load(os.path.join(os.path.dirname(__file__), "golden", "curriculum_spawn.npz"))["table"]
+    for a in range(181):
+        assert np.allclose(curriculum_spawn(60.1, 120.0, 11.119, a), t[a], rtol=0, atol=1e-12), a
+    base = pkg.default_config("scenario1")
+    data = {"task": "scenario1_curriculum", "sim_freq": 60, "agent_interaction_steps": 6,
+            "aircraft_configs": {"A0100": {"color": "Blue", "missile": 2, "init_state": {}}, "B0100": {"color": "Red", "missile": 2, "init_state": {}}}}
+    cfg = config_from_dict(data, hierarchical=True)
+    assert cfg.task == base.task and cfg.hierarchical == 1
+    assert abs(cfg.init[0].lat_geod_deg - t[0][0]) < 1e-12 and cfg.init[0].psi_deg == 0 and cfg.init[1].lat_geod_deg == 60.1
+    data["curriculum_angle"] = 45
+    cfg = config_from_dict(data)
+    assert abs(cfg.init[0].lon_deg - t[45][1]) < 1e-12 and cfg.init[0].psi_deg == 90
