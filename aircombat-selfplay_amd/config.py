@@ -27,14 +27,19 @@ TASK_IDS = {
 # default_config() keeps the control-index form unless asked (tests drive the weapon rules with explicit controls).
 ALWAYS_HIERARCHICAL = ("hierarchical_singlecombat", "hierarchical_multiplecombat")
 HIERARCHICAL_IN_REFERENCE = ALWAYS_HIERARCHICAL + ("scenario1", "scenario2_nvn", "scenario3_nvn", "scenario1_curriculum",
-                                                   "scenario2_nvn_curriculum", "scenario3_nvn_curriculum")
+                                                   "scenario2_nvn_curriculum", "scenario3_nvn_curriculum", "scenario1_rwr",
+                                                   "scenario2_rwr", "scenario3_rwr", "scenario1_rwr_curriculum",
+                                                   "scenario2_rwr_curriculum", "scenario3_rwr_curriculum")
 # The *_curriculum tasks (scenario1_task.py:147-195, scenario2_task.py:318-383) respawn the aircraft from
 # env.reset_simulators_curriculum(curriculum_angle) at every reset. The angle is meant to grow with the ego win rate, but it never
 # does in the reference: the 1v1 tasks AND `success` over conditions that start with LowAltitude (always False), and every task
 # pops its record back to 20 entries while the advance needs len(record) > 20. So these tasks are the base task with the
 # angle-0 spawn; `curriculum_angle` in the scenario dict selects another fixed angle for users who want one.
 CURRICULUM_BASE = {"scenario1_curriculum": "scenario1", "scenario2_nvn_curriculum": "scenario2_nvn",
-                   "scenario3_nvn_curriculum": "scenario3_nvn"}
+                   "scenario3_nvn_curriculum": "scenario3_nvn", "scenario1_rwr_curriculum": "scenario1_rwr",
+                   "scenario2_rwr_curriculum": "scenario2_rwr", "scenario3_rwr_curriculum": "scenario3_rwr"}
+# *_RWR variants (scenario1_task.py:197-314, scenario2_task.py:385-476): the base task with two reserved observation slots
+RWR_BASE = {"scenario1_rwr": "scenario1", "scenario2_rwr": "scenario2_nvn", "scenario3_rwr": "scenario3_nvn"}
 
 
 def curriculum_spawn(center_lat, center_lon, radius_km, angle_deg):
@@ -88,9 +93,13 @@ def config_from_dict(data, task=None, hierarchical=None):
         if hierarchical is None:
             hierarchical = False
         name = CURRICULUM_BASE[name]
+    rwr = name in RWR_BASE
+    if rwr:
+        name = RWR_BASE[name]
     if name not in TASK_IDS:
         raise NotImplementedError(f"Unknown taskname: {name} (available: {sorted(TASK_IDS)})")
     cfg.task = TASK_IDS[name]
+    cfg.rwr = int(rwr)
     cfg.hierarchical = int(name in ALWAYS_HIERARCHICAL if hierarchical is None else bool(hierarchical))
     acs = data["aircraft_configs"]
     uids = list(acs.keys())

@@ -96,6 +96,7 @@ struct DevCfg {
   float alt_safe, alt_danger, alt_kv;
   float max_attack_angle, max_attack_distance;
   int min_attack_interval, use_artillery, lock_len;
+  int rwr;                    // *_RWR variants: obs_dim carries two extra zero slots
   int num_missiles[AC_MAX_AGENTS];
   // battle-field origin for pymap3d-style geodetic <-> NED (metres, WGS84)
   double P0x, P0y, P0z, sLat0, cLat0, sLon0, cLon0;
@@ -1028,8 +1029,9 @@ __global__ void reset_all_kernel(DevPtrs P, DevCfg c) {
     if (P.MD) { MslD m{}; m.status = MSL_INACTIVE; store_msl(P.MD, P.MI, N, n, k, m); }
     else { Msl m{}; m.status = MSL_INACTIVE; store_msl(P.MF, P.MI, N, n, k, m); }
   }
-  const float* tobs = P.tF + (size_t)NF * c.A + slot * OBS;
-  for (int k = 0; k < OBS; ++k) P.obs[(size_t)n * OBS + k] = tobs[k];
+  const int TOBS = OBS - (c.rwr ? 2 : 0);   // the template holds the task's own layout; RWR appends two zero slots
+  const float* tobs = P.tF + (size_t)NF * c.A + slot * TOBS;
+  for (int k = 0; k < OBS; ++k) P.obs[(size_t)n * OBS + k] = (k < TOBS) ? tobs[k] : 0.0f;
   zero_controller_state(P, N, n, true);
   P.rew[n] = 0.0f; P.done[n] = 0;
   if (slot == 0) { int* inf = P.info + (size_t)(n / c.A) * 4; inf[0] = 0; inf[1] = 0; inf[2] = 0; inf[3] = 0; }
@@ -1166,6 +1168,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     return fail("ac_create: use_baseline (1 pursue, 2 maneuver) needs the hierarchical form and equal teams (enemy k is flown by scripted agent k)");
   if (cfg->hierarchical && (cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE))
     return fail("ac_create: the hierarchical form is available for AC_TASK_SINGLECOMBAT, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN");
+  if (cfg->rwr && !scenario) return fail("ac_create: rwr is a variant of the scenario tasks (Scenario1_RWR, Scenario2_RWR, Scenario3_RWR)");
   if (n_envs <= 0) return fail("ac_create: n_envs must be positive");
   if (cfg->sim_freq != 60) return fail("ac_create: sim_freq must be 60 (the FDM tick is compiled for 1/60 s)");
   for (int i = 0; i < cfg->n_agents; ++i)
@@ -1179,6 +1182,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   h->cfg = *cfg; h->E = n_envs; h->A = cfg->n_agents; h->N = n_envs * cfg->n_agents; h->device = device_id;
   h->obs_dim = heading ? 12 : (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
+  const int tmpl_obs = h->obs_dim;
+  if (cfg->rwr) h->obs_dim += 2;   // scenario1_task.py:213-216, scenario2_task.py:403-413
   h->act_low = scenario ? 8 : ((cfg->task == AC_TASK_SHOOT_MISSILE) ? 5 : 4);
   // hierarchical tasks (HierarchicalSingleCombatTask and everything built on it): [3,5,3] (+ the four weapon bits)
   h->act_dim = cfg->hierarchical ? (scenario ? 7 : 3) : h->act_low;
@@ -1188,6 +1193,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   c.obs_dim = h->obs_dim; c.act_dim = h->act_low; c.N = h->N;
   c.msl_slots = (cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE) ? AC_MAX_MISSILES_PER_AGENT : (scenario ? 2 : 0);
   c.chaff_seed = seed;
+  c.rwr = cfg->rwr ? 1 : 0;
   c.altitude_limit = (float)cfg->altitude_limit; c.acc_x = (float)cfg->acc_limit_x; c.acc_y = (float)cfg->acc_limit_y; c.acc_z = (float)cfg->acc_limit_z;
   c.posture_scale = (float)cfg->posture_scale; c.altitude_scale = (float)cfg->altitude_scale; c.event_scale = (float)cfg->event_scale;
   c.missile_posture_scale = (float)cfg->missile_posture_scale; c.shoot_penalty_scale = (float)cfg->shoot_penalty_scale;
@@ -1224,7 +1230,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   for (int i = 0; i < F16_PACK_LEN; ++i) tab[i] = (float)F16_PACK[i];
   HIP_OK(hipMalloc(&h->d_tab, sizeof(float) * F16_PACK_LEN));
   HIP_OK(hipMemcpy(h->d_tab, tab.data(), sizeof(float) * F16_PACK_LEN, hipMemcpyHostToDevice));
-  HIP_OK(hipMalloc(&h->d_tF, sizeof(float) * ((size_t)NF * h->A + (size_t)h->A * h->obs_dim)));
+  HIP_OK(hipMalloc(&h->d_tF, sizeof(float) * ((size_t)NF * h->A + (size_t)h->A * tmpl_obs)));
   HIP_OK(hipMalloc(&h->d_tI, sizeof(int) * NI * h->A));
   HIP_OK(hipMalloc(&h->d_tD, sizeof(double) * ND * h->A));
   if (scenario) {

@@ -303,7 +303,8 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_scenario(DevPtrs P, DevCf
   float ob[OBS];
   if (!MULTI) {
     Enemy E = gather_pose(pr, base + e_first);
-    observe_1v1<AC_TASK_SHOOT_MISSILE>(pr, E, inc, ob);   // Scenario1 keeps the 21-value layout (scenario1_task.py:31-32)
+    const Incoming none{false, 0, 0, 0, 0, 0, 0};
+    observe_1v1<AC_TASK_SHOOT_MISSILE>(pr, E, c.rwr ? none : inc, ob);   // Scenario1 keeps the 21-value layout (scenario1_task.py:31-32); Scenario1_RWR blanks the missile block (:298-300)
   } else {
     // scenario2_task.py:256-316: ego 9, partners, enemies, then the missile block directly after them; not clipped
 #pragma unroll
@@ -486,9 +487,10 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_scenario(DevPtrs P, DevCf
     store_ext(XF, XI, N, n, x);
 #pragma unroll
     for (int k = 0; k < MS; ++k) store_msl(P.MD, P.MI, N, n, k, ms[k]);
-    float* o = P.obs + (size_t)n * OBS;
+    float* o = P.obs + (size_t)n * c.obs_dim;
 #pragma unroll
     for (int k = 0; k < OBS; ++k) o[k] = ob[k];
+    for (int k = OBS; k < c.obs_dim; ++k) o[k] = 0.0f;   // the two reserved slots of the *_RWR variants
     P.rew[n] = reward;
     P.done[n] = done ? 1 : 0;
     if (slot == 0) {

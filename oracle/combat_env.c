@@ -308,7 +308,7 @@ static int extreme_state(const OrAircraft* a) { /* catalog.py:386-416 */
 void or_env_init(OrEnv* e, const OrEnvConfig* c) {
   memset(e, 0, sizeof *e);
   e->cfg = *c;
-  e->obs_dim = or_env_obs_dim_n(c->task, c->n_aircraft);
+  e->obs_dim = or_env_obs_dim_n(c->task, c->n_aircraft) + (c->rwr ? 2 : 0);   /* scenario1_task.py:213-216, scenario2_task.py:403-413 */
   e->act_dim = or_env_act_dim_h(c->task, c->hierarchical);
   for (int i = 0; i < c->n_aircraft; i++) e->ac[i].team = (i < c->n_ego) ? 0 : 1;
   e->mp_prev_missile = -1;
@@ -359,7 +359,7 @@ static void obs_combat(const OrEnv* e, int i, double* o) { /* singlecombat_task.
     for (int k = 0; k < 15; k++) o[k] = clampd(-10, o[k], 10);
     return;
   }
-  int mk = missile_warning(e, i);
+  int mk = e->cfg.rwr ? -1 : missile_warning(e, i);   /* Scenario1_RWR.get_obs: `missile_sim = None` (scenario1_task.py:298-300) */
   if (mk >= 0) {
     const OrMissile* m = &e->msl[mk];
     double mf[6] = {m->position[0], m->position[1], m->position[2], m->velocity[0], m->velocity[1], m->velocity[2]};

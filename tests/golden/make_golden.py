@@ -798,6 +798,37 @@ def gen_baseline_actor(rng):
     np.savez_compressed(os.path.join(OUT, "baseline_actor.npz"), x=X, action=ACT, hidden=H.astype(np.float32), logits=LOG.astype(np.float32))
 
 
+def gen_rwr_obs(rng):
+    """Observation builders of the RWR task variants: Scenario1_RWR (23 values: the 21-value layout with the missile block forced
+    to zero and two reserved slots, scenario1_task.py:213-314) and Scenario2_RWR (11 + 6 per other aircraft + 6, i.e. the NvN layout
+    plus two trailing reserved slots, scenario2_task.py:403-476)."""
+    from envs.JSBSim.tasks.scenario1_task import Scenario1_RWR
+    from envs.JSBSim.tasks.scenario2_task import Scenario2_RWR
+    from envs.JSBSim.core.simulatior import MissileSimulator
+    out = {}
+    for fam, cls, uids in (("s1", Scenario1_RWR, ("A0100", "B0100")), ("nvn", Scenario2_RWR, ("A0100", "A0200", "B0100", "B0200"))):
+        acs = {u: {"color": "Blue" if u[0] == "A" else "Red", "missile": 2} for u in uids}
+        task = _scenario_task(cls, make_config(aircraft_configs=acs))
+        poses, obs, msl = [], [], []
+        for i in range(40):
+            agents = [FakeAircraft(u, acs[u]["color"]) for u in uids]
+            link(agents)
+            env = FakeEnv(agents)
+            for a in agents:
+                random_pose(rng, a, spread_km=10.0)
+            mrow = np.zeros(7)
+            if i % 2:
+                m = MissileSimulator.create(agents[-1], agents[0], "B01001")
+                m._position[:] = agents[0]._position + rng.normal(size=3) * np.array([4000, 4000, 800])
+                m._velocity[:] = rng.normal(size=3) * np.array([400, 400, 80])
+                mrow = np.concatenate([[1.0], m._position, m._velocity])
+            poses.append(np.stack([pose_vector(a) for a in agents]))
+            obs.append(np.stack([task.get_obs(env, u) for u in uids]))
+            msl.append(mrow)
+        out[f"{fam}_pose"], out[f"{fam}_obs"], out[f"{fam}_missile"] = np.array(poses), np.array(obs), np.array(msl)
+    np.savez_compressed(os.path.join(OUT, "rwr_obs.npz"), **out)
+
+
 def gen_baseline_agents(rng):
     """Scripted opponents of the `use_baseline` YAMLs (envs/JSBSim/model/baseline.py): PursueAgent.set_delta_value /
     BaselineAgent.get_observation on random two-aircraft poses, and a ManeuverAgent('triangle') sequence (turn schedule + latched
@@ -856,6 +887,7 @@ def main():
     gen_scenario_sequences(np.random.default_rng(78))
     gen_baseline_actor(np.random.default_rng(79))
     gen_baseline_agents(np.random.default_rng(80))
+    gen_rwr_obs(np.random.default_rng(81))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -184,9 +184,10 @@ def test_nvn_multicombat_matches_oracle(pkg, oracle, per_side):
     env.close()
 
 
-@pytest.mark.parametrize("task,per_side,geometry", [("scenario1", 1, "closing"), ("scenario1", 1, "tail"),
-                                                    ("scenario_nvn", 2, "closing"), ("scenario_nvn", 4, "closing")])
-def test_scenario_weapon_tasks_match_oracle(pkg, oracle, task, per_side, geometry):
+@pytest.mark.parametrize("task,per_side,geometry,rwr", [("scenario1", 1, "closing", 0), ("scenario1", 1, "tail", 0),
+                                                        ("scenario_nvn", 2, "closing", 0), ("scenario_nvn", 4, "closing", 0),
+                                                        ("scenario1", 1, "closing", 1), ("scenario_nvn", 2, "closing", 1)])
+def test_scenario_weapon_tasks_match_oracle(pkg, oracle, task, per_side, geometry, rwr):
     """Scenario1 (1v1) / Scenario2_NvN (2v2) / Scenario3_NvN (4v4): gun, AIM-120B / AIM-9M with uid reuse, chaff + keyed decoy
     draws, eleven reward terms with their shared references, env-family order of rewards and terminations. The aircraft state
     is re-synchronised from the oracle every step; missiles, chaff and all weapon bookkeeping run open-loop on both sides."""
@@ -206,6 +207,7 @@ def test_scenario_weapon_tasks_match_oracle(pkg, oracle, task, per_side, geometr
             cfg.init[i].h_sl_ft += 300.0 * i
             if i >= per_side:
                 cfg.init[i].lat_geod_deg = 60.06
+    cfg.rwr = rwr   # *_RWR variants: two reserved observation slots (and no missile block in the 1v1 observation)
     A = cfg.n_agents
     E = 4
     seed = 1234
@@ -226,7 +228,7 @@ def test_scenario_weapon_tasks_match_oracle(pkg, oracle, task, per_side, geometr
     rng = np.random.default_rng(11)
     launched = 0
     seen = {"gun": False, "chaff": False, "shotdown": False}
-    for step in range(330):
+    for step in range(150 if rwr else 330):
         for e in range(E):
             for a in range(A):
                 v = env.get_state(e, a)                      # task bookkeeping (munition slots, potentials) stays the device's own:
@@ -260,7 +262,8 @@ def test_scenario_weapon_tasks_match_oracle(pkg, oracle, task, per_side, geometr
             launched = max(launched, len(ref.envs[e].missiles()))
     assert launched >= (1 if geometry == "tail" else 2)
     want = {"closing": ("shotdown",), "tail": ("gun",)}[geometry] + (("chaff",) if A > 2 else ())
-    assert all(seen[k] for k in want), seen
+    assert rwr or all(seen[k] for k in want), seen
+    assert obs.shape[-1] == ((21 if A == 2 else 9 + 6 * A + 6) + (2 if rwr else 0))
     env.close()
 
 

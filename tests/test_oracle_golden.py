@@ -299,3 +299,24 @@ def test_scripted_opponents_match_reference(oracle):
         L.or_env_maneuver(env.p, 1, float(g["man_turn_interval"]), float(g["time_interval"]), dv.ctypes.data_as(dp), x.ctypes.data_as(dp))
         assert np.allclose(dv, g["man_delta"][t], rtol=1e-9, atol=1e-9), (t, dv, g["man_delta"][t])
         assert np.allclose(x, g["man_obs"][t], rtol=1e-9, atol=1e-9), (t, x, g["man_obs"][t])
+
+
+def test_rwr_observation_variants(oracle):
+    """Scenario1_RWR (23 values, missile block blanked) and Scenario2_RWR (NvN layout + two reserved slots) against the
+    reference's get_obs."""
+    g = load("rwr_obs.npz")
+    for fam, task, n in (("s1", oracle.TASK_SCENARIO1, 2), ("nvn", oracle.TASK_SCENARIO_NVN, 4)):
+        cfg = oracle.default_config(task)
+        cfg.rwr = 1
+        env = oracle.OracleEnv(cfg)
+        env.reset()
+        assert env.obs_dim == g[f"{fam}_obs"].shape[-1]
+        for k in range(g[f"{fam}_pose"].shape[0]):
+            for i in range(n):
+                env.set_pose(i, g[f"{fam}_pose"][k, i])
+            env.L.or_env_clear_missiles(env.p)
+            m = g[f"{fam}_missile"][k]
+            if m[0]:
+                env.add_missile(n - 1, 0, 0, m[1:4], m[4:7])
+            obs, _, _, _ = env.evaluate()
+            assert np.allclose(obs, g[f"{fam}_obs"][k], rtol=1e-9, atol=5e-8), (fam, k, np.abs(obs - g[f"{fam}_obs"][k]).max())
