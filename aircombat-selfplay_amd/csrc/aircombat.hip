@@ -97,6 +97,7 @@ struct DevCfg {
   float max_attack_angle, max_attack_distance;
   int min_attack_interval, use_artillery, lock_len;
   int rwr;                    // *_RWR variants: obs_dim carries two extra zero slots
+  int tobs;                   // observation slots per aircraft in the reset template (the kernel family's own layout)
   int num_missiles[AC_MAX_AGENTS];
   // battle-field origin for pymap3d-style geodetic <-> NED (metres, WGS84)
   double P0x, P0y, P0z, sLat0, cLat0, sLon0, cLon0;
@@ -1029,7 +1030,7 @@ __global__ void reset_all_kernel(DevPtrs P, DevCfg c) {
     if (P.MD) { MslD m{}; m.status = MSL_INACTIVE; store_msl(P.MD, P.MI, N, n, k, m); }
     else { Msl m{}; m.status = MSL_INACTIVE; store_msl(P.MF, P.MI, N, n, k, m); }
   }
-  const int TOBS = OBS - (c.rwr ? 2 : 0);   // the template holds the task's own layout; RWR appends two zero slots
+  const int TOBS = c.tobs;   // the template holds the kernel family's own layout; RWR appends two zero slots, WVR uses the first 15
   const float* tobs = P.tF + (size_t)NF * c.A + slot * TOBS;
   for (int k = 0; k < OBS; ++k) P.obs[(size_t)n * OBS + k] = (k < TOBS) ? tobs[k] : 0.0f;
   zero_controller_state(P, N, n, true);
@@ -1091,7 +1092,7 @@ static int launch_step(ac_env* h, const float* d_actions) {
     HIP_OK(hipGetLastError());
     return 0;
   }
-  if (h->cfg.task == AC_TASK_SCENARIO1 || h->cfg.task == AC_TASK_SCENARIO_NVN) {
+  if (h->cfg.task == AC_TASK_SCENARIO1 || h->cfg.task == AC_TASK_SCENARIO_NVN || h->cfg.task == AC_TASK_WVR) {
 #define AC_LAUNCH_SCN(AA)                                                                                                        \
   do {                                                                                                                           \
     if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_scenario<AA, 1>), grid, block, 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr); \
@@ -1143,7 +1144,7 @@ const char* ac_state_field_name(int i) { return (i >= 0 && i < AC_STATE_LEN && k
 
 int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_t seed, ac_env_t** out) {
   if (!cfg || !out) return fail("ac_create: null argument");
-  const bool scenario = cfg->task == AC_TASK_SCENARIO1 || cfg->task == AC_TASK_SCENARIO_NVN;
+  const bool scenario = cfg->task == AC_TASK_SCENARIO1 || cfg->task == AC_TASK_SCENARIO_NVN || cfg->task == AC_TASK_WVR;
   const bool heading = cfg->task == AC_TASK_HEADING;
   if (cfg->task != AC_TASK_SINGLECOMBAT && cfg->task != AC_TASK_SHOOT_MISSILE && cfg->task != AC_TASK_DODGE_MISSILE &&
       cfg->task != AC_TASK_MULTICOMBAT && !scenario && !heading)
@@ -1156,7 +1157,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     if ((cfg->n_agents != 4 && cfg->n_agents != 8) || cfg->n_ego * 2 != cfg->n_agents)
       return fail("ac_create: AC_TASK_SCENARIO_NVN needs n_agents in {4, 8} split into two equal teams");
   }
-  if (scenario)
+  if (scenario && cfg->task != AC_TASK_WVR)
     for (int i = 0; i < cfg->n_agents; ++i)
       if (cfg->num_missiles[i] != 2) return fail("ac_create: the scenario tasks are built for 'missile: 2' (two munition uids per aircraft), as every shipped YAML has");
   if (cfg->task == AC_TASK_SCENARIO_NVN) {
@@ -1168,6 +1169,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     return fail("ac_create: use_baseline (1 pursue, 2 maneuver) needs the hierarchical form and equal teams (enemy k is flown by scripted agent k)");
   if (cfg->hierarchical && (cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE))
     return fail("ac_create: the hierarchical form is available for AC_TASK_SINGLECOMBAT, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN");
+  if (cfg->task == AC_TASK_WVR && (cfg->n_agents != 2 || cfg->n_ego != 1 || cfg->rwr)) return fail("ac_create: AC_TASK_WVR is a 1v1 task");
   if (cfg->rwr && !scenario) return fail("ac_create: rwr is a variant of the scenario tasks (Scenario1_RWR, Scenario2_RWR, Scenario3_RWR)");
   if (n_envs <= 0) return fail("ac_create: n_envs must be positive");
   if (cfg->sim_freq != 60) return fail("ac_create: sim_freq must be 60 (the FDM tick is compiled for 1/60 s)");
@@ -1182,11 +1184,13 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   h->cfg = *cfg; h->E = n_envs; h->A = cfg->n_agents; h->N = n_envs * cfg->n_agents; h->device = device_id;
   h->obs_dim = heading ? 12 : (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
-  const int tmpl_obs = h->obs_dim;
+  const int tmpl_obs = h->obs_dim;   // (the scenario kernel family's template keeps 21 slots for WVR too)
+  if (cfg->task == AC_TASK_WVR) h->obs_dim = 15;
   if (cfg->rwr) h->obs_dim += 2;   // scenario1_task.py:213-216, scenario2_task.py:403-413
-  h->act_low = scenario ? 8 : ((cfg->task == AC_TASK_SHOOT_MISSILE) ? 5 : 4);
+  const bool weapon_bits = scenario && cfg->task != AC_TASK_WVR;
+  h->act_low = weapon_bits ? 8 : ((cfg->task == AC_TASK_SHOOT_MISSILE) ? 5 : 4);
   // hierarchical tasks (HierarchicalSingleCombatTask and everything built on it): [3,5,3] (+ the four weapon bits)
-  h->act_dim = cfg->hierarchical ? (scenario ? 7 : 3) : h->act_low;
+  h->act_dim = cfg->hierarchical ? (weapon_bits ? 7 : 3) : h->act_low;
   DevCfg& c = h->dc;
   memset(&c, 0, sizeof c);
   c.task = cfg->task; c.A = h->A; c.n_ego = cfg->n_ego; c.substeps = cfg->agent_interaction_steps; c.max_steps = cfg->max_steps;
@@ -1194,6 +1198,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   c.msl_slots = (cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE) ? AC_MAX_MISSILES_PER_AGENT : (scenario ? 2 : 0);
   c.chaff_seed = seed;
   c.rwr = cfg->rwr ? 1 : 0;
+  c.tobs = tmpl_obs;
   c.altitude_limit = (float)cfg->altitude_limit; c.acc_x = (float)cfg->acc_limit_x; c.acc_y = (float)cfg->acc_limit_y; c.acc_z = (float)cfg->acc_limit_z;
   c.posture_scale = (float)cfg->posture_scale; c.altitude_scale = (float)cfg->altitude_scale; c.event_scale = (float)cfg->event_scale;
   c.missile_posture_scale = (float)cfg->missile_posture_scale; c.shoot_penalty_scale = (float)cfg->shoot_penalty_scale;

@@ -798,6 +798,72 @@ def gen_baseline_actor(rng):
     np.savez_compressed(os.path.join(OUT, "baseline_actor.npz"), x=X, action=ACT, hidden=H.astype(np.float32), logits=LOG.astype(np.float32))
 
 
+def gen_wvr_sequences(rng):
+    """WVRTask (tasks/WVR_task.py:10-90): the 15-value SingleCombatTask observation, the unlimited gun (-5 blood on the farthest
+    enemy inside 3 km and 5 deg, dead shooters included), eight reward terms, terminations WITHOUT SafeReturn."""
+    from envs.JSBSim.tasks.WVR_task import WVRTask
+    flat = {}
+    uids = ("A0100", "B0100")
+    acs = {u: {"color": "Blue" if u[0] == "A" else "Red", "missile": 2} for u in uids}
+    cfg = make_config(aircraft_configs=acs, max_steps=60)
+    for ep in range(4):
+        task = _scenario_task(WVRTask, cfg)
+        agents = [FakeAircraft(u, acs[u]["color"]) for u in uids]
+        link(agents)
+        env = WeaponEnv(agents)
+        env.reset_simulators_curriculum = lambda angle: None     # the spawn is the env's business; poses are scripted here
+        shooter, target = agents
+        kind = ep % 4      # 0 tail chase inside the gun envelope, 1 random poses, 2 slow closure into the envelope, 3 runs to max_steps
+
+        def chase_pose(t):
+            sep0 = {0: 1500.0, 2: 3600.0, 3: 9000.0}[kind]
+            vs, vt = 255.0, (235.0 if kind != 2 else 215.0)
+            ys, yt = vs * 0.1 * t, sep0 + vt * 0.1 * t
+            off = 20.0 * np.sin(0.07 * t)
+            shooter.set_pose(120.0, 60.0 + ys / 111412.0, 6000.0, (0.02, 0.01, 0.0), (vs, 0.0, -1.0), (vs, 0.5, 4.0), vc=240.0,
+                             npilot=(0.1, 0.0, -1.05), sim_time=12.0 + 0.1 * t)
+            target.set_pose(120.0 + off / 55660.0, 60.0 + yt / 111412.0, 6050.0, (0.0, 0.0, 0.0), (vt, 0.0, 1.0), (vt, -0.5, 3.0),
+                            vc=225.0, npilot=(0.0, 0.0, -1.0), sim_time=12.0 + 0.1 * t)
+        if kind == 1:
+            for a in agents:
+                random_pose(rng, a, spread_km=3.0, alt=(2600.0, 9000.0))
+        else:
+            chase_pose(0)
+        task.reset(env)
+        frames = []
+        for t in range(1, 70):
+            env.current_step = t
+            if kind == 1:
+                for a in agents:
+                    if a.is_alive:
+                        random_pose(rng, a, spread_km=3.0, alt=(2300.0 if t > 25 else 2600.0, 9000.0))
+            else:
+                chase_pose(t)
+            pose = np.stack([pose_vector(a) for a in agents])
+            env.run_projectiles(0)          # AircraftSimulator.run: bloods <= 0 -> shot down
+            task.step(env)
+            obs = np.stack([task.get_obs(env, u) for u in env.agents])
+            info = {"current_step": env.current_step}
+            done = []
+            for u in env.agents:
+                d, info = task.get_termination(env, u, info)
+                done.append(d)
+            rew = []
+            for u in env.agents:
+                r, info = task.get_reward(env, u, info)
+                rew.append(r)
+            state = np.array([[a.bloods, a.status] for a in agents], dtype=float)
+            frames.append(dict(pose=pose, obs=obs, rew=np.array(rew, dtype=float), done=np.array(done, dtype=float), state=state, step=t))
+            if all(done):
+                break
+        for key in ("pose", "obs", "rew", "done", "state"):
+            flat[f"ep{ep}_{key}"] = np.stack([f[key] for f in frames])
+        flat[f"ep{ep}_step"] = np.array([f["step"] for f in frames], dtype=float)
+    flat["n_episodes"] = np.array([4.0])
+    flat["max_steps"] = np.array([60.0])
+    np.savez_compressed(os.path.join(OUT, "wvr_sequences.npz"), **flat)
+
+
 def gen_rwr_obs(rng):
     """Observation builders of the RWR task variants: Scenario1_RWR (23 values: the 21-value layout with the missile block forced
     to zero and two reserved slots, scenario1_task.py:213-314) and Scenario2_RWR (11 + 6 per other aircraft + 6, i.e. the NvN layout
@@ -888,6 +954,7 @@ def main():
     gen_baseline_actor(np.random.default_rng(79))
     gen_baseline_agents(np.random.default_rng(80))
     gen_rwr_obs(np.random.default_rng(81))
+    gen_wvr_sequences(np.random.default_rng(82))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

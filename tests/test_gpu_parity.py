@@ -461,3 +461,48 @@ def test_heading_task_numpy_stream_on_device(pkg, oracle):
                 assert info[e].get("heading_turn_counts") == int(i[2])
     assert resets >= 3 and turns >= 1, (resets, turns)
     env.close()
+
+
+def test_wvr_task_gun_only(pkg, oracle):
+    """WVRTask on the device (the scenario kernel family in its gun-only mode): 15-value clipped observation, unlimited gun on
+    the farthest enemy with no aliveness checks, eight reward terms, no SafeReturn (a shot-down aircraft just stops flying until
+    the other one times out or crashes). Flight state re-synchronised each step; blood, statuses and references run open-loop."""
+    cfg = pkg.default_config("wvr_lowlevel")
+    cfg.max_steps = 120
+    cfg.init[0].psi_deg = 0.0   # tail chase 1.6 km behind, 1.5 deg off the nose: inside the 3 km / 5 deg gun envelope
+    cfg.init[1].lon_deg, cfg.init[1].lat_geod_deg, cfg.init[1].psi_deg = cfg.init[0].lon_deg + 0.0008, cfg.init[0].lat_geod_deg + 0.0145, 2.0
+    E = 4
+    env = pkg.HipVecEnv(cfg, E)
+    ref = oracle.OracleVecEnv(oracle.config_from_ac(cfg), E)
+    obs, robs = env.reset(), ref.reset()
+    assert obs.shape == robs.shape == (E, 2, 15) and env.act_dim == 4
+    assert obs_close(obs, robs).all()
+    names = env.lib.state_field_names()
+    ix = {nm: k for k, nm in enumerate(names) if nm}
+    task_fields = ("bloods", "pre_posture", "pre_altitude", "pre_event", "pre_shoot", "status", "die_flag", "remaining", "pre_remaining",
+                   "shoot_action", "last_missile", "last_shoot_time", "lock_bits", "lock_pos", "cur_step")
+    fdm_fields = np.array([k for k, nm in enumerate(names) if nm and not nm.startswith("x_") and nm not in task_fields])
+    rng = np.random.default_rng(31)
+    shot = resets = 0
+    for step in range(260):
+        for e in range(E):
+            for a in range(2):
+                v = env.get_state(e, a)
+                v[fdm_fields] = ref.envs[e].export_state(a)[fdm_fields]
+                env.set_state(e, a, v)
+        act = np.array([20, 18.6, 20, 15], dtype=np.float32) + rng.integers(-2, 3, size=(E, 2, 4)).astype(np.float32)
+        obs, rew, done, info = env.step(act)
+        robs, rrew, rdone, rinfo = ref.step(act)
+        assert (done == rdone).all(), (step, done[..., 0], rdone[..., 0])
+        ok = nvn_obs_close(obs, robs)
+        assert ok.all(), (step, np.argwhere(~ok)[:4], obs[~ok][:4], robs[~ok][:4])
+        assert (np.abs(rew - rrew) <= 10 * (5e-3 + 1e-3 * np.abs(rrew))).all(), (step, rew.ravel(), rrew.ravel())
+        for e in range(E):
+            resets += int(rinfo[e][3])
+            if not rinfo[e][3]:
+                for a in range(2):
+                    g, o = env.get_state(e, a), ref.envs[e].export_state(a)
+                    assert abs(g[ix["bloods"]] - o[ix["bloods"]]) < 1e-3 and g[ix["status"]] == o[ix["status"]], (step, e, a)
+                    shot += int(o[ix["status"]] == 2)
+    assert shot > 0 and resets >= E
+    env.close()

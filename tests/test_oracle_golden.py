@@ -320,3 +320,35 @@ def test_rwr_observation_variants(oracle):
                 env.add_missile(n - 1, 0, 0, m[1:4], m[4:7])
             obs, _, _, _ = env.evaluate()
             assert np.allclose(obs, g[f"{fam}_obs"][k], rtol=1e-9, atol=5e-8), (fam, k, np.abs(obs - g[f"{fam}_obs"][k]).max())
+
+
+def test_wvr_task_sequences(oracle):
+    """WVRTask: 15-value observation, unlimited gun on the farthest enemy (no aliveness checks), eight reward terms with the shared
+    reference lists, terminations LowAltitude / ExtremeState / Overload / Timeout only (a shot-down aircraft is not 'done')."""
+    g = load("wvr_sequences.npz")
+    shot = crashed = 0
+    for ep in range(int(g["n_episodes"][0])):
+        cfg = oracle.default_config(oracle.TASK_WVR)
+        cfg.max_steps = int(g["max_steps"][0])
+        env = oracle.OracleEnv(cfg)
+        pose, obs, rew, done, state, step = (g[f"ep{ep}_{k}"] for k in ("pose", "obs", "rew", "done", "state", "step"))
+        for t in range(len(pose)):
+            for i in range(2):
+                env.set_pose(i, pose[t][i])
+            if t == 0:
+                env.set_step(0)
+                env.task_reset()
+            env.set_step(int(step[t]))
+            env.L.or_env_run_projectiles(env.p, 0)
+            env.L.or_env_task_step(env.p)
+            o, r, d, info = env.evaluate()
+            assert close(o, obs[t], rtol=1e-9, atol=5e-8).all(), (ep, t, np.abs(o - obs[t]).max())
+            assert (d == done[t].astype(bool)).all(), (ep, t, d, done[t])
+            got = np.zeros((2, 6))
+            for i in range(2):
+                env.L.or_env_get_counters(env.p, i, got[i].ctypes.data_as(C.POINTER(C.c_double)))
+            assert (got[:, 4:6] == state[t]).all(), (ep, t, got[:, 4:6], state[t])
+            if t >= 1:
+                assert close(r, rew[t], rtol=1e-7, atol=1e-6).all(), (ep, t, r, rew[t])
+            shot += int((state[t][:, 1] == 2).any()); crashed += int((state[t][:, 1] == 1).any())
+    assert shot and crashed
