@@ -160,8 +160,44 @@ class HipVecEnv:
         self.step_async(actions)
         return self.step_wait()
 
-    def render(self, mode="txt", filepath="./JSBSimRecording.txt.acmi"):
-        raise NotImplementedError("ACMI rendering is SURVEY row N3 (not on the step() hot path)")
+    def render(self, mode="txt", filepath="./JSBSimRecording.txt.acmi", env=0):
+        """BaseEnv.render (env_base.py:207-250) for one env (the reference renders through DummyVecEnv, i.e. env 0): appends one
+        Tacview ACMI frame — every aircraft, every launched missile, explosions once — to `filepath`."""
+        from . import acmi
+        if mode != "txt":
+            raise NotImplementedError
+        self._assert_not_closed()
+        if not getattr(self, "_acmi_started", False):
+            with open(filepath, mode="w", encoding="utf-8-sig") as f:
+                f.write(acmi.HEADER)
+            self._acmi_started, self._acmi_exploded = True, set()
+        cfg = self.config
+        center = (cfg.center_lon, cfg.center_lat, cfg.center_alt)
+        uids = getattr(cfg, "uids", None) or [f"{'A' if a < cfg.n_ego else 'B'}0{(a if a < cfg.n_ego else a - cfg.n_ego) + 1}00" for a in range(self.num_agents)]
+        step = int(self.get_state(env, 0)[self._ix("cur_step")])
+        lines = [f"#{step * cfg.agent_interaction_steps / cfg.sim_freq:.2f}"]
+        for a in range(self.num_agents):
+            lines.append(acmi.aircraft_record(uids[a], "Blue" if a < cfg.n_ego else "Red", self.get_entity(env, a)))
+        slots = {AC_TASK_SHOOT_MISSILE: 4, 2: 4, AC_TASK_SCENARIO1: 2, AC_TASK_SCENARIO_NVN: 2}.get(cfg.task, 0)
+        for a in range(self.num_agents):
+            for k in range(slots):
+                m = self.get_missile(env, a, k)
+                if m[0] < 0:
+                    self._acmi_exploded.discard((a, k))
+                    continue
+                uid = f"{uids[a]}{k + 1}"
+                rec, boom = acmi.missile_records(uid, "Blue" if a < cfg.n_ego else "Red", int(m[0]), m[1:4], m[7], m[8], center,
+                                                 (a, k) in self._acmi_exploded, 300 if slots == 4 else 5)
+                if boom:
+                    self._acmi_exploded.add((a, k))
+                lines.append(rec)
+        with open(filepath, mode="a", encoding="utf-8-sig") as f:
+            f.write("\n".join(lines) + "\n")
+
+    def _ix(self, name):
+        if not hasattr(self, "_names"):
+            self._names = self.lib.state_field_names()
+        return self._names.index(name)
 
     def close(self):
         if self.closed:

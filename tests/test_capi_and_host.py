@@ -115,3 +115,29 @@ def test_curriculum_spawn_matches_reference_table():
     data["curriculum_angle"] = 45
     cfg = config_from_dict(data)
     assert abs(cfg.init[0].lon_deg - t[45][1]) < 1e-12 and cfg.init[0].psi_deg == 90
+
+
+def test_acmi_records_and_neu_inverse():
+    """Host-side ACMI formatting (BaseSimulator.log / MissileSimulator.log) and the NEU -> geodetic inverse used for missile
+    records, against the CPU checker's restatement of pymap3d (round trip < 1 mm, 1e-9 deg)."""
+    import importlib
+    import numpy as np
+    import aircombat_selfplay_amd as pkg
+    acmi = importlib.import_module(pkg.__name__ + ".acmi")
+    from oracle import oracle as O
+    L = O.lib()
+    dp = C.POINTER(C.c_double)
+    L.or_neu2lla.argtypes = [C.c_double] * 6 + [dp]
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        n, e, u = rng.uniform(-60000, 60000), rng.uniform(-60000, 60000), rng.uniform(0, 15000)
+        out = np.zeros(3)
+        L.or_neu2lla(n, e, u, 120.0, 60.0, 0.0, out.ctypes.data_as(dp))
+        got = acmi.neu_to_lla(n, e, u, 120.0, 60.0, 0.0)
+        assert abs(got[0] - out[0]) < 1e-9 and abs(got[1] - out[1]) < 1e-9 and abs(got[2] - out[2]) < 1e-3, (got, out)
+    rec = acmi.aircraft_record("A0100", "Blue", [120.0, 60.0, 6096.0, 0.0, 0.1, 1.0])
+    assert rec.startswith("A0100,T=120.0|60.0|6096.0|0.0|") and rec.endswith("Name=F16,Color=Blue")
+    r, boom = acmi.missile_records("A01001", "Blue", 1, (100.0, 50.0, 6000.0), 0.0, 0.5, (120.0, 60.0, 0.0), False, 300)
+    assert boom and r.startswith("-A01001\nA01001F,T=") and "Type=Misc+Explosion" in r
+    r2, boom2 = acmi.missile_records("A01001", "Blue", 1, (100.0, 50.0, 6000.0), 0.0, 0.5, (120.0, 60.0, 0.0), True, 300)
+    assert r2 == "-A01001" and boom2

@@ -506,3 +506,26 @@ def test_wvr_task_gun_only(pkg, oracle):
                     shot += int(o[ix["status"]] == 2)
     assert shot > 0 and resets >= E
     env.close()
+
+
+def test_render_writes_acmi_frames(pkg, tmp_path):
+    """BaseEnv.render's Tacview text records from the device state: header once, one '#time' frame per call, one record per
+    aircraft with its geodetic position and attitude in degrees, missile records once something is launched."""
+    cfg = pkg.default_config("singlecombat_shoot")
+    cfg.init[1].lon_deg, cfg.init[1].lat_geod_deg, cfg.init[1].psi_deg = 120.02, 60.06, 171.0
+    env = pkg.HipVecEnv(cfg, 2)
+    env.reset()
+    path = str(tmp_path / "rec.txt.acmi")
+    act = np.zeros((2, 2, 5), dtype=np.float32); act[..., :4] = [20, 18.6, 20, 15]; act[..., 4] = 1
+    for _ in range(3):
+        env.step(act)
+        env.render(filepath=path)
+    text = open(path, encoding="utf-8-sig").read().splitlines()
+    assert text[:3] == ["FileType=text/acmi/tacview", "FileVersion=2.1", "0,ReferenceTime=2020-04-01T00:00:00Z"]
+    assert [l for l in text if l.startswith("#")] == ["#0.10", "#0.20", "#0.30"]
+    a0 = [l for l in text if l.startswith("A0100,T=")]
+    assert len(a0) == 3 and a0[0].endswith("Name=F16,Color=Blue")
+    lon, lat, alt = (float(v) for v in a0[0].split("T=")[1].split(",")[0].split("|")[:3])
+    assert abs(lon - 120.0) < 1e-2 and abs(lat - 60.0) < 1e-2 and abs(alt - 6096) < 5
+    assert any(l.startswith("A01001,T=") and "Name=AIM-9L" in l for l in text)   # the shoot bit launched a missile
+    env.close()
