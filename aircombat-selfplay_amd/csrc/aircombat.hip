@@ -1057,6 +1057,7 @@ struct ac_env {
   float* d_tab;
   float* d_tF; int* d_tI; double* d_tD;
   float* d_XF; int* d_XI;                // scenario-task extension state
+  float* d_scripted;                     // [N][12] controller inputs of scripted opponents
   float* d_ctlW; float* d_low;           // hierarchical tasks: controller weights (device layout), low-level action buffer
   HeadingPtrs hp; HeadingCfg hc;         // HeadingTask: targets, check clock, numpy-PCG64 state per env
   int act_low;                           // width of the low-level action the step kernels decode
@@ -1081,7 +1082,11 @@ static int launch_step(ac_env* h, const float* d_actions) {
     if (!h->d_ctlW) return fail("hierarchical task: ac_load_controller has not been called");
     ctl::Args a{h->d_ctlW, p.actions, p.obs, p.H, h->d_low, h->N, h->obs_dim, h->act_dim, h->act_low,
                 h->cfg.use_baseline, h->A, h->cfg.n_ego, h->cfg.use_artillery,
-                (float)h->cfg.agent_interaction_steps / (float)h->cfg.sim_freq, p.man_step, p.man_h0, p, h->dc};
+                (float)h->cfg.agent_interaction_steps / (float)h->cfg.sim_freq, p.man_step, p.man_h0, p, h->dc, h->d_scripted};
+    if (h->cfg.use_baseline) {
+      hipLaunchKernelGGL(scripted_inputs_kernel, grid, block, 0, h->stream, a);
+      HIP_OK(hipGetLastError());
+    }
     hipLaunchKernelGGL(controller_kernel, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
     HIP_OK(hipGetLastError());
     p.actions = h->d_low;
@@ -1267,6 +1272,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     HIP_OK(hipMemset(p.H, 0, sizeof(float) * 128 * N));
     HIP_OK(hipMalloc(&h->d_low, sizeof(float) * N * h->act_low));
     HIP_OK(hipMemset(h->d_low, 0, sizeof(float) * N * h->act_low));
+    HIP_OK(hipMalloc(&h->d_scripted, sizeof(float) * 12 * N));
+    HIP_OK(hipMemset(h->d_scripted, 0, sizeof(float) * 12 * N));
     HIP_OK(hipMalloc(&p.man_step, sizeof(int) * N));
     HIP_OK(hipMemset(p.man_step, 0, sizeof(int) * N));
     HIP_OK(hipMalloc(&p.man_h0, sizeof(float) * N));
@@ -1303,7 +1310,7 @@ int ac_destroy(ac_env_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->dp.F, h->dp.I, h->dp.D, h->dp.MF, h->dp.MD, h->dp.MI, h->dp.obs, h->dp.rew, h->dp.done, h->dp.info,
-                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_ctlW, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
+                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_scripted, h->d_ctlW, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
   for (void* b : bufs) (void)hipFree(b);
   (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
   (void)hipStreamDestroy(h->stream);

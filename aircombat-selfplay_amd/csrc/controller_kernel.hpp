@@ -56,6 +56,7 @@ struct Args {
   int* man_step;           // [N] ManeuverAgent.step
   float* man_h0;           // [N] ManeuverAgent.init_heading (latched when step == 0)
   DevPtrs P; DevCfg c;     // aircraft state (scripted inputs are computed from it)
+  float* scripted;         // [N][12] controller inputs of the scripted aircraft (written by scripted_inputs_kernel)
 };
 __device__ __forceinline__ float in_range_rad_f(float a) {   // utils.py:114-119 with Python's % semantics
   a = fmodf(a, 6.283185307179586f);
@@ -63,7 +64,7 @@ __device__ __forceinline__ float in_range_rad_f(float a) {   // utils.py:114-119
   if (a > 3.14159265358979f) a -= 6.283185307179586f;
   return a;
 }
-__device__ __noinline__ void aircraft_props(const DevPtrs& P, const DevCfg& c, int n, Props& pr, float& psi) {
+__device__ __forceinline__ void aircraft_props(const DevPtrs& P, const DevCfg& c, int n, Props& pr, float& psi) {
   State s; Task t; Derived d;
   load_state(P.F, P.I, P.D, c.N, n, s, t);
   f16::locate(s, d); f16::body_frame(s, d);
@@ -78,24 +79,18 @@ __device__ __forceinline__ void load_a(const float* act, int lane, float (&A)[K 
 #pragma unroll
   for (int t = 0; t < K / 2; ++t) A[t] = act[(2 * t + (lane >> 5)) * LS + (lane & 31)];
 }
-// B operands of one column tile for this lane: K/8 coalesced 16-byte loads (4 MFMAs each). Kept separate from the MFMA loop so
-// that the NEXT tile's loads are in flight while the current tile multiplies (an L2 round trip is ~10 MFMAs long).
+// acc += A(32 x K) * tile(K x 32); the 16-byte weight loads are interleaved with the MFMAs by the scheduler (an explicit
+// double-buffered prefetch of whole tiles was tried: 400+ registers, 39 us instead of 31)
 template <int K>
-__device__ __forceinline__ void load_b(const float* __restrict__ tile, int lane, float4 (&B)[K / 8]) {
+__device__ __forceinline__ void mma_tile(const float* __restrict__ tile, int lane, const float (&A)[K / 2], floatx16& acc) {
   const float4* t4 = reinterpret_cast<const float4*>(tile) + lane;
 #pragma unroll
-  for (int g = 0; g < K / 8; ++g) B[g] = t4[g * 64];
-  __builtin_amdgcn_sched_barrier(0);   // keep these loads ahead of the MFMA chain that follows (the scheduler would sink them)
-}
-// acc += A(32 x K) * tile(K x 32)
-template <int K>
-__device__ __forceinline__ void mma_tile(const float (&A)[K / 2], const float4 (&B)[K / 8], floatx16& acc) {
-#pragma unroll
   for (int g = 0; g < K / 8; ++g) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 0], B[g].x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 1], B[g].y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 2], B[g].z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 3], B[g].w, acc, 0, 0, 0);
+    const float4 b = t4[g * 64];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 0], b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 1], b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 2], b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[4 * g + 3], b.w, acc, 0, 0, 0);
   }
 }
 __device__ __forceinline__ floatx16 splat(float v) {
@@ -137,6 +132,48 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __ex
 __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f); }
 }  // namespace ctl
 
+// Inputs of the scripted opponents (`use_baseline`): one lane per aircraft, enemy-team lanes only. Kept out of controller_kernel
+// so that the state -> pose code (fp64 geodesy) does not inflate the MFMA kernel's register allocation.
+__global__ __launch_bounds__(64) void scripted_inputs_kernel(ctl::Args a) {
+  using namespace ctl;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= a.N) return;
+  const int slot = n % a.A;
+  if (slot < a.n_ego) return;
+  float x[12];
+  {
+    // (singlecombat_task.py:224-228, scenario1_task.py:41-49, scenario2_task.py:49-58)
+    Props pr; float psi;
+    aircraft_props(a.P, a.c, n, pr, psi);
+    float dv0, dv1, dv2;
+    if (a.use_baseline == 2) {   // ManeuverAgent('triangle').set_delta_value (baseline.py:137-155)
+      int st = a.man_step[n];
+      float h0 = (st == 0) ? psi : a.man_h0[n];
+      int i = 0;
+      for (i = 0; i < 300; ++i) if ((float)st <= (float)(i + 1) * 30.0f / a.time_interval) break;
+      i = min(i, 299) % 3;
+      dv1 = h0 + (i == 0 ? 1.0471975511965976f : (i == 1 ? 3.14159265358979f : -1.0471975511965976f)) - psi;
+      dv0 = 6000.0f - pr.alt_m; dv2 = 243.0f - pr.ub;
+      a.man_step[n] = st + 1; a.man_h0[n] = h0;
+    } else {                      // PursueAgent.set_delta_value(env, task, k) (baseline.py:85-104): chase aircraft k of the list
+      Props pt; float psit;
+      aircraft_props(a.P, a.c, n - a.n_ego, pt, psit);
+      dv0 = pt.u - pr.u;
+      const float ev = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve), dx = pt.n - pr.n, dy = pt.e - pr.e;
+      const float R = sqrtf(dx * dx + dy * dy);
+      const float ao = acosf(clampf(-1.0f, (dx * pr.vn + dy * pr.ve) / (R * ev + 1e-8f), 1.0f));
+      const float cr = pr.vn * dy - pr.ve * dx;
+      dv1 = ao * (float)((cr > 0.0f) - (cr < 0.0f));
+      dv2 = pt.ub - pr.ub;
+    }
+    // BaselineAgent.get_observation (baseline.py:45-63)
+    x[0] = dv0 / 1000.0f; x[1] = in_range_rad_f(dv1); x[2] = dv2 / 340.0f; x[3] = pr.alt_m / 5000.0f;
+    x[4] = pr.sphi; x[5] = pr.cphi; x[6] = pr.stht; x[7] = pr.ctht;
+    x[8] = pr.ub / 340.0f; x[9] = pr.vb / 340.0f; x[10] = pr.wb / 340.0f; x[11] = pr.vc / 340.0f;
+  }
+  for (int k = 0; k < 12; ++k) a.scripted[(size_t)n * 12 + k] = x[k];
+}
+
 __global__ __launch_bounds__(256) void controller_kernel(ctl::Args a) {
   using namespace ctl;
   __shared__ float act0[HID * LS];   // activations, feature-major [k][row]
@@ -160,34 +197,9 @@ __global__ __launch_bounds__(256) void controller_kernel(ctl::Args a) {
       const int slot = n % a.A;
       float x[12];
       if (a.use_baseline && slot >= a.n_ego) {
-        // the enemy team is flown by BaselineAgent k (singlecombat_task.py:224-228, scenario1_task.py:41-49, scenario2_task.py:49-58)
-        Props pr; float psi;
-        aircraft_props(a.P, a.c, n, pr, psi);
-        float dv0, dv1, dv2;
-        if (a.use_baseline == 2) {   // ManeuverAgent('triangle').set_delta_value (baseline.py:137-155)
-          int st = a.man_step[n];
-          float h0 = (st == 0) ? psi : a.man_h0[n];
-          int i = 0;
-          for (i = 0; i < 300; ++i) if ((float)st <= (float)(i + 1) * 30.0f / a.time_interval) break;
-          i = min(i, 299) % 3;
-          dv1 = h0 + (i == 0 ? 1.0471975511965976f : (i == 1 ? 3.14159265358979f : -1.0471975511965976f)) - psi;
-          dv0 = 6000.0f - pr.alt_m; dv2 = 243.0f - pr.ub;
-          if (i0 + row < a.N) { a.man_step[n] = st + 1; a.man_h0[n] = h0; }
-        } else {                      // PursueAgent.set_delta_value(env, task, k) (baseline.py:85-104): chase aircraft k of the list
-          Props pt; float psit;
-          aircraft_props(a.P, a.c, n - a.n_ego, pt, psit);
-          dv0 = pt.u - pr.u;
-          const float ev = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve), dx = pt.n - pr.n, dy = pt.e - pr.e;
-          const float R = sqrtf(dx * dx + dy * dy);
-          const float ao = acosf(clampf(-1.0f, (dx * pr.vn + dy * pr.ve) / (R * ev + 1e-8f), 1.0f));
-          const float cr = pr.vn * dy - pr.ve * dx;
-          dv1 = ao * (float)((cr > 0.0f) - (cr < 0.0f));
-          dv2 = pt.ub - pr.ub;
-        }
-        // BaselineAgent.get_observation (baseline.py:45-63)
-        x[0] = dv0 / 1000.0f; x[1] = in_range_rad_f(dv1); x[2] = dv2 / 340.0f; x[3] = pr.alt_m / 5000.0f;
-        x[4] = pr.sphi; x[5] = pr.cphi; x[6] = pr.stht; x[7] = pr.ctht;
-        x[8] = pr.ub / 340.0f; x[9] = pr.vb / 340.0f; x[10] = pr.wb / 340.0f; x[11] = pr.vc / 340.0f;
+        // the enemy team is flown by BaselineAgent k: its 12 inputs were prepared by scripted_inputs_kernel
+#pragma unroll
+        for (int k = 0; k < 12; ++k) x[k] = a.scripted[(size_t)n * 12 + k];
       } else {
         const int c0 = (int)hi[0], c1 = (int)hi[1], c2 = (int)hi[2];
         // singlecombat_task.py:217-219, 235-241: below 3500 m the altitude choice is overridden by "climb"
@@ -211,25 +223,20 @@ __global__ __launch_bounds__(256) void controller_kernel(ctl::Args a) {
   // ---- MLP layer 1: Linear(12, 128) + ReLU + LayerNorm; wave w owns output columns 32 w .. 32 w + 31
   {
     float A[8];
-    float4 B[2];
-    load_b<16>(W + D_W1 + w * tile_floats(16), lane, B);
     load_a<16>(act0, lane, A);
     floatx16 acc = splat(W[D_B1 + w * 32 + col]);
-    mma_tile<16>(A, B, acc);
+    mma_tile<16>(W + D_W1 + w * tile_floats(16), lane, A, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) act1[(w * 32 + col) * LS + c_row(r, lane)] = fmaxf(acc[r], 0.0f);
   }
   __syncthreads();
-  float4 Bq[16], Bn[16];   // current / next weight tile
-  load_b<HID>(W + D_W2 + w * tile_floats(HID), lane, Bq);            // in flight across the LayerNorm
   layer_norm(act1, red, W + D_G1, W + D_BE1, tid);
   // ---- MLP layer 2
   {
     float A[64];
     load_a<HID>(act1, lane, A);
-    load_b<HID>(W + D_WIH + (0 + w) * tile_floats(HID), lane, Bn);   // first GRU tile
     floatx16 acc = splat(W[D_B2 + w * 32 + col]);
-    mma_tile<HID>(A, Bq, acc);
+    mma_tile<HID>(W + D_W2 + w * tile_floats(HID), lane, A, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) act0[(w * 32 + col) * LS + c_row(r, lane)] = fmaxf(acc[r], 0.0f);   // act0's inputs were consumed before the last barriers
   }
@@ -242,16 +249,16 @@ __global__ __launch_bounds__(256) void controller_kernel(ctl::Args a) {
     {
       float A[64];
       load_a<HID>(act0, lane, A);
-      load_b<HID>(W + D_WIH + (4 + w) * tile_floats(HID), lane, Bq); mma_tile<HID>(A, Bn, ir);
-      load_b<HID>(W + D_WIH + (8 + w) * tile_floats(HID), lane, Bn); mma_tile<HID>(A, Bq, iz);
-      load_b<HID>(W + D_WHH + (0 + w) * tile_floats(HID), lane, Bq); mma_tile<HID>(A, Bn, in_);
+      mma_tile<HID>(W + D_WIH + (0 + w) * tile_floats(HID), lane, A, ir);
+      mma_tile<HID>(W + D_WIH + (4 + w) * tile_floats(HID), lane, A, iz);
+      mma_tile<HID>(W + D_WIH + (8 + w) * tile_floats(HID), lane, A, in_);
     }
     {
       float A[64];
       load_a<HID>(hbuf, lane, A);
-      load_b<HID>(W + D_WHH + (4 + w) * tile_floats(HID), lane, Bn); mma_tile<HID>(A, Bq, hr);
-      load_b<HID>(W + D_WHH + (8 + w) * tile_floats(HID), lane, Bq); mma_tile<HID>(A, Bn, hz);
-      load_b<HID>(W + D_WA + w * tile_floats(HID), lane, Bn);        mma_tile<HID>(A, Bq, hn);   // Bn: this wave's head tile
+      mma_tile<HID>(W + D_WHH + (0 + w) * tile_floats(HID), lane, A, hr);
+      mma_tile<HID>(W + D_WHH + (4 + w) * tile_floats(HID), lane, A, hz);
+      mma_tile<HID>(W + D_WHH + (8 + w) * tile_floats(HID), lane, A, hn);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -270,14 +277,13 @@ __global__ __launch_bounds__(256) void controller_kernel(ctl::Args a) {
   {
     float A[64];
     load_a<HID>(act1, lane, A);
-    if (w == 0) load_b<HID>(W + D_WA + 4 * tile_floats(HID), lane, Bq);
     floatx16 acc = splat(W[D_BA + w * 32 + col]);
-    mma_tile<HID>(A, Bn, acc);
+    mma_tile<HID>(W + D_WA + w * tile_floats(HID), lane, A, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) lg[(w * 32 + col) * LS + c_row(r, lane)] = acc[r];
     if (w == 0) {
       floatx16 acc4 = splat(W[D_BA + 128 + col]);
-      mma_tile<HID>(A, Bq, acc4);
+      mma_tile<HID>(W + D_WA + 4 * tile_floats(HID), lane, A, acc4);
 #pragma unroll
       for (int r = 0; r < 16; ++r) lg[(128 + col) * LS + c_row(r, lane)] = acc4[r];
     }

@@ -74,7 +74,7 @@ def saturating_leg(pkg, cfg, local_rank, envs=524288, steps=40, warmup=8):
     for _ in range(4):
         a = np.stack([rng.integers(0, n, size=(envs, AGENTS)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
         if env.act_dim == 5:
-            a = np.concatenate([a, (rng.random((envs, AGENTS, 1)) < 0.05).astype(np.float32)], axis=-1)
+            a = np.concatenate([a, (rng.random((envs, AGENTS, 1)) < 0.05).astype(np.float32)], axis=-1)  # (only reached for 1v1 tasks)
         pool.append(torch.from_numpy(a).cuda(local_rank))
     ptrs = [t.data_ptr() for t in pool]
     for i in range(warmup):
@@ -121,7 +121,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU, help="envs per GPU (default: the BASELINE config)")
-    ap.add_argument("--task", default="singlecombat")
+    ap.add_argument("--task", default="singlecombat", help="any name of aircombat_selfplay_amd.config.TASK_IDS (default: BASELINE configs[1])")
+    ap.add_argument("--hierarchical", action="store_true", help="[3,5,3] actions through the low-level controller kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturating", action="store_true", help="skip the extra 2^20-aircraft leg (N=1 only)")
     ap.add_argument("--checksum-calls", type=int, default=0,
@@ -140,8 +141,13 @@ def main():
     dist = pkg.sharding.init_process_group("nccl")  # RCCL; used only for the timing barrier / max-over-ranks
 
     E = args.envs
-    cfg = pkg.default_config(args.task)
-    env = pkg.HipVecEnv(cfg, E, device_id=local_rank, seed=1 + 1000 * rank)
+    cfg = pkg.default_config(args.task, hierarchical=args.hierarchical) if args.task != "heading" else pkg.default_config("heading")
+    cls = pkg.HipShareVecEnv if cfg.n_agents > 2 else pkg.HipVecEnv
+    env = cls(cfg, E, device_id=local_rank, seed=1 + 1000 * rank)
+    global AGENTS, BYTES_PER_AGENT_STEP
+    AGENTS = env.num_agents
+    # 512 B state + action + 4 * obs_dim + reward + done
+    BYTES_PER_AGENT_STEP = 512.0 + 4.0 * env.act_dim + 4.0 * env.obs_dim + 5.0
     nvec = (3, 5, 3) if env.hierarchical else (41, 41, 41, 30)
     env.reset()
     act_dim = env.act_dim
@@ -152,8 +158,8 @@ def main():
     pool = []
     for _ in range(POOL):
         a = np.stack([rng.integers(0, n, size=(E, AGENTS)) for n in nvec], axis=-1).astype(np.float32)
-        if act_dim == 5:
-            a = np.concatenate([a, (rng.random((E, AGENTS, 1)) < 0.05).astype(np.float32)], axis=-1)
+        if act_dim > len(nvec):   # shoot bit / the four weapon bits: Bernoulli(0.05)
+            a = np.concatenate([a, (rng.random((E, AGENTS, act_dim - len(nvec))) < 0.05).astype(np.float32)], axis=-1)
         pool.append(torch.from_numpy(a).cuda(local_rank))
     ptrs = [t.data_ptr() for t in pool]
     torch.cuda.synchronize()
@@ -199,13 +205,14 @@ def main():
             "metric": "agent-steps/sec", "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SingleCombat 1v1 self-play (no weapons), BASELINE configs[1]", "task": args.task,
+            "config": {"workload": "SingleCombat 1v1 self-play (no weapons), BASELINE configs[1]" if args.task == "singlecombat" and not args.hierarchical
+                       else f"{args.task}{' (hierarchical)' if args.hierarchical else ''}", "task": args.task,
                        "envs_per_gpu": E, "aircraft_per_env": AGENTS, "fdm_ticks_per_step": 6,
                        "actions": "uniform random MultiDiscrete[41,41,41,30], new batch every step, device-resident",
                        "auto_reset": True, "parallelism": f"env-block x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.task, E),
-                         "kernel": "step_kernel_1v1", "kernel_ms": kernel_ms,
+                         "kernel": "step kernel of the task (+ controller_kernel when hierarchical)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes},
             "episode_check": {"max_current_step": int(info_h[:, 0].max()), "envs_reset_last_step": int(info_h[:, 3].sum())},
         }
@@ -226,7 +233,7 @@ def main():
         result["roofline"]["valu"] = {"achieved": VALU_PER_AGENT_STEP * rate / 1e12, "peak": VALU_PEAK_TINST, "unit": "T lane-inst/s",
                                       "frac": VALU_PER_AGENT_STEP * rate / 1e12 / VALU_PEAK_TINST,
                                       "note": "one wave per SIMD issues one instruction per 4 cycles; 128 waves on 1024 SIMDs at this batch"}
-        if not args.no_saturating:
+        if not args.no_saturating and args.task == "singlecombat" and not args.hierarchical:
             env.close()
             result["saturating"] = saturating_leg(pkg, cfg, local_rank)
         if not args.no_cpu_baseline:
