@@ -122,12 +122,21 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_scenario(DevPtrs P, DevCf
 
   const MslParam MP = aim120b();
   bool have_pose = false;
+  // Munitions only come into being in the weapons stage after the substeps, so whether this env has anything to fly during them
+  // is known up front. With no missile entry and no chaff cloud in the env, the fp64 pose of the intermediate substeps is needed
+  // by nobody and only the last substep computes it.
+  const unsigned long long env_mask = ((A == 64) ? ~0ull : ((1ull << A) - 1ull)) << base;
+  bool mine = x.n_ch > 0;
+#pragma unroll
+  for (int k = 0; k < MS; ++k) mine = mine || ms[k].status != MSL_INACTIVE;
+  const bool env_has_munitions = (__ballot(mine) & env_mask) != 0;
   for (int sub = 0; sub < c.substeps; ++sub) {
     if (t.status == AC_ALIVE) {
       if (t.bloods <= 0.0f) t.status = AC_SHOTDOWN;
       f16::tick<false>(s, d, T);
       have_pose = true;
     }
+    if (!env_has_munitions && sub + 1 < c.substeps) continue;
     f16::locate(s, d);
     if (!have_pose) { f16::body_frame(s, d); have_pose = true; }
     make_props(s, d, c, pr);
@@ -160,7 +169,6 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_scenario(DevPtrs P, DevCf
     for (int q = 0; q < 2; ++q)
       if (q < x.n_ch) { x.ct[q] += 1.0f / 60.0f; if (x.ct[q] > 20.0f) x.ch_status[q] = 1; }
     const unsigned long long any_cloud = __ballot(x.n_ch > 0 && (x.ch_status[0] == 0 || x.ch_status[1] == 0));
-    const unsigned long long env_mask = ((A == 64) ? ~0ull : ((1ull << A) - 1ull)) << base;
     if (any_cloud & env_mask) {
 #pragma unroll
       for (int j = 0; j < A; ++j)
