@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--task", default="singlecombat", help="any name of aircombat_selfplay_amd.config.TASK_IDS (default: BASELINE configs[1])")
     ap.add_argument("--hierarchical", action="store_true", help="[3,5,3] actions through the low-level controller kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-process rehearsal on a one-GPU box: every rank uses cuda:0 and the barrier / max-over-ranks go "
+                         "through gloo (RCCL refuses two ranks on one device); never a measurement")
     ap.add_argument("--no-saturating", action="store_true", help="skip the extra 2^20-aircraft leg (N=1 only)")
     ap.add_argument("--checksum-calls", type=int, default=0,
                     help="after the timed region launch the read-only state digest kernel this many times (a dispatch with a known "
@@ -137,8 +140,11 @@ def main():
     rank, world, local_rank = pkg.sharding.dist_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = pkg.sharding.init_process_group("nccl")  # RCCL; used only for the timing barrier / max-over-ranks
+    # RCCL; used only for the timing barrier / max-over-ranks
+    dist = pkg.sharding.init_process_group("gloo" if args.rehearse_on_one_gpu else "nccl")
 
     E = args.envs
     cfg = pkg.default_config(args.task, hierarchical=args.hierarchical) if args.task != "heading" else pkg.default_config("heading")
@@ -186,7 +192,8 @@ def main():
         dist.barrier()
     elapsed = t1 - t0
     kernel_ms = ev_ms.value / args.steps          # HIP events on the launch stream, average per launch
-    elapsed, kernel_ms = pkg.sharding.max_over_ranks([elapsed, kernel_ms], dist, device=f"cuda:{local_rank}")
+    elapsed, kernel_ms = pkg.sharding.max_over_ranks([elapsed, kernel_ms], dist,
+                                                     device="cpu" if args.rehearse_on_one_gpu else f"cuda:{local_rank}")
 
     for _ in range(args.checksum_calls):
         env.state_checksum()
