@@ -89,12 +89,7 @@ class HipVecEnv:
         if config.task == AC_TASK_HEADING:
             # env.seed(seed + 1000 i) -> seeding.np_random (env_base.py:252-258, train_jsbsim.py:33): hand numpy's own PCG64
             # state of every env to the device, so resets and UnreachHeading draw exactly numpy's stream
-            st = np.zeros((self.num_envs, 4), dtype=np.uint64)
-            m = (1 << 64) - 1
-            for i in range(self.num_envs):
-                b = np.random.PCG64(int(seed) + 1000 * i).state["state"]
-                st[i] = (b["state"] >> 64, b["state"] & m, b["inc"] >> 64, b["inc"] & m)
-            self.lib.check(self.lib.ac_seed_envs(self._h, st.ctypes.data), "ac_seed_envs")
+            self._seed_heading(int(seed))
         if self.hierarchical:
             # BaselineActor() + load_state_dict(model/baseline_model.pt) of HierarchicalSingleCombatTask.__init__
             # (singlecombat_task.py:211-219): the exported weights go to the device once
@@ -125,6 +120,20 @@ class HipVecEnv:
                 self._pinned.append(buf)
 
     # ---- reference surface
+    def seed(self, seed=None):
+        """env.seed(seed) of every env (env_base.py:252-258; env i gets seed + 1000 i like make_train_env): only the heading task
+        draws from env.np_random, so only it has something to re-seed."""
+        if seed is not None and self.config.task == AC_TASK_HEADING:
+            self._seed_heading(int(seed))
+
+    def _seed_heading(self, seed):
+        st = np.zeros((self.num_envs, 4), dtype=np.uint64)
+        m = (1 << 64) - 1
+        for i in range(self.num_envs):
+            b = np.random.PCG64(seed + 1000 * i).state["state"]
+            st[i] = (b["state"] >> 64, b["state"] & m, b["inc"] >> 64, b["inc"] & m)
+        self.lib.check(self.lib.ac_seed_envs(self._h, st.ctypes.data), "ac_seed_envs")
+
     def reset(self):
         self._assert_not_closed()
         self.lib.check(self.lib.ac_reset(self._h, self._obs.ctypes.data), "ac_reset")

@@ -529,3 +529,122 @@ def test_render_writes_acmi_frames(pkg, tmp_path):
     assert abs(lon - 120.0) < 1e-2 and abs(lat - 60.0) < 1e-2 and abs(alt - 6096) < 5
     assert any(l.startswith("A01001,T=") and "Name=AIM-9L" in l for l in text)   # the shoot bit launched a missile
     env.close()
+
+
+# ---- the reference's own harness (tests/test_jsbsim.py) re-expressed against the HIP VecEnv ----------------------------------
+
+@pytest.mark.parametrize("task", ["heading", "singlecombat", "singlecombat_dodge_missile", "scenario1"])
+def test_replay_is_deterministic(pkg, task):
+    """tests/test_jsbsim.py:18-64,97-146: same seed and same actions => the same episode, bit for bit (obs, rewards, dones),
+    across the auto-reset, for the random-reset heading task too."""
+    cfg = pkg.default_config(task)
+    env = pkg.HipVecEnv(cfg, 3, seed=0)
+    rng = np.random.default_rng(1)
+    env.seed(0)
+    first = env.reset().copy()
+    acts, outs = [], []
+    for t in range(330):
+        a = np.stack([rng.integers(0, n, size=(3, cfg.n_agents)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
+        if env.act_dim > 4:
+            a = np.concatenate([a, (rng.random((3, cfg.n_agents, env.act_dim - 4)) < 0.3).astype(np.float32)], axis=-1)
+        acts.append(a)
+        o, r, d, i = env.step(a)
+        outs.append((o.copy(), r.copy(), d.copy()))
+    env.seed(0)
+    again = env.reset()
+    assert (again == first).all()
+    for t in range(330):
+        o, r, d, i = env.step(acts[t])
+        assert (o == outs[t][0]).all() and (r == outs[t][1]).all() and (d == outs[t][2]).all(), t
+    assert any(o[2].any() for o in outs)   # at least one episode ended and was reset inside the replayed span
+    env.close()
+
+
+@pytest.mark.parametrize("task", ["heading", "singlecombat_dodge_missile", "multiplecombat"])
+def test_vec_env_shapes_and_types(pkg, task):
+    """tests/test_jsbsim.py:66-89,190-221,387-420: array shapes of the batched env, info dicts, loop until some env is done."""
+    cfg = pkg.default_config(task)
+    E, A = 4, cfg.n_agents
+    env = (pkg.HipShareVecEnv if A > 2 else pkg.HipVecEnv)(cfg, E)
+    out = env.reset()
+    obs = out[0] if A > 2 else out
+    assert obs.shape == (E, A, env.obs_dim) and obs.dtype == np.float32
+    rng = np.random.default_rng(0)
+    for t in range(2000):
+        a = np.stack([rng.integers(0, n, size=(E, A)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
+        res = env.step(a)
+        if A > 2:
+            o, share, r, d, infos = res
+            assert share.shape == (E, A, A * env.obs_dim)
+        else:
+            o, r, d, infos = res
+        assert o.shape == (E, A, env.obs_dim) and r.shape == (E, A, 1) and d.shape == (E, A, 1) and d.dtype == bool
+        assert infos.shape[0] == E and isinstance(infos[0], dict) and "current_step" in infos[0]
+        if d.any():
+            break
+    assert d.any()
+    env.close()
+    with pytest.raises(AssertionError):
+        env.step(a)    # "Trying to operate on a SubprocVecEnv after calling close()" (env_wrappers.py:301-302)
+
+
+def test_2v2_agents_die_one_by_one(pkg):
+    """tests/test_jsbsim.py:332-360: partner crashes at step 20, one enemy at 40, the other at 60 — dead agents stay done with
+    zero reward, and the env ends once one side is wiped out."""
+    cfg = pkg.default_config("multiplecombat")
+    env = pkg.HipShareVecEnv(cfg, 2)
+    env.reset()
+    act = np.tile(np.array([20, 18.6, 20, 0], dtype=np.float32), (2, 4, 1))
+    step = 0
+    while True:
+        if step == 20:
+            env.set_status(0, 1, 1)      # env.agents[partner_id].crash()
+        if step == 40:
+            env.set_status(0, 2, 1)      # enemy 0
+        if step == 60:
+            env.set_status(0, 3, 1)      # enemy 1
+        obs, share, rew, done, info = env.step(act)
+        step += 1
+        if step > 20 and step <= 60:
+            assert done[0, 1, 0] and not done[0, 0, 0]
+        if step > 21 and step <= 60:
+            # the dead agent's own term is zero; with the team mean it still shares its partner's reward (multiplecombat_env.py:170-175)
+            assert not done[1].any()
+        if step > 40 and step <= 60:
+            assert done[0, 2, 0]
+        if step == 61:
+            assert done[0].all() and info[0]["current_step"] == 61
+            break
+    assert not done[1].any()              # the other env is untouched
+    env.close()
+
+
+def test_shot_down_aircraft_freezes_while_its_missile_flies(pkg):
+    """tests/test_jsbsim.py:160-186: with weapons the env does not end when one aircraft dies while a missile is still in the
+    air; the dead aircraft's observation block stays frozen, its reward is zero after the -200 step, its done stays true."""
+    cfg = pkg.default_config("singlecombat_dodge_missile")
+    cfg.init[1].lon_deg, cfg.init[1].lat_geod_deg, cfg.init[1].psi_deg = 120.02, 60.06, 171.0
+    cfg.init[0].psi_deg = 9.0
+    env = pkg.HipVecEnv(cfg, 1)
+    obs = env.reset()
+    names = env.lib.state_field_names()
+    ix = {nm: k for k, nm in enumerate(names) if nm}
+    act = np.tile(np.array([20, 18.6, 20, 0], dtype=np.float32), (1, 2, 1))
+    killed_at = None
+    for step in range(400):
+        if killed_at is None and env.get_state(0, 0)[ix["remaining"]] < 2:   # agent 0 has a missile in the air: shoot agent 0 down
+            env.set_status(0, 0, 2)
+            killed_at = step
+            frozen = obs[0, 0, :9].copy()
+        obs, rew, done, info = env.step(act)
+        if killed_at is not None:
+            if done.all():
+                break
+            if step == killed_at:
+                assert rew[0, 0, 0] < -50 and done[0, 0, 0] and not done[0, 1, 0]
+                frozen = obs[0, 0, :9].copy()
+            else:
+                assert done[0, 0, 0] and rew[0, 0, 0] == 0.0 and (obs[0, 0, :9] == frozen).all(), step
+                assert any(env.get_missile(0, 0, k)[0] == 0 for k in range(4)), step   # a launched missile keeps the env alive
+    assert killed_at is not None and done.all() and step > killed_at + 3
+    env.close()
