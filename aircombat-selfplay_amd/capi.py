@@ -11,7 +11,7 @@ AC_MAX_MISSILES_PER_AGENT = 4
 AC_STATE_LEN = 128
 
 AC_TASK_HEADING, AC_TASK_SINGLECOMBAT, AC_TASK_DODGE_MISSILE, AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT = 0, 1, 2, 3, 4
-AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN, AC_TASK_WVR = 5, 6, 7
+AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN, AC_TASK_WVR, AC_TASK_MANEUVER = 5, 6, 7, 8
 AC_ALIVE, AC_CRASH, AC_SHOTDOWN = 0, 1, 2
 
 

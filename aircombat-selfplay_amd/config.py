@@ -6,7 +6,7 @@ overload.py:18-20, timeout.py:16), for the tasks the HIP path implements.
 """
 import yaml
 
-from .capi import (AcConfig, AC_MAX_AGENTS, AC_TASK_HEADING, AC_TASK_SINGLECOMBAT, AC_TASK_DODGE_MISSILE, AC_TASK_WVR,
+from .capi import (AcConfig, AC_MAX_AGENTS, AC_TASK_HEADING, AC_TASK_SINGLECOMBAT, AC_TASK_DODGE_MISSILE, AC_TASK_WVR, AC_TASK_MANEUVER,
                    AC_TASK_SHOOT_MISSILE, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN)
 
 TASK_IDS = {
@@ -19,6 +19,7 @@ TASK_IDS = {
     "scenario_nvn": AC_TASK_SCENARIO_NVN,            # Scenario2_NvN / Scenario3_NvN, low-level control
     "scenario2_nvn": AC_TASK_SCENARIO_NVN,
     "scenario3_nvn": AC_TASK_SCENARIO_NVN,
+    "maneuver_lowlevel": AC_TASK_MANEUVER,           # Maneuver_curriculum rules with explicit control indices and the YAML's own spawn
     "wvr_lowlevel": AC_TASK_WVR,                     # WVRTask rules with explicit control indices and the YAML's own spawn
     "hierarchical_singlecombat": AC_TASK_SINGLECOMBAT,        # HierarchicalSingleCombatTask: [3,5,3] through the low-level controller
     "hierarchical_multiplecombat": AC_TASK_MULTICOMBAT,       # HierarchicalMultipleCombatTask
@@ -30,13 +31,14 @@ ALWAYS_HIERARCHICAL = ("hierarchical_singlecombat", "hierarchical_multiplecombat
 HIERARCHICAL_IN_REFERENCE = ALWAYS_HIERARCHICAL + ("scenario1", "scenario2_nvn", "scenario3_nvn", "scenario1_curriculum",
                                                    "scenario2_nvn_curriculum", "scenario3_nvn_curriculum", "scenario1_rwr",
                                                    "scenario2_rwr", "scenario3_rwr", "scenario1_rwr_curriculum",
-                                                   "scenario2_rwr_curriculum", "scenario3_rwr_curriculum", "wvr")
+                                                   "scenario2_rwr_curriculum", "scenario3_rwr_curriculum", "wvr", "maneuver_curriculum")
 # The *_curriculum tasks (scenario1_task.py:147-195, scenario2_task.py:318-383) respawn the aircraft from
 # env.reset_simulators_curriculum(curriculum_angle) at every reset. The angle is meant to grow with the ego win rate, but it never
 # does in the reference: the 1v1 tasks AND `success` over conditions that start with LowAltitude (always False), and every task
 # pops its record back to 20 entries while the advance needs len(record) > 20. So these tasks are the base task with the
 # angle-0 spawn; `curriculum_angle` in the scenario dict selects another fixed angle for users who want one.
-CURRICULUM_BASE = {"wvr": "wvr_lowlevel",   # WVRTask.reset always respawns from reset_simulators_curriculum (WVR_task.py:41-46)
+CURRICULUM_BASE = {"maneuver_curriculum": "maneuver_lowlevel",
+                   "wvr": "wvr_lowlevel",   # WVRTask.reset always respawns from reset_simulators_curriculum (WVR_task.py:41-46)
                    "scenario1_curriculum": "scenario1", "scenario2_nvn_curriculum": "scenario2_nvn",
                    "scenario3_nvn_curriculum": "scenario3_nvn", "scenario1_rwr_curriculum": "scenario1_rwr",
                    "scenario2_rwr_curriculum": "scenario2_rwr", "scenario3_rwr_curriculum": "scenario3_rwr"}

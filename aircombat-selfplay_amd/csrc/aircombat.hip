@@ -1097,7 +1097,7 @@ static int launch_step(ac_env* h, const float* d_actions) {
     HIP_OK(hipGetLastError());
     return 0;
   }
-  if (h->cfg.task == AC_TASK_SCENARIO1 || h->cfg.task == AC_TASK_SCENARIO_NVN || h->cfg.task == AC_TASK_WVR) {
+  if (h->cfg.task == AC_TASK_SCENARIO1 || h->cfg.task == AC_TASK_SCENARIO_NVN || h->cfg.task == AC_TASK_WVR || h->cfg.task == AC_TASK_MANEUVER) {
 #define AC_LAUNCH_SCN(AA)                                                                                                        \
   do {                                                                                                                           \
     if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_scenario<AA, 1>), grid, block, 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr); \
@@ -1149,7 +1149,7 @@ const char* ac_state_field_name(int i) { return (i >= 0 && i < AC_STATE_LEN && k
 
 int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_t seed, ac_env_t** out) {
   if (!cfg || !out) return fail("ac_create: null argument");
-  const bool scenario = cfg->task == AC_TASK_SCENARIO1 || cfg->task == AC_TASK_SCENARIO_NVN || cfg->task == AC_TASK_WVR;
+  const bool scenario = cfg->task == AC_TASK_SCENARIO1 || cfg->task == AC_TASK_SCENARIO_NVN || cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER;
   const bool heading = cfg->task == AC_TASK_HEADING;
   if (cfg->task != AC_TASK_SINGLECOMBAT && cfg->task != AC_TASK_SHOOT_MISSILE && cfg->task != AC_TASK_DODGE_MISSILE &&
       cfg->task != AC_TASK_MULTICOMBAT && !scenario && !heading)
@@ -1162,7 +1162,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     if ((cfg->n_agents != 4 && cfg->n_agents != 8) || cfg->n_ego * 2 != cfg->n_agents)
       return fail("ac_create: AC_TASK_SCENARIO_NVN needs n_agents in {4, 8} split into two equal teams");
   }
-  if (scenario && cfg->task != AC_TASK_WVR)
+  const bool gun_only = cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER;
+  if (scenario && !gun_only)
     for (int i = 0; i < cfg->n_agents; ++i)
       if (cfg->num_missiles[i] != 2) return fail("ac_create: the scenario tasks are built for 'missile: 2' (two munition uids per aircraft), as every shipped YAML has");
   if (cfg->task == AC_TASK_SCENARIO_NVN) {
@@ -1174,7 +1175,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     return fail("ac_create: use_baseline (1 pursue, 2 maneuver) needs the hierarchical form and equal teams (enemy k is flown by scripted agent k)");
   if (cfg->hierarchical && (cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE))
     return fail("ac_create: the hierarchical form is available for AC_TASK_SINGLECOMBAT, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN");
-  if (cfg->task == AC_TASK_WVR && (cfg->n_agents != 2 || cfg->n_ego != 1 || cfg->rwr)) return fail("ac_create: AC_TASK_WVR is a 1v1 task");
+  if ((cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER) && (cfg->n_agents != 2 || cfg->n_ego != 1 || cfg->rwr))
+    return fail("ac_create: AC_TASK_WVR / AC_TASK_MANEUVER are 1v1 tasks");
   if (cfg->rwr && !scenario) return fail("ac_create: rwr is a variant of the scenario tasks (Scenario1_RWR, Scenario2_RWR, Scenario3_RWR)");
   if (n_envs <= 0) return fail("ac_create: n_envs must be positive");
   if (cfg->sim_freq != 60) return fail("ac_create: sim_freq must be 60 (the FDM tick is compiled for 1/60 s)");
@@ -1190,9 +1192,9 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   h->obs_dim = heading ? 12 : (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
   const int tmpl_obs = h->obs_dim;   // (the scenario kernel family's template keeps 21 slots for WVR too)
-  if (cfg->task == AC_TASK_WVR) h->obs_dim = 15;
+  if (gun_only) h->obs_dim = 15;
   if (cfg->rwr) h->obs_dim += 2;   // scenario1_task.py:213-216, scenario2_task.py:403-413
-  const bool weapon_bits = scenario && cfg->task != AC_TASK_WVR;
+  const bool weapon_bits = scenario && !gun_only;
   h->act_low = weapon_bits ? 8 : ((cfg->task == AC_TASK_SHOOT_MISSILE) ? 5 : 4);
   // hierarchical tasks (HierarchicalSingleCombatTask and everything built on it): [3,5,3] (+ the four weapon bits)
   h->act_dim = cfg->hierarchical ? (weapon_bits ? 7 : 3) : h->act_low;

@@ -116,8 +116,10 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_scenario(DevPtrs P, DevCf
   s.de = clampf(-1.0f, act[1] / 20.0f - 1.0f, 1.0f);
   s.dr = clampf(-1.0f, act[2] / 20.0f - 1.0f, 1.0f);
   s.thr = clampf(0.0f, act[3] / 58.0f + 0.4f, 0.9f);
-  const bool wvr = !MULTI && c.task == AC_TASK_WVR;   // WVRTask (WVR_task.py:10-90): gun only, no weapon bits in the action
-  if (!wvr && (MULTI || team == 0))
+  const bool maneuver = !MULTI && c.task == AC_TASK_MANEUVER;   // Maneuver_curriculum (singlecombat_task.py:264-359)
+  const bool gun_only = !MULTI && (c.task == AC_TASK_WVR || maneuver);   // WVRTask (WVR_task.py:10-90) / Maneuver_curriculum: no weapon bits
+  const bool wvr = gun_only && !maneuver;
+  if (!gun_only && (MULTI || team == 0))
     x.bits = (act[4] != 0.0f ? 1 : 0) | (act[5] != 0.0f ? 2 : 0) | (act[6] != 0.0f ? 4 : 0) | (act[7] != 0.0f ? 8 : 0);
 
   const MslParam MP = aim120b();
@@ -210,8 +212,8 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_scenario(DevPtrs P, DevCf
     for (int i = 0; i < A; ++i) {
       float gun_dmg = 0.0f; int gun_tgt = -1;
       bool launched = false;
-      if (wvr) {
-        // WVR_task.py:62-76: every aircraft, dead or alive, drains 5 blood from its farthest enemy inside 3 km and 5 deg, every step
+      if (gun_only) {
+        // WVR_task.py:62-76 / singlecombat_task.py:290-297: every aircraft, dead or alive, drains 5 blood from its farthest enemy inside 3 km and 5 deg, every step
         const float ang = 57.29577951f * acosf(clampf(-1.0f, (tdx * pr.vn + tdy * pr.ve + tdz * pr.vd) / (bd * hv + 1e-8f), 1.0f));
         if (slot == i && bd * 0.001f < 3.0f && ang < 5.0f) { gun_dmg = 5.0f; gun_tgt = tg; }
       } else if (slot == i && t.status == AC_ALIVE) {
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_scenario(DevPtrs P, DevCf
   if (!MULTI) {
     Enemy E = gather_pose(pr, base + e_first);
     const Incoming none{false, 0, 0, 0, 0, 0, 0};
-    if (wvr) observe_1v1<AC_TASK_SINGLECOMBAT>(pr, E, none, ob);   // HierarchicalSingleCombatTask keeps the clipped 15-value, 2-D observation
+    if (gun_only) observe_1v1<AC_TASK_SINGLECOMBAT>(pr, E, none, ob);   // HierarchicalSingleCombatTask keeps the clipped 15-value, 2-D observation
     else observe_1v1<AC_TASK_SHOOT_MISSILE>(pr, E, c.rwr ? none : inc, ob);   // Scenario1 keeps the 21-value layout (scenario1_task.py:31-32); Scenario1_RWR blanks the missile block (:298-300)
   } else {
     // scenario2_task.py:256-316: ego 9, partners, enemies, then the missile block directly after them; not clipped
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_scenario(DevPtrs P, DevCf
     float r_ev = potential(ev, c.event_scale, c.event_pot, t.pre_event);
     float r_pos = potential(posture, c.posture_scale, c.posture_pot, t.pre_posture);
     float r_ra = fminf(1.0f - fabsf(pr.u * 0.001f - e_u0 * 0.001f), 0.0f);
-    own = r_alt + cg + r_ev + behit + tailr + wezdot + wez + r_pos + (wvr ? 0.0f : r_ra + r_mp);   // ShootPenalty never fires: remaining_missiles is constant; WVR has eight terms (WVR_task.py:20-29)
+    own = r_alt + cg + r_ev + behit + tailr + wezdot + wez + r_pos + (wvr ? 0.0f : r_ra + (maneuver ? 0.0f : r_mp));   // ShootPenalty never fires: remaining_missiles is constant; WVR has eight terms (WVR_task.py:20-29), Maneuver_curriculum nine
   }
   float reward = own;
   if (MULTI) {   // team mean (multiplecombat_env.py:170-175), then the terminations
@@ -547,7 +549,7 @@ __global__ void init_kernel_scenario(InitArgs ia, DevCfg c, const float* tab, fl
   if (A == 2) {
     Enemy E = gather_pose(pr, base + e_first);
     for (int k = 0; k < OBS; ++k) ob[k] = 0.0f;
-    if (c.task == AC_TASK_WVR) observe_1v1<AC_TASK_SINGLECOMBAT>(pr, E, inc, ob);
+    if (c.task == AC_TASK_WVR || c.task == AC_TASK_MANEUVER) observe_1v1<AC_TASK_SINGLECOMBAT>(pr, E, inc, ob);
     else observe_1v1<AC_TASK_SHOOT_MISSILE>(pr, E, inc, ob);
   } else {
     for (int k = 0; k < OBS; ++k) ob[k] = 0.0f;

@@ -35,6 +35,7 @@ enum {
                                  act 8 = [41,41,41,30] + [gun, AIM-9M, AIM-120B, chaff] (low-level control; the controller net is row N1) */
   AC_TASK_SCENARIO_NVN = 6,   /* scenario2_task.py / scenario3_task.py *_NvN (2v2, 4v4) under MultipleCombatEnv.step: obs 9+6A+6, act 8 */
   AC_TASK_WVR = 7,            /* WVR_task.py:10-90 WVRTask (1v1): 15-value observation, unlimited gun, eight reward terms, no SafeReturn; act 4 (or [3,5,3]) */
+  AC_TASK_MANEUVER = 8,       /* singlecombat_task.py:264-359 Maneuver_curriculum (1v1): WVR's gun, nine reward terms, the ordinary 1v1 terminations */
   AC_TASK_MULTICOMBAT = 4     /* multiplecombat_task.py:15-151 MultipleCombatTask under MultipleCombatEnv.step (NvN, n_agents 4 or 8):
                                  obs 9+6*(A-1), act [41,41,41,30]; share_obs is obs flattened per env (env_base.py:183-189) */
 };

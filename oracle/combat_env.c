@@ -21,7 +21,7 @@ int or_env_obs_dim(int task) {
 int or_env_obs_dim_n(int task, int n_aircraft) {
   if (task == OR_TASK_MULTICOMBAT) return 9 + (n_aircraft - 1) * 6; /* multiplecombat_task.py:95-98 */
   if (task == OR_TASK_SCENARIO_NVN) return 9 + 6 * (n_aircraft / 2) + 6 * (n_aircraft / 2) + 6; /* scenario2_task.py:244-254 */
-  if (task == OR_TASK_WVR) return 15; /* HierarchicalSingleCombatTask keeps SingleCombatTask's 15-value observation */
+  if (task == OR_TASK_WVR || task == OR_TASK_MANEUVER) return 15; /* HierarchicalSingleCombatTask keeps SingleCombatTask's 15-value observation */
   return or_env_obs_dim(task);
 }
 /* ------------------------------------------------------------------ scripted opponents (model/baseline.py) */
@@ -350,7 +350,7 @@ static void obs_combat(const OrEnv* e, int i, double* o) { /* singlecombat_task.
   o[0] = h_sl_m(a) / 5000;
   o[1] = sin(a->fdm.phi); o[2] = cos(a->fdm.phi); o[3] = sin(a->fdm.tht); o[4] = cos(a->fdm.tht);
   o[5] = mps(a->fdm.uvw[0]) / 340; o[6] = mps(a->fdm.uvw[1]) / 340; o[7] = mps(a->fdm.uvw[2]) / 340; o[8] = vc_mps(a) / 340;
-  const int two_d = e->cfg.task == OR_TASK_SINGLECOMBAT || e->cfg.task == OR_TASK_WVR;
+  const int two_d = e->cfg.task == OR_TASK_SINGLECOMBAT || e->cfg.task == OR_TASK_WVR || e->cfg.task == OR_TASK_MANEUVER;
   or_get_AO_TA_R(ef, nf, two_d, r);
   o[9] = (mps(en->fdm.uvw[0]) - mps(a->fdm.uvw[0])) / 340;
   o[10] = (h_sl_m(en) - h_sl_m(a)) / 1000;
@@ -589,6 +589,11 @@ static double task_reward_terms(OrEnv* e, int i) {
       double r = rw_posture(e, i); r += rw_altitude(e, i); r += rw_event(e, i); r += rw_combat_geometry(e, i); r += rw_gun_behit(e, i);
       r += rw_gun_track(e, i, 1); r += rw_gun_wez(e, i); return r + rw_gun_track(e, i, 0);
     }
+    case OR_TASK_MANEUVER: { /* singlecombat_task.py:267-277 */
+      double r = rw_altitude(e, i); r += rw_combat_geometry(e, i); r += rw_event(e, i); r += rw_gun_behit(e, i);
+      r += rw_gun_track(e, i, 1); r += rw_gun_track(e, i, 0); r += rw_gun_wez(e, i); r += rw_posture(e, i);
+      return r + rw_relative_altitude(e, i);
+    }
     case OR_TASK_MULTICOMBAT: /* same three terms, multiplecombat_task.py:27-31 */
     case OR_TASK_SINGLECOMBAT: { double r = rw_altitude(e, i); r += rw_posture(e, i); return r + rw_event(e, i); }
     case OR_TASK_DODGE_MISSILE: { double r = rw_posture(e, i); r += rw_missile_posture(e, i); r += rw_altitude(e, i); return r + rw_event(e, i); }
@@ -806,7 +811,7 @@ static void task_step(OrEnv* e) {
     }
   }
   if (t == OR_TASK_SCENARIO1 || t == OR_TASK_SCENARIO_NVN) { scenario_weapons(e); return; }
-  if (t == OR_TASK_WVR) { wvr_gun(e); return; }
+  if (t == OR_TASK_WVR || t == OR_TASK_MANEUVER) { wvr_gun(e); return; }   /* Maneuver_curriculum.step: the same rule through a2a_launch_available (:290-297) */
   if (t == OR_TASK_DODGE_MISSILE) { /* singlecombat_with_missile_task.py:108-124 */
     for (int i = 0; i < e->cfg.n_aircraft; i++) {
       OrAircraft* a = &e->ac[i];

@@ -23,7 +23,8 @@ enum { OR_TASK_HEADING = 0, OR_TASK_SINGLECOMBAT = 1, OR_TASK_DODGE_MISSILE = 2,
        OR_TASK_MULTICOMBAT = 4 /* MultipleCombatTask (multiplecombat_task.py:15-151) under MultipleCombatEnv.step */,
        OR_TASK_SCENARIO1 = 5   /* Scenario1 weapon rules + 11 rewards, 1v1 (scenario1_task.py:11-145), low-level control */,
        OR_TASK_SCENARIO_NVN = 6 /* Scenario2_NvN / Scenario3_NvN (scenario2_task.py:14-316), low-level control */,
-       OR_TASK_WVR = 7         /* WVRTask gun-only 1v1 (WVR_task.py:10-90), low-level control */ };
+       OR_TASK_WVR = 7         /* WVRTask gun-only 1v1 (WVR_task.py:10-90), low-level control */,
+       OR_TASK_MANEUVER = 8    /* Maneuver_curriculum (singlecombat_task.py:264-359): WVR's gun, nine reward terms, ordinary 1v1 terminations */ };
 #define OR_MAX_CHAFF 64
 enum { OR_ALIVE = 0, OR_CRASH = 1, OR_SHOTDOWN = 2 };
 enum { OR_MSL_INACTIVE = -1, OR_MSL_LAUNCHED = 0, OR_MSL_HIT = 1, OR_MSL_MISS = 2 };

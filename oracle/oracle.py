@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 OR_MAX_AC = 8
 TASK_HEADING, TASK_SINGLECOMBAT, TASK_DODGE_MISSILE, TASK_SHOOT_MISSILE, TASK_MULTICOMBAT = 0, 1, 2, 3, 4
-TASK_SCENARIO1, TASK_SCENARIO_NVN, TASK_WVR = 5, 6, 7
+TASK_SCENARIO1, TASK_SCENARIO_NVN, TASK_WVR, TASK_MANEUVER = 5, 6, 7, 8
 STATE_LEN = 80
 
 

@@ -798,10 +798,15 @@ def gen_baseline_actor(rng):
     np.savez_compressed(os.path.join(OUT, "baseline_actor.npz"), x=X, action=ACT, hidden=H.astype(np.float32), logits=LOG.astype(np.float32))
 
 
-def gen_wvr_sequences(rng):
+def gen_wvr_sequences(rng, which="wvr"):
     """WVRTask (tasks/WVR_task.py:10-90): the 15-value SingleCombatTask observation, the unlimited gun (-5 blood on the farthest
-    enemy inside 3 km and 5 deg, dead shooters included), eight reward terms, terminations WITHOUT SafeReturn."""
+    enemy inside 3 km and 5 deg, dead shooters included), eight reward terms, terminations WITHOUT SafeReturn.
+    which="maneuver": Maneuver_curriculum (tasks/singlecombat_task.py:264-359): the same gun, nine reward terms (adds
+    RelativeAltitude), the ordinary 1v1 terminations (SafeReturn included)."""
     from envs.JSBSim.tasks.WVR_task import WVRTask
+    from envs.JSBSim.tasks.singlecombat_task import Maneuver_curriculum
+    if which == "maneuver":
+        WVRTask = Maneuver_curriculum
     flat = {}
     uids = ("A0100", "B0100")
     acs = {u: {"color": "Blue" if u[0] == "A" else "Red", "missile": 2} for u in uids}
@@ -861,7 +866,7 @@ def gen_wvr_sequences(rng):
         flat[f"ep{ep}_step"] = np.array([f["step"] for f in frames], dtype=float)
     flat["n_episodes"] = np.array([4.0])
     flat["max_steps"] = np.array([60.0])
-    np.savez_compressed(os.path.join(OUT, "wvr_sequences.npz"), **flat)
+    np.savez_compressed(os.path.join(OUT, f"{which}_sequences.npz"), **flat)
 
 
 def gen_rwr_obs(rng):
@@ -955,6 +960,7 @@ def main():
     gen_baseline_agents(np.random.default_rng(80))
     gen_rwr_obs(np.random.default_rng(81))
     gen_wvr_sequences(np.random.default_rng(82))
+    gen_wvr_sequences(np.random.default_rng(83), which="maneuver")
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

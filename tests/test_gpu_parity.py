@@ -463,11 +463,13 @@ def test_heading_task_numpy_stream_on_device(pkg, oracle):
     env.close()
 
 
-def test_wvr_task_gun_only(pkg, oracle):
+@pytest.mark.parametrize("task", ["wvr_lowlevel", "maneuver_lowlevel"])
+def test_wvr_task_gun_only(pkg, oracle, task):
     """WVRTask on the device (the scenario kernel family in its gun-only mode): 15-value clipped observation, unlimited gun on
     the farthest enemy with no aliveness checks, eight reward terms, no SafeReturn (a shot-down aircraft just stops flying until
-    the other one times out or crashes). Flight state re-synchronised each step; blood, statuses and references run open-loop."""
-    cfg = pkg.default_config("wvr_lowlevel")
+    the other one times out or crashes). Flight state re-synchronised each step; blood, statuses and references run open-loop.
+    maneuver_lowlevel = Maneuver_curriculum's rules: the same gun, nine reward terms, SafeReturn back in the termination list."""
+    cfg = pkg.default_config(task)
     cfg.max_steps = 120
     cfg.init[0].psi_deg = 0.0   # tail chase 1.6 km behind, 1.5 deg off the nose: inside the 3 km / 5 deg gun envelope
     cfg.init[1].lon_deg, cfg.init[1].lat_geod_deg, cfg.init[1].psi_deg = cfg.init[0].lon_deg + 0.0008, cfg.init[0].lat_geod_deg + 0.0145, 2.0
@@ -499,6 +501,7 @@ def test_wvr_task_gun_only(pkg, oracle):
         assert (np.abs(rew - rrew) <= 10 * (5e-3 + 1e-3 * np.abs(rrew))).all(), (step, rew.ravel(), rrew.ravel())
         for e in range(E):
             resets += int(rinfo[e][3])
+            shot += int(rinfo[e][1]) == 4          # Maneuver_curriculum: SafeReturn reports the shot-down aircraft and the env ends
             if not rinfo[e][3]:
                 for a in range(2):
                     g, o = env.get_state(e, a), ref.envs[e].export_state(a)

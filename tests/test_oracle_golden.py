@@ -322,13 +322,15 @@ def test_rwr_observation_variants(oracle):
             assert np.allclose(obs, g[f"{fam}_obs"][k], rtol=1e-9, atol=5e-8), (fam, k, np.abs(obs - g[f"{fam}_obs"][k]).max())
 
 
-def test_wvr_task_sequences(oracle):
+@pytest.mark.parametrize("which", ["wvr", "maneuver"])
+def test_wvr_task_sequences(oracle, which):
     """WVRTask: 15-value observation, unlimited gun on the farthest enemy (no aliveness checks), eight reward terms with the shared
-    reference lists, terminations LowAltitude / ExtremeState / Overload / Timeout only (a shot-down aircraft is not 'done')."""
-    g = load("wvr_sequences.npz")
+    reference lists, terminations LowAltitude / ExtremeState / Overload / Timeout only (a shot-down aircraft is not 'done').
+    Maneuver_curriculum: the same gun, nine reward terms, the ordinary 1v1 terminations."""
+    g = load(f"{which}_sequences.npz")
     shot = crashed = 0
     for ep in range(int(g["n_episodes"][0])):
-        cfg = oracle.default_config(oracle.TASK_WVR)
+        cfg = oracle.default_config(oracle.TASK_WVR if which == "wvr" else oracle.TASK_MANEUVER)
         cfg.max_steps = int(g["max_steps"][0])
         env = oracle.OracleEnv(cfg)
         pose, obs, rew, done, state, step = (g[f"ep{ep}_{k}"] for k in ("pose", "obs", "rew", "done", "state", "step"))
