@@ -43,6 +43,7 @@ class AcConfig(C.Structure):
         ("heading_scale", C.c_double), ("heading_potential", C.c_int32),
         ("max_heading_increment", C.c_double), ("max_altitude_increment", C.c_double),
         ("max_velocities_u_increment", C.c_double), ("check_interval", C.c_double),
+        ("legacy_obs", C.c_int32),
         ("rwr", C.c_int32),
         ("use_baseline", C.c_int32),
         ("hierarchical", C.c_int32),

@@ -31,7 +31,8 @@ ALWAYS_HIERARCHICAL = ("hierarchical_singlecombat", "hierarchical_multiplecombat
 HIERARCHICAL_IN_REFERENCE = ALWAYS_HIERARCHICAL + ("scenario1", "scenario2_nvn", "scenario3_nvn", "scenario1_curriculum",
                                                    "scenario2_nvn_curriculum", "scenario3_nvn_curriculum", "scenario1_rwr",
                                                    "scenario2_rwr", "scenario3_rwr", "scenario1_rwr_curriculum",
-                                                   "scenario2_rwr_curriculum", "scenario3_rwr_curriculum", "wvr", "maneuver_curriculum")
+                                                   "scenario2_rwr_curriculum", "scenario3_rwr_curriculum", "wvr", "maneuver_curriculum",
+                                                   "scenario2", "scenario3", "scenario2_curriculum", "scenario3_curriculum")
 # The *_curriculum tasks (scenario1_task.py:147-195, scenario2_task.py:318-383) respawn the aircraft from
 # env.reset_simulators_curriculum(curriculum_angle) at every reset. The angle is meant to grow with the ego win rate, but it never
 # does in the reference: the 1v1 tasks AND `success` over conditions that start with LowAltitude (always False), and every task
@@ -40,10 +41,13 @@ HIERARCHICAL_IN_REFERENCE = ALWAYS_HIERARCHICAL + ("scenario1", "scenario2_nvn",
 CURRICULUM_BASE = {"maneuver_curriculum": "maneuver_lowlevel",
                    "wvr": "wvr_lowlevel",   # WVRTask.reset always respawns from reset_simulators_curriculum (WVR_task.py:41-46)
                    "scenario1_curriculum": "scenario1", "scenario2_nvn_curriculum": "scenario2_nvn",
-                   "scenario3_nvn_curriculum": "scenario3_nvn", "scenario1_rwr_curriculum": "scenario1_rwr",
+                   "scenario3_nvn_curriculum": "scenario3_nvn", "scenario2_curriculum": "scenario2", "scenario3_curriculum": "scenario3",
+                   "scenario1_rwr_curriculum": "scenario1_rwr",
                    "scenario2_rwr_curriculum": "scenario2_rwr", "scenario3_rwr_curriculum": "scenario3_rwr"}
 # *_RWR variants (scenario1_task.py:197-314, scenario2_task.py:385-476): the base task with two reserved observation slots
 RWR_BASE = {"scenario1_rwr": "scenario1", "scenario2_rwr": "scenario2_nvn", "scenario3_rwr": "scenario3_nvn"}
+# Scenario2 / Scenario3 themselves (scenario2_task.py:14-157): the NvN rules with the older 21-value paired-enemy observation
+LEGACY_OBS_BASE = {"scenario2": "scenario2_nvn", "scenario3": "scenario3_nvn"}
 
 
 def curriculum_spawn(center_lat, center_lon, radius_km, angle_deg):
@@ -100,10 +104,14 @@ def config_from_dict(data, task=None, hierarchical=None):
     rwr = name in RWR_BASE
     if rwr:
         name = RWR_BASE[name]
+    legacy = name in LEGACY_OBS_BASE
+    if legacy:
+        name = LEGACY_OBS_BASE[name]
     if name not in TASK_IDS:
         raise NotImplementedError(f"Unknown taskname: {name} (available: {sorted(TASK_IDS)})")
     cfg.task = TASK_IDS[name]
     cfg.rwr = int(rwr)
+    cfg.legacy_obs = int(legacy)
     cfg.hierarchical = int(name in ALWAYS_HIERARCHICAL if hierarchical is None else bool(hierarchical))
     acs = data["aircraft_configs"]
     uids = list(acs.keys())

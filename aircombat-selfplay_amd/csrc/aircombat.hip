@@ -97,6 +97,7 @@ struct DevCfg {
   float max_attack_angle, max_attack_distance;
   int min_attack_interval, use_artillery, lock_len;
   int rwr;                    // *_RWR variants: obs_dim carries two extra zero slots
+  int legacy_obs;             // Scenario2 / Scenario3 (not _NvN): 21-value observation against the paired enemy
   int tobs;                   // observation slots per aircraft in the reset template (the kernel family's own layout)
   int num_missiles[AC_MAX_AGENTS];
   // battle-field origin for pymap3d-style geodetic <-> NED (metres, WGS84)
@@ -1177,6 +1178,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     return fail("ac_create: the hierarchical form is available for AC_TASK_SINGLECOMBAT, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN");
   if ((cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER) && (cfg->n_agents != 2 || cfg->n_ego != 1 || cfg->rwr))
     return fail("ac_create: AC_TASK_WVR / AC_TASK_MANEUVER are 1v1 tasks");
+  if (cfg->legacy_obs && (cfg->task != AC_TASK_SCENARIO_NVN || cfg->rwr)) return fail("ac_create: legacy_obs is the observation of Scenario2 / Scenario3 (AC_TASK_SCENARIO_NVN without rwr)");
   if (cfg->rwr && !scenario) return fail("ac_create: rwr is a variant of the scenario tasks (Scenario1_RWR, Scenario2_RWR, Scenario3_RWR)");
   if (n_envs <= 0) return fail("ac_create: n_envs must be positive");
   if (cfg->sim_freq != 60) return fail("ac_create: sim_freq must be 60 (the FDM tick is compiled for 1/60 s)");
@@ -1193,6 +1195,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
   const int tmpl_obs = h->obs_dim;   // (the scenario kernel family's template keeps 21 slots for WVR too)
   if (gun_only) h->obs_dim = 15;
+  if (cfg->task == AC_TASK_SCENARIO_NVN && cfg->legacy_obs) h->obs_dim = 21;   // multiplecombat_with_missile_task.py:30-31
   if (cfg->rwr) h->obs_dim += 2;   // scenario1_task.py:213-216, scenario2_task.py:403-413
   const bool weapon_bits = scenario && !gun_only;
   h->act_low = weapon_bits ? 8 : ((cfg->task == AC_TASK_SHOOT_MISSILE) ? 5 : 4);
@@ -1206,6 +1209,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   c.chaff_seed = seed;
   c.rwr = cfg->rwr ? 1 : 0;
   c.tobs = tmpl_obs;
+  c.legacy_obs = (cfg->task == AC_TASK_SCENARIO_NVN && cfg->legacy_obs) ? 1 : 0;
   c.altitude_limit = (float)cfg->altitude_limit; c.acc_x = (float)cfg->acc_limit_x; c.acc_y = (float)cfg->acc_limit_y; c.acc_z = (float)cfg->acc_limit_z;
   c.posture_scale = (float)cfg->posture_scale; c.altitude_scale = (float)cfg->altitude_scale; c.event_scale = (float)cfg->event_scale;
   c.missile_posture_scale = (float)cfg->missile_posture_scale; c.shoot_penalty_scale = (float)cfg->shoot_penalty_scale;

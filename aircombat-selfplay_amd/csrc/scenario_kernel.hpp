@@ -321,6 +321,13 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_scenario(DevPtrs P, DevCf
     const Incoming none{false, 0, 0, 0, 0, 0, 0};
     if (gun_only) observe_1v1<AC_TASK_SINGLECOMBAT>(pr, E, none, ob);   // HierarchicalSingleCombatTask keeps the clipped 15-value, 2-D observation
     else observe_1v1<AC_TASK_SHOOT_MISSILE>(pr, E, c.rwr ? none : inc, ob);   // Scenario1 keeps the 21-value layout (scenario1_task.py:31-32); Scenario1_RWR blanks the missile block (:298-300)
+  } else if (c.legacy_obs) {
+    // Scenario2 / Scenario3 (not _NvN) keep MultipleCombatShootMissileTask's 21 values against the enemy with the same index in
+    // its team (multiplecombat_with_missile_task.py:30-117)
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) ob[k] = 0.0f;
+    Enemy E = gather_pose(pr, base + e_first + (slot - (team == 0 ? 0 : n_ego)));
+    observe_1v1<AC_TASK_SHOOT_MISSILE>(pr, E, inc, ob);
   } else {
     // scenario2_task.py:256-316: ego 9, partners, enemies, then the missile block directly after them; not clipped
 #pragma unroll
@@ -551,6 +558,10 @@ __global__ void init_kernel_scenario(InitArgs ia, DevCfg c, const float* tab, fl
     for (int k = 0; k < OBS; ++k) ob[k] = 0.0f;
     if (c.task == AC_TASK_WVR || c.task == AC_TASK_MANEUVER) observe_1v1<AC_TASK_SINGLECOMBAT>(pr, E, inc, ob);
     else observe_1v1<AC_TASK_SHOOT_MISSILE>(pr, E, inc, ob);
+  } else if (c.legacy_obs) {
+    for (int k = 0; k < OBS; ++k) ob[k] = 0.0f;
+    Enemy E = gather_pose(pr, base + e_first + (slot - (team == 0 ? 0 : c.n_ego)));
+    observe_1v1<AC_TASK_SHOOT_MISSILE>(pr, E, inc, ob);
   } else {
     for (int k = 0; k < OBS; ++k) ob[k] = 0.0f;
     ob[0] = pr.alt_m / 5000.0f;

@@ -74,6 +74,8 @@ typedef struct ac_config {
   /* HeadingTask only: HeadingReward_scale / _potential (reward_function_base.py:14-15), UnreachHeading limits (unreach_heading.py:27-31) */
   double heading_scale; int32_t heading_potential;
   double max_heading_increment, max_altitude_increment, max_velocities_u_increment, check_interval;
+  int32_t legacy_obs;               /* Scenario2 / Scenario3 (the non-_NvN classes, scenario2_task.py:14-157): AC_TASK_SCENARIO_NVN rules with the 21-value
+                                       observation of MultipleCombatShootMissileTask against the enemy of the same team index */
   int32_t rwr;                      /* *_RWR variants of the scenario tasks: obs_dim + 2 reserved zero slots; Scenario1_RWR also blanks the
                                        missile block of its observation (scenario1_task.py:213-314, scenario2_task.py:385-476) */
   int32_t use_baseline;             /* scripted enemy team (`use_baseline: true`, `baseline_type`, singlecombat_task.py:19-27, model/baseline.py):

@@ -60,6 +60,8 @@ typedef struct {
   double relative_altitude_scale, relative_altitude_KH;   /* RelativeAltitudeReward_scale / _KH */
   double gun_scale;                                       /* common scale of the CombatGeometry / Gun* terms (all default 1) */
   uint64_t chaff_seed;                                    /* counter-based stand-in for the global np.random of env_base.py:153 */
+  int legacy_obs;     /* Scenario2 / Scenario3 (not _NvN): MultipleCombatShootMissileTask's 21-value observation against the enemy with the
+                         same index in its team (multiplecombat_with_missile_task.py:30-117) */
   int rwr;            /* *_RWR task variants: two reserved zero slots appended to the observation; Scenario1_RWR also blanks its missile block */
   int use_baseline;   /* the enemy team is flown by a scripted BaselineAgent (singlecombat_task.py:19-27): 0 none, 1 pursue, 2 maneuver('triangle') */
   int hierarchical;   /* Hierarchical* / Scenario* tasks as shipped: action = [3,5,3] (+4 weapon bits) through the low-level controller */

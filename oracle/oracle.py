@@ -42,6 +42,7 @@ class OrEnvConfig(C.Structure):
         ("use_artillery", C.c_int),
         ("relative_altitude_scale", C.c_double), ("relative_altitude_KH", C.c_double), ("gun_scale", C.c_double),
         ("chaff_seed", C.c_uint64),
+        ("legacy_obs", C.c_int),
         ("rwr", C.c_int),
         ("use_baseline", C.c_int),
         ("hierarchical", C.c_int),
@@ -154,7 +155,7 @@ def config_from_ac(ac_cfg):
                  "altitude_scale", "altitude_potential", "event_scale", "event_potential", "missile_posture_scale",
                  "shoot_penalty_scale", "shoot_penalty_potential", "alt_safe", "alt_danger", "alt_kv", "max_attack_angle",
                  "max_attack_distance", "min_attack_interval", "use_artillery", "hierarchical", "heading_scale", "heading_potential",
-                 "max_heading_increment", "max_altitude_increment", "max_velocities_u_increment", "check_interval", "use_baseline", "rwr"):
+                 "max_heading_increment", "max_altitude_increment", "max_velocities_u_increment", "check_interval", "use_baseline", "rwr", "legacy_obs"):
         setattr(c, name, getattr(ac_cfg, name))
     for i in range(OR_MAX_AC):
         src, dst = ac_cfg.init[i], c.init[i]
@@ -177,6 +178,8 @@ class OracleEnv:
         L.or_env_init(self.p, C.byref(cfg))
         self.A = cfg.n_aircraft
         self.obs_dim = L.or_env_obs_dim_n(cfg.task, cfg.n_aircraft) + (2 if cfg.rwr else 0)
+        if cfg.task == TASK_SCENARIO_NVN and cfg.legacy_obs:
+            self.obs_dim = 21
         self.act_dim = L.or_env_act_dim_h(cfg.task, cfg.hierarchical)
         if cfg.hierarchical:
             actor_load()

@@ -874,10 +874,12 @@ def gen_rwr_obs(rng):
     to zero and two reserved slots, scenario1_task.py:213-314) and Scenario2_RWR (11 + 6 per other aircraft + 6, i.e. the NvN layout
     plus two trailing reserved slots, scenario2_task.py:403-476)."""
     from envs.JSBSim.tasks.scenario1_task import Scenario1_RWR
-    from envs.JSBSim.tasks.scenario2_task import Scenario2_RWR
+    from envs.JSBSim.tasks.scenario2_task import Scenario2_RWR, Scenario2
     from envs.JSBSim.core.simulatior import MissileSimulator
     out = {}
-    for fam, cls, uids in (("s1", Scenario1_RWR, ("A0100", "B0100")), ("nvn", Scenario2_RWR, ("A0100", "A0200", "B0100", "B0200"))):
+    # "legacy": Scenario2 itself keeps MultipleCombatShootMissileTask's 21-value observation against the enemy with the same index
+    for fam, cls, uids in (("s1", Scenario1_RWR, ("A0100", "B0100")), ("nvn", Scenario2_RWR, ("A0100", "A0200", "B0100", "B0200")),
+                           ("legacy", Scenario2, ("A0100", "A0200", "B0100", "B0200"))):
         acs = {u: {"color": "Blue" if u[0] == "A" else "Red", "missile": 2} for u in uids}
         task = _scenario_task(cls, make_config(aircraft_configs=acs))
         poses, obs, msl = [], [], []

@@ -186,7 +186,8 @@ def test_nvn_multicombat_matches_oracle(pkg, oracle, per_side):
 
 @pytest.mark.parametrize("task,per_side,geometry,rwr", [("scenario1", 1, "closing", 0), ("scenario1", 1, "tail", 0),
                                                         ("scenario_nvn", 2, "closing", 0), ("scenario_nvn", 4, "closing", 0),
-                                                        ("scenario1", 1, "closing", 1), ("scenario_nvn", 2, "closing", 1)])
+                                                        ("scenario1", 1, "closing", 1), ("scenario_nvn", 2, "closing", 1),
+                                                        ("scenario_nvn", 2, "closing", 2)])
 def test_scenario_weapon_tasks_match_oracle(pkg, oracle, task, per_side, geometry, rwr):
     """Scenario1 (1v1) / Scenario2_NvN (2v2) / Scenario3_NvN (4v4): gun, AIM-120B / AIM-9M with uid reuse, chaff + keyed decoy
     draws, eleven reward terms with their shared references, env-family order of rewards and terminations. The aircraft state
@@ -207,7 +208,8 @@ def test_scenario_weapon_tasks_match_oracle(pkg, oracle, task, per_side, geometr
             cfg.init[i].h_sl_ft += 300.0 * i
             if i >= per_side:
                 cfg.init[i].lat_geod_deg = 60.06
-    cfg.rwr = rwr   # *_RWR variants: two reserved observation slots (and no missile block in the 1v1 observation)
+    cfg.rwr = int(rwr == 1)         # *_RWR variants: two reserved observation slots (and no missile block in the 1v1 observation)
+    cfg.legacy_obs = int(rwr == 2)  # Scenario2 (not _NvN): the 21-value observation against the paired enemy
     A = cfg.n_agents
     E = 4
     seed = 1234
@@ -263,7 +265,7 @@ def test_scenario_weapon_tasks_match_oracle(pkg, oracle, task, per_side, geometr
     assert launched >= (1 if geometry == "tail" else 2)
     want = {"closing": ("shotdown",), "tail": ("gun",)}[geometry] + (("chaff",) if A > 2 else ())
     assert rwr or all(seen[k] for k in want), seen
-    assert obs.shape[-1] == ((21 if A == 2 else 9 + 6 * A + 6) + (2 if rwr else 0))
+    assert obs.shape[-1] == (21 if rwr == 2 else (21 if A == 2 else 9 + 6 * A + 6) + (2 if rwr else 0))
     env.close()
 
 

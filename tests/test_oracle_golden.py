@@ -305,9 +305,10 @@ def test_rwr_observation_variants(oracle):
     """Scenario1_RWR (23 values, missile block blanked) and Scenario2_RWR (NvN layout + two reserved slots) against the
     reference's get_obs."""
     g = load("rwr_obs.npz")
-    for fam, task, n in (("s1", oracle.TASK_SCENARIO1, 2), ("nvn", oracle.TASK_SCENARIO_NVN, 4)):
+    for fam, task, n in (("s1", oracle.TASK_SCENARIO1, 2), ("nvn", oracle.TASK_SCENARIO_NVN, 4), ("legacy", oracle.TASK_SCENARIO_NVN, 4)):
         cfg = oracle.default_config(task)
-        cfg.rwr = 1
+        cfg.rwr = int(fam != "legacy")
+        cfg.legacy_obs = int(fam == "legacy")   # Scenario2 (not _NvN): 21 values against the enemy with the same team index
         env = oracle.OracleEnv(cfg)
         env.reset()
         assert env.obs_dim == g[f"{fam}_obs"].shape[-1]
