@@ -363,6 +363,77 @@ __device__ __forceinline__ void missile_run(MslT<R>& m, const MslParam& P, R tx,
   }
 }
 
+// fp64 munitions of the scenario tasks: the same update, still entirely in fp64, without the three fp64 sincos calls (~200
+// instructions each). After its first update a missile's velocity IS (v cos(theta) cos(psi), v cos(theta) sin(psi), v sin(theta)),
+// so sin / cos of the current angles are ratios of the velocity components, and the angles after the update follow by the
+// angle-addition formulas with the per-tick increment (|d| <= 0.03 rad: degree-9 Taylor terms are below 1e-18). Only the first
+// tick after launch, whose velocity was inherited from the aircraft (with its down-for-up z component) while theta / psi came
+// from the aircraft attitude, evaluates the trigonometric functions.
+__device__ __forceinline__ void small_sincos(double d, double* s, double* c) {
+  const double d2 = d * d;
+  *s = d * (1.0 + d2 * (-1.0 / 6.0 + d2 * (1.0 / 120.0 + d2 * (-1.0 / 5040.0 + d2 * (1.0 / 362880.0)))));
+  *c = 1.0 + d2 * (-0.5 + d2 * (1.0 / 24.0 + d2 * (-1.0 / 720.0 + d2 * (1.0 / 40320.0))));
+}
+__device__ __forceinline__ void missile_run(MslD& m, const MslParam& P, double tx, double ty, double tz, double tvx, double tvy, double tvz,
+                                            bool target_alive, const DevCfg& c) {
+  const double dt = 1.0 / 60.0;
+  const int k = (int)rint(m.t * 60.0) + 1;
+  m.t = (double)k * dt;
+  const bool burning = k < P.k_burnout;
+  const double g = P.g, t_max = P.t_max, nyz_max = P.nyz_max;
+  const double hxy2 = m.vx * m.vx + m.vy * m.vy;
+  const double vm = sqrt(hxy2 + m.vz * m.vz);
+  const double ivm = 1.0 / vm;
+  const double cth = sqrt(fmax(0.0, 1.0 - (m.vz * ivm) * (m.vz * ivm)));  // cos(asin(dz/v))
+  const double ddx = tx - m.px, ddy = ty - m.py, ddz = tz - m.pz;
+  const double Rxy2 = ddx * ddx + ddy * ddy, Rxy = sqrt(Rxy2);
+  const double R2 = Rxy2 + ddz * ddz, Rxyz = sqrt(R2);
+  const double dbeta = ((tvy - m.vy) * ddx - (tvx - m.vx) * ddy) / Rxy2;
+  const double deps = ((tvz - m.vz) * Rxy2 - ddz * (ddx * (tvx - m.vx) + ddy * (tvy - m.vy))) / (R2 * Rxy);
+  const double K = fmax((double)P.K * (t_max - m.t) / t_max, 0.0);
+  const double ny = m_clamp(-nyz_max, K * vm / g * cth * dbeta, nyz_max);
+  const double nz = m_clamp(-nyz_max, K * vm / g * deps + cth, nyz_max);
+  m.recede = (Rxyz > m.dprev) ? m.recede + 1 : 0;
+  m.dprev = Rxyz;
+  if (Rxyz < (double)P.Rc && target_alive && m.status != MSL_MISS) {
+    m.status = MSL_HIT;
+  } else if (k >= P.k_timeout || vm < (double)P.v_min || m.recede >= P.recede_max || !target_alive) {
+    m.status = MSL_MISS;
+  } else {
+    m.px += dt * m.vx; m.py += dt * m.vy; m.pz += dt * m.vz;
+    const double alt = neu_height64(m.px, m.py, m.pz, c);
+    const double Tt = burning ? g * (double)P.Isp * (double)P.dm : 0.0;
+    const double sd = sin(m.dth), sp = sin(m.dph);
+    const double D0 = P.Diameter, L0 = P.Length;
+    const double S = 3.14159265358979323846 * 0.25 * D0 * D0 + sqrt(sd * sd + sp * sp) * D0 * L0;
+    const double rho = 1.225 * exp(-alt / 9300.0);
+    const double D = 0.5 * (double)P.cD * S * rho * vm * vm;
+    const double nx = (Tt - D) / (m.m * g);
+    double st, ct, sps, cps;   // of the CURRENT theta, psi
+    if (k == 1) { sincos(m.theta, &st, &ct); sincos(m.psi, &sps, &cps); }
+    else {
+      const double hxy = sqrt(hxy2), ih = 1.0 / hxy;
+      st = m.vz * ivm; ct = hxy * ivm; cps = m.vx * ih; sps = m.vy * ih;
+    }
+    const double dv = g * (nx - st);
+    m.dph = g * ivm * (ny / ct);
+    m.dth = g * ivm * (nz - ct);
+    const double v = vm + dt * dv;
+    const double dps = dt * m.dph, dts = dt * m.dth;
+    m.psi += dps; m.theta += dts;
+    double s2, c2, s3, c3;
+    if (fabs(dps) > 0.05 || fabs(dts) > 0.05) { sincos(m.theta, &s2, &c2); sincos(m.psi, &s3, &c3); }   // (never in the guidance envelope)
+    else {
+      double sa, ca, sb, cb;
+      small_sincos(dts, &sa, &ca); small_sincos(dps, &sb, &cb);
+      s2 = st * ca + ct * sa; c2 = ct * ca - st * sa;
+      s3 = sps * cb + cps * sb; c3 = cps * cb - sps * sb;
+    }
+    m.vx = v * c2 * c3; m.vy = v * c2 * s3; m.vz = v * s2;
+    if (burning) m.m -= dt * (double)P.dm;
+  }
+}
+
 // Stage the 7 KB table pack into LDS: every lane issues all of its 16-byte global loads before the first LDS store, so
 // the workgroup pays one L2 round trip instead of one per loop iteration.
 __device__ __forceinline__ void stage_tables(float* lds, const float* __restrict__ g) {
