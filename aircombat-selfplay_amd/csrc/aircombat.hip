@@ -18,6 +18,7 @@
 #include <cmath>
 #include "../../include/aircombat.h"
 #include "f16_device.hpp"
+#include "f16_split.hpp"
 
 using f16::State;
 using f16::Derived;
@@ -512,23 +513,128 @@ struct TaskTraits {
 // Occupancy: WPE = waves per SIMD the register allocation is bounded for. WPE = 2 (256 VGPRs, 12 dwords of scratch) lets two
 // waves share a SIMD and fill its 2-cycle issue rate: +38 % throughput once there are more waves than SIMDs. WPE = 1 keeps
 // everything in registers (269 incl. accumulation VGPRs): 5 % less latency when each SIMD has at most one wave (E*A <= 65536).
-template <int TASK, int WPE>
-__global__ __launch_bounds__(64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) {
+//
+// SPLIT (no-missile task, small grids): a workgroup is TWO waves over the same 64 aircraft. Wave 0 ("dynamics") runs the rigid-body
+// part of every tick and the whole environment layer; wave 1 ("systems") runs the flight control system and the turbine of the same
+// aircraft on another SIMD, concurrently with wave 0's atmosphere / mass / auxiliary / table look-up work. The two exchange ~25 floats
+// per aircraft and tick through LDS, with three workgroup barriers per tick (f16_split.hpp holds the statements of tick(), cut into
+// those pieces). A lone wave issues one dependent instruction every ~4.3 cycles, so below one wave per SIMD this shortens the tick's
+// critical path instead of competing for issue slots.
+namespace mail {  // LDS mailbox rows (64 floats each)
+enum { CTH, VB,                                                    // dynamics -> systems after part 1
+       MACH, QBAR, RHO, TEMP, HSL, ALPHA, BETA, QC, VG, NPY, NPZ, AP, AQ, AR,   // dynamics -> systems after part 2
+       S_AIL, S_FLAP, S_ELEV, S_RUD, S_LEF, S_SB,                   // systems -> dynamics after the FCS
+       THRUST,                                                      // systems -> dynamics after the turbine
+       LK_CNDR, LK_M0, LK_M1 = LK_M0 + 4,   // ... and its share of the table look-ups
+       MASS0 = LK_M1 + 4, MASS_N = 18,                              // systems -> dynamics: mass properties of the coming tick
+       F_TEF = MASS0 + MASS_N, F_PINR, F_PINP, F_PINY, F_PIR, F_PIP, F_PIY, F_AIL, F_ELEV, F_SBDEG, F_N1, F_N2, F_N2NORM, F_FF, F_TANK0, F_TANK1,
+       F_ENG,                                                       // final hand-over of the fields the systems wave owns
+       ROWS };
+}
+// mass, CG, inertia tensor, its cofactors / determinant, 1/mass: sys_mass() on the systems wave -> DynVars of the dynamics wave
+__device__ __forceinline__ void post_mass(float (*M)[64], int l, const f16::DynVars& k) {
+  const float v[mail::MASS_N] = {k.mass, k.cgx, k.cgy, k.cgz, k.Jxx, k.Jyy, k.Jzz, k.Jxy, k.Jxz, k.Jyz, k.c00, k.c01, k.c02, k.c11, k.c12, k.c22, k.idet, k.im_};
+#pragma unroll
+  for (int i = 0; i < mail::MASS_N; ++i) M[mail::MASS0 + i][l] = v[i];
+}
+__device__ __forceinline__ void fetch_mass(float (*M)[64], int l, f16::DynVars& k) {
+  float v[mail::MASS_N];
+#pragma unroll
+  for (int i = 0; i < mail::MASS_N; ++i) v[i] = M[mail::MASS0 + i][l];
+  k.mass = v[0]; k.cgx = v[1]; k.cgy = v[2]; k.cgz = v[3]; k.Jxx = v[4]; k.Jyy = v[5]; k.Jzz = v[6]; k.Jxy = v[7]; k.Jxz = v[8]; k.Jyz = v[9];
+  k.c00 = v[10]; k.c01 = v[11]; k.c02 = v[12]; k.c11 = v[13]; k.c12 = v[14]; k.c22 = v[15]; k.idet = v[16]; k.im_ = v[17];
+}
+#ifdef AC_SPLIT_TIMING   // scratch builds only (variants/): cycle stamps of workgroup 0's dynamics wave
+__device__ unsigned long long g_clk[64];
+#define AC_CLK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_clk[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" void ac_debug_clocks(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof g_clk); }
+#else
+#define AC_CLK(i) do {} while (0)
+#endif
+__device__ __forceinline__ void wg_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// The systems wave of a SPLIT workgroup: FCS and turbine of every substep, then the final values of the fields it owns.
+__device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::Tab& T, float (*M)[64], int l, int substeps) {
+  using namespace mail;
+  f16::DynVars km{};
+  f16::sys_mass(s, km);
+  post_mass(M, l, km);                                     // read by the dynamics wave after B1 of the first tick
+  for (int sub = 0; sub < substeps; ++sub) {
+    const bool run = t.status == AC_ALIVE;
+    if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;   // the same latch the dynamics wave applies
+    f16::Surf sf{};
+    wg_sync();                                             // B1: this tick's attitude is known
+    if (run) {
+      f16::sys_fcs(s, M[CTH][l], M[VB][l], sf);
+      M[S_AIL][l] = sf.aileron_rad; M[S_FLAP][l] = sf.flaperon_rad; M[S_ELEV][l] = sf.elevator_rad;
+      M[S_RUD][l] = sf.rudder_rad;  M[S_LEF][l] = sf.lef_rad;       M[S_SB][l] = sf.sb_rad;
+    }
+    wg_sync();                                             // B2: this tick's air data are known
+    if (run) {
+      f16::Atmos A{};
+      A.rho = M[RHO][l]; A.T = M[TEMP][l];
+      const float mach = M[MACH][l], alpha = M[ALPHA][l], h_sl = M[HSL][l];
+      float thrust;
+      f16::sys_engine(s, T, mach, M[QBAR][l], A, h_sl, sf.throttle_pos, thrust);
+      M[THRUST][l] = thrust;
+      // this wave's share of the aerodynamic tables (those on the Mach axis); everything else dyn_p3 computes here is dead
+      f16::Derived dd{};
+      dd.h_sl_ft = h_sl;
+      km.alpha = alpha; km.beta = M[BETA][l]; km.mach = mach; km.vt = 1.0f; km.qbar = 0.0f;
+      f16::dyn_p3(dd, T, km, sf);
+      M[LK_CNDR][l] = km.cndr_m;
+      M[LK_M0][l] = km.m0.x; M[LK_M0 + 1][l] = km.m0.y; M[LK_M0 + 2][l] = km.m0.z; M[LK_M0 + 3][l] = km.m0.w;
+      M[LK_M1][l] = km.m1.x; M[LK_M1 + 1][l] = km.m1.y; M[LK_M1 + 2][l] = km.m1.z; M[LK_M1 + 3][l] = km.m1.w;
+      // what FGAuxiliary published this tick is what the next tick's FCS reads
+      s.alpha = alpha; s.mach = mach; s.qc = M[QC][l]; s.vg = M[VG][l];
+      s.npy = M[NPY][l]; s.npz = M[NPZ][l]; s.ap = M[AP][l]; s.aq = M[AQ][l]; s.ar = M[AR][l];
+    }
+    wg_sync();                                             // B3: surfaces, thrust and the shared look-ups are known
+    if (run) {                                             // while the dynamics wave assembles, integrates and propagates:
+      f16::sys_mass(s, km);                                // the tanks after this tick's draw give the next tick's mass balance
+      post_mass(M, l, km);
+    }
+  }
+  M[F_TEF][l] = s.tef; M[F_PINR][l] = s.pin_r; M[F_PINP][l] = s.pin_p; M[F_PINY][l] = s.pin_y;
+  M[F_PIR][l] = s.pi_r; M[F_PIP][l] = s.pi_p; M[F_PIY][l] = s.pi_y; M[F_AIL][l] = s.ail; M[F_ELEV][l] = s.elev; M[F_SBDEG][l] = s.sbdeg;
+  M[F_N1][l] = s.n1; M[F_N2][l] = s.n2; M[F_N2NORM][l] = s.n2norm; M[F_FF][l] = s.ff; M[F_TANK0][l] = s.tank0; M[F_TANK1][l] = s.tank1;
+  M[F_ENG][l] = __int_as_float(s.eng);
+  wg_sync();
+}
+template <int TASK, int WPE, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 128 : 64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) {
   using TT = TaskTraits<TASK>;
   constexpr bool HAS_MSL = TT::HAS_MSL;
   constexpr int MSLOTS = TT::MSLOTS;
   constexpr int OBS = TT::OBS;
+  static_assert(!SPLIT || !HAS_MSL, "the two-wave form covers the task without munitions");
+  AC_CLK(0);
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
+  __shared__ float M[SPLIT ? mail::ROWS : 1][64];
   stage_tables(lds_tab, P.tab);
   const Tab T{lds_tab};
   const int N = c.N;
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int l = threadIdx.x & 63;
+  const int n = blockIdx.x * 64 + l;
   const bool live = n < N;           // N is even, so both lanes of a pair are live or not together
   const int nn = live ? n : (N - 2 + (n & 1));  // tail lanes shadow the last env and never store
   const int slot = nn & 1;
 
+  AC_CLK(1);
   State s; Task t; Derived d; Props pr;
   load_state(P.F, P.I, P.D, N, nn, s, t);
+  if (SPLIT && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1) {
+    const float* act = P.actions + (size_t)nn * c.act_dim;
+    s.da = clampf(-1.0f, act[0] / 20.0f - 1.0f, 1.0f);
+    s.de = clampf(-1.0f, act[1] / 20.0f - 1.0f, 1.0f);
+    s.dr = clampf(-1.0f, act[2] / 20.0f - 1.0f, 1.0f);
+    s.thr = clampf(0.0f, act[3] / 58.0f + 0.4f, 0.9f);
+    systems_wave(s, t, T, M, l, c.substeps);
+    return;
+  }
   Msl ms[MSLOTS];
   int nslots = 0;
   if (HAS_MSL) {
@@ -553,7 +659,47 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) 
   const MslParam MP = aim9l();
   bool have_pose = false;
   for (int sub = 0; sub < c.substeps; ++sub) {
-    if (t.status == AC_ALIVE) {
+    if (SPLIT) {
+      using namespace mail;
+      const bool run = t.status == AC_ALIVE;
+      if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;
+      f16::DynVars k;
+      AC_CLK(2 + sub * 8);
+      if (run) {
+        f16::dyn_p1(s, d, k);
+        M[CTH][l] = d.T[6] * d.d_eci[0] + d.T[7] * d.d_eci[1] + d.T[8] * d.d_eci[2];
+        M[VB][l] = d.v;
+        have_pose = true;
+      }
+      AC_CLK(3 + sub * 8);
+      wg_sync();                                               // B1
+      AC_CLK(4 + sub * 8);
+      if (run) {
+        fetch_mass(M, l, k);
+        f16::dyn_p2(s, d, k);
+        M[BETA][l] = k.beta;
+        M[MACH][l] = k.mach; M[QBAR][l] = k.qbar; M[RHO][l] = k.A.rho; M[TEMP][l] = k.A.T; M[HSL][l] = d.h_sl_ft;
+        M[ALPHA][l] = k.alpha; M[QC][l] = k.qc; M[VG][l] = k.vg; M[NPY][l] = k.npy; M[NPZ][l] = k.npz;
+        M[AP][l] = d.p; M[AQ][l] = d.q; M[AR][l] = d.r;
+      }
+      AC_CLK(5 + sub * 8);
+      wg_sync();                                               // B2
+      AC_CLK(6 + sub * 8);
+      f16::Surf sf{};
+      if (run) {
+        sf = f16::Surf{M[S_AIL][l], M[S_FLAP][l], M[S_ELEV][l], M[S_RUD][l], M[S_LEF][l], M[S_SB][l], 0.0f};
+        f16::dyn_p3(d, T, k, sf);
+      }
+      AC_CLK(7 + sub * 8);
+      wg_sync();                                               // B3
+      AC_CLK(8 + sub * 8);
+      if (run) {
+        k.cndr_m = M[LK_CNDR][l];
+        k.m0 = make_float4(M[LK_M0][l], M[LK_M0 + 1][l], M[LK_M0 + 2][l], M[LK_M0 + 3][l]);
+        k.m1 = make_float4(M[LK_M1][l], M[LK_M1 + 1][l], M[LK_M1 + 2][l], M[LK_M1 + 3][l]);
+        f16::dyn_p4(s, d, k, sf, M[THRUST][l]);
+      }
+    } else if (t.status == AC_ALIVE) {
       if (t.bloods <= 0.0f) t.status = AC_SHOTDOWN;  // simulatior.py:220-222: this tick still integrates
       f16::tick<false>(s, d, T);
       have_pose = true;
@@ -576,11 +722,22 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) 
       if (__shfl_xor((int)hit_now, 1) && t.status == AC_ALIVE) t.status = AC_SHOTDOWN;
     }
   }
+  if (SPLIT) {   // the systems wave's fields after its last tick
+    using namespace mail;
+    AC_CLK(50);
+    wg_sync();
+    AC_CLK(51);
+    s.tef = M[F_TEF][l]; s.pin_r = M[F_PINR][l]; s.pin_p = M[F_PINP][l]; s.pin_y = M[F_PINY][l];
+    s.pi_r = M[F_PIR][l]; s.pi_p = M[F_PIP][l]; s.pi_y = M[F_PIY][l]; s.ail = M[F_AIL][l]; s.elev = M[F_ELEV][l]; s.sbdeg = M[F_SBDEG][l];
+    s.n1 = M[F_N1][l]; s.n2 = M[F_N2][l]; s.n2norm = M[F_N2NORM][l]; s.ff = M[F_FF][l]; s.tank0 = M[F_TANK0][l]; s.tank1 = M[F_TANK1][l];
+    s.eng = __float_as_int(M[F_ENG][l]);
+  }
   if (!HAS_MSL || c.substeps == 0) {
     f16::locate(s, d);
     if (!have_pose) f16::body_frame(s, d);
     make_props(s, d, c, pr);
   }
+  AC_CLK(52);
   Enemy E = exchange_1v1(pr);
 
   // ---- task.step
@@ -753,6 +910,7 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) 
 #pragma unroll
     for (int k = 0; k < OBS; ++k) ob[k] = tobs[k];
   }
+  AC_CLK(53);
   if (live) {
     store_state(P.F, P.I, P.D, N, n, s, t);
     if (HAS_MSL) {
@@ -772,6 +930,7 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) 
       inf[3] = all_done ? 1 : 0;
     }
   }
+  AC_CLK(54);
 }
 
 // ------------------------------------------------------------------------------------------------ NvN (MultipleCombat)
@@ -1135,6 +1294,7 @@ struct ac_env {
   int act_low;                           // width of the low-level action the step kernels decode
   hipEvent_t ev0, ev1;
   bool timing;
+  bool split_waves;                      // SingleCombat below one wave per SIMD: two waves per 64 aircraft (step_kernel_1v1<.., SPLIT>)
 };
 
 static void geodetic2ecef_m(double lat_deg, double lon_deg, double alt, double* x, double* y, double* z) {
@@ -1186,7 +1346,8 @@ static int launch_step(ac_env* h, const float* d_actions) {
       else hipLaunchKernelGGL((step_kernel_nvn<8, 2>), grid, block, 0, h->stream, p, h->dc);
     }
   } else if (h->cfg.task == AC_TASK_SINGLECOMBAT) {
-    if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 1>), grid, block, 0, h->stream, p, h->dc);
+    if (h->split_waves) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 1, true>), grid, dim3(128), 0, h->stream, p, h->dc);
+    else if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 1>), grid, block, 0, h->stream, p, h->dc);
     else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 2>), grid, block, 0, h->stream, p, h->dc);
   } else if (h->cfg.task == AC_TASK_DODGE_MISSILE) {
     hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_DODGE_MISSILE, 2>), grid, block, 0, h->stream, p, h->dc);
@@ -1262,6 +1423,10 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   ac_env* h = new ac_env();
   memset(h, 0, sizeof *h);
   h->cfg = *cfg; h->E = n_envs; h->A = cfg->n_agents; h->N = n_envs * cfg->n_agents; h->device = device_id;
+  {  // two waves per workgroup while that still leaves every wave a SIMD of its own (256 CUs x 4); AIRCOMBAT_SPLIT=0/1 overrides
+    const char* e = getenv("AIRCOMBAT_SPLIT");
+    h->split_waves = cfg->task == AC_TASK_SINGLECOMBAT && (e ? (e[0] == '1') : ((h->N + 63) / 64 * 2 <= 1024));
+  }
   h->obs_dim = heading ? 12 : (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
   const int tmpl_obs = h->obs_dim;   // (the scenario kernel family's template keeps 21 slots for WVR too)

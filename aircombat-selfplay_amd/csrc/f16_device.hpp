@@ -556,33 +556,40 @@ __device__ __forceinline__ void tick(State& s, Derived& d, const Tab& T) {
     float i2v = (vt != 0.0f) ? 0.5f / vt : 0.0f;
     float bi2vel = bw * i2v, ci2vel = cbar * i2v;
     float qS = qbar * Sw;
-    // segment indices from immediates, then every LDS read of the tick in one batch
+    // segment indices from immediates, then every LDS read of the tick issued as ONE batch (breakpoints and table rows depend on
+    // the indices only), then the interpolation: one LDS round trip per tick instead of one per table group
     constexpr float kAX[] = C_ALPHA_X, kDX[] = C_DE_X, kB13X[] = C_B13_X, kB7X[] = C_B7_X, kMX[] = C_MACH_X;
     const int ia = seg_index(kAX, alpha), ide = seg_index(kDX, elevator_rad), ib13 = seg_index(kB13X, beta),
               ib7 = seg_index(kB7X, beta), im = seg_index(kMX, mach);
-    const float fa = seg_frac(T[P_ALPHA_X_OFF + ia - 1], T[P_ALPHA_X_OFF + ia], alpha);
-    const float fde = seg_frac(T[P_DE_X_OFF + ide - 1], T[P_DE_X_OFF + ide], elevator_rad);
-    const float fb13 = seg_frac(T[P_B13_X_OFF + ib13 - 1], T[P_B13_X_OFF + ib13], beta);
-    const float fb7 = seg_frac(T[P_B7_X_OFF + ib7 - 1], T[P_B7_X_OFF + ib7], beta);
-    const float fmach = seg_frac(T[P_MACH_X_OFF + im - 1], T[P_MACH_X_OFF + im], mach);
     const int a1 = P_A1_OFF + (ia - 1) * P_A1_STRIDE;
-    float4 g0 = lerp4(T.v4(a1), T.v4(a1 + 16), fa);            // CDDlef CDq CDq_Dlef CLDlef
-    float4 g1 = lerp4(T.v4(a1 + 4), T.v4(a1 + 20), fa);        // CYp CYr Clp Clr
-    float4 g2 = lerp4(T.v4(a1 + 8), T.v4(a1 + 24), fa);        // CLq Cmq Cnp Cnr
+    const int ae = P_AE_OFF + ((ia - 1) * 5 + (ide - 1)) * 4;
+    const int ab13 = P_AB13_OFF + ((ia - 1) * 13 + (ib13 - 1)) * 2;
+    const int ab7 = P_AB7_OFF + ((ia - 1) * 7 + (ib7 - 1)) * 4;
+    const int am = P_M_OFF + (im - 1) * P_M_STRIDE;
+    const float xa0 = T[P_ALPHA_X_OFF + ia - 1], xa1 = T[P_ALPHA_X_OFF + ia], xe0 = T[P_DE_X_OFF + ide - 1], xe1 = T[P_DE_X_OFF + ide];
+    const float xb0 = T[P_B13_X_OFF + ib13 - 1], xb1 = T[P_B13_X_OFF + ib13], xc0 = T[P_B7_X_OFF + ib7 - 1], xc1 = T[P_B7_X_OFF + ib7];
+    const float xm0 = T[P_MACH_X_OFF + im - 1], xm1 = T[P_MACH_X_OFF + im];
+    const float4 ra0 = T.v4(a1), ra1 = T.v4(a1 + 16), ra2 = T.v4(a1 + 4), ra3 = T.v4(a1 + 20), ra4 = T.v4(a1 + 8), ra5 = T.v4(a1 + 24);
+    const float4 re0 = T.v4(ae), re1 = T.v4(ae + 20), re2 = T.v4(ae + 4), re3 = T.v4(ae + 24);
+    const float2 h00 = T.v2(ab13), h01 = T.v2(ab13 + 2), h10 = T.v2(ab13 + 26), h11 = T.v2(ab13 + 28);
+    const float4 rb0 = T.v4(ab7), rb1 = T.v4(ab7 + 28), rb2 = T.v4(ab7 + 4), rb3 = T.v4(ab7 + 32);
+    const float4 rm0 = T.v4(am), rm1 = T.v4(am + 12), rm2 = T.v4(am + 4), rm3 = T.v4(am + 16);
+    const float rn0 = T[am + 8], rn1 = T[am + 20];
+    __builtin_amdgcn_sched_barrier(0);
+    const float fa = seg_frac(xa0, xa1, alpha), fde = seg_frac(xe0, xe1, elevator_rad), fb13 = seg_frac(xb0, xb1, beta),
+                fb7 = seg_frac(xc0, xc1, beta), fmach = seg_frac(xm0, xm1, mach);
+    float4 g0 = lerp4(ra0, ra1, fa);                           // CDDlef CDq CDq_Dlef CLDlef
+    float4 g1 = lerp4(ra2, ra3, fa);                           // CYp CYr Clp Clr
+    float4 g2 = lerp4(ra4, ra5, fa);                           // CLq Cmq Cnp Cnr
     float4 g3 = make_float4(0.f, 0.f, 0.f, 0.f);               // CDDsb CLDsb CLq_Dsb CmDsb: only with the speedbrake out
     if (sb_rad != 0.0f) g3 = lerp4(T.v4(a1 + 12), T.v4(a1 + 28), fa);
-    const int ae = P_AE_OFF + ((ia - 1) * 5 + (ide - 1)) * 4;
-    float4 ge = lerp4(lerp4(T.v4(ae), T.v4(ae + 20), fa), lerp4(T.v4(ae + 4), T.v4(ae + 24), fa), fde);      // CDDh CLDh CmDh
-    const int ab13 = P_AB13_OFF + ((ia - 1) * 13 + (ib13 - 1)) * 2;
-    float2 h00 = T.v2(ab13), h01 = T.v2(ab13 + 2), h10 = T.v2(ab13 + 26), h11 = T.v2(ab13 + 28);
+    float4 ge = lerp4(lerp4(re0, re1, fa), lerp4(re2, re3, fa), fde);      // CDDh CLDh CmDh
     float clb = lerpf(lerpf(h00.x, h10.x, fa), lerpf(h01.x, h11.x, fa), fb13);
     float cnb = lerpf(lerpf(h00.y, h10.y, fa), lerpf(h01.y, h11.y, fa), fb13);
-    const int ab7 = P_AB7_OFF + ((ia - 1) * 7 + (ib7 - 1)) * 4;
-    float4 g7 = lerp4(lerp4(T.v4(ab7), T.v4(ab7 + 28), fa), lerp4(T.v4(ab7 + 4), T.v4(ab7 + 32), fa), fb7);  // Clda Cldr Cnda Cndr
-    const int am = P_M_OFF + (im - 1) * P_M_STRIDE;
-    float4 m0 = lerp4(T.v4(am), T.v4(am + 12), fmach);         // CDmach CYb_M Clb_M Clda_M
-    float4 m1 = lerp4(T.v4(am + 4), T.v4(am + 16), fmach);     // Cldr_M Cma_M Cnb_M Cnda_M
-    float cndr_m = lerpf(T[am + 8], T[am + 20], fmach);        // Cndr_M
+    float4 g7 = lerp4(lerp4(rb0, rb1, fa), lerp4(rb2, rb3, fa), fb7);      // Clda Cldr Cnda Cndr
+    float4 m0 = lerp4(rm0, rm1, fmach);                        // CDmach CYb_M Clb_M Clda_M
+    float4 m1 = lerp4(rm2, rm3, fmach);                        // Cldr_M Cma_M Cnb_M Cnda_M
+    float cndr_m = lerpf(rn0, rn1, fmach);                     // Cndr_M
     // hoverbmac > 1.1 everywhere above the 2500 m floor, kCLge = 1 there; the table only matters for very low floors
     // (altitude above the sea-level radius stands in for AGL; the reference-point offset is < 2 ft)
     float hb = d.h_sl_ft * (1.0f / (float)F16_WINGSPAN);

@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -95,6 +96,12 @@ def test_generated_table_copies_are_in_sync():
     a = open(os.path.join(ROOT, "oracle", "f16_tables.h")).read()
     b = open(os.path.join(ROOT, "aircombat-selfplay_amd", "csrc", "f16_tables.h")).read()
     assert a == b
+
+
+def test_two_wave_tick_pieces_are_generated_from_the_current_tick():
+    """csrc/f16_split.hpp holds the statements of tick() cut into the pieces of the two-wave kernel; it must be what
+    tools/gen_split_tick.py makes of the current f16_device.hpp, so that the two kernel forms compute the same arithmetic."""
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_split_tick.py"), "--check"]).returncode == 0
 
 
 def test_curriculum_spawn_matches_reference_table():

@@ -100,6 +100,41 @@ def test_teacher_forced_steps(pkg, oracle, task):
     env.close()
 
 
+@pytest.mark.parametrize("two_waves", ["0", "1"])
+def test_singlecombat_kernel_forms_teacher_forced(pkg, oracle, monkeypatch, two_waves):
+    """SingleCombat has two kernel forms: one wave per 64 aircraft, and (below one wave per SIMD) two waves per 64 aircraft that
+    split every FDM tick between them through LDS. AIRCOMBAT_SPLIT pins the form; both must agree with the oracle step by step,
+    full state vector included, on a batch with a ragged last workgroup (70 envs = 140 lanes), and with one another."""
+    monkeypatch.setenv("AIRCOMBAT_SPLIT", two_waves)
+    cfg = pkg.default_config("singlecombat")
+    E = 70
+    env = pkg.HipVecEnv(cfg, E)
+    ref = oracle.OracleVecEnv(oracle.config_from_ac(cfg), E)
+    env.reset(); ref.reset()
+    names = env.lib.state_field_names()
+    ix = {nm: k for k, nm in enumerate(names) if nm}
+    rng = np.random.default_rng(314)
+    for step in range(25):
+        for e in range(E):
+            for a in range(2):
+                env.set_state(e, a, ref.envs[e].export_state(a))
+        act = rand_actions(rng, E, 2, 4)
+        obs, rew, done, info = env.step(act)
+        robs, rrew, rdone, rinfo = ref.step(act)
+        assert obs_close(obs, robs).all(), step
+        assert (np.abs(rew - rrew) <= 5e-3 + 1e-3 * np.abs(rrew)).all(), step
+        assert (done == rdone).all(), step
+        for e in (0, 31, 32, 63, 64, 69):                 # both lanes of a pair, workgroup edges, the ragged tail
+            for a in range(2):
+                got, want = env.get_state(e, a), ref.envs[e].export_state(a)
+                for f in ("tef", "ail", "elev", "sbdeg", "pi_r", "pi_p", "pi_y", "pin_r", "pin_p", "pin_y", "n1", "n2", "n2norm", "ff",
+                          "tank0", "tank1", "alpha", "mach", "qc", "vg", "vx", "vy", "vz", "wp", "wq", "wr"):
+                    rel = 5e-4 if f == "ff" else 2e-5      # fuel flow = thrust x a sqrt-of-temperature factor, both fp32 here
+                    assert abs(got[ix[f]] - want[ix[f]]) <= rel * max(1.0, abs(want[ix[f]])) + 1e-6, (step, e, a, f, got[ix[f]], want[ix[f]])
+                assert got[ix["eng"]] == want[ix["eng"]] and got[ix["ticks"]] == want[ix["ticks"]]
+    env.close()
+
+
 def test_open_loop_rollout_with_terminations(pkg, oracle):
     """Random actions from reset until episodes end: dones and auto-reset observations line up with the oracle."""
     cfg = pkg.default_config("singlecombat")
