@@ -525,11 +525,31 @@ enum { CTH, VB,                                                    // dynamics -
        MACH, QBAR, RHO, TEMP, HSL, ALPHA, BETA, QC, VG, NPY, NPZ, AP, AQ, AR,   // dynamics -> systems after part 2
        S_AIL, S_FLAP, S_ELEV, S_RUD, S_LEF, S_SB,                   // systems -> dynamics after the FCS
        THRUST,                                                      // systems -> dynamics after the turbine
-       LK_CNDR, LK_M0, LK_M1 = LK_M0 + 4,   // ... and its share of the table look-ups
-       MASS0 = LK_M1 + 4, MASS_N = 18,                              // systems -> dynamics: mass properties of the coming tick
+       LK_CLB, LK_CNB, LK_G7,                                       // kinematics -> dynamics: its share of the table look-ups
+       MASS0 = LK_G7 + 4, MASS_N = 18,                              // systems -> dynamics: mass properties of the coming tick
        F_TEF = MASS0 + MASS_N, F_PINR, F_PINP, F_PINY, F_PIR, F_PIP, F_PIY, F_AIL, F_ELEV, F_SBDEG, F_N1, F_N2, F_N2NORM, F_FF, F_TANK0, F_TANK1,
        F_ENG,                                                       // final hand-over of the fields the systems wave owns
-       ROWS };
+       K_W, K_V = K_W + 3,                                          // dynamics -> kinematics after part 1: body rates, ECI velocity
+       K_OUT = K_V + 3, K_OUT_N = 27,                               // kinematics -> dynamics: f16::KinOut of the coming tick
+       G_Q = K_OUT + K_OUT_N, G_H = G_Q + 4, G_NED = G_H + 1,        // kinematics -> dynamics at the end: quaternion, env-layer frame
+       ROWS = G_NED + 8 };
+enum { GD_R, GD_X = GD_R + 3, GD_LAT = GD_X + 3, DROWS = GD_LAT + 4 };   // ... and the fp64 rows: ECI / ECEF position, geodetic cosines
+}
+__device__ __forceinline__ void post_kin(float (*M)[64], int l, const f16::KinOut& o) {
+  const float v[mail::K_OUT_N] = {o.T[0], o.T[1], o.T[2], o.T[3], o.T[4], o.T[5], o.T[6], o.T[7], o.T[8], o.h_sl_ft, o.n_eci[0], o.n_eci[1], o.n_eci[2],
+                                  o.e_eci[0], o.e_eci[1], o.d_eci[0], o.d_eci[1], o.d_eci[2], o.gx, o.gy, o.gz, o.rxf, o.ryf, o.A.T, o.A.P, o.A.rho, o.A.a};
+#pragma unroll
+  for (int i = 0; i < mail::K_OUT_N; ++i) M[mail::K_OUT + i][l] = v[i];
+}
+__device__ __forceinline__ void fetch_kin(float (*M)[64], int l, f16::KinOut& o) {
+  float v[mail::K_OUT_N];
+#pragma unroll
+  for (int i = 0; i < mail::K_OUT_N; ++i) v[i] = M[mail::K_OUT + i][l];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o.T[i] = v[i];
+  o.h_sl_ft = v[9]; o.n_eci[0] = v[10]; o.n_eci[1] = v[11]; o.n_eci[2] = v[12]; o.e_eci[0] = v[13]; o.e_eci[1] = v[14];
+  o.d_eci[0] = v[15]; o.d_eci[1] = v[16]; o.d_eci[2] = v[17]; o.gx = v[18]; o.gy = v[19]; o.gz = v[20]; o.rxf = v[21]; o.ryf = v[22];
+  o.A.T = v[23]; o.A.P = v[24]; o.A.rho = v[25]; o.A.a = v[26];
 }
 // mass, CG, inertia tensor, its cofactors / determinant, 1/mass: sys_mass() on the systems wave -> DynVars of the dynamics wave
 __device__ __forceinline__ void post_mass(float (*M)[64], int l, const f16::DynVars& k) {
@@ -580,20 +600,12 @@ __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::
       float thrust;
       f16::sys_engine(s, T, mach, M[QBAR][l], A, h_sl, sf.throttle_pos, thrust);
       M[THRUST][l] = thrust;
-      // this wave's share of the aerodynamic tables (those on the Mach axis); everything else dyn_p3 computes here is dead
-      f16::Derived dd{};
-      dd.h_sl_ft = h_sl;
-      km.alpha = alpha; km.beta = M[BETA][l]; km.mach = mach; km.vt = 1.0f; km.qbar = 0.0f;
-      f16::dyn_p3(dd, T, km, sf);
-      M[LK_CNDR][l] = km.cndr_m;
-      M[LK_M0][l] = km.m0.x; M[LK_M0 + 1][l] = km.m0.y; M[LK_M0 + 2][l] = km.m0.z; M[LK_M0 + 3][l] = km.m0.w;
-      M[LK_M1][l] = km.m1.x; M[LK_M1 + 1][l] = km.m1.y; M[LK_M1 + 2][l] = km.m1.z; M[LK_M1 + 3][l] = km.m1.w;
-      // what FGAuxiliary published this tick is what the next tick's FCS reads
-      s.alpha = alpha; s.mach = mach; s.qc = M[QC][l]; s.vg = M[VG][l];
-      s.npy = M[NPY][l]; s.npz = M[NPZ][l]; s.ap = M[AP][l]; s.aq = M[AQ][l]; s.ar = M[AR][l];
     }
-    wg_sync();                                             // B3: surfaces, thrust and the shared look-ups are known
+    wg_sync();                                             // B3: surfaces and thrust are known
     if (run) {                                             // while the dynamics wave assembles, integrates and propagates:
+      // what FGAuxiliary published this tick is what the next tick's FCS reads
+      s.alpha = M[ALPHA][l]; s.mach = M[MACH][l]; s.qc = M[QC][l]; s.vg = M[VG][l];
+      s.npy = M[NPY][l]; s.npz = M[NPZ][l]; s.ap = M[AP][l]; s.aq = M[AQ][l]; s.ar = M[AR][l];
       f16::sys_mass(s, km);                                // the tanks after this tick's draw give the next tick's mass balance
       post_mass(M, l, km);
     }
@@ -604,8 +616,58 @@ __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::
   M[F_ENG][l] = __int_as_float(s.eng);
   wg_sync();
 }
+// The kinematics wave of a SPLIT workgroup. Attitude and position are integrated explicitly from the PREVIOUS tick's rates and
+// velocity, so the quaternion, the fp64 position, the geodetic reduction, the direction cosine matrix and gravity of tick k+1 are
+// computed here while the other two waves are still in tick k; on an aircraft's last tick of the step it does the fp64 geodetic
+// reduction of the environment layer instead.
+__device__ __forceinline__ void kinematics_wave(f16::State& s, Task& t, const f16::Tab& T, float (*M)[64], double (*MD)[64], int l, int substeps) {
+  using namespace mail;
+  f16::KinOut o;
+  int nrun = 0;
+  if (t.status == AC_ALIVE && substeps > 0) { f16::kin_position(s, o); f16::kin_attitude(s, o); nrun = 1; }   // tick 0 (the dynamics wave does its own)
+  for (int sub = 0; sub < substeps; ++sub) {
+    const bool run = t.status == AC_ALIVE;
+    if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;   // the same latch the dynamics wave applies
+    const bool run_next = run && t.status == AC_ALIVE && sub + 1 < substeps;
+    wg_sync();                                             // B1: this tick's rates and velocity are known
+    if (run_next) {
+      s.wp = M[K_W][l]; s.wq = M[K_W + 1][l]; s.wr = M[K_W + 2][l];
+      s.vx = M[K_V][l]; s.vy = M[K_V + 1][l]; s.vz = M[K_V + 2][l];
+      f16::kin_position(s, o);
+      nrun += 1;
+    } else if (run) {                                      // last tick of this aircraft in this step: the pose the env layer reads
+      f16::Derived d;
+      s.ticks += nrun;
+      f16::locate(s, d);
+      M[G_Q][l] = s.q0; M[G_Q + 1][l] = s.q1; M[G_Q + 2][l] = s.q2; M[G_Q + 3][l] = s.q3;
+      M[G_H][l] = d.h_sl_ft;
+      M[G_NED][l] = d.n_eci[0]; M[G_NED + 1][l] = d.n_eci[1]; M[G_NED + 2][l] = d.n_eci[2];
+      M[G_NED + 3][l] = d.e_eci[0]; M[G_NED + 4][l] = d.e_eci[1];
+      M[G_NED + 5][l] = d.d_eci[0]; M[G_NED + 6][l] = d.d_eci[1]; M[G_NED + 7][l] = d.d_eci[2];
+      MD[GD_R][l] = s.rx; MD[GD_R + 1][l] = s.ry; MD[GD_R + 2][l] = s.rz;
+      MD[GD_X][l] = d.X; MD[GD_X + 1][l] = d.Y; MD[GD_X + 2][l] = d.Z;
+      MD[GD_LAT][l] = d.sLat64; MD[GD_LAT + 1][l] = d.cLat64; MD[GD_LAT + 2][l] = d.sLon64; MD[GD_LAT + 3][l] = d.cLon64;
+    }
+    wg_sync();                                             // B2: this tick's air data are known
+    if (run) {   // this wave's share of the aerodynamic tables: those on the sideslip axis (all else dyn_p3 computes is dead here)
+      f16::DynVars kl{};
+      f16::Derived dd{};
+      dd.h_sl_ft = 1e6f;
+      kl.alpha = M[ALPHA][l]; kl.beta = M[BETA][l]; kl.mach = M[MACH][l]; kl.vt = 1.0f;
+      f16::dyn_p3(dd, T, kl, f16::Surf{});
+      M[LK_CLB][l] = kl.clb; M[LK_CNB][l] = kl.cnb;
+      M[LK_G7][l] = kl.g7.x; M[LK_G7 + 1][l] = kl.g7.y; M[LK_G7 + 2][l] = kl.g7.z; M[LK_G7 + 3][l] = kl.g7.w;
+    }
+    if (run_next) {
+      f16::kin_attitude(s, o);
+      post_kin(M, l, o);
+    }
+    wg_sync();                                             // B3
+  }
+  wg_sync();
+}
 template <int TASK, int WPE, bool SPLIT = false>
-__global__ __launch_bounds__(SPLIT ? 128 : 64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) {
+__global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) {
   using TT = TaskTraits<TASK>;
   constexpr bool HAS_MSL = TT::HAS_MSL;
   constexpr int MSLOTS = TT::MSLOTS;
@@ -614,6 +676,7 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, WPE) void step_kernel_1v1(DevPtrs
   AC_CLK(0);
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
   __shared__ float M[SPLIT ? mail::ROWS : 1][64];
+  __shared__ double MD[SPLIT ? mail::DROWS : 1][64];
   stage_tables(lds_tab, P.tab);
   const Tab T{lds_tab};
   const int N = c.N;
@@ -626,6 +689,10 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, WPE) void step_kernel_1v1(DevPtrs
   AC_CLK(1);
   State s; Task t; Derived d; Props pr;
   load_state(P.F, P.I, P.D, N, nn, s, t);
+  if (SPLIT && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 2) {
+    kinematics_wave(s, t, T, M, MD, l, c.substeps);
+    return;
+  }
   if (SPLIT && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1) {
     const float* act = P.actions + (size_t)nn * c.act_dim;
     s.da = clampf(-1.0f, act[0] / 20.0f - 1.0f, 1.0f);
@@ -666,7 +733,14 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, WPE) void step_kernel_1v1(DevPtrs
       f16::DynVars k;
       AC_CLK(2 + sub * 8);
       if (run) {
-        f16::dyn_p1(s, d, k);
+        if (sub == 0) f16::dyn_p1(s, d, k);                    // (its attitude / position members go stale from here on: the
+        else {                                                 //  kinematics wave hands the final ones over)
+          f16::KinOut o;
+          fetch_kin(M, l, o);
+          f16::dyn_p1_lite(s, d, k, o);
+        }
+        M[K_W][l] = s.wp; M[K_W + 1][l] = s.wq; M[K_W + 2][l] = s.wr;
+        M[K_V][l] = s.vx; M[K_V + 1][l] = s.vy; M[K_V + 2][l] = s.vz;
         M[CTH][l] = d.T[6] * d.d_eci[0] + d.T[7] * d.d_eci[1] + d.T[8] * d.d_eci[2];
         M[VB][l] = d.v;
         have_pose = true;
@@ -676,7 +750,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, WPE) void step_kernel_1v1(DevPtrs
       AC_CLK(4 + sub * 8);
       if (run) {
         fetch_mass(M, l, k);
-        f16::dyn_p2(s, d, k);
+        if (sub == 0) f16::dyn_p2<false>(s, d, k);
+        else f16::dyn_p2<true>(s, d, k);                      // the atmosphere at this altitude came with the kinematics
         M[BETA][l] = k.beta;
         M[MACH][l] = k.mach; M[QBAR][l] = k.qbar; M[RHO][l] = k.A.rho; M[TEMP][l] = k.A.T; M[HSL][l] = d.h_sl_ft;
         M[ALPHA][l] = k.alpha; M[QC][l] = k.qc; M[VG][l] = k.vg; M[NPY][l] = k.npy; M[NPZ][l] = k.npz;
@@ -694,9 +769,8 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, WPE) void step_kernel_1v1(DevPtrs
       wg_sync();                                               // B3
       AC_CLK(8 + sub * 8);
       if (run) {
-        k.cndr_m = M[LK_CNDR][l];
-        k.m0 = make_float4(M[LK_M0][l], M[LK_M0 + 1][l], M[LK_M0 + 2][l], M[LK_M0 + 3][l]);
-        k.m1 = make_float4(M[LK_M1][l], M[LK_M1 + 1][l], M[LK_M1 + 2][l], M[LK_M1 + 3][l]);
+        k.clb = M[LK_CLB][l]; k.cnb = M[LK_CNB][l];
+        k.g7 = make_float4(M[LK_G7][l], M[LK_G7 + 1][l], M[LK_G7 + 2][l], M[LK_G7 + 3][l]);
         f16::dyn_p4(s, d, k, sf, M[THRUST][l]);
       }
     } else if (t.status == AC_ALIVE) {
@@ -732,7 +806,18 @@ __global__ __launch_bounds__(SPLIT ? 128 : 64, WPE) void step_kernel_1v1(DevPtrs
     s.n1 = M[F_N1][l]; s.n2 = M[F_N2][l]; s.n2norm = M[F_N2NORM][l]; s.ff = M[F_FF][l]; s.tank0 = M[F_TANK0][l]; s.tank1 = M[F_TANK1][l];
     s.eng = __float_as_int(M[F_ENG][l]);
   }
-  if (!HAS_MSL || c.substeps == 0) {
+  if (SPLIT && have_pose) {   // the kinematics wave's attitude, position and fp64 geodetic reduction of the final pose
+    using namespace mail;
+    s.q0 = M[G_Q][l]; s.q1 = M[G_Q + 1][l]; s.q2 = M[G_Q + 2][l]; s.q3 = M[G_Q + 3][l];
+    s.rx = MD[GD_R][l]; s.ry = MD[GD_R + 1][l]; s.rz = MD[GD_R + 2][l];
+    d.X = MD[GD_X][l]; d.Y = MD[GD_X + 1][l]; d.Z = MD[GD_X + 2][l];
+    d.sLat64 = MD[GD_LAT][l]; d.cLat64 = MD[GD_LAT + 1][l]; d.sLon64 = MD[GD_LAT + 2][l]; d.cLon64 = MD[GD_LAT + 3][l];
+    d.h_sl_ft = M[G_H][l];
+    d.n_eci[0] = M[G_NED][l]; d.n_eci[1] = M[G_NED + 1][l]; d.n_eci[2] = M[G_NED + 2][l];
+    d.e_eci[0] = M[G_NED + 3][l]; d.e_eci[1] = M[G_NED + 4][l]; d.e_eci[2] = 0.0f;
+    d.d_eci[0] = M[G_NED + 5][l]; d.d_eci[1] = M[G_NED + 6][l]; d.d_eci[2] = M[G_NED + 7][l];
+    make_props(s, d, c, pr);
+  } else if (!HAS_MSL || c.substeps == 0) {
     f16::locate(s, d);
     if (!have_pose) f16::body_frame(s, d);
     make_props(s, d, c, pr);
@@ -1294,7 +1379,7 @@ struct ac_env {
   int act_low;                           // width of the low-level action the step kernels decode
   hipEvent_t ev0, ev1;
   bool timing;
-  bool split_waves;                      // SingleCombat below one wave per SIMD: two waves per 64 aircraft (step_kernel_1v1<.., SPLIT>)
+  bool split_waves;                      // SingleCombat below one wave per SIMD: three waves per 64 aircraft (step_kernel_1v1<.., SPLIT>)
 };
 
 static void geodetic2ecef_m(double lat_deg, double lon_deg, double alt, double* x, double* y, double* z) {
@@ -1346,7 +1431,7 @@ static int launch_step(ac_env* h, const float* d_actions) {
       else hipLaunchKernelGGL((step_kernel_nvn<8, 2>), grid, block, 0, h->stream, p, h->dc);
     }
   } else if (h->cfg.task == AC_TASK_SINGLECOMBAT) {
-    if (h->split_waves) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 1, true>), grid, dim3(128), 0, h->stream, p, h->dc);
+    if (h->split_waves) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 1, true>), grid, dim3(192), 0, h->stream, p, h->dc);
     else if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 1>), grid, block, 0, h->stream, p, h->dc);
     else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 2>), grid, block, 0, h->stream, p, h->dc);
   } else if (h->cfg.task == AC_TASK_DODGE_MISSILE) {
@@ -1423,9 +1508,10 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   ac_env* h = new ac_env();
   memset(h, 0, sizeof *h);
   h->cfg = *cfg; h->E = n_envs; h->A = cfg->n_agents; h->N = n_envs * cfg->n_agents; h->device = device_id;
-  {  // two waves per workgroup while that still leaves every wave a SIMD of its own (256 CUs x 4); AIRCOMBAT_SPLIT=0/1 overrides
+  {  // three waves per 64 aircraft up to 512 workgroups (1536 waves on 256 CUs x 4 SIMDs: measured faster than one wave per
+     // 64 aircraft up to there, slower from 768 workgroups on); AIRCOMBAT_SPLIT=0/1 overrides
     const char* e = getenv("AIRCOMBAT_SPLIT");
-    h->split_waves = cfg->task == AC_TASK_SINGLECOMBAT && (e ? (e[0] == '1') : ((h->N + 63) / 64 * 2 <= 1024));
+    h->split_waves = cfg->task == AC_TASK_SINGLECOMBAT && (e ? (e[0] == '1') : ((h->N + 63) / 64 <= 512));
   }
   h->obs_dim = heading ? 12 : (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;

@@ -239,7 +239,11 @@ def main():
         rate = E * AGENTS / (kernel_ms * 1e-3)
         result["roofline"]["valu"] = {"achieved": VALU_PER_AGENT_STEP * rate / 1e12, "peak": VALU_PEAK_TINST, "unit": "T lane-inst/s",
                                       "frac": VALU_PER_AGENT_STEP * rate / 1e12 / VALU_PEAK_TINST,
-                                      "note": "one wave per SIMD issues one instruction per 4 cycles; 128 waves on 1024 SIMDs at this batch"}
+                                      "note": "lane-instructions of the one-wave kernel form (the algorithm's count) over the measured time; a lone "
+                                              "wave issues one instruction per ~4 cycles, so at this batch the step time is the length of a lane's "
+                                              "instruction stream: %d workgroups x %d wave(s) on 1024 SIMDs" % (
+                                                  (E * AGENTS + 63) // 64, 3 if (args.task == "singlecombat" and not args.hierarchical and (E * AGENTS + 63) // 64 <= 512
+                                                                                 and os.environ.get("AIRCOMBAT_SPLIT", "1") != "0") else 1)}
         if not args.no_saturating and args.task == "singlecombat" and not args.hierarchical:
             env.close()
             result["saturating"] = saturating_leg(pkg, cfg, local_rank)

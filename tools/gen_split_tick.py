@@ -49,7 +49,31 @@ def generate():
     # ---- dynamics, part 1: propagate .. gravity (DT_ZERO = false only: the suspended passes exist in the init kernels alone)
     prop = rep(prop, "  if (!DT_ZERO) {", "  {")
     prop = rep(prop, "  const float* Tb = d.T;\n", "")
+    # the kinematics wave integrates attitude and position (they depend on LAST tick's rates and velocity only: explicit
+    # integrators), the dynamics wave integrates rates and velocity with this tick's accelerations
+    kin, kinq, lite = [], [], []
+    for line in prop.split("\n"):
+        t = line.strip()
+        if t.startswith(("float qd", "float a0", "float rn", "s.q0 =")):
+            kinq.append(line)
+        elif t.startswith(("const float k =", "s.rx +=", "s.ry +=", "s.rz +=")):
+            kin.append(line)
+        elif t.startswith(("s.hv2x =", "s.hv1x =")):
+            kin.append(line); lite.append(line)
+        elif t.startswith(("s.wp =", "s.vx +=", "s.vy +=", "s.vz +=", "s.ha1x =", "s.ticks +=")):
+            lite.append(line)
+        else:
+            assert t in ("", "{", "}", "locate_fast(s, d);", "body_frame(s, d);") or t.startswith("//"), t
+    kin, kinq, lite = "\n".join(kin) + "\n", "\n".join(kinq) + "\n", "\n".join(lite) + "\n"
+    bf = s[s.index("__device__ __forceinline__ void body_frame(const State& s, Derived& d) {"):]
+    bf = bf[bf.index("{") + 2:bf.index("\n}\n")] + "\n"
+    i_om = bf.index("  const float om = (float)kOmega;")
+    bf_T, bf_rest = bf[:i_om], bf[i_om:]
+    bf_T = rep(bf_T, "  float* T = d.T;\n", "")
+    bf_rest = rep(bf_rest, "om * (float)s.ry", "om * ryf")
+    bf_rest = rep(bf_rest, "om * (float)s.rx", "om * rxf")
     grav = rep(grav, "  float gx = kxy * rxf, gy = kxy * ryf, gz = kz * rzf;", "  gx = kxy * rxf; gy = kxy * ryf; gz = kz * rzf;")
+    grav = rep(grav, "  float rxf = (float)s.rx, ryf = (float)s.ry, rzf = (float)s.rz;", "  const float rxf = (float)s.rx, ryf = (float)s.ry, rzf = (float)s.rz;")
     # ---- dynamics, part 2: atmosphere, mass balance, auxiliary
     mass = rep(mass, "  float mass = kLb2Slug * weight;", "  mass = kLb2Slug * weight;")
     mass = rep(mass, "  float cgx = ((float)(F16_EMPTYWT", "  cgx = ((float)(F16_EMPTYWT")
@@ -134,7 +158,23 @@ struct DynVars {
 '''
     out = head
     out += "// dynamics wave, part 1: this tick's kinematics and gravity\n__device__ __forceinline__ void dyn_p1(State& s, Derived& d, DynVars& k) {\n  F16_DYN_REFS(k);\n  constexpr float dt = 1.0f / 60.0f;\n" + prop + grav + "}\n\n"
-    out += "// dynamics wave, part 2: atmosphere and auxiliary (the mass properties in k come from the systems wave)\n__device__ __forceinline__ void dyn_p2(State& s, Derived& d, DynVars& k) {\n  F16_DYN_REFS(k);\n  A = atmosphere(d.h_sl_ft);\n" + aux + "}\n\n"
+    out += ("// kinematics wave: position of the coming tick (from the velocities up to this tick), its geodetic frame and gravity ...\n"
+            "struct KinOut { float T[9]; float h_sl_ft, n_eci[3], e_eci[2], d_eci[3], gx, gy, gz, rxf, ryf; Atmos A; };\n"
+            "__device__ __forceinline__ void kin_position(State& s, KinOut& o) {\n  constexpr float dt = 1.0f / 60.0f;\n  Derived d;\n  float gx, gy, gz;\n"
+            + kin + "  locate_fast(s, d);\n" + grav +
+            "  o.h_sl_ft = d.h_sl_ft; o.gx = gx; o.gy = gy; o.gz = gz; o.rxf = (float)s.rx; o.ryf = (float)s.ry;\n"
+            "#pragma unroll\n  for (int i = 0; i < 3; ++i) { o.n_eci[i] = d.n_eci[i]; o.d_eci[i] = d.d_eci[i]; }\n  o.e_eci[0] = d.e_eci[0]; o.e_eci[1] = d.e_eci[1];\n}\n"
+            "// ... and its attitude (from this tick's rates), direction cosine matrix, and the atmosphere at the new altitude\n"
+            "__device__ __forceinline__ void kin_attitude(State& s, KinOut& o) {\n  constexpr float dt = 1.0f / 60.0f;\n  float* T = o.T;\n"
+            + kinq + bf_T + "  o.A = atmosphere(o.h_sl_ft);\n}\n\n")
+    out += ("// dynamics wave, part 1 when the kinematics wave has prepared the tick: rates and velocity, then the body-frame quantities\n"
+            "__device__ __forceinline__ void dyn_p1_lite(State& s, Derived& d, DynVars& k, const KinOut& o) {\n  constexpr float dt = 1.0f / 60.0f;\n"
+            + lite +
+            "  d.h_sl_ft = o.h_sl_ft; k.gx = o.gx; k.gy = o.gy; k.gz = o.gz; k.A = o.A;\n  const float rxf = o.rxf, ryf = o.ryf;\n  float* T = d.T;\n"
+            "#pragma unroll\n  for (int i = 0; i < 9; ++i) T[i] = o.T[i];\n"
+            "#pragma unroll\n  for (int i = 0; i < 3; ++i) { d.n_eci[i] = o.n_eci[i]; d.d_eci[i] = o.d_eci[i]; }\n  d.e_eci[0] = o.e_eci[0]; d.e_eci[1] = o.e_eci[1]; d.e_eci[2] = 0.0f;\n"
+            + bf_rest + "}\n\n")
+    out += "// dynamics wave, part 2: atmosphere and auxiliary (the mass properties in k come from the systems wave)\ntemplate <bool HAVE_ATMOSPHERE>\n__device__ __forceinline__ void dyn_p2(State& s, Derived& d, DynVars& k) {\n  F16_DYN_REFS(k);\n  if (!HAVE_ATMOSPHERE) A = atmosphere(d.h_sl_ft);\n" + aux + "}\n\n"
     out += ("// dynamics wave, part 3: every table look-up of the tick (the elevator and speedbrake deflections come from the systems wave)\n"
             "__device__ __forceinline__ void dyn_p3(const Derived& d, const Tab& T, DynVars& k, const Surf& sf) {\n  F16_DYN_REFS(k);\n"
             "  const float elevator_rad = sf.elevator_rad, sb_rad = sf.sb_rad;\n"
