@@ -119,51 +119,61 @@ struct DevPtrs {
 };
 
 // ------------------------------------------------------------------------------------------------ device helpers
+// Field f of lane n at byte offset (f*N + n)*sizeof from ONE wave-uniform base pointer: the offset is a 32-bit lane value (one VALU
+// add per field), so each access is `global_load/store v, v_off, s[base]` instead of per-field 64-bit VALU address arithmetic
+// (~4 VALU per field before). Arrays stay below 4 GB (ac_create checks).
+#define AC_LANE_INDEX(n) const unsigned un_ = (unsigned)(n), uN_ = (unsigned)N
+#define AC_AT(base, f) \
+  (*(decltype(base))((char*)(base) + (size_t)((unsigned)(f) * (uN_ * (unsigned)sizeof(*(base))) + un_ * (unsigned)sizeof(*(base)))))
 __device__ __forceinline__ void load_state(const float* F, const int* I, const double* D, int N, int n, State& s, Task& t) {
-#define X(f) s.f = F[FF_##f * N + n];
+  AC_LANE_INDEX(n);
+#define X(f) s.f = AC_AT(F, FF_##f);
   AC_F_FIELDS(X)
 #undef X
-#define X(f) t.f = F[FF_##f * N + n];
+#define X(f) t.f = AC_AT(F, FF_##f);
   AC_TF_FIELDS(X)
 #undef X
-  s.eng = I[FI_eng * N + n]; s.ticks = I[FI_ticks * N + n];
-#define X(f) t.f = I[FI_##f * N + n];
+  s.eng = AC_AT(I, FI_eng); s.ticks = AC_AT(I, FI_ticks);
+#define X(f) t.f = AC_AT(I, FI_##f);
   AC_TI_FIELDS(X)
 #undef X
-  s.rx = D[0 * N + n]; s.ry = D[1 * N + n]; s.rz = D[2 * N + n];
+  s.rx = AC_AT(D, 0); s.ry = AC_AT(D, 1); s.rz = AC_AT(D, 2);
 }
 __device__ __forceinline__ void store_state(float* F, int* I, double* D, int N, int n, const State& s, const Task& t) {
-#define X(f) F[FF_##f * N + n] = s.f;
+  AC_LANE_INDEX(n);
+#define X(f) AC_AT(F, FF_##f) = s.f;
   AC_F_FIELDS(X)
 #undef X
-#define X(f) F[FF_##f * N + n] = t.f;
+#define X(f) AC_AT(F, FF_##f) = t.f;
   AC_TF_FIELDS(X)
 #undef X
-  I[FI_eng * N + n] = s.eng; I[FI_ticks * N + n] = s.ticks;
-#define X(f) I[FI_##f * N + n] = t.f;
+  AC_AT(I, FI_eng) = s.eng; AC_AT(I, FI_ticks) = s.ticks;
+#define X(f) AC_AT(I, FI_##f) = t.f;
   AC_TI_FIELDS(X)
 #undef X
-  D[0 * N + n] = s.rx; D[1 * N + n] = s.ry; D[2 * N + n] = s.rz;
+  AC_AT(D, 0) = s.rx; AC_AT(D, 1) = s.ry; AC_AT(D, 2) = s.rz;
 }
 template <typename R>
 __device__ __forceinline__ void load_msl(const R* MF, const int* MI, int N, int n, int slot, MslT<R>& m) {
+  AC_LANE_INDEX(n);
   const R* f = MF + (size_t)slot * NMF * N;
   const int* i = MI + (size_t)slot * NMI * N;
-  m.px = f[MF_px * N + n]; m.py = f[MF_py * N + n]; m.pz = f[MF_pz * N + n];
-  m.vx = f[MF_vx * N + n]; m.vy = f[MF_vy * N + n]; m.vz = f[MF_vz * N + n];
-  m.theta = f[MF_theta * N + n]; m.psi = f[MF_psi * N + n]; m.t = f[MF_t * N + n]; m.m = f[MF_m * N + n];
-  m.dth = f[MF_dth * N + n]; m.dph = f[MF_dph * N + n]; m.dprev = f[MF_dprev * N + n];
-  m.status = i[MI_status * N + n]; m.recede = i[MI_recede * N + n]; m.order = i[MI_order * N + n];
+  m.px = AC_AT(f, MF_px); m.py = AC_AT(f, MF_py); m.pz = AC_AT(f, MF_pz);
+  m.vx = AC_AT(f, MF_vx); m.vy = AC_AT(f, MF_vy); m.vz = AC_AT(f, MF_vz);
+  m.theta = AC_AT(f, MF_theta); m.psi = AC_AT(f, MF_psi); m.t = AC_AT(f, MF_t); m.m = AC_AT(f, MF_m);
+  m.dth = AC_AT(f, MF_dth); m.dph = AC_AT(f, MF_dph); m.dprev = AC_AT(f, MF_dprev);
+  m.status = AC_AT(i, MI_status); m.recede = AC_AT(i, MI_recede); m.order = AC_AT(i, MI_order);
 }
 template <typename R>
 __device__ __forceinline__ void store_msl(R* MF, int* MI, int N, int n, int slot, const MslT<R>& m) {
+  AC_LANE_INDEX(n);
   R* f = MF + (size_t)slot * NMF * N;
   int* i = MI + (size_t)slot * NMI * N;
-  f[MF_px * N + n] = m.px; f[MF_py * N + n] = m.py; f[MF_pz * N + n] = m.pz;
-  f[MF_vx * N + n] = m.vx; f[MF_vy * N + n] = m.vy; f[MF_vz * N + n] = m.vz;
-  f[MF_theta * N + n] = m.theta; f[MF_psi * N + n] = m.psi; f[MF_t * N + n] = m.t; f[MF_m * N + n] = m.m;
-  f[MF_dth * N + n] = m.dth; f[MF_dph * N + n] = m.dph; f[MF_dprev * N + n] = m.dprev;
-  i[MI_status * N + n] = m.status; i[MI_recede * N + n] = m.recede; i[MI_order * N + n] = m.order;
+  AC_AT(f, MF_px) = m.px; AC_AT(f, MF_py) = m.py; AC_AT(f, MF_pz) = m.pz;
+  AC_AT(f, MF_vx) = m.vx; AC_AT(f, MF_vy) = m.vy; AC_AT(f, MF_vz) = m.vz;
+  AC_AT(f, MF_theta) = m.theta; AC_AT(f, MF_psi) = m.psi; AC_AT(f, MF_t) = m.t; AC_AT(f, MF_m) = m.m;
+  AC_AT(f, MF_dth) = m.dth; AC_AT(f, MF_dph) = m.dph; AC_AT(f, MF_dprev) = m.dprev;
+  AC_AT(i, MI_status) = m.status; AC_AT(i, MI_recede) = m.recede; AC_AT(i, MI_order) = m.order;
 }
 
 // task.reset() of the hierarchical tasks clears _inner_rnn_states (singlecombat_task.py:258-262)
@@ -437,19 +447,44 @@ __device__ __forceinline__ void missile_run(MslD& m, const MslParam& P, double t
 
 // Stage the 7 KB table pack into LDS: every lane issues all of its 16-byte global loads before the first LDS store, so
 // the workgroup pays one L2 round trip instead of one per loop iteration.
+// The same copy in two halves, so that a kernel can put its state loads between them: the table loads are issued first, the
+// state loads behind them, and the LDS writes wait (in-order vmcnt) for the table loads alone.
+template <int THREADS>
+struct TableCopy {
+  static constexpr int NV = F16_PACK_LEN / 4;
+  static constexpr int PER = (NV + THREADS - 1) / THREADS;
+  float4 v[PER];
+  __device__ __forceinline__ void issue(const float* __restrict__ g) {
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      int i = threadIdx.x + k * THREADS;
+      v[k] = (i < NV) ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void commit(float* lds) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      int i = threadIdx.x + k * THREADS;
+      if (i < NV) reinterpret_cast<float4*>(lds)[i] = v[k];
+    }
+    __syncthreads();
+  }
+};
+template <int THREADS = 64>
 __device__ __forceinline__ void stage_tables(float* lds, const float* __restrict__ g) {
   constexpr int NV = F16_PACK_LEN / 4;               // float4 count (the pack is padded to a multiple of 4)
-  constexpr int PER = (NV + 63) / 64;
+  constexpr int PER = (NV + THREADS - 1) / THREADS;
   const float4* g4 = reinterpret_cast<const float4*>(g);
   float4 v[PER];
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
-    int i = threadIdx.x + k * 64;
+    int i = threadIdx.x + k * THREADS;
     v[k] = (i < NV) ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
-    int i = threadIdx.x + k * 64;
+    int i = threadIdx.x + k * THREADS;
     if (i < NV) reinterpret_cast<float4*>(lds)[i] = v[k];
   }
   __syncthreads();
@@ -677,7 +712,6 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
   __shared__ float M[SPLIT ? mail::ROWS : 1][64];
   __shared__ double MD[SPLIT ? mail::DROWS : 1][64];
-  stage_tables(lds_tab, P.tab);
   const Tab T{lds_tab};
   const int N = c.N;
   const int l = threadIdx.x & 63;
@@ -686,9 +720,17 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
   const int nn = live ? n : (N - 2 + (n & 1));  // tail lanes shadow the last env and never store
   const int slot = nn & 1;
 
-  AC_CLK(1);
   State s; Task t; Derived d; Props pr;
-  load_state(P.F, P.I, P.D, N, nn, s, t);
+  if (SPLIT) {   // table loads, then state loads behind them, then the LDS copy: one HBM round trip for both
+    TableCopy<192> tc;
+    tc.issue(P.tab);
+    load_state(P.F, P.I, P.D, N, nn, s, t);
+    tc.commit(lds_tab);
+  } else {
+    stage_tables<64>(lds_tab, P.tab);
+    load_state(P.F, P.I, P.D, N, nn, s, t);
+  }
+  AC_CLK(1);
   if (SPLIT && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 2) {
     kinematics_wave(s, t, T, M, MD, l, c.substeps);
     return;
@@ -1498,6 +1540,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   if (cfg->legacy_obs && (cfg->task != AC_TASK_SCENARIO_NVN || cfg->rwr)) return fail("ac_create: legacy_obs is the observation of Scenario2 / Scenario3 (AC_TASK_SCENARIO_NVN without rwr)");
   if (cfg->rwr && !scenario) return fail("ac_create: rwr is a variant of the scenario tasks (Scenario1_RWR, Scenario2_RWR, Scenario3_RWR)");
   if (n_envs <= 0) return fail("ac_create: n_envs must be positive");
+  if ((long long)n_envs * cfg->n_agents > (1 << 23))   // 32-bit byte offsets into the per-field arrays (AC_AT): 63 fields x 4 B x N < 4 GB
+    return fail("ac_create: more than 2^23 aircraft in one handle; shard the envs over handles / GPUs");
   if (cfg->sim_freq != 60) return fail("ac_create: sim_freq must be 60 (the FDM tick is compiled for 1/60 s)");
   for (int i = 0; i < cfg->n_agents; ++i)
     if (cfg->num_missiles[i] < 0 || cfg->num_missiles[i] > AC_MAX_MISSILES_PER_AGENT) return fail("ac_create: num_missiles out of range");

@@ -24,28 +24,30 @@ struct Ext {
   float cx[2], cy[2], cz[2], ct[2];
 };
 __device__ __forceinline__ void load_ext(const float* XF, const int* XI, int N, int n, Ext& x) {
-  x.rem_gun = XI[XI_rem_gun * N + n]; x.rem_9m = XI[XI_rem_9m * N + n]; x.rem_120b = XI[XI_rem_120b * N + n];
-  x.rem_chaff = XI[XI_rem_chaff * N + n]; x.bits = XI[XI_bits * N + n]; x.last_chaff = XI[XI_last_chaff * N + n];
-  x.orphan_hits = XI[XI_orphan_hits * N + n]; x.mp_prev = XI[XI_mp_prev * N + n]; x.ref_set = XI[XI_ref_set * N + n];
-  x.ch_status[0] = XI[XI_ch_status0 * N + n]; x.ch_mult[0] = XI[XI_ch_mult0 * N + n];
-  x.ch_status[1] = XI[XI_ch_status1 * N + n]; x.ch_mult[1] = XI[XI_ch_mult1 * N + n]; x.n_ch = XI[XI_n_ch * N + n];
-  x.cg_AO = XF[XF_cg_AO * N + n]; x.cg_TA = XF[XF_cg_TA * N + n];
+  AC_LANE_INDEX(n);
+  x.rem_gun = AC_AT(XI, XI_rem_gun); x.rem_9m = AC_AT(XI, XI_rem_9m); x.rem_120b = AC_AT(XI, XI_rem_120b);
+  x.rem_chaff = AC_AT(XI, XI_rem_chaff); x.bits = AC_AT(XI, XI_bits); x.last_chaff = AC_AT(XI, XI_last_chaff);
+  x.orphan_hits = AC_AT(XI, XI_orphan_hits); x.mp_prev = AC_AT(XI, XI_mp_prev); x.ref_set = AC_AT(XI, XI_ref_set);
+  x.ch_status[0] = AC_AT(XI, XI_ch_status0); x.ch_mult[0] = AC_AT(XI, XI_ch_mult0);
+  x.ch_status[1] = AC_AT(XI, XI_ch_status1); x.ch_mult[1] = AC_AT(XI, XI_ch_mult1); x.n_ch = AC_AT(XI, XI_n_ch);
+  x.cg_AO = AC_AT(XF, XF_cg_AO); x.cg_TA = AC_AT(XF, XF_cg_TA);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { x.wez[k] = XF[(XF_wez0 + k) * N + n]; x.tail[k] = XF[(XF_tail0 + k) * N + n]; }
-  x.cx[0] = XF[XF_c0x * N + n]; x.cy[0] = XF[XF_c0y * N + n]; x.cz[0] = XF[XF_c0z * N + n]; x.ct[0] = XF[XF_c0t * N + n];
-  x.cx[1] = XF[XF_c1x * N + n]; x.cy[1] = XF[XF_c1y * N + n]; x.cz[1] = XF[XF_c1z * N + n]; x.ct[1] = XF[XF_c1t * N + n];
+  for (int k = 0; k < 4; ++k) { x.wez[k] = AC_AT(XF, XF_wez0 + k); x.tail[k] = AC_AT(XF, XF_tail0 + k); }
+  x.cx[0] = AC_AT(XF, XF_c0x); x.cy[0] = AC_AT(XF, XF_c0y); x.cz[0] = AC_AT(XF, XF_c0z); x.ct[0] = AC_AT(XF, XF_c0t);
+  x.cx[1] = AC_AT(XF, XF_c1x); x.cy[1] = AC_AT(XF, XF_c1y); x.cz[1] = AC_AT(XF, XF_c1z); x.ct[1] = AC_AT(XF, XF_c1t);
 }
 __device__ __forceinline__ void store_ext(float* XF, int* XI, int N, int n, const Ext& x) {
-  XI[XI_rem_gun * N + n] = x.rem_gun; XI[XI_rem_9m * N + n] = x.rem_9m; XI[XI_rem_120b * N + n] = x.rem_120b;
-  XI[XI_rem_chaff * N + n] = x.rem_chaff; XI[XI_bits * N + n] = x.bits; XI[XI_last_chaff * N + n] = x.last_chaff;
-  XI[XI_orphan_hits * N + n] = x.orphan_hits; XI[XI_mp_prev * N + n] = x.mp_prev; XI[XI_ref_set * N + n] = x.ref_set;
-  XI[XI_ch_status0 * N + n] = x.ch_status[0]; XI[XI_ch_mult0 * N + n] = x.ch_mult[0];
-  XI[XI_ch_status1 * N + n] = x.ch_status[1]; XI[XI_ch_mult1 * N + n] = x.ch_mult[1]; XI[XI_n_ch * N + n] = x.n_ch;
-  XF[XF_cg_AO * N + n] = x.cg_AO; XF[XF_cg_TA * N + n] = x.cg_TA;
+  AC_LANE_INDEX(n);
+  AC_AT(XI, XI_rem_gun) = x.rem_gun; AC_AT(XI, XI_rem_9m) = x.rem_9m; AC_AT(XI, XI_rem_120b) = x.rem_120b;
+  AC_AT(XI, XI_rem_chaff) = x.rem_chaff; AC_AT(XI, XI_bits) = x.bits; AC_AT(XI, XI_last_chaff) = x.last_chaff;
+  AC_AT(XI, XI_orphan_hits) = x.orphan_hits; AC_AT(XI, XI_mp_prev) = x.mp_prev; AC_AT(XI, XI_ref_set) = x.ref_set;
+  AC_AT(XI, XI_ch_status0) = x.ch_status[0]; AC_AT(XI, XI_ch_mult0) = x.ch_mult[0];
+  AC_AT(XI, XI_ch_status1) = x.ch_status[1]; AC_AT(XI, XI_ch_mult1) = x.ch_mult[1]; AC_AT(XI, XI_n_ch) = x.n_ch;
+  AC_AT(XF, XF_cg_AO) = x.cg_AO; AC_AT(XF, XF_cg_TA) = x.cg_TA;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { XF[(XF_wez0 + k) * N + n] = x.wez[k]; XF[(XF_tail0 + k) * N + n] = x.tail[k]; }
-  XF[XF_c0x * N + n] = x.cx[0]; XF[XF_c0y * N + n] = x.cy[0]; XF[XF_c0z * N + n] = x.cz[0]; XF[XF_c0t * N + n] = x.ct[0];
-  XF[XF_c1x * N + n] = x.cx[1]; XF[XF_c1y * N + n] = x.cy[1]; XF[XF_c1z * N + n] = x.cz[1]; XF[XF_c1t * N + n] = x.ct[1];
+  for (int k = 0; k < 4; ++k) { AC_AT(XF, XF_wez0 + k) = x.wez[k]; AC_AT(XF, XF_tail0 + k) = x.tail[k]; }
+  AC_AT(XF, XF_c0x) = x.cx[0]; AC_AT(XF, XF_c0y) = x.cy[0]; AC_AT(XF, XF_c0z) = x.cz[0]; AC_AT(XF, XF_c0t) = x.ct[0];
+  AC_AT(XF, XF_c1x) = x.cx[1]; AC_AT(XF, XF_c1y) = x.cy[1]; AC_AT(XF, XF_c1z) = x.cz[1]; AC_AT(XF, XF_c1t) = x.ct[1];
 }
 __device__ __forceinline__ Ext fresh_ext(int num) {
   Ext x{};
