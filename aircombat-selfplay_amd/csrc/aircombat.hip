@@ -548,159 +548,9 @@ struct TaskTraits {
 // Occupancy: WPE = waves per SIMD the register allocation is bounded for. WPE = 2 (256 VGPRs, 12 dwords of scratch) lets two
 // waves share a SIMD and fill its 2-cycle issue rate: +38 % throughput once there are more waves than SIMDs. WPE = 1 keeps
 // everything in registers (269 incl. accumulation VGPRs): 5 % less latency when each SIMD has at most one wave (E*A <= 65536).
-//
-// SPLIT (no-missile task, small grids): a workgroup is TWO waves over the same 64 aircraft. Wave 0 ("dynamics") runs the rigid-body
-// part of every tick and the whole environment layer; wave 1 ("systems") runs the flight control system and the turbine of the same
-// aircraft on another SIMD, concurrently with wave 0's atmosphere / mass / auxiliary / table look-up work. The two exchange ~25 floats
-// per aircraft and tick through LDS, with three workgroup barriers per tick (f16_split.hpp holds the statements of tick(), cut into
-// those pieces). A lone wave issues one dependent instruction every ~4.3 cycles, so below one wave per SIMD this shortens the tick's
-// critical path instead of competing for issue slots.
-namespace mail {  // LDS mailbox rows (64 floats each)
-enum { CTH, VB,                                                    // dynamics -> systems after part 1
-       MACH, QBAR, RHO, TEMP, HSL, ALPHA, BETA, QC, VG, NPY, NPZ, AP, AQ, AR,   // dynamics -> systems after part 2
-       S_AIL, S_FLAP, S_ELEV, S_RUD, S_LEF, S_SB,                   // systems -> dynamics after the FCS
-       THRUST,                                                      // systems -> dynamics after the turbine
-       LK_CLB, LK_CNB, LK_G7,                                       // kinematics -> dynamics: its share of the table look-ups
-       MASS0 = LK_G7 + 4, MASS_N = 18,                              // systems -> dynamics: mass properties of the coming tick
-       F_TEF = MASS0 + MASS_N, F_PINR, F_PINP, F_PINY, F_PIR, F_PIP, F_PIY, F_AIL, F_ELEV, F_SBDEG, F_N1, F_N2, F_N2NORM, F_FF, F_TANK0, F_TANK1,
-       F_ENG,                                                       // final hand-over of the fields the systems wave owns
-       K_W, K_V = K_W + 3,                                          // dynamics -> kinematics after part 1: body rates, ECI velocity
-       K_OUT = K_V + 3, K_OUT_N = 27,                               // kinematics -> dynamics: f16::KinOut of the coming tick
-       G_Q = K_OUT + K_OUT_N, G_H = G_Q + 4, G_NED = G_H + 1,        // kinematics -> dynamics at the end: quaternion, env-layer frame
-       ROWS = G_NED + 8 };
-enum { GD_R, GD_X = GD_R + 3, GD_LAT = GD_X + 3, DROWS = GD_LAT + 4 };   // ... and the fp64 rows: ECI / ECEF position, geodetic cosines
-}
-__device__ __forceinline__ void post_kin(float (*M)[64], int l, const f16::KinOut& o) {
-  const float v[mail::K_OUT_N] = {o.T[0], o.T[1], o.T[2], o.T[3], o.T[4], o.T[5], o.T[6], o.T[7], o.T[8], o.h_sl_ft, o.n_eci[0], o.n_eci[1], o.n_eci[2],
-                                  o.e_eci[0], o.e_eci[1], o.d_eci[0], o.d_eci[1], o.d_eci[2], o.gx, o.gy, o.gz, o.rxf, o.ryf, o.A.T, o.A.P, o.A.rho, o.A.a};
-#pragma unroll
-  for (int i = 0; i < mail::K_OUT_N; ++i) M[mail::K_OUT + i][l] = v[i];
-}
-__device__ __forceinline__ void fetch_kin(float (*M)[64], int l, f16::KinOut& o) {
-  float v[mail::K_OUT_N];
-#pragma unroll
-  for (int i = 0; i < mail::K_OUT_N; ++i) v[i] = M[mail::K_OUT + i][l];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) o.T[i] = v[i];
-  o.h_sl_ft = v[9]; o.n_eci[0] = v[10]; o.n_eci[1] = v[11]; o.n_eci[2] = v[12]; o.e_eci[0] = v[13]; o.e_eci[1] = v[14];
-  o.d_eci[0] = v[15]; o.d_eci[1] = v[16]; o.d_eci[2] = v[17]; o.gx = v[18]; o.gy = v[19]; o.gz = v[20]; o.rxf = v[21]; o.ryf = v[22];
-  o.A.T = v[23]; o.A.P = v[24]; o.A.rho = v[25]; o.A.a = v[26];
-}
-// mass, CG, inertia tensor, its cofactors / determinant, 1/mass: sys_mass() on the systems wave -> DynVars of the dynamics wave
-__device__ __forceinline__ void post_mass(float (*M)[64], int l, const f16::DynVars& k) {
-  const float v[mail::MASS_N] = {k.mass, k.cgx, k.cgy, k.cgz, k.Jxx, k.Jyy, k.Jzz, k.Jxy, k.Jxz, k.Jyz, k.c00, k.c01, k.c02, k.c11, k.c12, k.c22, k.idet, k.im_};
-#pragma unroll
-  for (int i = 0; i < mail::MASS_N; ++i) M[mail::MASS0 + i][l] = v[i];
-}
-__device__ __forceinline__ void fetch_mass(float (*M)[64], int l, f16::DynVars& k) {
-  float v[mail::MASS_N];
-#pragma unroll
-  for (int i = 0; i < mail::MASS_N; ++i) v[i] = M[mail::MASS0 + i][l];
-  k.mass = v[0]; k.cgx = v[1]; k.cgy = v[2]; k.cgz = v[3]; k.Jxx = v[4]; k.Jyy = v[5]; k.Jzz = v[6]; k.Jxy = v[7]; k.Jxz = v[8]; k.Jyz = v[9];
-  k.c00 = v[10]; k.c01 = v[11]; k.c02 = v[12]; k.c11 = v[13]; k.c12 = v[14]; k.c22 = v[15]; k.idet = v[16]; k.im_ = v[17];
-}
-#ifdef AC_SPLIT_TIMING   // scratch builds only (variants/): cycle stamps of workgroup 0's dynamics wave
-__device__ unsigned long long g_clk[64];
-#define AC_CLK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_clk[i] = __builtin_readcyclecounter(); } while (0)
-extern "C" void ac_debug_clocks(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof g_clk); }
-#else
-#define AC_CLK(i) do {} while (0)
-#endif
-__device__ __forceinline__ void wg_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-// The systems wave of a SPLIT workgroup: FCS and turbine of every substep, then the final values of the fields it owns.
-__device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::Tab& T, float (*M)[64], int l, int substeps) {
-  using namespace mail;
-  f16::DynVars km{};
-  f16::sys_mass(s, km);
-  post_mass(M, l, km);                                     // read by the dynamics wave after B1 of the first tick
-  for (int sub = 0; sub < substeps; ++sub) {
-    const bool run = t.status == AC_ALIVE;
-    if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;   // the same latch the dynamics wave applies
-    f16::Surf sf{};
-    wg_sync();                                             // B1: this tick's attitude is known
-    if (run) {
-      f16::sys_fcs(s, M[CTH][l], M[VB][l], sf);
-      M[S_AIL][l] = sf.aileron_rad; M[S_FLAP][l] = sf.flaperon_rad; M[S_ELEV][l] = sf.elevator_rad;
-      M[S_RUD][l] = sf.rudder_rad;  M[S_LEF][l] = sf.lef_rad;       M[S_SB][l] = sf.sb_rad;
-    }
-    wg_sync();                                             // B2: this tick's air data are known
-    if (run) {
-      f16::Atmos A{};
-      A.rho = M[RHO][l]; A.T = M[TEMP][l];
-      const float mach = M[MACH][l], alpha = M[ALPHA][l], h_sl = M[HSL][l];
-      float thrust;
-      f16::sys_engine(s, T, mach, M[QBAR][l], A, h_sl, sf.throttle_pos, thrust);
-      M[THRUST][l] = thrust;
-    }
-    wg_sync();                                             // B3: surfaces and thrust are known
-    if (run) {                                             // while the dynamics wave assembles, integrates and propagates:
-      // what FGAuxiliary published this tick is what the next tick's FCS reads
-      s.alpha = M[ALPHA][l]; s.mach = M[MACH][l]; s.qc = M[QC][l]; s.vg = M[VG][l];
-      s.npy = M[NPY][l]; s.npz = M[NPZ][l]; s.ap = M[AP][l]; s.aq = M[AQ][l]; s.ar = M[AR][l];
-      f16::sys_mass(s, km);                                // the tanks after this tick's draw give the next tick's mass balance
-      post_mass(M, l, km);
-    }
-  }
-  M[F_TEF][l] = s.tef; M[F_PINR][l] = s.pin_r; M[F_PINP][l] = s.pin_p; M[F_PINY][l] = s.pin_y;
-  M[F_PIR][l] = s.pi_r; M[F_PIP][l] = s.pi_p; M[F_PIY][l] = s.pi_y; M[F_AIL][l] = s.ail; M[F_ELEV][l] = s.elev; M[F_SBDEG][l] = s.sbdeg;
-  M[F_N1][l] = s.n1; M[F_N2][l] = s.n2; M[F_N2NORM][l] = s.n2norm; M[F_FF][l] = s.ff; M[F_TANK0][l] = s.tank0; M[F_TANK1][l] = s.tank1;
-  M[F_ENG][l] = __int_as_float(s.eng);
-  wg_sync();
-}
-// The kinematics wave of a SPLIT workgroup. Attitude and position are integrated explicitly from the PREVIOUS tick's rates and
-// velocity, so the quaternion, the fp64 position, the geodetic reduction, the direction cosine matrix and gravity of tick k+1 are
-// computed here while the other two waves are still in tick k; on an aircraft's last tick of the step it does the fp64 geodetic
-// reduction of the environment layer instead.
-__device__ __forceinline__ void kinematics_wave(f16::State& s, Task& t, const f16::Tab& T, float (*M)[64], double (*MD)[64], int l, int substeps) {
-  using namespace mail;
-  f16::KinOut o;
-  int nrun = 0;
-  if (t.status == AC_ALIVE && substeps > 0) { f16::kin_position(s, o); f16::kin_attitude(s, o); nrun = 1; }   // tick 0 (the dynamics wave does its own)
-  for (int sub = 0; sub < substeps; ++sub) {
-    const bool run = t.status == AC_ALIVE;
-    if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;   // the same latch the dynamics wave applies
-    const bool run_next = run && t.status == AC_ALIVE && sub + 1 < substeps;
-    wg_sync();                                             // B1: this tick's rates and velocity are known
-    if (run_next) {
-      s.wp = M[K_W][l]; s.wq = M[K_W + 1][l]; s.wr = M[K_W + 2][l];
-      s.vx = M[K_V][l]; s.vy = M[K_V + 1][l]; s.vz = M[K_V + 2][l];
-      f16::kin_position(s, o);
-      nrun += 1;
-    } else if (run) {                                      // last tick of this aircraft in this step: the pose the env layer reads
-      f16::Derived d;
-      s.ticks += nrun;
-      f16::locate(s, d);
-      M[G_Q][l] = s.q0; M[G_Q + 1][l] = s.q1; M[G_Q + 2][l] = s.q2; M[G_Q + 3][l] = s.q3;
-      M[G_H][l] = d.h_sl_ft;
-      M[G_NED][l] = d.n_eci[0]; M[G_NED + 1][l] = d.n_eci[1]; M[G_NED + 2][l] = d.n_eci[2];
-      M[G_NED + 3][l] = d.e_eci[0]; M[G_NED + 4][l] = d.e_eci[1];
-      M[G_NED + 5][l] = d.d_eci[0]; M[G_NED + 6][l] = d.d_eci[1]; M[G_NED + 7][l] = d.d_eci[2];
-      MD[GD_R][l] = s.rx; MD[GD_R + 1][l] = s.ry; MD[GD_R + 2][l] = s.rz;
-      MD[GD_X][l] = d.X; MD[GD_X + 1][l] = d.Y; MD[GD_X + 2][l] = d.Z;
-      MD[GD_LAT][l] = d.sLat64; MD[GD_LAT + 1][l] = d.cLat64; MD[GD_LAT + 2][l] = d.sLon64; MD[GD_LAT + 3][l] = d.cLon64;
-    }
-    wg_sync();                                             // B2: this tick's air data are known
-    if (run) {   // this wave's share of the aerodynamic tables: those on the sideslip axis (all else dyn_p3 computes is dead here)
-      f16::DynVars kl{};
-      f16::Derived dd{};
-      dd.h_sl_ft = 1e6f;
-      kl.alpha = M[ALPHA][l]; kl.beta = M[BETA][l]; kl.mach = M[MACH][l]; kl.vt = 1.0f;
-      f16::dyn_p3(dd, T, kl, f16::Surf{});
-      M[LK_CLB][l] = kl.clb; M[LK_CNB][l] = kl.cnb;
-      M[LK_G7][l] = kl.g7.x; M[LK_G7 + 1][l] = kl.g7.y; M[LK_G7 + 2][l] = kl.g7.z; M[LK_G7 + 3][l] = kl.g7.w;
-    }
-    if (run_next) {
-      f16::kin_attitude(s, o);
-      post_kin(M, l, o);
-    }
-    wg_sync();                                             // B3
-  }
-  wg_sync();
-}
+#include "split_kernel.hpp"
+
+// SPLIT: the three-wave form (split_kernel.hpp) for the task without munitions at small grids.
 template <int TASK, int WPE, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) {
   using TT = TaskTraits<TASK>;
@@ -710,8 +560,8 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
   static_assert(!SPLIT || !HAS_MSL, "the two-wave form covers the task without munitions");
   AC_CLK(0);
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
-  __shared__ float M[SPLIT ? mail::ROWS : 1][64];
-  __shared__ double MD[SPLIT ? mail::DROWS : 1][64];
+  __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : 16];
+  SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
   const Tab T{lds_tab};
   const int N = c.N;
   const int l = threadIdx.x & 63;
@@ -731,18 +581,13 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
     load_state(P.F, P.I, P.D, N, nn, s, t);
   }
   AC_CLK(1);
-  if (SPLIT && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 2) {
-    kinematics_wave(s, t, T, M, MD, l, c.substeps);
-    return;
-  }
-  if (SPLIT && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1) {
+  if (SPLIT) {   // helper waves: decode the commands they integrate, run their part of every substep, done
     const float* act = P.actions + (size_t)nn * c.act_dim;
     s.da = clampf(-1.0f, act[0] / 20.0f - 1.0f, 1.0f);
     s.de = clampf(-1.0f, act[1] / 20.0f - 1.0f, 1.0f);
     s.dr = clampf(-1.0f, act[2] / 20.0f - 1.0f, 1.0f);
     s.thr = clampf(0.0f, act[3] / 58.0f + 0.4f, 0.9f);
-    systems_wave(s, t, T, M, l, c.substeps);
-    return;
+    if (split_helper_wave(s, t, T, L, l, c.substeps)) return;
   }
   Msl ms[MSLOTS];
   int nslots = 0;
@@ -767,55 +612,12 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
   // ---- substeps (env_base.py:139-154): every aircraft, then every missile against this substep's aircraft poses
   const MslParam MP = aim9l();
   bool have_pose = false;
+  int nrun_split = 0;
+  const bool split_located = SPLIT && dynamics_wave_ticks(s, t, d, T, L, l, c.substeps, nrun_split);
+  if (split_located) have_pose = true;
   for (int sub = 0; sub < c.substeps; ++sub) {
-    if (SPLIT) {
-      using namespace mail;
-      const bool run = t.status == AC_ALIVE;
-      if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;
-      f16::DynVars k;
-      AC_CLK(2 + sub * 8);
-      if (run) {
-        if (sub == 0) f16::dyn_p1(s, d, k);                    // (its attitude / position members go stale from here on: the
-        else {                                                 //  kinematics wave hands the final ones over)
-          f16::KinOut o;
-          fetch_kin(M, l, o);
-          f16::dyn_p1_lite(s, d, k, o);
-        }
-        M[K_W][l] = s.wp; M[K_W + 1][l] = s.wq; M[K_W + 2][l] = s.wr;
-        M[K_V][l] = s.vx; M[K_V + 1][l] = s.vy; M[K_V + 2][l] = s.vz;
-        M[CTH][l] = d.T[6] * d.d_eci[0] + d.T[7] * d.d_eci[1] + d.T[8] * d.d_eci[2];
-        M[VB][l] = d.v;
-        have_pose = true;
-      }
-      AC_CLK(3 + sub * 8);
-      wg_sync();                                               // B1
-      AC_CLK(4 + sub * 8);
-      if (run) {
-        fetch_mass(M, l, k);
-        if (sub == 0) f16::dyn_p2<false>(s, d, k);
-        else f16::dyn_p2<true>(s, d, k);                      // the atmosphere at this altitude came with the kinematics
-        M[BETA][l] = k.beta;
-        M[MACH][l] = k.mach; M[QBAR][l] = k.qbar; M[RHO][l] = k.A.rho; M[TEMP][l] = k.A.T; M[HSL][l] = d.h_sl_ft;
-        M[ALPHA][l] = k.alpha; M[QC][l] = k.qc; M[VG][l] = k.vg; M[NPY][l] = k.npy; M[NPZ][l] = k.npz;
-        M[AP][l] = d.p; M[AQ][l] = d.q; M[AR][l] = d.r;
-      }
-      AC_CLK(5 + sub * 8);
-      wg_sync();                                               // B2
-      AC_CLK(6 + sub * 8);
-      f16::Surf sf{};
-      if (run) {
-        sf = f16::Surf{M[S_AIL][l], M[S_FLAP][l], M[S_ELEV][l], M[S_RUD][l], M[S_LEF][l], M[S_SB][l], 0.0f};
-        f16::dyn_p3(d, T, k, sf);
-      }
-      AC_CLK(7 + sub * 8);
-      wg_sync();                                               // B3
-      AC_CLK(8 + sub * 8);
-      if (run) {
-        k.clb = M[LK_CLB][l]; k.cnb = M[LK_CNB][l];
-        k.g7 = make_float4(M[LK_G7][l], M[LK_G7 + 1][l], M[LK_G7 + 2][l], M[LK_G7 + 3][l]);
-        f16::dyn_p4(s, d, k, sf, M[THRUST][l]);
-      }
-    } else if (t.status == AC_ALIVE) {
+    if (SPLIT) break;   // (the three-wave form ran its substeps above)
+    if (t.status == AC_ALIVE) {
       if (t.bloods <= 0.0f) t.status = AC_SHOTDOWN;  // simulatior.py:220-222: this tick still integrates
       f16::tick<false>(s, d, T);
       have_pose = true;
@@ -838,26 +640,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
       if (__shfl_xor((int)hit_now, 1) && t.status == AC_ALIVE) t.status = AC_SHOTDOWN;
     }
   }
-  if (SPLIT) {   // the systems wave's fields after its last tick
-    using namespace mail;
-    AC_CLK(50);
-    wg_sync();
-    AC_CLK(51);
-    s.tef = M[F_TEF][l]; s.pin_r = M[F_PINR][l]; s.pin_p = M[F_PINP][l]; s.pin_y = M[F_PINY][l];
-    s.pi_r = M[F_PIR][l]; s.pi_p = M[F_PIP][l]; s.pi_y = M[F_PIY][l]; s.ail = M[F_AIL][l]; s.elev = M[F_ELEV][l]; s.sbdeg = M[F_SBDEG][l];
-    s.n1 = M[F_N1][l]; s.n2 = M[F_N2][l]; s.n2norm = M[F_N2NORM][l]; s.ff = M[F_FF][l]; s.tank0 = M[F_TANK0][l]; s.tank1 = M[F_TANK1][l];
-    s.eng = __float_as_int(M[F_ENG][l]);
-  }
-  if (SPLIT && have_pose) {   // the kinematics wave's attitude, position and fp64 geodetic reduction of the final pose
-    using namespace mail;
-    s.q0 = M[G_Q][l]; s.q1 = M[G_Q + 1][l]; s.q2 = M[G_Q + 2][l]; s.q3 = M[G_Q + 3][l];
-    s.rx = MD[GD_R][l]; s.ry = MD[GD_R + 1][l]; s.rz = MD[GD_R + 2][l];
-    d.X = MD[GD_X][l]; d.Y = MD[GD_X + 1][l]; d.Z = MD[GD_X + 2][l];
-    d.sLat64 = MD[GD_LAT][l]; d.cLat64 = MD[GD_LAT + 1][l]; d.sLon64 = MD[GD_LAT + 2][l]; d.cLon64 = MD[GD_LAT + 3][l];
-    d.h_sl_ft = M[G_H][l];
-    d.n_eci[0] = M[G_NED][l]; d.n_eci[1] = M[G_NED + 1][l]; d.n_eci[2] = M[G_NED + 2][l];
-    d.e_eci[0] = M[G_NED + 3][l]; d.e_eci[1] = M[G_NED + 4][l]; d.e_eci[2] = 0.0f;
-    d.d_eci[0] = M[G_NED + 5][l]; d.d_eci[1] = M[G_NED + 6][l]; d.d_eci[2] = M[G_NED + 7][l];
+  if (split_located) {
     make_props(s, d, c, pr);
   } else if (!HAS_MSL || c.substeps == 0) {
     f16::locate(s, d);
@@ -1112,18 +895,21 @@ __device__ __forceinline__ float observe_nvn(const Props& pr, int slot, int base
   return posture;
 }
 
-template <int A, int WPE>
-__global__ __launch_bounds__(64, WPE) void step_kernel_nvn(DevPtrs P, DevCfg c) {
+template <int A, int WPE, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs P, DevCfg c) {
   constexpr int OBS = 9 + 6 * (A - 1);
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
-  stage_tables(lds_tab, P.tab);
+  __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : 16];
+  SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
+  stage_tables<SPLIT ? 192 : 64>(lds_tab, P.tab);
   const Tab T{lds_tab};
   const int N = c.N;
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int l = threadIdx.x & 63;
+  const int n = blockIdx.x * 64 + l;
   const bool live = n < N;                      // N is a multiple of A, so an env is live or not as a whole
-  const int slot = threadIdx.x % A;
+  const int slot = l % A;
   const int nn = live ? n : (N - A + slot);     // tail lanes shadow the last env and never store
-  const int base_lane = (threadIdx.x & 63) - slot;
+  const int base_lane = l - slot;
   const int team = slot < c.n_ego ? 0 : 1;
 
   State s; Task t; Derived d; Props pr;
@@ -1134,16 +920,21 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_nvn(DevPtrs P, DevCfg c) 
   s.de = clampf(-1.0f, act[1] / 20.0f - 1.0f, 1.0f);
   s.dr = clampf(-1.0f, act[2] / 20.0f - 1.0f, 1.0f);
   s.thr = clampf(0.0f, act[3] / 58.0f + 0.4f, 0.9f);
+  if (SPLIT && split_helper_wave(s, t, T, L, l, c.substeps)) return;
   bool have_pose = false;
-  for (int sub = 0; sub < c.substeps; ++sub) {
+  int nrun_split = 0;
+  const bool split_located = SPLIT && dynamics_wave_ticks(s, t, d, T, L, l, c.substeps, nrun_split);
+  for (int sub = 0; sub < c.substeps && !SPLIT; ++sub) {
     if (t.status == AC_ALIVE) {
       if (t.bloods <= 0.0f) t.status = AC_SHOTDOWN;
       f16::tick<false>(s, d, T);
       have_pose = true;
     }
   }
-  f16::locate(s, d);
-  if (!have_pose) f16::body_frame(s, d);
+  if (!split_located) {
+    f16::locate(s, d);
+    if (!have_pose) f16::body_frame(s, d);
+  }
   make_props(s, d, c, pr);
 
   float ob[OBS];
@@ -1452,7 +1243,8 @@ static int launch_step(ac_env* h, const float* d_actions) {
   }
   const bool one_wave_per_simd = grid.x <= 1024;  // 256 CUs x 4 SIMDs
   if (h->cfg.task == AC_TASK_HEADING) {
-    hipLaunchKernelGGL(step_kernel_heading, grid, block, 0, h->stream, p, h->dc, h->hp, h->hc, 0);
+    if (h->split_waves) hipLaunchKernelGGL(step_kernel_heading<true>, grid, dim3(192), 0, h->stream, p, h->dc, h->hp, h->hc, 0);
+    else hipLaunchKernelGGL(step_kernel_heading<false>, grid, block, 0, h->stream, p, h->dc, h->hp, h->hc, 0);
     HIP_OK(hipGetLastError());
     return 0;
   }
@@ -1465,7 +1257,10 @@ static int launch_step(ac_env* h, const float* d_actions) {
     if (h->A == 2) AC_LAUNCH_SCN(2); else if (h->A == 4) AC_LAUNCH_SCN(4); else AC_LAUNCH_SCN(8);
 #undef AC_LAUNCH_SCN
   } else if (h->cfg.task == AC_TASK_MULTICOMBAT) {
-    if (h->A == 4) {
+    if (h->split_waves) {
+      if (h->A == 4) hipLaunchKernelGGL((step_kernel_nvn<4, 1, true>), grid, dim3(192), 0, h->stream, p, h->dc);
+      else hipLaunchKernelGGL((step_kernel_nvn<8, 1, true>), grid, dim3(192), 0, h->stream, p, h->dc);
+    } else if (h->A == 4) {
       if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_nvn<4, 1>), grid, block, 0, h->stream, p, h->dc);
       else hipLaunchKernelGGL((step_kernel_nvn<4, 2>), grid, block, 0, h->stream, p, h->dc);
     } else {
@@ -1488,7 +1283,7 @@ static int launch_step(ac_env* h, const float* d_actions) {
 static int launch_reset(ac_env* h) {
   dim3 block(64), grid((h->N + 63) / 64);
   if (h->cfg.task == AC_TASK_HEADING) {   // every env draws a new episode from its own generator
-    hipLaunchKernelGGL(step_kernel_heading, grid, block, 0, h->stream, h->dp, h->dc, h->hp, h->hc, 1);
+    hipLaunchKernelGGL(step_kernel_heading<false>, grid, block, 0, h->stream, h->dp, h->dc, h->hp, h->hc, 1);
     HIP_OK(hipGetLastError());
     return 0;
   }
@@ -1555,7 +1350,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   {  // three waves per 64 aircraft up to 512 workgroups (1536 waves on 256 CUs x 4 SIMDs: measured faster than one wave per
      // 64 aircraft up to there, slower from 768 workgroups on); AIRCOMBAT_SPLIT=0/1 overrides
     const char* e = getenv("AIRCOMBAT_SPLIT");
-    h->split_waves = cfg->task == AC_TASK_SINGLECOMBAT && (e ? (e[0] == '1') : ((h->N + 63) / 64 <= 512));
+    h->split_waves = (cfg->task == AC_TASK_SINGLECOMBAT || cfg->task == AC_TASK_MULTICOMBAT || cfg->task == AC_TASK_HEADING) && (e ? (e[0] == '1') : ((h->N + 63) / 64 <= 512));
   }
   h->obs_dim = heading ? 12 : (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;

@@ -116,13 +116,17 @@ __device__ void heading_reset(const HeadingCfg& hc, const DevCfg& c, const Tab& 
   heading_obs(pr, d, x, ob);
 }
 
-__global__ __launch_bounds__(64, 2) void step_kernel_heading(DevPtrs P, DevCfg c, HeadingPtrs H, HeadingCfg hc, int reset_only) {
+template <bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 192 : 64, SPLIT ? 1 : 2) void step_kernel_heading(DevPtrs P, DevCfg c, HeadingPtrs H, HeadingCfg hc, int reset_only) {
   constexpr int OBS = 12;
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
-  stage_tables(lds_tab, P.tab);
+  __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : 16];
+  SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
+  stage_tables<SPLIT ? 192 : 64>(lds_tab, P.tab);
   const Tab T{lds_tab};
   const int N = c.N;
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int l = threadIdx.x & 63;
+  const int n = blockIdx.x * 64 + l;
   const bool live = n < N;
   const int nn = live ? n : N - 1;
   State s; Task t; Derived d; Props pr; HeadingState x;
@@ -148,8 +152,12 @@ __global__ __launch_bounds__(64, 2) void step_kernel_heading(DevPtrs P, DevCfg c
   s.de = clampf(-1.0f, act[1] * (2.0f / 40.0f) - 1.0f, 1.0f);
   s.dr = clampf(-1.0f, act[2] * (2.0f / 40.0f) - 1.0f, 1.0f);
   s.thr = clampf(0.0f, act[3] * (0.5f / 29.0f) + 0.4f, 0.9f);
+  if (SPLIT && split_helper_wave(s, t, T, L, l, c.substeps)) return;
   bool have_pose = false;
-  for (int sub = 0; sub < c.substeps; ++sub) {
+  int nrun_split = 0;
+  const bool split_located = SPLIT && dynamics_wave_ticks(s, t, d, T, L, l, c.substeps, nrun_split);
+  for (int k = 0; k < nrun_split; ++k) x.sim_time += 1.0 / 60.0;
+  for (int sub = 0; sub < c.substeps && !SPLIT; ++sub) {
     if (t.status == AC_ALIVE) {
       if (t.bloods <= 0.0f) t.status = AC_SHOTDOWN;
       f16::tick<false>(s, d, T);
@@ -157,8 +165,10 @@ __global__ __launch_bounds__(64, 2) void step_kernel_heading(DevPtrs P, DevCfg c
       have_pose = true;
     }
   }
-  f16::locate(s, d);
-  if (!have_pose) f16::body_frame(s, d);
+  if (!split_located) {
+    f16::locate(s, d);
+    if (!have_pose) f16::body_frame(s, d);
+  }
   make_props(s, d, c, pr);
   heading_obs(pr, d, x, ob);
 

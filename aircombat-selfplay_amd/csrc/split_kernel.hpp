@@ -1,0 +1,254 @@
+// The three-wave form of the step kernels (included by aircombat.hip after the state layout and before the kernels).
+//
+// Below one wave per SIMD the step time is the length of ONE lane's instruction stream (a lone wave64 issues one instruction per
+// ~4 cycles and the ticks are a dependent chain) while most SIMDs idle, so the FDM tick is cut by function over three waves that
+// work on the same 64 aircraft: wave 0 "dynamics" (the critical path and the whole environment layer), wave 1 "systems" (flight
+// control system, turbine and fuel, mass balance) and wave 2 "kinematics" (attitude / position / geodetic frame / gravity /
+// atmosphere of the NEXT tick, which depend on this tick's rates and velocities only, plus a share of the table look-ups).
+// f16_split.hpp holds the statements of tick() cut into those pieces (generated, so every kernel form runs the same arithmetic);
+// this file holds the LDS mailbox and the per-wave drivers.
+#pragma once
+
+// SPLIT (tasks without munitions, small grids): a workgroup is THREE waves over the same 64 aircraft. Wave 0 ("dynamics") runs the rigid-body
+// part of every tick and the whole environment layer; wave 1 ("systems") runs the flight control system and the turbine of the same
+// aircraft on another SIMD, concurrently with wave 0's atmosphere / mass / auxiliary / table look-up work. The two exchange ~25 floats
+// per aircraft and tick through LDS, with three workgroup barriers per tick (f16_split.hpp holds the statements of tick(), cut into
+// those pieces). A lone wave issues one dependent instruction every ~4.3 cycles, so below one wave per SIMD this shortens the tick's
+// critical path instead of competing for issue slots.
+namespace mail {  // LDS mailbox rows (64 floats each)
+enum { CTH, VB,                                                    // dynamics -> systems after part 1
+       MACH, QBAR, RHO, TEMP, HSL, ALPHA, BETA, QC, VG, NPY, NPZ, AP, AQ, AR,   // dynamics -> systems after part 2
+       S_AIL, S_FLAP, S_ELEV, S_RUD, S_LEF, S_SB,                   // systems -> dynamics after the FCS
+       THRUST,                                                      // systems -> dynamics after the turbine
+       LK_CLB, LK_CNB, LK_G7,                                       // kinematics -> dynamics: its share of the table look-ups
+       MASS0 = LK_G7 + 4, MASS_N = 18,                              // systems -> dynamics: mass properties of the coming tick
+       F_TEF = MASS0 + MASS_N, F_PINR, F_PINP, F_PINY, F_PIR, F_PIP, F_PIY, F_AIL, F_ELEV, F_SBDEG, F_N1, F_N2, F_N2NORM, F_FF, F_TANK0, F_TANK1,
+       F_ENG,                                                       // final hand-over of the fields the systems wave owns
+       K_W, K_V = K_W + 3,                                          // dynamics -> kinematics after part 1: body rates, ECI velocity
+       K_OUT = K_V + 3, K_OUT_N = 27,                               // kinematics -> dynamics: f16::KinOut of the coming tick
+       G_Q = K_OUT + K_OUT_N, G_H = G_Q + 4, G_NED = G_H + 1,        // kinematics -> dynamics at the end: quaternion, env-layer frame
+       ROWS = G_NED + 8 };
+enum { GD_R, GD_X = GD_R + 3, GD_LAT = GD_X + 3, DROWS = GD_LAT + 4 };   // ... and the fp64 rows: ECI / ECEF position, geodetic cosines
+}
+__device__ __forceinline__ void post_kin(float (*M)[64], int l, const f16::KinOut& o) {
+  const float v[mail::K_OUT_N] = {o.T[0], o.T[1], o.T[2], o.T[3], o.T[4], o.T[5], o.T[6], o.T[7], o.T[8], o.h_sl_ft, o.n_eci[0], o.n_eci[1], o.n_eci[2],
+                                  o.e_eci[0], o.e_eci[1], o.d_eci[0], o.d_eci[1], o.d_eci[2], o.gx, o.gy, o.gz, o.rxf, o.ryf, o.A.T, o.A.P, o.A.rho, o.A.a};
+#pragma unroll
+  for (int i = 0; i < mail::K_OUT_N; ++i) M[mail::K_OUT + i][l] = v[i];
+}
+__device__ __forceinline__ void fetch_kin(float (*M)[64], int l, f16::KinOut& o) {
+  float v[mail::K_OUT_N];
+#pragma unroll
+  for (int i = 0; i < mail::K_OUT_N; ++i) v[i] = M[mail::K_OUT + i][l];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o.T[i] = v[i];
+  o.h_sl_ft = v[9]; o.n_eci[0] = v[10]; o.n_eci[1] = v[11]; o.n_eci[2] = v[12]; o.e_eci[0] = v[13]; o.e_eci[1] = v[14];
+  o.d_eci[0] = v[15]; o.d_eci[1] = v[16]; o.d_eci[2] = v[17]; o.gx = v[18]; o.gy = v[19]; o.gz = v[20]; o.rxf = v[21]; o.ryf = v[22];
+  o.A.T = v[23]; o.A.P = v[24]; o.A.rho = v[25]; o.A.a = v[26];
+}
+// mass, CG, inertia tensor, its cofactors / determinant, 1/mass: sys_mass() on the systems wave -> DynVars of the dynamics wave
+__device__ __forceinline__ void post_mass(float (*M)[64], int l, const f16::DynVars& k) {
+  const float v[mail::MASS_N] = {k.mass, k.cgx, k.cgy, k.cgz, k.Jxx, k.Jyy, k.Jzz, k.Jxy, k.Jxz, k.Jyz, k.c00, k.c01, k.c02, k.c11, k.c12, k.c22, k.idet, k.im_};
+#pragma unroll
+  for (int i = 0; i < mail::MASS_N; ++i) M[mail::MASS0 + i][l] = v[i];
+}
+__device__ __forceinline__ void fetch_mass(float (*M)[64], int l, f16::DynVars& k) {
+  float v[mail::MASS_N];
+#pragma unroll
+  for (int i = 0; i < mail::MASS_N; ++i) v[i] = M[mail::MASS0 + i][l];
+  k.mass = v[0]; k.cgx = v[1]; k.cgy = v[2]; k.cgz = v[3]; k.Jxx = v[4]; k.Jyy = v[5]; k.Jzz = v[6]; k.Jxy = v[7]; k.Jxz = v[8]; k.Jyz = v[9];
+  k.c00 = v[10]; k.c01 = v[11]; k.c02 = v[12]; k.c11 = v[13]; k.c12 = v[14]; k.c22 = v[15]; k.idet = v[16]; k.im_ = v[17];
+}
+#ifdef AC_SPLIT_TIMING   // scratch builds only (variants/): cycle stamps of workgroup 0's dynamics wave
+__device__ unsigned long long g_clk[64];
+#define AC_CLK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_clk[i] = __builtin_readcyclecounter(); } while (0)
+extern "C" void ac_debug_clocks(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof g_clk); }
+#else
+#define AC_CLK(i) do {} while (0)
+#endif
+__device__ __forceinline__ void wg_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// The systems wave of a SPLIT workgroup: FCS and turbine of every substep, then the final values of the fields it owns.
+__device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::Tab& T, float (*M)[64], int l, int substeps) {
+  using namespace mail;
+  f16::DynVars km{};
+  f16::sys_mass(s, km);
+  post_mass(M, l, km);                                     // read by the dynamics wave after B1 of the first tick
+  for (int sub = 0; sub < substeps; ++sub) {
+    const bool run = t.status == AC_ALIVE;
+    if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;   // the same latch the dynamics wave applies
+    f16::Surf sf{};
+    wg_sync();                                             // B1: this tick's attitude is known
+    if (run) {
+      f16::sys_fcs(s, M[CTH][l], M[VB][l], sf);
+      M[S_AIL][l] = sf.aileron_rad; M[S_FLAP][l] = sf.flaperon_rad; M[S_ELEV][l] = sf.elevator_rad;
+      M[S_RUD][l] = sf.rudder_rad;  M[S_LEF][l] = sf.lef_rad;       M[S_SB][l] = sf.sb_rad;
+    }
+    wg_sync();                                             // B2: this tick's air data are known
+    if (run) {
+      f16::Atmos A{};
+      A.rho = M[RHO][l]; A.T = M[TEMP][l];
+      const float mach = M[MACH][l], alpha = M[ALPHA][l], h_sl = M[HSL][l];
+      float thrust;
+      f16::sys_engine(s, T, mach, M[QBAR][l], A, h_sl, sf.throttle_pos, thrust);
+      M[THRUST][l] = thrust;
+    }
+    wg_sync();                                             // B3: surfaces and thrust are known
+    if (run) {                                             // while the dynamics wave assembles, integrates and propagates:
+      // what FGAuxiliary published this tick is what the next tick's FCS reads
+      s.alpha = M[ALPHA][l]; s.mach = M[MACH][l]; s.qc = M[QC][l]; s.vg = M[VG][l];
+      s.npy = M[NPY][l]; s.npz = M[NPZ][l]; s.ap = M[AP][l]; s.aq = M[AQ][l]; s.ar = M[AR][l];
+      f16::sys_mass(s, km);                                // the tanks after this tick's draw give the next tick's mass balance
+      post_mass(M, l, km);
+    }
+  }
+  M[F_TEF][l] = s.tef; M[F_PINR][l] = s.pin_r; M[F_PINP][l] = s.pin_p; M[F_PINY][l] = s.pin_y;
+  M[F_PIR][l] = s.pi_r; M[F_PIP][l] = s.pi_p; M[F_PIY][l] = s.pi_y; M[F_AIL][l] = s.ail; M[F_ELEV][l] = s.elev; M[F_SBDEG][l] = s.sbdeg;
+  M[F_N1][l] = s.n1; M[F_N2][l] = s.n2; M[F_N2NORM][l] = s.n2norm; M[F_FF][l] = s.ff; M[F_TANK0][l] = s.tank0; M[F_TANK1][l] = s.tank1;
+  M[F_ENG][l] = __int_as_float(s.eng);
+  wg_sync();
+}
+// The kinematics wave of a SPLIT workgroup. Attitude and position are integrated explicitly from the PREVIOUS tick's rates and
+// velocity, so the quaternion, the fp64 position, the geodetic reduction, the direction cosine matrix and gravity of tick k+1 are
+// computed here while the other two waves are still in tick k; on an aircraft's last tick of the step it does the fp64 geodetic
+// reduction of the environment layer instead.
+__device__ __forceinline__ void kinematics_wave(f16::State& s, Task& t, const f16::Tab& T, float (*M)[64], double (*MD)[64], int l, int substeps) {
+  using namespace mail;
+  f16::KinOut o;
+  int nrun = 0;
+  if (t.status == AC_ALIVE && substeps > 0) { f16::kin_position(s, o); f16::kin_attitude(s, o); nrun = 1; }   // tick 0 (the dynamics wave does its own)
+  for (int sub = 0; sub < substeps; ++sub) {
+    const bool run = t.status == AC_ALIVE;
+    if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;   // the same latch the dynamics wave applies
+    const bool run_next = run && t.status == AC_ALIVE && sub + 1 < substeps;
+    wg_sync();                                             // B1: this tick's rates and velocity are known
+    if (run_next) {
+      s.wp = M[K_W][l]; s.wq = M[K_W + 1][l]; s.wr = M[K_W + 2][l];
+      s.vx = M[K_V][l]; s.vy = M[K_V + 1][l]; s.vz = M[K_V + 2][l];
+      f16::kin_position(s, o);
+      nrun += 1;
+    } else if (run) {                                      // last tick of this aircraft in this step: the pose the env layer reads
+      f16::Derived d;
+      s.ticks += nrun;
+      f16::locate(s, d);
+      M[G_Q][l] = s.q0; M[G_Q + 1][l] = s.q1; M[G_Q + 2][l] = s.q2; M[G_Q + 3][l] = s.q3;
+      M[G_H][l] = d.h_sl_ft;
+      M[G_NED][l] = d.n_eci[0]; M[G_NED + 1][l] = d.n_eci[1]; M[G_NED + 2][l] = d.n_eci[2];
+      M[G_NED + 3][l] = d.e_eci[0]; M[G_NED + 4][l] = d.e_eci[1];
+      M[G_NED + 5][l] = d.d_eci[0]; M[G_NED + 6][l] = d.d_eci[1]; M[G_NED + 7][l] = d.d_eci[2];
+      MD[GD_R][l] = s.rx; MD[GD_R + 1][l] = s.ry; MD[GD_R + 2][l] = s.rz;
+      MD[GD_X][l] = d.X; MD[GD_X + 1][l] = d.Y; MD[GD_X + 2][l] = d.Z;
+      MD[GD_LAT][l] = d.sLat64; MD[GD_LAT + 1][l] = d.cLat64; MD[GD_LAT + 2][l] = d.sLon64; MD[GD_LAT + 3][l] = d.cLon64;
+    }
+    wg_sync();                                             // B2: this tick's air data are known
+    if (run) {   // this wave's share of the aerodynamic tables: those on the sideslip axis (all else dyn_p3 computes is dead here)
+      f16::DynVars kl{};
+      f16::Derived dd{};
+      dd.h_sl_ft = 1e6f;
+      kl.alpha = M[ALPHA][l]; kl.beta = M[BETA][l]; kl.mach = M[MACH][l]; kl.vt = 1.0f;
+      f16::dyn_p3(dd, T, kl, f16::Surf{});
+      M[LK_CLB][l] = kl.clb; M[LK_CNB][l] = kl.cnb;
+      M[LK_G7][l] = kl.g7.x; M[LK_G7 + 1][l] = kl.g7.y; M[LK_G7 + 2][l] = kl.g7.z; M[LK_G7 + 3][l] = kl.g7.w;
+    }
+    if (run_next) {
+      f16::kin_attitude(s, o);
+      post_kin(M, l, o);
+    }
+    wg_sync();                                             // B3
+  }
+  wg_sync();
+}
+
+// LDS of a three-wave workgroup
+struct SplitLds {
+  float M[mail::ROWS][64];
+  double MD[mail::DROWS][64];
+};
+// Helper waves of a three-wave workgroup: run their part of every substep and return true (the caller returns); the dynamics
+// wave (wave 0) gets false. Commands (s.da .. s.thr) must be decoded before the call.
+__device__ __forceinline__ bool split_helper_wave(f16::State& s, Task& t, const f16::Tab& T, SplitLds& L, int l, int substeps) {
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (role == 2) { kinematics_wave(s, t, T, L.M, L.MD, l, substeps); return true; }
+  if (role == 1) { systems_wave(s, t, T, L.M, l, substeps); return true; }
+  return false;
+}
+// The dynamics wave's substeps of one env step: the same result as `for (sub) if (alive) { latch; tick<false>(s, d, T); }` followed by
+// f16::locate(s, d) when any tick ran (returns that, and the number of ticks run); d holds the last tick's body-frame quantities.
+__device__ __forceinline__ bool dynamics_wave_ticks(f16::State& s, Task& t, f16::Derived& d, const f16::Tab& T, SplitLds& L, int l, int substeps,
+                                                    int& nrun) {
+  using namespace mail;
+  float (*M)[64] = L.M;
+  double (*MD)[64] = L.MD;
+  bool ran = false;
+  nrun = 0;
+  for (int sub = 0; sub < substeps; ++sub) {
+    const bool run = t.status == AC_ALIVE;
+    if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;      // simulatior.py:220-222: this tick still integrates
+    f16::DynVars k;
+    AC_CLK(2 + sub * 8);
+    if (run) {
+      if (sub == 0) f16::dyn_p1(s, d, k);                      // (its attitude / position members go stale from here on: the
+      else {                                                   //  kinematics wave hands the final ones over)
+        f16::KinOut o;
+        fetch_kin(M, l, o);
+        f16::dyn_p1_lite(s, d, k, o);
+      }
+      M[K_W][l] = s.wp; M[K_W + 1][l] = s.wq; M[K_W + 2][l] = s.wr;
+      M[K_V][l] = s.vx; M[K_V + 1][l] = s.vy; M[K_V + 2][l] = s.vz;
+      M[CTH][l] = d.T[6] * d.d_eci[0] + d.T[7] * d.d_eci[1] + d.T[8] * d.d_eci[2];
+      M[VB][l] = d.v;
+      ran = true;
+      nrun += 1;
+    }
+    AC_CLK(3 + sub * 8);
+    wg_sync();                                                 // B1
+    AC_CLK(4 + sub * 8);
+    if (run) {
+      fetch_mass(M, l, k);
+      if (sub == 0) f16::dyn_p2<false>(s, d, k);
+      else f16::dyn_p2<true>(s, d, k);                        // the atmosphere at this altitude came with the kinematics
+      M[BETA][l] = k.beta;
+      M[MACH][l] = k.mach; M[QBAR][l] = k.qbar; M[RHO][l] = k.A.rho; M[TEMP][l] = k.A.T; M[HSL][l] = d.h_sl_ft;
+      M[ALPHA][l] = k.alpha; M[QC][l] = k.qc; M[VG][l] = k.vg; M[NPY][l] = k.npy; M[NPZ][l] = k.npz;
+      M[AP][l] = d.p; M[AQ][l] = d.q; M[AR][l] = d.r;
+    }
+    AC_CLK(5 + sub * 8);
+    wg_sync();                                                 // B2
+    AC_CLK(6 + sub * 8);
+    f16::Surf sf{};
+    if (run) {
+      sf = f16::Surf{M[S_AIL][l], M[S_FLAP][l], M[S_ELEV][l], M[S_RUD][l], M[S_LEF][l], M[S_SB][l], 0.0f};
+      f16::dyn_p3(d, T, k, sf);
+    }
+    AC_CLK(7 + sub * 8);
+    wg_sync();                                                 // B3
+    AC_CLK(8 + sub * 8);
+    if (run) {
+      k.clb = M[LK_CLB][l]; k.cnb = M[LK_CNB][l];
+      k.g7 = make_float4(M[LK_G7][l], M[LK_G7 + 1][l], M[LK_G7 + 2][l], M[LK_G7 + 3][l]);
+      f16::dyn_p4(s, d, k, sf, M[THRUST][l]);
+    }
+  }
+  // the systems wave's fields after its last tick
+  AC_CLK(50);
+  wg_sync();
+  AC_CLK(51);
+  s.tef = M[F_TEF][l]; s.pin_r = M[F_PINR][l]; s.pin_p = M[F_PINP][l]; s.pin_y = M[F_PINY][l];
+  s.pi_r = M[F_PIR][l]; s.pi_p = M[F_PIP][l]; s.pi_y = M[F_PIY][l]; s.ail = M[F_AIL][l]; s.elev = M[F_ELEV][l]; s.sbdeg = M[F_SBDEG][l];
+  s.n1 = M[F_N1][l]; s.n2 = M[F_N2][l]; s.n2norm = M[F_N2NORM][l]; s.ff = M[F_FF][l]; s.tank0 = M[F_TANK0][l]; s.tank1 = M[F_TANK1][l];
+  s.eng = __float_as_int(M[F_ENG][l]);
+  if (ran) {   // the kinematics wave's attitude, position and fp64 geodetic reduction of the final pose
+    s.q0 = M[G_Q][l]; s.q1 = M[G_Q + 1][l]; s.q2 = M[G_Q + 2][l]; s.q3 = M[G_Q + 3][l];
+    s.rx = MD[GD_R][l]; s.ry = MD[GD_R + 1][l]; s.rz = MD[GD_R + 2][l];
+    d.X = MD[GD_X][l]; d.Y = MD[GD_X + 1][l]; d.Z = MD[GD_X + 2][l];
+    d.sLat64 = MD[GD_LAT][l]; d.cLat64 = MD[GD_LAT + 1][l]; d.sLon64 = MD[GD_LAT + 2][l]; d.cLon64 = MD[GD_LAT + 3][l];
+    d.h_sl_ft = M[G_H][l];
+    d.n_eci[0] = M[G_NED][l]; d.n_eci[1] = M[G_NED + 1][l]; d.n_eci[2] = M[G_NED + 2][l];
+    d.e_eci[0] = M[G_NED + 3][l]; d.e_eci[1] = M[G_NED + 4][l]; d.e_eci[2] = 0.0f;
+    d.d_eci[0] = M[G_NED + 5][l]; d.d_eci[1] = M[G_NED + 6][l]; d.d_eci[2] = M[G_NED + 7][l];
+  }
+  return ran;
+}

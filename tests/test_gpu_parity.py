@@ -135,6 +135,39 @@ def test_singlecombat_kernel_forms_teacher_forced(pkg, oracle, monkeypatch, two_
     env.close()
 
 
+@pytest.mark.parametrize("task", ["singlecombat", "multiplecombat", "heading"])
+def test_one_wave_and_three_wave_forms_agree(pkg, monkeypatch, task):
+    """The tasks without munitions run their FDM ticks in the three-wave form at small batches (and in the one-wave form
+    above 512 workgroups). Both forms are built from the same statements, so from the same reset and the same actions they
+    must stay together inside the oracle tolerance over a short open-loop run (ragged last workgroup included)."""
+    cfg = pkg.default_config(task)
+    A = cfg.n_agents
+    if task == "multiplecombat":   # off the shipped head-on geometry, where PostureReward's atanh is singular (see the NvN test)
+        for i in range(A):
+            cfg.init[i].lon_deg += 0.013 * (i % 3) + (0.02 if i >= A // 2 else 0.0)
+            cfg.init[i].psi_deg = (7.0 + 3.0 * i) if i < A // 2 else (171.0 + 2.0 * i)
+    E = 72 // A + 3
+    envs = []
+    for form in ("0", "1"):
+        monkeypatch.setenv("AIRCOMBAT_SPLIT", form)
+        env = pkg.HipVecEnv(cfg, E, seed=11)
+        env.seed(11)
+        envs.append(env)
+    o0, o1 = envs[0].reset(), envs[1].reset()
+    assert (o0 == o1).all()
+    rng = np.random.default_rng(8)
+    for step in range(15):
+        act = rand_actions(rng, E, A, 4)
+        o0, r0, d0, _ = envs[0].step(act)
+        o1, r1, d1, _ = envs[1].step(act)
+        assert (d0 == d1).all(), step
+        ok = nvn_obs_close(o0, o1) if task == "multiplecombat" else obs_close(o0, o1, 0.25)   # (acos near pi amplifies an ulp)
+        assert ok.all(), (step, np.abs(o0 - o1).max())
+        assert (np.abs(r0 - r1) <= 1e-3 + 2.5e-4 * np.abs(r1)).all(), (step, np.abs(r0 - r1).max())
+    for env in envs:
+        env.close()
+
+
 def test_open_loop_rollout_with_terminations(pkg, oracle):
     """Random actions from reset until episodes end: dones and auto-reset observations line up with the oracle."""
     cfg = pkg.default_config("singlecombat")
