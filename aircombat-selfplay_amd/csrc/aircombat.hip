@@ -1254,7 +1254,8 @@ static int launch_step(ac_env* h, const float* d_actions) {
     if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_scenario<AA, 1>), grid, block, 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr); \
     else hipLaunchKernelGGL((step_kernel_scenario<AA, 2>), grid, block, 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);                  \
   } while (0)
-    if (h->A == 2) AC_LAUNCH_SCN(2); else if (h->A == 4) AC_LAUNCH_SCN(4); else AC_LAUNCH_SCN(8);
+    if (h->split_waves) hipLaunchKernelGGL((step_kernel_scenario<2, 1, true>), grid, dim3(192), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
+    else if (h->A == 2) AC_LAUNCH_SCN(2); else if (h->A == 4) AC_LAUNCH_SCN(4); else AC_LAUNCH_SCN(8);
 #undef AC_LAUNCH_SCN
   } else if (h->cfg.task == AC_TASK_MULTICOMBAT) {
     if (h->split_waves) {
@@ -1350,7 +1351,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   {  // three waves per 64 aircraft up to 512 workgroups (1536 waves on 256 CUs x 4 SIMDs: measured faster than one wave per
      // 64 aircraft up to there, slower from 768 workgroups on); AIRCOMBAT_SPLIT=0/1 overrides
     const char* e = getenv("AIRCOMBAT_SPLIT");
-    h->split_waves = (cfg->task == AC_TASK_SINGLECOMBAT || cfg->task == AC_TASK_MULTICOMBAT || cfg->task == AC_TASK_HEADING) && (e ? (e[0] == '1') : ((h->N + 63) / 64 <= 512));
+    h->split_waves = (cfg->task == AC_TASK_SINGLECOMBAT || cfg->task == AC_TASK_MULTICOMBAT || cfg->task == AC_TASK_HEADING ||
+                      cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER) && (e ? (e[0] == '1') : ((h->N + 63) / 64 <= 512));
   }
   h->obs_dim = heading ? 12 : (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;

@@ -83,22 +83,27 @@ struct ScenarioDims {
 // Relative-geometry quantities of every reward term towards the enemies of this lane, in enemy order.
 struct EnemyGeo { float AO, TA, R; };
 
-template <int A, int WPE>
-__global__ __launch_bounds__(64, WPE) void step_kernel_scenario(DevPtrs P, DevCfg c, float* XF, int* XI, const float* tXF, const int* tXI) {
+// SPLIT: the three-wave form of the substeps (split_kernel.hpp), for the gun-only tasks (WVR, Maneuver_curriculum), which never
+// have munitions in flight and therefore no per-substep work beside the FDM tick.
+template <int A, int WPE, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_scenario(DevPtrs P, DevCfg c, float* XF, int* XI, const float* tXF, const int* tXI) {
   using SD = ScenarioDims<A>;
   constexpr bool MULTI = SD::MULTI;
   constexpr int OBS = SD::OBS;
   constexpr int NE = SD::NE;
   constexpr int MS = 2;  // munition slots (uids) per aircraft
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
-  stage_tables(lds_tab, P.tab);
+  __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : 16];
+  SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
+  stage_tables<SPLIT ? 192 : 64>(lds_tab, P.tab);
   const Tab T{lds_tab};
   const int N = c.N;
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 64 + lane;
   const bool live = n < N;
-  const int slot = threadIdx.x % A;
+  const int slot = lane % A;
   const int nn = live ? n : (N - A + slot);
-  const int base = (threadIdx.x & 63) - slot;
+  const int base = lane - slot;
   const int n_ego = c.n_ego;
   const int team = slot < n_ego ? 0 : 1;
   const int e_first = team == 0 ? n_ego : 0;   // my enemies are slots e_first .. e_first + NE - 1
@@ -134,7 +139,14 @@ __global__ __launch_bounds__(64, WPE) void step_kernel_scenario(DevPtrs P, DevCf
 #pragma unroll
   for (int k = 0; k < MS; ++k) mine = mine || ms[k].status != MSL_INACTIVE;
   const bool env_has_munitions = (__ballot(mine) & env_mask) != 0;
-  for (int sub = 0; sub < c.substeps; ++sub) {
+  if (SPLIT) {   // (launched for the gun-only tasks alone: nothing flies, so only the last substep's pose is needed)
+    if (split_helper_wave(s, t, T, L, lane, c.substeps)) return;
+    int nrun_split = 0;
+    if (!dynamics_wave_ticks(s, t, d, T, L, lane, c.substeps, nrun_split)) { f16::locate(s, d); f16::body_frame(s, d); }
+    have_pose = true;
+    if (c.substeps > 0) make_props(s, d, c, pr);
+  }
+  for (int sub = 0; sub < c.substeps && !SPLIT; ++sub) {
     if (t.status == AC_ALIVE) {
       if (t.bloods <= 0.0f) t.status = AC_SHOTDOWN;
       f16::tick<false>(s, d, T);

@@ -135,7 +135,7 @@ def test_singlecombat_kernel_forms_teacher_forced(pkg, oracle, monkeypatch, two_
     env.close()
 
 
-@pytest.mark.parametrize("task", ["singlecombat", "multiplecombat", "heading"])
+@pytest.mark.parametrize("task", ["singlecombat", "multiplecombat", "heading", "wvr_lowlevel", "maneuver_lowlevel"])
 def test_one_wave_and_three_wave_forms_agree(pkg, monkeypatch, task):
     """The tasks without munitions run their FDM ticks in the three-wave form at small batches (and in the one-wave form
     above 512 workgroups). Both forms are built from the same statements, so from the same reset and the same actions they
