@@ -19,6 +19,27 @@ class HipExtensionMissing(RuntimeError):
     pass
 
 
+# ---- include/aircombat_buffer.h
+(AC_BUF_OBS, AC_BUF_SHARE_OBS, AC_BUF_ACTIONS, AC_BUF_REWARDS, AC_BUF_MASKS, AC_BUF_BAD_MASKS, AC_BUF_ACTIVE_MASKS, AC_BUF_LOGP,
+ AC_BUF_VALUES, AC_BUF_RETURNS, AC_BUF_RNN_ACTOR, AC_BUF_RNN_CRITIC, AC_BUF_ADVANTAGES, AC_BUF_NFIELDS) = range(14)
+
+
+class AcBufferConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("buffer_size", "n_envs", "n_agents", "obs_dim", "share_obs_dim", "act_dim", "logp_dim",
+                                         "hidden_layers", "hidden_size", "use_gae", "use_proper_time_limits")] + \
+               [("gamma", C.c_double), ("gae_lambda", C.c_double)]
+
+
+class AcBufferStep(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "actions", "rewards", "masks", "action_log_probs", "value_preds", "rnn_states_actor",
+                                          "rnn_states_critic", "bad_masks", "share_obs", "active_masks")]
+
+
+class AcBufferBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "share_obs", "actions", "masks", "active_masks", "action_log_probs", "advantages", "returns",
+                                          "value_preds", "rnn_states_actor", "rnn_states_critic")]
+
+
 class AcInitState(C.Structure):
     _fields_ = [(n, C.c_double) for n in
                 ("lon_deg", "lat_geod_deg", "h_sl_ft", "psi_deg", "u_fps", "v_fps", "w_fps",
@@ -83,6 +104,20 @@ SIGNATURES = {
     "ac_set_controller_state": (C.c_int, [_p, C.c_int32, C.c_int32, _p]),
     "ac_last_error": (C.c_char_p, []),
     "ac_version": (C.c_char_p, []),
+    # include/aircombat_buffer.h
+    "ac_buffer_create": (_p, [C.POINTER(AcBufferConfig), C.c_int]),
+    "ac_buffer_destroy": (None, [_p]),
+    "ac_buffer_insert": (C.c_int, [_p, C.POINTER(AcBufferStep), C.c_int]),
+    "ac_buffer_step_index": (C.c_int, [_p]),
+    "ac_buffer_after_update": (C.c_int, [_p]),
+    "ac_buffer_clear": (C.c_int, [_p]),
+    "ac_buffer_compute_returns": (C.c_int, [_p, _p, C.c_int]),
+    "ac_buffer_advantages": (C.c_int, [_p]),
+    "ac_buffer_minibatch": (C.c_int, [_p, _p, C.c_int32, C.c_int32, C.POINTER(AcBufferBatch), C.c_int]),
+    "ac_buffer_device_ptr": (C.c_int, [_p, C.c_int32, C.POINTER(_p), C.POINTER(C.c_int64)]),
+    "ac_buffer_read": (C.c_int, [_p, C.c_int32, _p]),
+    "ac_buffer_write_slot": (C.c_int, [_p, C.c_int32, C.c_int32, _p]),
+    "ac_buffer_last_kernel_ms": (C.c_int, [_p, C.POINTER(C.c_float)]),
 }
 
 

@@ -16,7 +16,9 @@
 #include <string>
 #include <vector>
 #include <cmath>
+#include <algorithm>
 #include "../../include/aircombat.h"
+#include "../../include/aircombat_buffer.h"
 #include "f16_device.hpp"
 #include "f16_split.hpp"
 
@@ -1761,3 +1763,5 @@ int ac_get_missile(ac_env_t* h, int32_t env, int32_t agent, int32_t k, double ou
 }
 
 }  // extern "C"
+
+#include "rollout_buffer.hpp"

@@ -25,6 +25,14 @@ def built():
 
 @pytest.fixture(scope="session")
 def pkg(built):
+    # torch ships its own copy of the HIP / ROCr runtime; when a test wants torch tensors on the GPU next to the library's handles
+    # (device-side insert, torch views of HBM buffers), torch has to bring its runtime up first, as bench.py does
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:  # pragma: no cover
+        pass
     import aircombat_selfplay_amd as m
     return m
 

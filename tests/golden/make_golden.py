@@ -98,12 +98,17 @@ def install_standins():
     class MultiDiscrete:
         def __init__(self, nvec):
             self.nvec = np.array(nvec)
+            self.shape = self.nvec.shape
+
+    class MultiBinary:
+        def __init__(self, n):
+            self.n, self.shape = n, (n,)
 
     class Tuple(tuple):
         def __new__(cls, xs):
             return tuple.__new__(cls, xs)
 
-    sp.Box, sp.Discrete, sp.MultiDiscrete, sp.Tuple, sp.Space = Box, Discrete, MultiDiscrete, Tuple, object
+    sp.Box, sp.Discrete, sp.MultiDiscrete, sp.MultiBinary, sp.Tuple, sp.Space = Box, Discrete, MultiDiscrete, MultiBinary, Tuple, object
     g.spaces, g.Space, g.Env = sp, object, object
     sd.np_random = lambda seed=None: (np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed))), seed)
     ut.seeding, g.utils = sd, ut
@@ -944,6 +949,72 @@ def gen_baseline_agents(rng):
                         man_poses=mposes, man_delta=mdelta, man_obs=mobs, man_turn_interval=1.5, time_interval=env.time_interval)
 
 
+def gen_rollout_buffer(rng):
+    """ReplayBuffer / SharedReplayBuffer (algorithms/utils/buffer.py): inserts with episode ends and time-limit ends, the four
+    compute_returns modes, the normalised advantages, after_update, and the mini-batches of recurrent_generator for a recorded
+    chunk permutation (torch.randperm is replaced by that recorded permutation while the generator runs)."""
+    import torch
+    from algorithms.utils.buffer import ReplayBuffer, SharedReplayBuffer
+    sp = sys.modules["gymnasium.spaces"]
+    T, E, A, OBS, SH, H = 12, 3, 2, 5, 10, 4
+    obs_space, share_space = sp.Box(low=-10, high=10, shape=(OBS,)), sp.Box(low=-10, high=10, shape=(SH,))
+    act_space = sp.MultiDiscrete([41, 41, 41, 30])
+    out = {"dims": np.array([T, E, A, OBS, SH, 4, 1, H])}
+    f32 = lambda x: x.astype(np.float32)
+    stream = {
+        "obs": f32(rng.normal(size=(T + 1, E, A, OBS))), "share_obs": f32(rng.normal(size=(T + 1, E, A, SH))),
+        "actions": f32(rng.integers(0, 30, size=(T, E, A, 4))), "rewards": f32(rng.normal(size=(T, E, A, 1)) * 3),
+        "masks": f32(rng.random((T, E, A, 1)) > 0.15), "bad_masks": f32(rng.random((T, E, A, 1)) > 0.1),
+        "active_masks": f32(rng.random((T, E, A, 1)) > 0.2),
+        "logp": f32(rng.normal(size=(T, E, A, 1))), "logp_shared": f32(rng.normal(size=(T, E, A, 4))),
+        "values": f32(rng.normal(size=(T, E, A, 1))), "next_value": f32(rng.normal(size=(E, A, 1))),
+        "rnn_a": f32(rng.normal(size=(T + 1, E, A, 1, H))), "rnn_c": f32(rng.normal(size=(T + 1, E, A, 1, H))),
+    }
+    out.update({"in_" + k: v for k, v in stream.items()})
+    L, MB = 4, 3                                   # data_chunk_length, num_mini_batch: 36 rows per column set -> 9 chunks, 3 per batch
+    perm = rng.permutation(T * E * A // L)
+    out["perm"], out["chunk"] = perm, np.array([L, MB])
+    real_randperm = torch.randperm
+    for shared in (False, True):
+        for proper in (False, True):
+            for gae in (False, True):
+                args = types.SimpleNamespace(buffer_size=T, n_rollout_threads=E, gamma=0.99, use_proper_time_limits=proper, use_gae=gae,
+                                             gae_lambda=0.95, recurrent_hidden_size=H, recurrent_hidden_layers=1)
+                buf = SharedReplayBuffer(args, A, obs_space, share_space, act_space) if shared else ReplayBuffer(args, A, obs_space, act_space)
+                buf.obs[0] = stream["obs"][0]
+                buf.rnn_states_actor[0], buf.rnn_states_critic[0] = stream["rnn_a"][0], stream["rnn_c"][0]
+                if shared:
+                    buf.share_obs[0] = stream["share_obs"][0]
+                for t in range(T):
+                    kw = dict(obs=stream["obs"][t + 1], actions=stream["actions"][t], rewards=stream["rewards"][t], masks=stream["masks"][t],
+                              action_log_probs=stream["logp_shared" if shared else "logp"][t], value_preds=stream["values"][t],
+                              rnn_states_actor=stream["rnn_a"][t + 1], rnn_states_critic=stream["rnn_c"][t + 1], bad_masks=stream["bad_masks"][t])
+                    if shared:
+                        kw.update(share_obs=stream["share_obs"][t + 1], active_masks=stream["active_masks"][t])
+                    buf.insert(**kw)
+                assert buf.step == 0
+                buf.compute_returns(stream["next_value"])
+                key = f"{'shared' if shared else 'single'}_{'proper' if proper else 'plain'}_{'gae' if gae else 'mc'}"
+                out[key + "_returns"] = buf.returns.copy()
+                out[key + "_advantages"] = buf.advantages.copy()
+                if proper and gae:      # one mode per buffer class is enough for the data movement
+                    out[key + "_masks"], out[key + "_bad_masks"] = buf.masks.copy(), buf.bad_masks.copy()
+                    torch.randperm = lambda n: torch.from_numpy(perm.copy())
+                    try:
+                        if shared:
+                            batches = list(buf.recurrent_generator(buf.advantages, MB, L))
+                        else:
+                            batches = list(ReplayBuffer.recurrent_generator(buf, MB, L))
+                    finally:
+                        torch.randperm = real_randperm
+                    for b, batch in enumerate(batches):
+                        for j, arr in enumerate(batch):
+                            out[f"{key}_batch{b}_{j}"] = np.asarray(arr)
+                    buf.after_update()
+                    out[key + "_after_obs0"], out[key + "_after_masks0"] = buf.obs[0].copy(), buf.masks[0].copy()
+    np.savez_compressed(os.path.join(OUT, "rollout_buffer.npz"), **out)
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit(f"{REF} not present: golden vectors are generated in the build container only")
@@ -963,6 +1034,7 @@ def main():
     gen_rwr_obs(np.random.default_rng(81))
     gen_wvr_sequences(np.random.default_rng(82))
     gen_wvr_sequences(np.random.default_rng(83), which="maneuver")
+    gen_rollout_buffer(np.random.default_rng(84))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol(pkg):
-    hdr = open(os.path.join(ROOT, "include", "aircombat.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", f)).read() for f in sorted(os.listdir(os.path.join(ROOT, "include"))) if f.endswith(".h"))
     declared = set(re.findall(r"\b(ac_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(pkg.capi.SIGNATURES), declared ^ set(pkg.capi.SIGNATURES)
     lib = pkg.load_library()
@@ -29,11 +29,14 @@ def test_library_exports_every_declared_symbol(pkg):
 def test_config_struct_layout_matches_header(pkg, tmp_path):
     """sizeof(ac_config_t) as the C compiler sees it == ctypes.sizeof(AcConfig)."""
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "aircombat.h"\nint main(){printf("%zu %zu", sizeof(ac_config_t), sizeof(ac_init_state_t));return 0;}\n')
+    src.write_text('#include <stdio.h>\n#include "aircombat.h"\n#include "aircombat_buffer.h"\n'
+                   'int main(){printf("%zu %zu %zu %zu %zu", sizeof(ac_config_t), sizeof(ac_init_state_t), sizeof(ac_buffer_config_t), '
+                   'sizeof(ac_buffer_step_t), sizeof(ac_buffer_batch_t));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
-    a, b = map(int, subprocess.check_output([str(exe)], text=True).split())
+    a, b, c, d, e = map(int, subprocess.check_output([str(exe)], text=True).split())
     assert a == C.sizeof(pkg.AcConfig) and b == C.sizeof(pkg.AcInitState)
+    assert (c, d, e) == (C.sizeof(pkg.capi.AcBufferConfig), C.sizeof(pkg.capi.AcBufferStep), C.sizeof(pkg.capi.AcBufferBatch))
 
 
 def test_missing_library_fails_loudly(pkg, tmp_path):
