@@ -5,8 +5,8 @@
 // Kernels, all HBM-bound streaming work (no reuse, no contraction):
 //   returns_kernel<GAE, PROPER>   the reverse-time recurrence of compute_returns (buffer.py:134-167): one lane per (env, agent)
 //                                 column, float32 operations in the reference's order with fused multiply-add contraction switched off, so
-//                                 the result is bit-identical to the numpy code; loads of a block of time steps are issued
-//                                 together, one block ahead of the recurrence, so the dependent chain only touches registers
+//                                 the result is bit-identical to the numpy code; the (independent) loads are spread over eight waves
+//                                 per 64 columns and staged through LDS one tile ahead, so the dependent chain only touches LDS
 //   advantage_* kernels           returns - values, fp64 mean / variance by block reduction, normalisation (buffer.py:72-75)
 //   gather_rows_kernel            a mini-batch of recurrent_generator (buffer.py:196-268): rows of the column-major sequence view
 #pragma once
@@ -27,57 +27,86 @@ struct ac_buffer {
 };
 
 namespace rbuf {
-constexpr int U = 8;   // time steps per load block
-
-template <bool GAE, bool PROPER>
-__global__ __launch_bounds__(64) void returns_kernel(const float* __restrict__ r, const float* __restrict__ v, const float* __restrict__ m,
+// One workgroup = COLS columns x 512 threads. Only the recurrence is sequential: the loads are not, so all eight waves fetch a tile
+// of TT time steps x COLS columns of the four input arrays (32 loads in flight per lane, issued one tile AHEAD), stage it in LDS, the
+// first COLS lanes run the TT dependent steps out of LDS while the next tile's loads fly, and all waves store the tile of returns.
+// 64 KB in flight per workgroup. COLS = 32 (128-byte rows, TT = 128) doubles the workgroup count when 64-column workgroups would
+// not cover the 256 CUs: the BASELINE batch's 8192 columns become 256 workgroups with 16 MB in flight.
+// The recurrence runs on a ninth wave that issues no global loads of its own: a wave that both prefetches and scans would have
+// to drain its own prefetch (in-order vmcnt) before the first dependent operation of the scan.
+constexpr int NT = 512, NT_ALL = NT + 64;
+template <bool GAE, bool PROPER, int COLS, int TT>
+__global__ __launch_bounds__(NT_ALL) void returns_kernel(const float* __restrict__ r, const float* __restrict__ v, const float* __restrict__ m,
                                                      const float* __restrict__ b, float* __restrict__ R, int T, int N, float g, float gl) {
 #pragma clang fp contract(off)   // every product is rounded before it is added, as in the numpy code (plain operators on purpose:
                                  // HIP's __fmul_rn / __fadd_rn are header inlines compiled with contraction allowed)
-  const int n = blockIdx.x * 64 + threadIdx.x;
-  if (n >= N) return;
-  const size_t sN = (size_t)N;
-  // carried across steps: the value at t+1 (GAE: V[t+1]; MC: R[t+1]) and the accumulator
-  float next = GAE ? v[(size_t)T * sN + n] : R[(size_t)T * sN + n];
-  float acc = 0.0f;
-  float rr[2][U], mm[2][U], bb[2][U], vv[2][U];
-  auto load = [&](int buf, int t0) {
+  constexpr int SPW = TT / (NT / COLS);   // time steps per thread and tile
+  __shared__ float sr[TT][COLS], sm[TT][COLS], sb[PROPER ? TT : 1][COLS], sv[(GAE || PROPER) ? TT : 1][COLS], sR[TT][COLS];
+  const bool scanner = threadIdx.x >= NT;
+  const int lane = threadIdx.x % COLS, w = (threadIdx.x % NT) / COLS;
+  const int n = blockIdx.x * COLS + lane;
+  const bool col_ok = n < N;
+  const size_t sN = (size_t)N, col = (size_t)(col_ok ? n : 0);
+  float pr[SPW], pm[SPW], pb[SPW], pv[SPW], pn[SPW];
+  auto fetch = [&](int t_hi) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int t = t0 - u;
-      const bool ok = t >= 0;
-      const size_t at = (size_t)(ok ? t : 0) * sN + n, at1 = at + sN;
-      rr[buf][u] = ok ? r[at] : 0.0f;
-      mm[buf][u] = ok ? m[at1] : 0.0f;
-      if (PROPER) bb[buf][u] = ok ? b[at1] : 0.0f;
-      if (GAE || PROPER) vv[buf][u] = ok ? v[at] : 0.0f;
+    for (int u = 0; u < SPW; ++u) {
+      // rows before t = 0 (ragged last tile) and columns past N (ragged last workgroup) read a valid clamped address instead of
+      // branching; what they read is never used: the recurrence stops at t = 0 and the stores are guarded
+      const int t = max(t_hi - (w * SPW + u), 0);
+      const size_t at = (size_t)t * sN + col, at1 = at + sN;
+      pr[u] = r[at];
+      pm[u] = m[at1];
+      if (PROPER) pb[u] = b[at1];
+      if (GAE || PROPER) pv[u] = v[at];
+      if (GAE) pn[u] = v[at1];      // V[t+1] (the neighbouring step's V[t]: the same cache line, an L2 hit)
     }
   };
-  load(0, T - 1);
-  int cur = 0;
-  for (int t0 = T - 1; t0 >= 0; t0 -= U) {
-    if (t0 - U >= 0) load(cur ^ 1, t0 - U);     // the next block's loads fly while this block's recurrence runs
+  // carried by the scanning lanes across steps: the value at t+1 (GAE: V[t+1]; MC: R[t+1]) and the accumulator
+  float next = (scanner && !GAE) ? R[(size_t)T * sN + col] : 0.0f;
+  float acc = 0.0f;
+  if (!scanner) fetch(T - 1);
+  for (int t_hi = T - 1; t_hi >= 0; t_hi -= TT) {
+    if (!scanner) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int t = t0 - u;
-      if (t < 0) break;
-      const float rt = rr[cur][u], mt = mm[cur][u];
-      float out;
-      if (GAE) {
-        const float vt = vv[cur][u];
-        const float delta = (rt + (g * next) * mt) - vt;
-        acc = delta + (gl * mt) * acc;
-        if (PROPER) acc = acc * bb[cur][u];
-        out = acc + vt;
-        next = vt;
-      } else {
-        const float disc = (next * g) * mt + rt;
-        out = PROPER ? disc * bb[cur][u] + (1.0f - bb[cur][u]) * vv[cur][u] : disc;
-        next = out;
+      for (int u = 0; u < SPW; ++u) {
+        const int s_ = w * SPW + u;
+        // GAE: the TD residual and the decay factor do not depend on the accumulator, so the loading waves compute them (same
+        // operations, same order as the reference's expression) and only  acc = delta + c * acc  is left on the dependent chain
+        sr[s_][lane] = GAE ? (pr[u] + (g * pn[u]) * pm[u]) - pv[u] : pr[u];
+        sm[s_][lane] = GAE ? gl * pm[u] : pm[u];
+        if (PROPER) sb[s_][lane] = pb[u];
+        if (GAE || PROPER) sv[s_][lane] = pv[u];
       }
-      R[(size_t)t * sN + n] = out;
     }
-    cur ^= 1;
+    __syncthreads();
+    if (!scanner && t_hi - TT >= 0) fetch(t_hi - TT);       // the next tile's loads fly while the ninth wave runs this tile's recurrence
+    if (scanner && threadIdx.x - NT < COLS) {
+      const int steps = min(TT, t_hi + 1);
+#pragma unroll 8
+      for (int s_ = 0; s_ < steps; ++s_) {
+        const float rt = sr[s_][lane], mt = sm[s_][lane];
+        float out;
+        if (GAE) {
+          acc = rt + mt * acc;                       // rt = delta_t, mt = gamma * lambda * mask_{t+1}
+          if (PROPER) acc = acc * sb[s_][lane];
+          out = acc + sv[s_][lane];
+        } else {
+          const float disc = (next * g) * mt + rt;
+          out = PROPER ? disc * sb[s_][lane] + (1.0f - sb[s_][lane]) * sv[s_][lane] : disc;
+          next = out;
+        }
+        sR[s_][lane] = out;
+      }
+    }
+    __syncthreads();
+    if (!scanner) {
+#pragma unroll
+      for (int u = 0; u < SPW; ++u) {
+        const int s_ = w * SPW + u, t = t_hi - s_;
+        if (t >= 0 && col_ok) R[(size_t)t * sN + col] = sR[s_][lane];
+      }
+    }
   }
 }
 
@@ -254,12 +283,16 @@ int ac_buffer_compute_returns(ac_buffer_t* b, const float* next_value, int on_de
   const float g = (float)b->cfg.gamma, gl = (float)(b->cfg.gamma * b->cfg.gae_lambda);
   const float *r = b->f[AC_BUF_REWARDS], *v = b->f[AC_BUF_VALUES], *m = b->f[AC_BUF_MASKS], *bm = b->f[AC_BUF_BAD_MASKS];
   float* R = b->f[AC_BUF_RETURNS];
-  dim3 grid((N + 63) / 64), block(64);
+  const bool wide = N >= 64 * 256;   // enough 64-column workgroups for every CU
+  dim3 grid(wide ? (N + 63) / 64 : (N + 31) / 32), block(rbuf::NT_ALL);
   HIP_OK(hipEventRecord(b->ev0, b->stream));
-  if (gae && proper) hipLaunchKernelGGL((rbuf::returns_kernel<true, true>), grid, block, 0, b->stream, r, v, m, bm, R, T, N, g, gl);
-  else if (gae) hipLaunchKernelGGL((rbuf::returns_kernel<true, false>), grid, block, 0, b->stream, r, v, m, bm, R, T, N, g, gl);
-  else if (proper) hipLaunchKernelGGL((rbuf::returns_kernel<false, true>), grid, block, 0, b->stream, r, v, m, bm, R, T, N, g, gl);
-  else hipLaunchKernelGGL((rbuf::returns_kernel<false, false>), grid, block, 0, b->stream, r, v, m, bm, R, T, N, g, gl);
+#define AC_RET(G, P)                                                                                                                \
+  do {                                                                                                                              \
+    if (wide) hipLaunchKernelGGL((rbuf::returns_kernel<G, P, 64, 64>), grid, block, 0, b->stream, r, v, m, bm, R, T, N, g, gl);     \
+    else hipLaunchKernelGGL((rbuf::returns_kernel<G, P, 32, 128>), grid, block, 0, b->stream, r, v, m, bm, R, T, N, g, gl);        \
+  } while (0)
+  if (gae && proper) AC_RET(true, true); else if (gae) AC_RET(true, false); else if (proper) AC_RET(false, true); else AC_RET(false, false);
+#undef AC_RET
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(b->ev1, b->stream));
   HIP_OK(hipStreamSynchronize(b->stream));
