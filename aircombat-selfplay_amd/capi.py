@@ -67,7 +67,7 @@ class AcConfig(C.Structure):
         ("legacy_obs", C.c_int32),
         ("rwr", C.c_int32),
         ("use_baseline", C.c_int32),
-        ("hierarchical", C.c_int32),
+        ("hierarchical", C.c_int32), ("approach", C.c_int32),
     ]
 
 

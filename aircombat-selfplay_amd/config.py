@@ -11,6 +11,7 @@ from .capi import (AcConfig, AC_MAX_AGENTS, AC_TASK_HEADING, AC_TASK_SINGLECOMBA
 
 TASK_IDS = {
     "heading": AC_TASK_HEADING,
+    "approach": AC_TASK_HEADING,                     # ApproachTask: the heading env with AltitudeReward alone and no UnreachHeading
     "singlecombat": AC_TASK_SINGLECOMBAT,            # SingleCombatTask (1v1, no weapons)
     "singlecombat_dodge_missile": AC_TASK_DODGE_MISSILE,
     "singlecombat_shoot": AC_TASK_SHOOT_MISSILE,     # SingleCombatShootMissileTask
@@ -112,6 +113,7 @@ def config_from_dict(data, task=None, hierarchical=None):
     cfg.task = TASK_IDS[name]
     cfg.rwr = int(rwr)
     cfg.legacy_obs = int(legacy)
+    cfg.approach = int(name == "approach")
     cfg.hierarchical = int(name in ALWAYS_HIERARCHICAL if hierarchical is None else bool(hierarchical))
     acs = data["aircraft_configs"]
     uids = list(acs.keys())
@@ -224,6 +226,10 @@ def default_config(task="singlecombat", hierarchical=False):
     """The 1v1 block of reference configs/scenario1/WVR_selfplay.yaml (BASELINE configs C2 / C3)."""
     if task == "heading":
         return default_heading_config()
+    if task == "approach":                           # configs/singlecontrol/approach.yaml: the heading aircraft block, task approach
+        cfg = default_heading_config()
+        cfg.approach = 1
+        return cfg
     if task in ALWAYS_HIERARCHICAL:
         hierarchical = True
     if task in ("multiplecombat", "hierarchical_multiplecombat"):

@@ -1436,6 +1436,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     h->hc.max_heading_increment = cfg->max_heading_increment; h->hc.max_altitude_increment = cfg->max_altitude_increment;
     h->hc.max_velocities_u_increment = cfg->max_velocities_u_increment; h->hc.check_interval = cfg->check_interval;
     h->hc.heading_scale = (float)cfg->heading_scale; h->hc.heading_pot = cfg->heading_potential;
+    h->hc.approach = cfg->approach ? 1 : 0;
   }
   p.H = nullptr; p.man_step = nullptr; p.man_h0 = nullptr;
   if (cfg->hierarchical) {

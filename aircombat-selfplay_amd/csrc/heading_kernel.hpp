@@ -17,6 +17,7 @@ struct HeadingCfg {
   ac_init_state_t ic;                      // the YAML's init_state; heading / altitude / speed are overwritten by the draws
   double max_heading_increment, max_altitude_increment, max_velocities_u_increment, check_interval;
   float heading_scale; int heading_pot;
+  int approach;                            // ApproachTask (approach_task.py): no HeadingReward, no UnreachHeading, 1v1-style termination order
 };
 
 // numpy's PCG64 (128-bit LCG, XSL-RR output) and Generator.uniform -> random() = (next64 >> 11) * 2^-53
@@ -107,7 +108,7 @@ __device__ void heading_reset(const HeadingCfg& hc, const DevCfg& c, const Tab& 
   f16::locate(s, d);
   make_props(s, d, c, pr);
   // RewardFunction.reset (reward_function_base.py:20-32): potential terms seed their memory with one evaluation, in list order
-  if (hc.heading_pot) {
+  if (hc.heading_pot && !hc.approach) {
     float p, q;
     x.pre_heading = heading_reward_raw(pr, d, x, 0, p, q) * hc.heading_scale;
     x.last_p = p; x.last_q = q;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, SPLIT ? 1 : 2) void step_kernel_h
   {
     // UnreachHeading (unreach_heading.py:22-65): at each check time either give up or draw the next targets
     const double inc_size[15] = {0.2, 0.4, 0.6, 0.8, 1.0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
-    if (x.sim_time >= x.check_time) {
+    if (!hc.approach && x.sim_time >= x.check_time) {
       float psi_deg = atan2f(pr.m12, pr.m11) * 57.29577951f;
       if (psi_deg < 0.0f) psi_deg += 360.0f;
       const float d_hdg = clampf(-180.0f, in_range_deg_f((float)x.tgt_hdg - psi_deg), 180.0f);
@@ -202,19 +203,24 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, SPLIT ? 1 : 2) void step_kernel_h
       const float pqr = sqrtf(d.p * d.p + d.q * d.q + d.r * d.r);
       const bool extreme = (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);
       const bool overload = (s.ticks >= kTickOverload) && (fabsf(s.npx) > c.acc_x || fabsf(s.npy) > c.acc_y || fabsf(s.npz + 1.0f) > c.acc_z);
-      if (extreme) { t.status = AC_CRASH; code = AC_DONE_EXTREME_STATE; done = true; }
+      const bool low = pr.alt_m <= c.altitude_limit;
+      if (hc.approach && low) { t.status = AC_CRASH; code = AC_DONE_LOW_ALTITUDE; done = true; }   // approach_task.py:23-28: LowAltitude first
+      else if (extreme) { t.status = AC_CRASH; code = AC_DONE_EXTREME_STATE; done = true; }
       else if (overload) { t.status = AC_CRASH; code = AC_DONE_OVERLOAD; done = true; }
-      else if (pr.alt_m <= c.altitude_limit) { t.status = AC_CRASH; code = AC_DONE_LOW_ALTITUDE; done = true; }
+      else if (low) { t.status = AC_CRASH; code = AC_DONE_LOW_ALTITUDE; done = true; }
       else if (t.cur_step >= c.max_steps) { code = AC_DONE_TIMEOUT; done = true; }
     }
   }
   // ---- rewards: HeadingReward + AltitudeReward (heading_task.py:14-18), BaseTask.get_reward (no death latch)
   float reward;
   {
-    float p, q;
-    float r_h = heading_reward_raw(pr, d, x, t.cur_step, p, q);
-    x.last_p = p; x.last_q = q;
-    r_h = potential(r_h, hc.heading_scale, hc.heading_pot, x.pre_heading);
+    float r_h = 0.0f;
+    if (!hc.approach) {
+      float p, q;
+      r_h = heading_reward_raw(pr, d, x, t.cur_step, p, q);
+      x.last_p = p; x.last_q = q;
+      r_h = potential(r_h, hc.heading_scale, hc.heading_pot, x.pre_heading);
+    }
     reward = r_h + potential(altitude_raw(pr, c), c.altitude_scale, c.altitude_pot, t.pre_altitude);
   }
   const int step_out = t.cur_step, turns_out = x.turn_counts;

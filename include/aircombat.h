@@ -82,6 +82,9 @@ typedef struct ac_config {
                                        0 none, 1 PursueAgent, 2 ManeuverAgent('triangle'); the enemy rows of `actions` are ignored */
   int32_t hierarchical;             /* Hierarchical* / Scenario* tasks as shipped: actions are MultiDiscrete [3,5,3] (+ the four weapon
                                        bits) and go through the low-level controller (singlecombat_task.py:209-262); 0 = control indices */
+  int32_t approach;                 /* AC_TASK_HEADING only: ApproachTask (`task: approach`, tasks/approach_task.py:9-120): the same env, reset
+                                       draws and observation, reward = AltitudeReward alone, terminations LowAltitude, ExtremeState,
+                                       Overload, Timeout (no UnreachHeading: the targets stay at their reset values) */
 } ac_config_t;
 
 typedef struct ac_env ac_env_t;

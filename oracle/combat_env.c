@@ -583,7 +583,7 @@ static double rw_heading(OrEnv* e, int i) { /* heading_reward.py:18-71 */
 }
 static double task_reward_terms(OrEnv* e, int i) {
   switch (e->cfg.task) {
-    case OR_TASK_HEADING: { double r = rw_heading(e, i); return r + rw_altitude(e, i); }
+    case OR_TASK_HEADING: { double r = e->cfg.approach ? 0.0 : rw_heading(e, i); return r + rw_altitude(e, i); }  /* approach_task.py:20-22 */
     case OR_TASK_SCENARIO1: case OR_TASK_SCENARIO_NVN: { /* scenario1_task.py:13-25 / scenario2_task.py:228-240, list order */
       double r = rw_altitude(e, i); r += rw_combat_geometry(e, i); r += rw_event(e, i); r += rw_gun_behit(e, i);
       r += rw_gun_track(e, i, 1); r += rw_gun_track(e, i, 0); r += rw_gun_wez(e, i); r += rw_posture(e, i);
@@ -624,7 +624,7 @@ static void reward_reset(OrEnv* e) { /* reward_function_base.py:20-32 — each p
   int t = e->cfg.task;
   /* reset order = reward_functions list order of the task */
   if (t == OR_TASK_HEADING) {
-    if (e->cfg.heading_potential) for (int i = 0; i < e->cfg.n_aircraft; i++) rw_heading(e, i);
+    if (e->cfg.heading_potential && !e->cfg.approach) for (int i = 0; i < e->cfg.n_aircraft; i++) rw_heading(e, i);
     if (e->cfg.altitude_potential) for (int i = 0; i < e->cfg.n_aircraft; i++) rw_altitude(e, i);
     return;
   }
@@ -690,6 +690,8 @@ static int t_unreach_heading(OrEnv* e, int i, int* code) { /* unreach_heading.py
   return done;
 }
 static int get_termination(OrEnv* e, int i, int* code) {
+  if (e->cfg.task == OR_TASK_HEADING && e->cfg.approach) /* approach_task.py:23-28 */
+    return t_low_altitude(e, i, code) || t_extreme(e, i, code) || t_overload(e, i, code) || t_timeout(e, i, code);
   if (e->cfg.task == OR_TASK_HEADING) /* heading_task.py:20-26 */
     return t_unreach_heading(e, i, code) || t_extreme(e, i, code) || t_overload(e, i, code) || t_low_altitude(e, i, code) || t_timeout(e, i, code);
   if (e->cfg.task == OR_TASK_WVR) /* WVR_task.py:31-36: no SafeReturn */

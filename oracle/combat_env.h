@@ -65,6 +65,8 @@ typedef struct {
   int rwr;            /* *_RWR task variants: two reserved zero slots appended to the observation; Scenario1_RWR also blanks its missile block */
   int use_baseline;   /* the enemy team is flown by a scripted BaselineAgent (singlecombat_task.py:19-27): 0 none, 1 pursue, 2 maneuver('triangle') */
   int hierarchical;   /* Hierarchical* / Scenario* tasks as shipped: action = [3,5,3] (+4 weapon bits) through the low-level controller */
+  int approach;       /* OR_TASK_HEADING only: ApproachTask (approach_task.py:9-120) = the heading env without HeadingReward and without
+                         UnreachHeading; terminations LowAltitude, ExtremeState, Overload, Timeout in that order */
 } OrEnvConfig;
 
 typedef struct {

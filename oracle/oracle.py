@@ -46,6 +46,7 @@ class OrEnvConfig(C.Structure):
         ("rwr", C.c_int),
         ("use_baseline", C.c_int),
         ("hierarchical", C.c_int),
+        ("approach", C.c_int),
     ]
 
 
@@ -155,7 +156,8 @@ def config_from_ac(ac_cfg):
                  "altitude_scale", "altitude_potential", "event_scale", "event_potential", "missile_posture_scale",
                  "shoot_penalty_scale", "shoot_penalty_potential", "alt_safe", "alt_danger", "alt_kv", "max_attack_angle",
                  "max_attack_distance", "min_attack_interval", "use_artillery", "hierarchical", "heading_scale", "heading_potential",
-                 "max_heading_increment", "max_altitude_increment", "max_velocities_u_increment", "check_interval", "use_baseline", "rwr", "legacy_obs"):
+                 "max_heading_increment", "max_altitude_increment", "max_velocities_u_increment", "check_interval", "use_baseline", "rwr", "legacy_obs",
+                 "approach"):
         setattr(c, name, getattr(ac_cfg, name))
     for i in range(OR_MAX_AC):
         src, dst = ac_cfg.init[i], c.init[i]

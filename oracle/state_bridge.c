@@ -151,6 +151,11 @@ void or_env_heading_pose(OrEnv* e, double psi_deg, double h_ft, double u_mps, do
   s->lon = 120.0 * M_PI / 180.0; s->lat_geod = 60.0 * M_PI / 180.0; s->vel_ned[0] = s->vel_ned[1] = s->vel_ned[2] = 0;
   or_env_refresh_cache(e, 0);
 }
+/* vertical speed (m/s, positive down) of the scripted pose: AltitudeReward reads it (altitude_reward.py:30) */
+void or_env_heading_vdown(OrEnv* e, double vd_mps) {
+  e->ac[0].fdm.vel_ned[2] = vd_mps / 0.3048;
+  or_env_refresh_cache(e, 0);
+}
 void or_env_heading_get(const OrEnv* e, double out[5]) {
   out[0] = e->ac[0].target_heading_deg; out[1] = e->ac[0].target_altitude_ft; out[2] = e->ac[0].target_velocities_u_mps;
   out[3] = e->ac[0].heading_check_time; out[4] = e->heading_turn_counts;

@@ -489,6 +489,58 @@ def gen_heading(rng):
 
 
 
+def gen_approach(rng):
+    """ApproachTask (tasks/approach_task.py): the heading observation, AltitudeReward alone, LowAltitude / ExtremeState / Overload /
+    Timeout in that order. A scripted descent through the safe, danger and limit altitudes ends the episode by LowAltitude."""
+    from envs.JSBSim.tasks.approach_task import ApproachTask
+    cfg = make_config(max_steps=10000, aircraft_configs={"A0100": {"color": "Blue"}}, PostureReward_potential=False, EventDrivenReward_potential=False)
+    task = ApproachTask(cfg)
+
+    class ApproachAircraft(FakeAircraft):
+        def get_property_value(self, prop):
+            p = self.props
+            if prop.name_jsbsim == "position/delta-altitude-to-target-m":
+                return float(np.clip((p["tc/h-sl-ft"] - p["position/h-sl-ft"]) * 0.3048, -40000, 40000))
+            if prop.name_jsbsim == "position/delta-heading-to-target-deg":
+                x = (p["tc/target-heading-deg"] - p["attitude/psi-deg"]) % 360
+                return float(np.clip(x - 360 if x > 180 else x, -180, 180))
+            if prop.name_jsbsim == "position/delta-velocities_u-to-target-mps":
+                return float(np.clip(p["tc/target-velocity-u-mps"] - p["velocities/u-mps"], -1400, 1400))
+            return p[prop.name_jsbsim]
+
+    a = ApproachAircraft("A0100", "Blue")
+    env = FakeEnv([a])
+    hdg0, alt0_ft, u0 = 35.0, 16000.0, 800.0
+    a.props.update({"tc/target-heading-deg": hdg0, "tc/h-sl-ft": alt0_ft, "tc/target-velocity-u-mps": u0 * 0.3048, "heading_check_time": 0.0})
+    rows = []
+    psi, h_ft, u_mps, roll = hdg0, alt0_ft, u0 * 0.3048, 0.0
+    a.props.update({"position/h-sl-ft": h_ft, "position/h-sl-m": h_ft * 0.3048})
+    a._position[:] = (0, 0, h_ft * 0.3048)
+    task.reset(env)
+    for t in range(1, 400):
+        env.current_step = t
+        psi = (psi + rng.normal() * 3.0) % 360
+        sink = 30.0 + 0.25 * t                       # m/s down, growing: crosses 4 km, 3.5 km and the 2.5 km limit
+        h_ft -= sink * 0.1 / 0.3048
+        u_mps += rng.normal() * 0.3
+        roll = float(np.clip(roll + rng.normal() * 0.01, -0.5, 0.5))
+        a.props.update({
+            "position/h-sl-ft": h_ft, "attitude/psi-deg": psi, "position/h-sl-m": h_ft * 0.3048, "attitude/roll-rad": roll, "attitude/pitch-rad": -0.1,
+            "velocities/u-mps": u_mps, "velocities/v-mps": 0.5, "velocities/w-mps": 3.0, "velocities/vc-mps": 200.0,
+            "velocities/p-rad_sec": 0.0, "velocities/q-rad_sec": 0.0, "simulation/sim-time-sec": t * 0.1,
+            "accelerations/n-pilot-x-norm": 0.0, "accelerations/n-pilot-y-norm": 0.0, "accelerations/n-pilot-z-norm": -1.0, "detect/extreme-state": 0,
+        })
+        a._position[:] = (0, 0, h_ft * 0.3048)
+        a._velocity[:] = (0, 0, sink)
+        obs = task.get_obs(env, "A0100")
+        done, info = task.get_termination(env, "A0100", {"current_step": t})
+        rew, info = task.get_reward(env, "A0100", info)
+        rows.append(np.concatenate([[t, psi, h_ft, u_mps, roll, sink, t * 0.1, done, rew], obs]))
+        if done:
+            break
+    np.savez_compressed(os.path.join(OUT, "approach.npz"), rows=np.array(rows), init=np.array([hdg0, alt0_ft, u0 * 0.3048]))
+
+
 def gen_multicombat_sequences(rng):
     """MultipleCombatTask (2v2) over scripted four-aircraft pose sequences. The tail of MultipleCombatEnv.step
     (multiplecombat_env.py:160-182: obs, rewards for every agent, team mean, then terminations) is replayed here around the
@@ -1035,6 +1087,7 @@ def main():
     gen_wvr_sequences(np.random.default_rng(82))
     gen_wvr_sequences(np.random.default_rng(83), which="maneuver")
     gen_rollout_buffer(np.random.default_rng(84))
+    gen_approach(np.random.default_rng(85))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -533,6 +533,48 @@ def test_heading_task_numpy_stream_on_device(pkg, oracle):
     env.close()
 
 
+def test_approach_task_on_device(pkg, oracle):
+    """configs/singlecontrol/approach.yaml: ApproachTask on the SingleControlEnv. Same reset draws and observation as the heading
+    task, AltitudeReward alone, LowAltitude / ExtremeState / Overload / Timeout in that order, no UnreachHeading (so the targets
+    keep their reset values). A nose-down stick drives every env through the altitude floor; flight state re-synchronised each step."""
+    cfg = pkg.default_config("approach")
+    assert cfg.approach == 1
+    E, seed = 5, 3
+    env = pkg.HipVecEnv(cfg, E, seed=seed)
+    ocfg = oracle.config_from_ac(cfg)
+    refs = [oracle.OracleEnv(ocfg, pcg64_state=np.random.PCG64(seed + 1000 * i).state) for i in range(E)]
+    obs = env.reset()
+    robs = np.stack([r.reset() for r in refs])
+    assert obs.shape == (E, 1, 12) and obs_close(obs, robs).all()
+    names = env.lib.state_field_names()
+    task_fields = ("bloods", "pre_posture", "pre_altitude", "pre_event", "pre_shoot", "status", "die_flag", "remaining", "pre_remaining",
+                   "shoot_action", "last_missile", "last_shoot_time", "lock_bits", "lock_pos", "cur_step")
+    fdm_fields = np.array([k for k, nm in enumerate(names) if nm and not nm.startswith("x_") and nm not in task_fields])
+    targets0 = [env.get_heading_state(e)[1:4].copy() for e in range(E)]
+    codes, resets = set(), 0
+    for step in range(420):
+        for e in range(E):
+            v = env.get_state(e, 0)
+            v[fdm_fields] = refs[e].export_state(0)[fdm_fields]
+            env.set_state(e, 0, v)
+        act = np.tile(np.array([20, 30, 20, 29], dtype=np.float32), (E, 1, 1))      # stick forward, full throttle
+        obs, rew, done, info = env.step(act)
+        for e in range(E):
+            o, r, d, i = refs[e].step(act[e])
+            if i[3]:
+                codes.add(int(i[1]))
+                o = refs[e].reset()
+                resets += 1
+                targets0[e] = env.get_heading_state(e)[1:4].copy()
+            assert bool(done[e, 0, 0]) == bool(d[0]), (step, e)
+            assert obs_close(obs[e], o, 10.0).all(), (step, e, obs[e], o)
+            assert abs(rew[e, 0, 0] - r[0]) <= 10 * (5e-3 + 1e-3 * abs(r[0])), (step, e, rew[e, 0, 0], r[0])
+            hs = env.get_heading_state(e)
+            assert (hs[1:4] == targets0[e]).all() and int(hs[5]) == 0          # no UnreachHeading: targets never move
+    assert resets >= E and codes <= {1, 2, 3}, (resets, codes)                 # crash-type endings only (LowAltitude / ExtremeState / Overload)
+    env.close()
+
+
 @pytest.mark.parametrize("task", ["wvr_lowlevel", "maneuver_lowlevel"])
 def test_wvr_task_gun_only(pkg, oracle, task):
     """WVRTask on the device (the scenario kernel family in its gun-only mode): 15-value clipped observation, unlimited gun on

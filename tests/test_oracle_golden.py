@@ -157,6 +157,33 @@ def test_heading_task_with_numpy_pcg64(oracle):
     assert turns >= 2 and bool(done)
 
 
+def test_approach_task_sequence(oracle):
+    """ApproachTask (tasks/approach_task.py): heading observation, AltitudeReward alone, LowAltitude first among the terminations;
+    a scripted descent through the safe / danger / limit altitudes."""
+    g = load("approach.npz")
+    cfg = oracle.default_config(oracle.TASK_HEADING)
+    cfg.approach = 1
+    env = oracle.OracleEnv(cfg)
+    hdg0, alt0, u0 = g["init"]
+    env.L.or_env_heading_vdown.argtypes = [C.c_void_p, C.c_double]
+    env.L.or_env_heading_targets(env.p, hdg0, alt0, u0, 0.0)
+    env.L.or_env_heading_pose(env.p, hdg0, alt0, u0, 0.0, -0.1, 0.5, 3.0, 200.0, 0.0, 0.0, 0.0)
+    env.set_step(0)
+    env.task_reset()
+    env.L.or_env_heading_targets(env.p, hdg0, alt0, u0, 0.0)
+    done = False
+    for row in g["rows"]:
+        t, psi, h_ft, u_mps, roll, sink, sim_time, done, rew = row[:9]
+        env.L.or_env_heading_pose(env.p, psi, h_ft, u_mps, roll, -0.1, 0.5, 3.0, 200.0, 0.0, 0.0, sim_time)
+        env.L.or_env_heading_vdown(env.p, sink)
+        env.set_step(int(t))
+        o, r, d, info = env.evaluate()
+        assert close(o[0], row[9:], rtol=1e-9, atol=1e-9).all(), (t, o[0], row[9:])
+        assert bool(d[0]) == bool(done), t
+        assert close(r[0], rew, rtol=1e-9, atol=1e-9), (t, r[0], rew)
+    assert bool(done) and g["rows"][:, 8].min() < -1.5      # the danger-zone term fired before the limit ended the episode
+
+
 def test_pcg64_uniform_stream(oracle):
     gen = np.random.Generator(np.random.PCG64(np.random.SeedSequence(2024)))
     env = oracle.OracleEnv(oracle.default_config(oracle.TASK_HEADING))
