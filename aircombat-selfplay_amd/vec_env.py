@@ -55,6 +55,54 @@ class _Tuple(tuple):
     pass
 
 
+class LazyInfos:
+    """`infos` of VecEnv.step: a read-only sequence of one info dict per env (`current_step`, and on an episode end
+    `done_condition` / `heading_turn_counts`), equal element by element to the object array np.stack makes of the workers' dicts
+    (env_wrappers.py:276-282). The dicts are built from the kernel's int32 codes when an element is read: the reference's runners
+    only iterate them in the heading task (runner/jsbsim_runner.py:55-57), and building 4096 fresh dicts per step otherwise costs
+    more host time than the whole device step. np.asarray(infos) gives the reference's object array."""
+
+    __slots__ = ("_codes",)
+
+    def __init__(self, codes):
+        self._codes = codes          # [E, 4] int32: current_step, done code, heading_turn_counts, env-reset flag
+
+    def __len__(self):
+        return len(self._codes)
+
+    shape = property(lambda self: (len(self._codes),))      # what callers read off the reference's ndarray
+    ndim, dtype = 1, np.dtype(object)
+
+    def _one(self, i):
+        step, code, turns = (int(v) for v in self._codes[i, :3])
+        d = {"current_step": step}
+        if code:
+            d["done_condition"] = DONE_MESSAGES.get(code, "")
+            if code == 8:   # UnreachHeading reports its curriculum stage when it ends the episode (unreach_heading.py:60-63)
+                d["heading_turn_counts"] = turns
+        return d
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._one(k) for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return self._one(i)
+
+    def __iter__(self):
+        return (self._one(i) for i in range(len(self)))
+
+    def __array__(self, dtype=None, copy=None):
+        out = np.empty(len(self), dtype=object)
+        out[:] = list(self)
+        return out
+
+    def __repr__(self):
+        return f"LazyInfos({len(self)} envs)"
+
+
 def _spaces():
     try:
         from gymnasium import spaces  # the reference's own dependency, used when present
@@ -155,15 +203,8 @@ class HipVecEnv:
         return self._obs.copy(), self._rew.copy(), self._done.astype(bool), self._infos()
 
     def _infos(self):
-        """ndarray of one fresh dict per env, like np.stack of the workers' info dicts (env_wrappers.py:276-282)."""
-        infos = np.empty(self.num_envs, dtype=object)
-        infos[:] = [{"current_step": c} for c in self._info[:, 0].tolist()]
-        code = self._info[:, 1]
-        for i in np.flatnonzero(code).tolist():
-            infos[i]["done_condition"] = DONE_MESSAGES.get(int(code[i]), "")
-            if code[i] == 8:   # UnreachHeading reports its curriculum stage when it ends the episode (unreach_heading.py:60-63)
-                infos[i]["heading_turn_counts"] = int(self._info[i, 2])
-        return infos
+        """The workers' info dicts (env_wrappers.py:276-282), one per env, built when read: see LazyInfos."""
+        return LazyInfos(self._info.copy())
 
     def step(self, actions):
         self.step_async(actions)

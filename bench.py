@@ -235,7 +235,7 @@ def main():
             env.step(a_host[i % 8])
         hb = time.perf_counter() - t0
         result["host_boundary"] = {"value": E * AGENTS * HB / hb, "unit": "agent-steps/s", "ms_per_step": hb / HB * 1e3,
-                                   "note": "VecEnv.step(numpy) incl. H2D actions, kernel, D2H obs/reward/done, info dicts"}
+                                   "note": "VecEnv.step(numpy) incl. H2D actions, kernel, D2H obs/reward/done and the info codes (dicts are built when read)"}
         rate = E * AGENTS / (kernel_ms * 1e-3)
         result["roofline"]["valu"] = {"achieved": VALU_PER_AGENT_STEP * rate / 1e12, "peak": VALU_PEAK_TINST, "unit": "T lane-inst/s",
                                       "frac": VALU_PER_AGENT_STEP * rate / 1e12 / VALU_PEAK_TINST,
