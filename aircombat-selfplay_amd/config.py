@@ -24,11 +24,15 @@ TASK_IDS = {
     "wvr_lowlevel": AC_TASK_WVR,                     # WVRTask rules with explicit control indices and the YAML's own spawn
     "hierarchical_singlecombat": AC_TASK_SINGLECOMBAT,        # HierarchicalSingleCombatTask: [3,5,3] through the low-level controller
     "hierarchical_multiplecombat": AC_TASK_MULTICOMBAT,       # HierarchicalMultipleCombatTask
+    # HierarchicalMultipleCombatShootTask (multiplecombat_env.py:31-32 -> multiplecombat_with_missile_task.py:206-238): the only
+    # missile variant of MultipleCombat an env can select. Its step() launches nothing, so it is MultipleCombat with the 21-value
+    # paired-enemy observation and a [3,5,3] + shoot-bit action whose bit is ignored.
+    "hierarchical_multiplecombat_shoot": AC_TASK_MULTICOMBAT,
 }
 # task names whose reference class takes the [3,5,3] (+ weapon bits) action through the low-level controller. The scenario tasks
 # are hierarchical in the reference (scenario1_task.py:11, scenario2_task.py:14); config_from_yaml follows that, while
 # default_config() keeps the control-index form unless asked (tests drive the weapon rules with explicit controls).
-ALWAYS_HIERARCHICAL = ("hierarchical_singlecombat", "hierarchical_multiplecombat")
+ALWAYS_HIERARCHICAL = ("hierarchical_singlecombat", "hierarchical_multiplecombat", "hierarchical_multiplecombat_shoot")
 HIERARCHICAL_IN_REFERENCE = ALWAYS_HIERARCHICAL + ("scenario1", "scenario2_nvn", "scenario3_nvn", "scenario1_curriculum",
                                                    "scenario2_nvn_curriculum", "scenario3_nvn_curriculum", "scenario1_rwr",
                                                    "scenario2_rwr", "scenario3_rwr", "scenario1_rwr_curriculum",
@@ -112,7 +116,7 @@ def config_from_dict(data, task=None, hierarchical=None):
         raise NotImplementedError(f"Unknown taskname: {name} (available: {sorted(TASK_IDS)})")
     cfg.task = TASK_IDS[name]
     cfg.rwr = int(rwr)
-    cfg.legacy_obs = int(legacy)
+    cfg.legacy_obs = int(legacy or name == "hierarchical_multiplecombat_shoot")
     cfg.approach = int(name == "approach")
     cfg.hierarchical = int(name in ALWAYS_HIERARCHICAL if hierarchical is None else bool(hierarchical))
     acs = data["aircraft_configs"]
@@ -232,8 +236,8 @@ def default_config(task="singlecombat", hierarchical=False):
         return cfg
     if task in ALWAYS_HIERARCHICAL:
         hierarchical = True
-    if task in ("multiplecombat", "hierarchical_multiplecombat"):
-        return default_nvn_config(2, hierarchical=hierarchical)
+    if task in ("multiplecombat", "hierarchical_multiplecombat", "hierarchical_multiplecombat_shoot"):
+        return default_nvn_config(2, task=task if task.endswith("_shoot") else "multiplecombat", hierarchical=hierarchical)
     if task in ("scenario_nvn", "scenario2_nvn"):
         return default_nvn_config(2, task="scenario_nvn", hierarchical=hierarchical)
     if task == "scenario3_nvn":

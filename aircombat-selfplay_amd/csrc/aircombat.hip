@@ -897,6 +897,21 @@ __device__ __forceinline__ float observe_nvn(const Props& pr, int slot, int base
   return posture;
 }
 
+// HierarchicalMultipleCombatShootTask (`hierarchical_multiplecombat_shoot`, multiplecombat_with_missile_task.py:206-238) observes
+// like MultipleCombatDodgeMissileTask.get_obs (:33-117): 21 values, 3-D AO / TA, unclipped, against the enemy with the agent's own
+// index in its team, and a missile block that stays zero (this task's step() never launches anything, :202-203).
+template <int A>
+__device__ __forceinline__ void legacy_obs_nvn(const Props& pr, int slot, int base_lane, int n_ego, float* ob) {
+  const int team = slot < n_ego ? 0 : 1;
+  const int paired = (team == 0 ? n_ego : 0) + (slot - (team == 0 ? 0 : n_ego));
+  const Enemy E = gather_pose(pr, base_lane + paired);
+  const Incoming none{false, 0, 0, 0, 0, 0, 0};
+  float o21[21];
+  observe_1v1<AC_TASK_SHOOT_MISSILE>(pr, E, none, o21);
+#pragma unroll
+  for (int k = 0; k < 9 + 6 * (A - 1); ++k) ob[k] = (k < 21) ? o21[k] : 0.0f;
+}
+
 template <int A, int WPE, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs P, DevCfg c) {
   constexpr int OBS = 9 + 6 * (A - 1);
@@ -943,6 +958,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
 #pragma unroll
   for (int k = 0; k < OBS; ++k) ob[k] = 0.0f;
   float posture = observe_nvn<A>(pr, slot, base_lane, c.n_ego, ob);
+  if (c.legacy_obs) legacy_obs_nvn<A>(pr, slot, base_lane, c.n_ego, ob);
 
   // ---- rewards first (multiplecombat_env.py:166-175), only while alive (multiplecombat_task.py:147-151)
   float own = 0.0f;
@@ -1008,9 +1024,10 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
   }
   if (live) {
     store_state(P.F, P.I, P.D, N, n, s, t);
-    float* o = P.obs + (size_t)n * OBS;
+    const int ow = c.legacy_obs ? 21 : OBS;    // (the template keeps the kernel's own OBS stride)
+    float* o = P.obs + (size_t)n * ow;
 #pragma unroll
-    for (int k = 0; k < OBS; ++k) o[k] = ob[k];
+    for (int k = 0; k < OBS; ++k) if (k < ow) o[k] = ob[k];
     P.rew[n] = reward;
     P.done[n] = done ? 1 : 0;
     if (slot == 0) {
@@ -1154,6 +1171,7 @@ __global__ void init_kernel_nvn(InitArgs ia, DevCfg c, const float* tab, float* 
   float ob[OBS];
   for (int k = 0; k < OBS; ++k) ob[k] = 0.0f;
   float posture = observe_nvn<A>(pr, slot, base_lane, c.n_ego, ob);
+  if (c.legacy_obs) legacy_obs_nvn<A>(pr, slot, base_lane, c.n_ego, ob);
   if (c.altitude_pot) t.pre_altitude = altitude_raw(pr, c) * c.altitude_scale;
   if (c.posture_pot) t.pre_posture = posture * c.posture_scale;
   if (threadIdx.x < A) {
@@ -1335,7 +1353,11 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     return fail("ac_create: the hierarchical form is available for AC_TASK_SINGLECOMBAT, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN");
   if ((cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER) && (cfg->n_agents != 2 || cfg->n_ego != 1 || cfg->rwr))
     return fail("ac_create: AC_TASK_WVR / AC_TASK_MANEUVER are 1v1 tasks");
-  if (cfg->legacy_obs && (cfg->task != AC_TASK_SCENARIO_NVN || cfg->rwr)) return fail("ac_create: legacy_obs is the observation of Scenario2 / Scenario3 (AC_TASK_SCENARIO_NVN without rwr)");
+  if (cfg->legacy_obs && ((cfg->task != AC_TASK_SCENARIO_NVN && cfg->task != AC_TASK_MULTICOMBAT) || cfg->rwr))
+    return fail("ac_create: legacy_obs is the observation of Scenario2 / Scenario3 (AC_TASK_SCENARIO_NVN without rwr) and of "
+                "hierarchical_multiplecombat_shoot (AC_TASK_MULTICOMBAT, hierarchical)");
+  if (cfg->legacy_obs && cfg->task == AC_TASK_MULTICOMBAT && !cfg->hierarchical)
+    return fail("ac_create: the paired-enemy observation of AC_TASK_MULTICOMBAT belongs to hierarchical_multiplecombat_shoot (set hierarchical)");
   if (cfg->rwr && !scenario) return fail("ac_create: rwr is a variant of the scenario tasks (Scenario1_RWR, Scenario2_RWR, Scenario3_RWR)");
   if (n_envs <= 0) return fail("ac_create: n_envs must be positive");
   if ((long long)n_envs * cfg->n_agents > (1 << 23))   // 32-bit byte offsets into the per-field arrays (AC_AT): 63 fields x 4 B x N < 4 GB
@@ -1360,12 +1382,14 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
   const int tmpl_obs = h->obs_dim;   // (the scenario kernel family's template keeps 21 slots for WVR too)
   if (gun_only) h->obs_dim = 15;
-  if (cfg->task == AC_TASK_SCENARIO_NVN && cfg->legacy_obs) h->obs_dim = 21;   // multiplecombat_with_missile_task.py:30-31
+  if ((cfg->task == AC_TASK_SCENARIO_NVN || cfg->task == AC_TASK_MULTICOMBAT) && cfg->legacy_obs) h->obs_dim = 21;   // multiplecombat_with_missile_task.py:30-31
   if (cfg->rwr) h->obs_dim += 2;   // scenario1_task.py:213-216, scenario2_task.py:403-413
   const bool weapon_bits = scenario && !gun_only;
   h->act_low = weapon_bits ? 8 : ((cfg->task == AC_TASK_SHOOT_MISSILE) ? 5 : 4);
   // hierarchical tasks (HierarchicalSingleCombatTask and everything built on it): [3,5,3] (+ the four weapon bits)
   h->act_dim = cfg->hierarchical ? (weapon_bits ? 7 : 3) : h->act_low;
+  // hierarchical_multiplecombat_shoot: Tuple([3,5,3], Discrete(2)); the shoot bit is stored and never used (the task's step() launches nothing)
+  if (cfg->hierarchical && cfg->task == AC_TASK_MULTICOMBAT && cfg->legacy_obs) h->act_dim = 4;
   DevCfg& c = h->dc;
   memset(&c, 0, sizeof c);
   c.task = cfg->task; c.A = h->A; c.n_ego = cfg->n_ego; c.substeps = cfg->agent_interaction_steps; c.max_steps = cfg->max_steps;
@@ -1374,7 +1398,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   c.chaff_seed = seed;
   c.rwr = cfg->rwr ? 1 : 0;
   c.tobs = tmpl_obs;
-  c.legacy_obs = (cfg->task == AC_TASK_SCENARIO_NVN && cfg->legacy_obs) ? 1 : 0;
+  c.legacy_obs = ((cfg->task == AC_TASK_SCENARIO_NVN || cfg->task == AC_TASK_MULTICOMBAT) && cfg->legacy_obs) ? 1 : 0;
   c.altitude_limit = (float)cfg->altitude_limit; c.acc_x = (float)cfg->acc_limit_x; c.acc_y = (float)cfg->acc_limit_y; c.acc_z = (float)cfg->acc_limit_z;
   c.posture_scale = (float)cfg->posture_scale; c.altitude_scale = (float)cfg->altitude_scale; c.event_scale = (float)cfg->event_scale;
   c.missile_posture_scale = (float)cfg->missile_posture_scale; c.shoot_penalty_scale = (float)cfg->shoot_penalty_scale;

@@ -145,6 +145,8 @@ class HipVecEnv:
             self.lib.check(self.lib.ac_load_controller(self._h, w.ctypes.data, int(w.size)), "ac_load_controller")
         if self.hierarchical and config.task in (AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN):
             self.action_space = Tuple([MultiDiscrete([3, 5, 3]), MultiDiscrete([2, 2, 2, 2])])     # scenario1_task.py:29-31
+        elif self.hierarchical and config.legacy_obs:
+            self.action_space = Tuple([MultiDiscrete([3, 5, 3]), Discrete(2)])                     # multiplecombat_with_missile_task.py:221-223
         elif self.hierarchical:
             self.action_space = MultiDiscrete([3, 5, 3])                                           # singlecombat_task.py:221-222
         elif config.task == AC_TASK_SHOOT_MISSILE:

@@ -311,6 +311,10 @@ void or_env_init(OrEnv* e, const OrEnvConfig* c) {
   e->obs_dim = or_env_obs_dim_n(c->task, c->n_aircraft) + (c->rwr ? 2 : 0);
   if (c->task == OR_TASK_SCENARIO_NVN && c->legacy_obs) e->obs_dim = 21;   /* multiplecombat_with_missile_task.py:30-31 */   /* scenario1_task.py:213-216, scenario2_task.py:403-413 */
   e->act_dim = or_env_act_dim_h(c->task, c->hierarchical);
+  if (c->task == OR_TASK_MULTICOMBAT && c->legacy_obs) { /* hierarchical_multiplecombat_shoot (multiplecombat_with_missile_task.py:206-238) */
+    e->obs_dim = 21;                      /* :180-183 */
+    if (c->hierarchical) e->act_dim = 4;  /* Tuple([3,5,3], Discrete(2)) (:221-223); the bit is stored (:231) and never used (:202-203) */
+  }
   for (int i = 0; i < c->n_aircraft; i++) e->ac[i].team = (i < c->n_ego) ? 0 : 1;
   e->mp_prev_missile = -1;
 }
@@ -344,7 +348,7 @@ static void feature6(const OrAircraft* a, double f[6]) {
 static void obs_combat(const OrEnv* e, int i, double* o) { /* singlecombat_task.py:88-139, singlecombat_with_missile_task.py:31-99 */
   const OrAircraft* a = &e->ac[i];
   const OrAircraft* en = &e->ac[first_enemy(e, i)];
-  if (e->cfg.task == OR_TASK_SCENARIO_NVN) { /* legacy layout: `target` = own index within the team (:62-78) */
+  if (e->cfg.task == OR_TASK_SCENARIO_NVN || e->cfg.task == OR_TASK_MULTICOMBAT) { /* legacy layout: `target` = own index within the team (:62-78) */
     int idx = (a->team == 0) ? i : i - e->cfg.n_ego;
     en = &e->ac[(a->team == 0) ? e->cfg.n_ego + idx : idx];
   }
@@ -435,7 +439,7 @@ static void obs_scenario_nvn(const OrEnv* e, int i, double* o) { /* scenario2_ta
 static void get_obs(const OrEnv* e, double* obs) {
   for (int i = 0; i < e->cfg.n_aircraft; i++) {
     if (e->cfg.task == OR_TASK_HEADING) obs_heading(e, i, obs + i * e->obs_dim);
-    else if (e->cfg.task == OR_TASK_MULTICOMBAT) obs_multicombat(e, i, obs + i * e->obs_dim);
+    else if (e->cfg.task == OR_TASK_MULTICOMBAT && !e->cfg.legacy_obs) obs_multicombat(e, i, obs + i * e->obs_dim);
     else if (e->cfg.task == OR_TASK_SCENARIO_NVN && !e->cfg.legacy_obs) obs_scenario_nvn(e, i, obs + i * e->obs_dim);
     else obs_combat(e, i, obs + i * e->obs_dim);
   }

@@ -183,6 +183,10 @@ class OracleEnv:
         if cfg.task == TASK_SCENARIO_NVN and cfg.legacy_obs:
             self.obs_dim = 21
         self.act_dim = L.or_env_act_dim_h(cfg.task, cfg.hierarchical)
+        if cfg.task == TASK_MULTICOMBAT and cfg.legacy_obs:   # hierarchical_multiplecombat_shoot (or_env_init)
+            self.obs_dim = 21
+            if cfg.hierarchical:
+                self.act_dim = 4
         if cfg.hierarchical:
             actor_load()
         if pcg64_state is not None:

@@ -427,7 +427,8 @@ def test_dodge_missile_rule_based_launch(pkg, oracle):
 
 
 @pytest.mark.parametrize("task,baseline", [("hierarchical_singlecombat", 0), ("scenario1", 0), ("scenario_nvn", 0),
-                                           ("scenario1", 1), ("scenario_nvn", 1), ("hierarchical_singlecombat", 2)])
+                                           ("scenario1", 1), ("scenario_nvn", 1), ("hierarchical_singlecombat", 2),
+                                           ("hierarchical_multiplecombat_shoot", 0)])
 def test_hierarchical_tasks_lowlevel_controller(pkg, oracle, task, baseline):
     """The as-shipped action space: MultiDiscrete [3,5,3] (+ four weapon bits) -> BaselineActor (MLP + GRU + four argmax
     heads) -> control indices -> step. Each step both sides start from the oracle's flight state and GRU state; compared are the
@@ -437,6 +438,10 @@ def test_hierarchical_tasks_lowlevel_controller(pkg, oracle, task, baseline):
     if task == "scenario1":
         cfg.init[1].lon_deg, cfg.init[1].lat_geod_deg, cfg.init[1].psi_deg = 120.02, 60.06, 171.0
         cfg.init[0].psi_deg = 9.0
+    if task == "hierarchical_multiplecombat_shoot":   # off the shipped head-on geometry, where PostureReward's atanh is singular
+        for i in range(4):
+            cfg.init[i].lon_deg += 0.013 * (i % 3) + (0.02 if i >= 2 else 0.0)
+            cfg.init[i].psi_deg = (7.0 + 3.0 * i) if i < 2 else (171.0 + 2.0 * i)
     A = cfg.n_agents
     E = 6
     cls = pkg.HipShareVecEnv if A > 2 else pkg.HipVecEnv
@@ -446,7 +451,9 @@ def test_hierarchical_tasks_lowlevel_controller(pkg, oracle, task, baseline):
     obs = out[0] if A > 2 else out
     robs = ref.reset()
     assert obs.shape == robs.shape
-    assert env.act_dim == (3 if task == "hierarchical_singlecombat" else 7)
+    assert env.act_dim == {"hierarchical_singlecombat": 3, "hierarchical_multiplecombat_shoot": 4}.get(task, 7)
+    if task == "hierarchical_multiplecombat_shoot":   # the only MultipleCombat missile variant an env can select: 21-value paired-enemy
+        assert obs.shape == (E, 4, 21)                 # observation, [3,5,3] + a shoot bit that the task stores and never uses
     names = env.lib.state_field_names()
     task_fields = ("bloods", "pre_posture", "pre_altitude", "pre_event", "pre_shoot", "status", "die_flag", "remaining", "pre_remaining",
                    "shoot_action", "last_missile", "last_shoot_time", "lock_bits", "lock_pos", "cur_step")
@@ -457,7 +464,7 @@ def test_hierarchical_tasks_lowlevel_controller(pkg, oracle, task, baseline):
     for step in range(120):
         if step % 7 == 0:   # hold a high-level choice for a while, like a policy acting at 10 Hz
             hi = np.stack([rng.integers(0, n, size=(E, A)) for n in (3, 5, 3)], axis=-1).astype(np.float32)
-        act = hi if env.act_dim == 3 else np.concatenate([hi, (rng.random((E, A, 4)) < 0.3).astype(np.float32)], axis=-1)
+        act = hi if env.act_dim == 3 else np.concatenate([hi, (rng.random((E, A, env.act_dim - 3)) < 0.3).astype(np.float32)], axis=-1)
         for e in range(E):
             for a in range(A):
                 v = env.get_state(e, a)
