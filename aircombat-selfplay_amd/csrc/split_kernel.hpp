@@ -16,7 +16,8 @@
 // those pieces). A lone wave issues one dependent instruction every ~4.3 cycles, so below one wave per SIMD this shortens the tick's
 // critical path instead of competing for issue slots.
 namespace mail {  // LDS mailbox rows (64 floats each)
-enum { CTH, VB,                                                    // dynamics -> systems after part 1
+enum { RUNF,                                                       // dynamics -> both helpers before B1: does this aircraft run this tick
+       CTH, VB,                                                    // dynamics -> systems after part 1
        MACH, QBAR, RHO, TEMP, HSL, ALPHA, BETA, QC, VG, NPY, NPZ, AP, AQ, AR,   // dynamics -> systems after part 2
        S_AIL, S_FLAP, S_ELEV, S_RUD, S_LEF, S_SB,                   // systems -> dynamics after the FCS
        THRUST,                                                      // systems -> dynamics after the turbine
@@ -26,9 +27,12 @@ enum { CTH, VB,                                                    // dynamics -
        F_ENG,                                                       // final hand-over of the fields the systems wave owns
        K_W, K_V = K_W + 3,                                          // dynamics -> kinematics after part 1: body rates, ECI velocity
        K_OUT = K_V + 3, K_OUT_N = 27,                               // kinematics -> dynamics: f16::KinOut of the coming tick
-       G_Q = K_OUT + K_OUT_N, G_H = G_Q + 4, G_NED = G_H + 1,        // kinematics -> dynamics at the end: quaternion, env-layer frame
+       G_Q = K_OUT + K_OUT_N,                                       // kinematics -> dynamics: quaternion of tick k in rows G_Q + 4 (k & 1) ..
+       G_H = G_Q + 8, G_NED = G_H + 1,                              // ... and, from the step's last substep, the env-layer frame
        ROWS = G_NED + 8 };
-enum { GD_R, GD_X = GD_R + 3, GD_LAT = GD_X + 3, DROWS = GD_LAT + 4 };   // ... and the fp64 rows: ECI / ECEF position, geodetic cosines
+// fp64 rows: ECI position of tick k in rows GD_R + 3 (k & 1) .. (double-buffered: the kinematics wave is one tick ahead), ECEF
+// position and geodetic cosines of the step's last substep
+enum { GD_R, GD_X = GD_R + 6, GD_LAT = GD_X + 3, DROWS = GD_LAT + 4 };
 }
 __device__ __forceinline__ void post_kin(float (*M)[64], int l, const f16::KinOut& o) {
   const float v[mail::K_OUT_N] = {o.T[0], o.T[1], o.T[2], o.T[3], o.T[4], o.T[5], o.T[6], o.T[7], o.T[8], o.h_sl_ft, o.n_eci[0], o.n_eci[1], o.n_eci[2],
@@ -77,11 +81,11 @@ __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::
   f16::DynVars km{};
   f16::sys_mass(s, km);
   post_mass(M, l, km);                                     // read by the dynamics wave after B1 of the first tick
+  (void)t;
   for (int sub = 0; sub < substeps; ++sub) {
-    const bool run = t.status == AC_ALIVE;
-    if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;   // the same latch the dynamics wave applies
     f16::Surf sf{};
     wg_sync();                                             // B1: this tick's attitude is known
+    const bool run = M[RUNF][l] != 0.0f;                   // the dynamics wave decides who flies (status can change between substeps)
     if (run) {
       f16::sys_fcs(s, M[CTH][l], M[VB][l], sf);
       M[S_AIL][l] = sf.aileron_rad; M[S_FLAP][l] = sf.flaperon_rad; M[S_ELEV][l] = sf.elevator_rad;
@@ -118,28 +122,29 @@ __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::
 __device__ __forceinline__ void kinematics_wave(f16::State& s, Task& t, const f16::Tab& T, float (*M)[64], double (*MD)[64], int l, int substeps) {
   using namespace mail;
   f16::KinOut o;
-  int nrun = 0;
-  if (t.status == AC_ALIVE && substeps > 0) { f16::kin_position(s, o); f16::kin_attitude(s, o); nrun = 1; }   // tick 0 (the dynamics wave does its own)
+  // tick 0 (the dynamics wave integrates its own): from the stored state, if the aircraft is alive at all
+  if (t.status == AC_ALIVE && substeps > 0) { f16::kin_position(s, o); f16::kin_attitude(s, o); }
   for (int sub = 0; sub < substeps; ++sub) {
-    const bool run = t.status == AC_ALIVE;
-    if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;   // the same latch the dynamics wave applies
-    const bool run_next = run && t.status == AC_ALIVE && sub + 1 < substeps;
     wg_sync();                                             // B1: this tick's rates and velocity are known
-    if (run_next) {
+    const bool run = M[RUNF][l] != 0.0f;                   // the dynamics wave decides who flies (status can change between substeps)
+    const bool last = sub + 1 == substeps;
+    if (run) {                                             // this wave's position / attitude ARE tick `sub`'s: hand them over
+      const int pb = sub & 1;
+      MD[GD_R + 3 * pb][l] = s.rx; MD[GD_R + 3 * pb + 1][l] = s.ry; MD[GD_R + 3 * pb + 2][l] = s.rz;
+      M[G_Q + 4 * pb][l] = s.q0; M[G_Q + 4 * pb + 1][l] = s.q1; M[G_Q + 4 * pb + 2][l] = s.q2; M[G_Q + 4 * pb + 3][l] = s.q3;
+    }
+    if (run && !last) {                                    // one tick ahead (unused if the aircraft is shot down in between)
       s.wp = M[K_W][l]; s.wq = M[K_W + 1][l]; s.wr = M[K_W + 2][l];
       s.vx = M[K_V][l]; s.vy = M[K_V + 1][l]; s.vz = M[K_V + 2][l];
       f16::kin_position(s, o);
-      nrun += 1;
-    } else if (run) {                                      // last tick of this aircraft in this step: the pose the env layer reads
+    } else if (run) {                                      // last substep of the step: the pose the env layer reads
       f16::Derived d;
-      s.ticks += nrun;
+      s.ticks += substeps;
       f16::locate(s, d);
-      M[G_Q][l] = s.q0; M[G_Q + 1][l] = s.q1; M[G_Q + 2][l] = s.q2; M[G_Q + 3][l] = s.q3;
       M[G_H][l] = d.h_sl_ft;
       M[G_NED][l] = d.n_eci[0]; M[G_NED + 1][l] = d.n_eci[1]; M[G_NED + 2][l] = d.n_eci[2];
       M[G_NED + 3][l] = d.e_eci[0]; M[G_NED + 4][l] = d.e_eci[1];
       M[G_NED + 5][l] = d.d_eci[0]; M[G_NED + 6][l] = d.d_eci[1]; M[G_NED + 7][l] = d.d_eci[2];
-      MD[GD_R][l] = s.rx; MD[GD_R + 1][l] = s.ry; MD[GD_R + 2][l] = s.rz;
       MD[GD_X][l] = d.X; MD[GD_X + 1][l] = d.Y; MD[GD_X + 2][l] = d.Z;
       MD[GD_LAT][l] = d.sLat64; MD[GD_LAT + 1][l] = d.cLat64; MD[GD_LAT + 2][l] = d.sLon64; MD[GD_LAT + 3][l] = d.cLon64;
     }
@@ -153,7 +158,7 @@ __device__ __forceinline__ void kinematics_wave(f16::State& s, Task& t, const f1
       M[LK_CLB][l] = kl.clb; M[LK_CNB][l] = kl.cnb;
       M[LK_G7][l] = kl.g7.x; M[LK_G7 + 1][l] = kl.g7.y; M[LK_G7 + 2][l] = kl.g7.z; M[LK_G7 + 3][l] = kl.g7.w;
     }
-    if (run_next) {
+    if (run && !last) {
       f16::kin_attitude(s, o);
       post_kin(M, l, o);
     }
@@ -161,7 +166,6 @@ __device__ __forceinline__ void kinematics_wave(f16::State& s, Task& t, const f1
   }
   wg_sync();
 }
-
 // LDS of a three-wave workgroup
 struct SplitLds {
   float M[mail::ROWS][64];
@@ -175,64 +179,71 @@ __device__ __forceinline__ bool split_helper_wave(f16::State& s, Task& t, const 
   if (role == 1) { systems_wave(s, t, T, L.M, l, substeps); return true; }
   return false;
 }
-// The dynamics wave's substeps of one env step: the same result as `for (sub) if (alive) { latch; tick<false>(s, d, T); }` followed by
-// f16::locate(s, d) when any tick ran (returns that, and the number of ticks run); d holds the last tick's body-frame quantities.
-__device__ __forceinline__ bool dynamics_wave_ticks(f16::State& s, Task& t, f16::Derived& d, const f16::Tab& T, SplitLds& L, int l, int substeps,
-                                                    int& nrun) {
+// One substep of the dynamics wave (three workgroup barriers inside; every lane of the wave must call it). Returns whether this
+// aircraft flew the tick. Afterwards s holds the tick's state except the quaternion (handed over by dynamics_wave_finish); the fp64
+// ECI position IS current, so the caller may run f16::locate(s, d) after any substep (the missile tasks do).
+__device__ __forceinline__ bool dynamics_wave_tick(f16::State& s, Task& t, f16::Derived& d, const f16::Tab& T, SplitLds& L, int l, int sub) {
   using namespace mail;
   float (*M)[64] = L.M;
   double (*MD)[64] = L.MD;
-  bool ran = false;
-  nrun = 0;
-  for (int sub = 0; sub < substeps; ++sub) {
-    const bool run = t.status == AC_ALIVE;
-    if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;      // simulatior.py:220-222: this tick still integrates
-    f16::DynVars k;
-    AC_CLK(2 + sub * 8);
-    if (run) {
-      if (sub == 0) f16::dyn_p1(s, d, k);                      // (its attitude / position members go stale from here on: the
-      else {                                                   //  kinematics wave hands the final ones over)
-        f16::KinOut o;
-        fetch_kin(M, l, o);
-        f16::dyn_p1_lite(s, d, k, o);
-      }
-      M[K_W][l] = s.wp; M[K_W + 1][l] = s.wq; M[K_W + 2][l] = s.wr;
-      M[K_V][l] = s.vx; M[K_V + 1][l] = s.vy; M[K_V + 2][l] = s.vz;
-      M[CTH][l] = d.T[6] * d.d_eci[0] + d.T[7] * d.d_eci[1] + d.T[8] * d.d_eci[2];
-      M[VB][l] = d.v;
-      ran = true;
-      nrun += 1;
+  const bool run = t.status == AC_ALIVE;
+  if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;        // simulatior.py:220-222: this tick still integrates
+  f16::DynVars k;
+  AC_CLK(2 + sub * 8);
+  M[RUNF][l] = run ? 1.0f : 0.0f;
+  if (run) {
+    if (sub == 0) f16::dyn_p1(s, d, k);                        // (its quaternion goes stale from here on: the kinematics wave
+    else {                                                     //  hands the final one over)
+      f16::KinOut o;
+      fetch_kin(M, l, o);
+      f16::dyn_p1_lite(s, d, k, o);
     }
-    AC_CLK(3 + sub * 8);
-    wg_sync();                                                 // B1
-    AC_CLK(4 + sub * 8);
-    if (run) {
-      fetch_mass(M, l, k);
-      if (sub == 0) f16::dyn_p2<false>(s, d, k);
-      else f16::dyn_p2<true>(s, d, k);                        // the atmosphere at this altitude came with the kinematics
-      M[BETA][l] = k.beta;
-      M[MACH][l] = k.mach; M[QBAR][l] = k.qbar; M[RHO][l] = k.A.rho; M[TEMP][l] = k.A.T; M[HSL][l] = d.h_sl_ft;
-      M[ALPHA][l] = k.alpha; M[QC][l] = k.qc; M[VG][l] = k.vg; M[NPY][l] = k.npy; M[NPZ][l] = k.npz;
-      M[AP][l] = d.p; M[AQ][l] = d.q; M[AR][l] = d.r;
-    }
-    AC_CLK(5 + sub * 8);
-    wg_sync();                                                 // B2
-    AC_CLK(6 + sub * 8);
-    f16::Surf sf{};
-    if (run) {
-      sf = f16::Surf{M[S_AIL][l], M[S_FLAP][l], M[S_ELEV][l], M[S_RUD][l], M[S_LEF][l], M[S_SB][l], 0.0f};
-      f16::dyn_p3(d, T, k, sf);
-    }
-    AC_CLK(7 + sub * 8);
-    wg_sync();                                                 // B3
-    AC_CLK(8 + sub * 8);
-    if (run) {
-      k.clb = M[LK_CLB][l]; k.cnb = M[LK_CNB][l];
-      k.g7 = make_float4(M[LK_G7][l], M[LK_G7 + 1][l], M[LK_G7 + 2][l], M[LK_G7 + 3][l]);
-      f16::dyn_p4(s, d, k, sf, M[THRUST][l]);
+    M[K_W][l] = s.wp; M[K_W + 1][l] = s.wq; M[K_W + 2][l] = s.wr;
+    M[K_V][l] = s.vx; M[K_V + 1][l] = s.vy; M[K_V + 2][l] = s.vz;
+    M[CTH][l] = d.T[6] * d.d_eci[0] + d.T[7] * d.d_eci[1] + d.T[8] * d.d_eci[2];
+    M[VB][l] = d.v;
+  }
+  AC_CLK(3 + sub * 8);
+  wg_sync();                                                   // B1
+  AC_CLK(4 + sub * 8);
+  if (run) {
+    fetch_mass(M, l, k);
+    if (sub == 0) f16::dyn_p2<false>(s, d, k);
+    else f16::dyn_p2<true>(s, d, k);                          // the atmosphere at this altitude came with the kinematics
+    M[BETA][l] = k.beta;
+    M[MACH][l] = k.mach; M[QBAR][l] = k.qbar; M[RHO][l] = k.A.rho; M[TEMP][l] = k.A.T; M[HSL][l] = d.h_sl_ft;
+    M[ALPHA][l] = k.alpha; M[QC][l] = k.qc; M[VG][l] = k.vg; M[NPY][l] = k.npy; M[NPZ][l] = k.npz;
+    M[AP][l] = d.p; M[AQ][l] = d.q; M[AR][l] = d.r;
+  }
+  AC_CLK(5 + sub * 8);
+  wg_sync();                                                   // B2
+  AC_CLK(6 + sub * 8);
+  f16::Surf sf{};
+  if (run) {
+    sf = f16::Surf{M[S_AIL][l], M[S_FLAP][l], M[S_ELEV][l], M[S_RUD][l], M[S_LEF][l], M[S_SB][l], 0.0f};
+    f16::dyn_p3(d, T, k, sf);
+  }
+  AC_CLK(7 + sub * 8);
+  wg_sync();                                                   // B3
+  AC_CLK(8 + sub * 8);
+  if (run) {
+    k.clb = M[LK_CLB][l]; k.cnb = M[LK_CNB][l];
+    k.g7 = make_float4(M[LK_G7][l], M[LK_G7 + 1][l], M[LK_G7 + 2][l], M[LK_G7 + 3][l]);
+    f16::dyn_p4(s, d, k, sf, M[THRUST][l]);
+    if (sub > 0) {                                             // this tick's fp64 position, integrated by the kinematics wave a tick ago
+      const int pb = sub & 1;
+      s.rx = MD[GD_R + 3 * pb][l]; s.ry = MD[GD_R + 3 * pb + 1][l]; s.rz = MD[GD_R + 3 * pb + 2][l];
     }
   }
-  // the systems wave's fields after its last tick
+  return run;
+}
+// After the last substep: the fields the helper waves integrated. `last_tick` = the last substep this aircraft flew (-1: none).
+// Returns true when d also holds the fp64 geodetic reduction of the final pose (f16::locate's outputs), which the kinematics wave
+// prepares when the aircraft flew the step's last substep; otherwise the caller runs f16::locate(s, d) itself.
+__device__ __forceinline__ bool dynamics_wave_finish(f16::State& s, f16::Derived& d, SplitLds& L, int l, int last_tick, int substeps) {
+  using namespace mail;
+  float (*M)[64] = L.M;
+  double (*MD)[64] = L.MD;
   AC_CLK(50);
   wg_sync();
   AC_CLK(51);
@@ -240,15 +251,29 @@ __device__ __forceinline__ bool dynamics_wave_ticks(f16::State& s, Task& t, f16:
   s.pi_r = M[F_PIR][l]; s.pi_p = M[F_PIP][l]; s.pi_y = M[F_PIY][l]; s.ail = M[F_AIL][l]; s.elev = M[F_ELEV][l]; s.sbdeg = M[F_SBDEG][l];
   s.n1 = M[F_N1][l]; s.n2 = M[F_N2][l]; s.n2norm = M[F_N2NORM][l]; s.ff = M[F_FF][l]; s.tank0 = M[F_TANK0][l]; s.tank1 = M[F_TANK1][l];
   s.eng = __float_as_int(M[F_ENG][l]);
-  if (ran) {   // the kinematics wave's attitude, position and fp64 geodetic reduction of the final pose
-    s.q0 = M[G_Q][l]; s.q1 = M[G_Q + 1][l]; s.q2 = M[G_Q + 2][l]; s.q3 = M[G_Q + 3][l];
-    s.rx = MD[GD_R][l]; s.ry = MD[GD_R + 1][l]; s.rz = MD[GD_R + 2][l];
-    d.X = MD[GD_X][l]; d.Y = MD[GD_X + 1][l]; d.Z = MD[GD_X + 2][l];
-    d.sLat64 = MD[GD_LAT][l]; d.cLat64 = MD[GD_LAT + 1][l]; d.sLon64 = MD[GD_LAT + 2][l]; d.cLon64 = MD[GD_LAT + 3][l];
-    d.h_sl_ft = M[G_H][l];
-    d.n_eci[0] = M[G_NED][l]; d.n_eci[1] = M[G_NED + 1][l]; d.n_eci[2] = M[G_NED + 2][l];
-    d.e_eci[0] = M[G_NED + 3][l]; d.e_eci[1] = M[G_NED + 4][l]; d.e_eci[2] = 0.0f;
-    d.d_eci[0] = M[G_NED + 5][l]; d.d_eci[1] = M[G_NED + 6][l]; d.d_eci[2] = M[G_NED + 7][l];
+  if (last_tick >= 1) {
+    const int pb = last_tick & 1;
+    s.q0 = M[G_Q + 4 * pb][l]; s.q1 = M[G_Q + 4 * pb + 1][l]; s.q2 = M[G_Q + 4 * pb + 2][l]; s.q3 = M[G_Q + 4 * pb + 3][l];
   }
-  return ran;
+  if (last_tick < 0 || last_tick != substeps - 1) return false;
+  d.X = MD[GD_X][l]; d.Y = MD[GD_X + 1][l]; d.Z = MD[GD_X + 2][l];
+  d.sLat64 = MD[GD_LAT][l]; d.cLat64 = MD[GD_LAT + 1][l]; d.sLon64 = MD[GD_LAT + 2][l]; d.cLon64 = MD[GD_LAT + 3][l];
+  d.h_sl_ft = M[G_H][l];
+  d.n_eci[0] = M[G_NED][l]; d.n_eci[1] = M[G_NED + 1][l]; d.n_eci[2] = M[G_NED + 2][l];
+  d.e_eci[0] = M[G_NED + 3][l]; d.e_eci[1] = M[G_NED + 4][l]; d.e_eci[2] = 0.0f;
+  d.d_eci[0] = M[G_NED + 5][l]; d.d_eci[1] = M[G_NED + 6][l]; d.d_eci[2] = M[G_NED + 7][l];
+  return true;
+}
+// All substeps of a task without per-substep work: the same result as `for (sub) if (alive) { latch; tick<false>(s, d, T); }`
+// followed by f16::locate(s, d) when any tick ran (returns that, and the number of ticks run); d holds the last tick's body-frame
+// quantities.
+__device__ __forceinline__ bool dynamics_wave_ticks(f16::State& s, Task& t, f16::Derived& d, const f16::Tab& T, SplitLds& L, int l, int substeps,
+                                                    int& nrun) {
+  int last_tick = -1;
+  nrun = 0;
+  for (int sub = 0; sub < substeps; ++sub)
+    if (dynamics_wave_tick(s, t, d, T, L, l, sub)) { last_tick = sub; nrun += 1; }
+  const bool located = dynamics_wave_finish(s, d, L, l, last_tick, substeps);
+  if (last_tick >= 0 && !located) { f16::locate(s, d); return true; }
+  return located;
 }
