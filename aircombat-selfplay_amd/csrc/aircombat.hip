@@ -559,7 +559,6 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
   constexpr bool HAS_MSL = TT::HAS_MSL;
   constexpr int MSLOTS = TT::MSLOTS;
   constexpr int OBS = TT::OBS;
-  static_assert(!SPLIT || !HAS_MSL, "the two-wave form covers the task without munitions");
   AC_CLK(0);
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
   __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : 16];
@@ -614,12 +613,11 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
   // ---- substeps (env_base.py:139-154): every aircraft, then every missile against this substep's aircraft poses
   const MslParam MP = aim9l();
   bool have_pose = false;
-  int nrun_split = 0;
-  const bool split_located = SPLIT && dynamics_wave_ticks(s, t, d, T, L, l, c.substeps, nrun_split);
-  if (split_located) have_pose = true;
+  int last_tick = -1;   // three-wave form: the last substep this aircraft flew
   for (int sub = 0; sub < c.substeps; ++sub) {
-    if (SPLIT) break;   // (the three-wave form ran its substeps above)
-    if (t.status == AC_ALIVE) {
+    if (SPLIT) {        // the FDM tick over three waves; what follows in the substep (munitions) stays on this wave
+      if (dynamics_wave_tick(s, t, d, T, L, l, sub)) { have_pose = true; last_tick = sub; }
+    } else if (t.status == AC_ALIVE) {
       if (t.bloods <= 0.0f) t.status = AC_SHOTDOWN;  // simulatior.py:220-222: this tick still integrates
       f16::tick<false>(s, d, T);
       have_pose = true;
@@ -642,10 +640,9 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
       if (__shfl_xor((int)hit_now, 1) && t.status == AC_ALIVE) t.status = AC_SHOTDOWN;
     }
   }
-  if (split_located) {
-    make_props(s, d, c, pr);
-  } else if (!HAS_MSL || c.substeps == 0) {
-    f16::locate(s, d);
+  const bool split_located = SPLIT && dynamics_wave_finish(s, d, L, l, last_tick, c.substeps);   // (+ the helper waves' fields)
+  if (!HAS_MSL || c.substeps == 0) {
+    if (!split_located) f16::locate(s, d);
     if (!have_pose) f16::body_frame(s, d);
     make_props(s, d, c, pr);
   }
@@ -1293,9 +1290,11 @@ static int launch_step(ac_env* h, const float* d_actions) {
     else if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 1>), grid, block, 0, h->stream, p, h->dc);
     else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 2>), grid, block, 0, h->stream, p, h->dc);
   } else if (h->cfg.task == AC_TASK_DODGE_MISSILE) {
-    hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_DODGE_MISSILE, 2>), grid, block, 0, h->stream, p, h->dc);
+    if (h->split_waves) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_DODGE_MISSILE, 1, true>), grid, dim3(192), 0, h->stream, p, h->dc);
+    else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_DODGE_MISSILE, 2>), grid, block, 0, h->stream, p, h->dc);
   } else {
-    if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 1>), grid, block, 0, h->stream, p, h->dc);
+    if (h->split_waves) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 1, true>), grid, dim3(192), 0, h->stream, p, h->dc);
+    else if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 1>), grid, block, 0, h->stream, p, h->dc);
     else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 2>), grid, block, 0, h->stream, p, h->dc);
   }
   HIP_OK(hipGetLastError());
@@ -1376,7 +1375,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
      // 64 aircraft up to there, slower from 768 workgroups on); AIRCOMBAT_SPLIT=0/1 overrides
     const char* e = getenv("AIRCOMBAT_SPLIT");
     h->split_waves = (cfg->task == AC_TASK_SINGLECOMBAT || cfg->task == AC_TASK_MULTICOMBAT || cfg->task == AC_TASK_HEADING ||
-                      cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER) && (e ? (e[0] == '1') : ((h->N + 63) / 64 <= 512));
+                      cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER || cfg->task == AC_TASK_SHOOT_MISSILE ||
+                      cfg->task == AC_TASK_DODGE_MISSILE) && (e ? (e[0] == '1') : ((h->N + 63) / 64 <= 512));
   }
   h->obs_dim = heading ? 12 : (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
