@@ -1271,8 +1271,10 @@ static int launch_step(ac_env* h, const float* d_actions) {
     if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_scenario<AA, 1>), grid, block, 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr); \
     else hipLaunchKernelGGL((step_kernel_scenario<AA, 2>), grid, block, 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);                  \
   } while (0)
-    if (h->split_waves) hipLaunchKernelGGL((step_kernel_scenario<2, 1, true>), grid, dim3(192), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
+#define AC_LAUNCH_SCN3(AA) hipLaunchKernelGGL((step_kernel_scenario<AA, 1, true>), grid, dim3(192), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr)
+    if (h->split_waves) { if (h->A == 2) AC_LAUNCH_SCN3(2); else if (h->A == 4) AC_LAUNCH_SCN3(4); else AC_LAUNCH_SCN3(8); }
     else if (h->A == 2) AC_LAUNCH_SCN(2); else if (h->A == 4) AC_LAUNCH_SCN(4); else AC_LAUNCH_SCN(8);
+#undef AC_LAUNCH_SCN3
 #undef AC_LAUNCH_SCN
   } else if (h->cfg.task == AC_TASK_MULTICOMBAT) {
     if (h->split_waves) {
@@ -1371,12 +1373,15 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   ac_env* h = new ac_env();
   memset(h, 0, sizeof *h);
   h->cfg = *cfg; h->E = n_envs; h->A = cfg->n_agents; h->N = n_envs * cfg->n_agents; h->device = device_id;
-  {  // three waves per 64 aircraft up to 512 workgroups (1536 waves on 256 CUs x 4 SIMDs: measured faster than one wave per
-     // 64 aircraft up to there, slower from 768 workgroups on); AIRCOMBAT_SPLIT=0/1 overrides
+  {  // Three waves per 64 aircraft (split_kernel.hpp) while the chip has SIMDs to spare. Tasks whose substeps are the FDM tick alone:
+     // up to 512 workgroups (1536 waves on 256 CUs x 4 SIMDs; measured faster than one wave per 64 aircraft up to there, slower from
+     // 768 on). Tasks with munitions, whose dynamics wave also flies the missiles between ticks: while every wave still gets a SIMD
+     // of its own (341 workgroups; at 512 the 4v4 scenario measured 159 us against 111). AIRCOMBAT_SPLIT=0/1 overrides.
     const char* e = getenv("AIRCOMBAT_SPLIT");
-    h->split_waves = (cfg->task == AC_TASK_SINGLECOMBAT || cfg->task == AC_TASK_MULTICOMBAT || cfg->task == AC_TASK_HEADING ||
-                      cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER || cfg->task == AC_TASK_SHOOT_MISSILE ||
-                      cfg->task == AC_TASK_DODGE_MISSILE) && (e ? (e[0] == '1') : ((h->N + 63) / 64 <= 512));
+    const int wgs = (h->N + 63) / 64;
+    const bool ticks_only = cfg->task == AC_TASK_SINGLECOMBAT || cfg->task == AC_TASK_MULTICOMBAT || cfg->task == AC_TASK_HEADING ||
+                            cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER;
+    h->split_waves = e ? (e[0] == '1') : (wgs <= (ticks_only ? 512 : 341));
   }
   h->obs_dim = heading ? 12 : (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;

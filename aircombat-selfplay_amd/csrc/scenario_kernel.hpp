@@ -83,8 +83,7 @@ struct ScenarioDims {
 // Relative-geometry quantities of every reward term towards the enemies of this lane, in enemy order.
 struct EnemyGeo { float AO, TA, R; };
 
-// SPLIT: the three-wave form of the substeps (split_kernel.hpp), for the gun-only tasks (WVR, Maneuver_curriculum), which never
-// have munitions in flight and therefore no per-substep work beside the FDM tick.
+// SPLIT: the FDM ticks in the three-wave form (split_kernel.hpp); the munitions of a substep stay on the dynamics wave.
 template <int A, int WPE, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_scenario(DevPtrs P, DevCfg c, float* XF, int* XI, const float* tXF, const int* tXI) {
   using SD = ScenarioDims<A>;
@@ -139,20 +138,19 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_scenario(De
 #pragma unroll
   for (int k = 0; k < MS; ++k) mine = mine || ms[k].status != MSL_INACTIVE;
   const bool env_has_munitions = (__ballot(mine) & env_mask) != 0;
-  if (SPLIT) {   // (launched for the gun-only tasks alone: nothing flies, so only the last substep's pose is needed)
-    if (split_helper_wave(s, t, T, L, lane, c.substeps)) return;
-    int nrun_split = 0;
-    if (!dynamics_wave_ticks(s, t, d, T, L, lane, c.substeps, nrun_split)) { f16::locate(s, d); f16::body_frame(s, d); }
-    have_pose = true;
-    if (c.substeps > 0) make_props(s, d, c, pr);
-  }
-  for (int sub = 0; sub < c.substeps && !SPLIT; ++sub) {
-    if (t.status == AC_ALIVE) {
+  if (SPLIT && split_helper_wave(s, t, T, L, lane, c.substeps)) return;
+  int last_tick = -1;   // three-wave form: the last substep this aircraft flew
+  for (int sub = 0; sub < c.substeps; ++sub) {
+    if (SPLIT) {
+      if (dynamics_wave_tick(s, t, d, T, L, lane, sub)) { have_pose = true; last_tick = sub; }
+    } else if (t.status == AC_ALIVE) {
       if (t.bloods <= 0.0f) t.status = AC_SHOTDOWN;
       f16::tick<false>(s, d, T);
       have_pose = true;
     }
-    if (!env_has_munitions && sub + 1 < c.substeps) continue;
+    // (three-wave form with nothing in flight: the last substep's pose is taken after the loop, where the kinematics wave's fp64
+    //  geodetic reduction is available; the block below would only compute that pose)
+    if (!env_has_munitions && (sub + 1 < c.substeps || SPLIT)) continue;
     f16::locate(s, d);
     if (!have_pose) { f16::body_frame(s, d); have_pose = true; }
     make_props(s, d, c, pr);
@@ -207,7 +205,13 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_scenario(De
         }
     }
   }
+  const bool split_located = SPLIT && dynamics_wave_finish(s, d, L, lane, last_tick, c.substeps);   // (+ the helper waves' fields)
   if (c.substeps == 0) { f16::locate(s, d); f16::body_frame(s, d); make_props(s, d, c, pr); }
+  else if (SPLIT && !env_has_munitions) {
+    if (!split_located) f16::locate(s, d);
+    if (!have_pose) { f16::body_frame(s, d); have_pose = true; }
+    make_props(s, d, c, pr);
+  }
 
   // ---- weapons (scenario1_task.py:61-103): agents act one after another in env order
   {

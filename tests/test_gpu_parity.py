@@ -22,6 +22,8 @@ def rand_actions(rng, E, A, act_dim):
     a = np.stack([rng.integers(0, n, size=(E, A)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
     if act_dim == 5:
         a = np.concatenate([a, (rng.random((E, A, 1)) < 0.05).astype(np.float32)], axis=-1)
+    if act_dim == 8:   # scenario tasks in control-index form: + [gun, AIM-9M, AIM-120B, chaff]
+        a = np.concatenate([a, (rng.random((E, A, 4)) < 0.3).astype(np.float32)], axis=-1)
     return a
 
 
@@ -136,18 +138,18 @@ def test_singlecombat_kernel_forms_teacher_forced(pkg, oracle, monkeypatch, two_
 
 
 @pytest.mark.parametrize("task", ["singlecombat", "multiplecombat", "heading", "wvr_lowlevel", "maneuver_lowlevel", "singlecombat_shoot",
-                                  "singlecombat_dodge_missile"])
+                                  "singlecombat_dodge_missile", "scenario1", "scenario_nvn"])
 def test_one_wave_and_three_wave_forms_agree(pkg, monkeypatch, task):
     """The 1v1 tasks, MultipleCombat and the single-aircraft tasks run their FDM ticks in the three-wave form at small batches (and
     in the one-wave form above 512 workgroups; in the missile tasks the munitions stay on the dynamics wave between ticks). Both forms are built from the same statements, so from the same reset and the same actions they
     must stay together inside the oracle tolerance over a short open-loop run (ragged last workgroup included)."""
     cfg = pkg.default_config(task)
     A = cfg.n_agents
-    if task == "multiplecombat":   # off the shipped head-on geometry, where PostureReward's atanh is singular (see the NvN test)
+    if task in ("multiplecombat", "scenario_nvn"):   # off the shipped head-on geometry, where PostureReward's atanh is singular (see the NvN test)
         for i in range(A):
             cfg.init[i].lon_deg += 0.013 * (i % 3) + (0.02 if i >= A // 2 else 0.0)
             cfg.init[i].psi_deg = (7.0 + 3.0 * i) if i < A // 2 else (171.0 + 2.0 * i)
-    if task in ("singlecombat_dodge_missile", "singlecombat_shoot"):   # close and nose-on: missiles fly during the comparison
+    if task in ("singlecombat_dodge_missile", "singlecombat_shoot", "scenario1"):   # close and nose-on: missiles fly during the comparison
         cfg.init[1].lon_deg, cfg.init[1].lat_geod_deg, cfg.init[1].psi_deg = 120.02, 60.06, 171.0
         cfg.init[0].psi_deg = 9.0
     E = 72 // A + 3
@@ -160,15 +162,15 @@ def test_one_wave_and_three_wave_forms_agree(pkg, monkeypatch, task):
     o0, o1 = envs[0].reset(), envs[1].reset()
     assert (o0 == o1).all()
     rng = np.random.default_rng(8)
-    for step in range(40 if "missile" in task or "shoot" in task else 15):
+    for step in range(40 if "missile" in task or "shoot" in task or "scenario" in task else 15):
         act = rand_actions(rng, E, A, envs[0].act_dim)
         if task == "singlecombat_shoot":
             act[..., 4] = (rng.random((E, A)) < 0.3)
         o0, r0, d0, _ = envs[0].step(act)
         o1, r1, d1, _ = envs[1].step(act)
         assert (d0 == d1).all(), step
-        weapons = "shoot" in task or "missile" in task          # (40 open-loop steps there: the oracle tolerance itself)
-        ok = nvn_obs_close(o0, o1) if task == "multiplecombat" else obs_close(o0, o1, 1.0 if weapons else 0.25)   # (acos near pi amplifies an ulp)
+        weapons = "shoot" in task or "missile" in task or "scenario" in task         # (40 open-loop steps there: the oracle tolerance itself)
+        ok = nvn_obs_close(o0, o1) if task in ("multiplecombat", "scenario_nvn") else obs_close(o0, o1, 1.0 if weapons else 0.25)   # (acos near pi amplifies an ulp)
         assert ok.all(), (step, np.abs(o0 - o1).max())
         rtol = (5e-2, 1e-2) if weapons else (1e-3, 2.5e-4)   # the bound of the oracle tests of these tasks: PostureReward (x15,
         assert (np.abs(r0 - r1) <= rtol[0] + rtol[1] * np.abs(r1)).all(), (step, np.abs(r0 - r1).max())   # differenced) is steep in TA there
