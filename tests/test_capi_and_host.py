@@ -102,7 +102,7 @@ def test_generated_table_copies_are_in_sync():
 
 
 def test_two_wave_tick_pieces_are_generated_from_the_current_tick():
-    """csrc/f16_split.hpp holds the statements of tick() cut into the pieces of the two-wave kernel; it must be what
+    """csrc/f16_split.hpp holds the statements of tick() cut into the pieces of the three-wave kernels; it must be what
     tools/gen_split_tick.py makes of the current f16_device.hpp, so that the two kernel forms compute the same arithmetic."""
     assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_split_tick.py"), "--check"]).returncode == 0
 

@@ -104,7 +104,7 @@ def test_teacher_forced_steps(pkg, oracle, task):
 
 @pytest.mark.parametrize("two_waves", ["0", "1"])
 def test_singlecombat_kernel_forms_teacher_forced(pkg, oracle, monkeypatch, two_waves):
-    """SingleCombat has two kernel forms: one wave per 64 aircraft, and (below one wave per SIMD) two waves per 64 aircraft that
+    """SingleCombat has two kernel forms: one wave per 64 aircraft, and (at small batches) three waves per 64 aircraft that
     split every FDM tick between them through LDS. AIRCOMBAT_SPLIT pins the form; both must agree with the oracle step by step,
     full state vector included, on a batch with a ragged last workgroup (70 envs = 140 lanes), and with one another."""
     monkeypatch.setenv("AIRCOMBAT_SPLIT", two_waves)

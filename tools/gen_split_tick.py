@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generate aircombat-selfplay_amd/csrc/f16_split.hpp from tick() of f16_device.hpp: the same statements, cut at the section
-comments into the pieces the two-wave step kernel runs on different waves (dynamics wave: propagate .. gravity, atmosphere / mass /
-auxiliary, table look-ups, assembly + accelerations; systems wave: FCS, propulsion). tick() stays the single source of the
+comments into the pieces the three-wave step kernels run on different waves (dynamics wave: rates / velocity update, auxiliary, table
+look-ups, assembly + accelerations; systems wave: FCS, propulsion, mass balance; kinematics wave: attitude / position / frame /
+gravity / atmosphere of the coming tick). tick() stays the single source of the
 arithmetic; re-run this script after editing it (the build checks that the generated file is current)."""
 import os
 import sys
@@ -126,9 +127,10 @@ def generate():
                      ("    float kge = 1.0f;", "    kge = 1.0f;")):
         look = rep(look, old, new)
     head = '''// GENERATED by tools/gen_split_tick.py from tick() of f16_device.hpp — do not edit; edit tick() and re-run the script.
-// The statements of one executive tick, cut at the section comments into the pieces the two-wave step kernel (split_kernel.hpp) runs
-// on different waves of a workgroup: the dynamics wave (propagate .. gravity | atmosphere, mass balance, auxiliary | table look-ups |
-// assembly + accelerations) and the systems wave (FCS | propulsion), which exchange a handful of floats per aircraft through LDS.
+// The statements of one executive tick, cut at the section comments into the pieces the three-wave step kernels (split_kernel.hpp) run
+// on different waves of a workgroup: the dynamics wave (rates / velocity | auxiliary | table look-ups | assembly + accelerations), the
+// systems wave (FCS | propulsion | mass balance) and the kinematics wave (attitude, position, geodetic frame, gravity and atmosphere of
+// the coming tick), which exchange their results per aircraft through LDS.
 #pragma once
 
 namespace f16 {
