@@ -234,6 +234,22 @@ def main():
         for i in range(HB):
             env.step(a_host[i % 8])
         hb = time.perf_counter() - t0
+        # SURVEY 8(d)'s second, "benign" run: the reference's straight-fly action [20, 18.6 -> 19, 20, 0] (baseline.py:168) held in
+        # every env, so no aircraft crashes early and the timed mix is all level flight (device-resident, like the headline run)
+        if args.task == "singlecombat" and not args.hierarchical:
+            env.reset()
+            hold = torch.from_numpy(np.tile(np.array([20, 19, 20, 0], dtype=np.float32), (E, AGENTS, 1))).cuda(local_rank)
+            for _ in range(50):
+                env.step_device(hold.data_ptr())
+            env.sync()
+            t0 = time.perf_counter()
+            BN = 500
+            for _ in range(BN):
+                env.step_device(hold.data_ptr())
+            env.sync()
+            bn = time.perf_counter() - t0
+            result["benign_actions"] = {"value": E * AGENTS * BN / bn, "unit": "agent-steps/s", "ms_per_step": bn / BN * 1e3,
+                                        "note": "same batch, every aircraft holds the straight-fly action: no early crashes in the mix"}
         result["host_boundary"] = {"value": E * AGENTS * HB / hb, "unit": "agent-steps/s", "ms_per_step": hb / HB * 1e3,
                                    "note": "VecEnv.step(numpy) incl. H2D actions, kernel, D2H obs/reward/done and the info codes (dicts are built when read)"}
         rate = E * AGENTS / (kernel_ms * 1e-3)
