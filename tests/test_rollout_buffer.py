@@ -156,3 +156,44 @@ def test_device_buffer_rejects_bad_arguments(pkg):
     assert dev.lib.ac_buffer_device_ptr(dev._h, pkg.capi.AC_BUF_SHARE_OBS, C.byref(ptr), C.byref(n)) != 0
     assert "no such field" in dev.lib.last_error()
     dev.close()
+
+
+@pytest.mark.gpu
+def test_env_to_buffer_rollout_stays_on_the_device(pkg):
+    """N2 + N4 together: a rollout in which nothing crosses PCIe. The env handle steps on device-resident actions
+    (step_device), its own HBM output buffers (obs, rewards, dones) go into the rollout buffer device-to-device, and the returns
+    are computed in place. Checked against the same rollout collected through the host interface and the numpy oracle buffer."""
+    import torch
+    from oracle.rollout_buffer import OracleRolloutBuffer
+    T, E, H = 24, 33, 16
+    cfg = pkg.default_config("singlecombat")
+    env_d, env_h = pkg.HipVecEnv(cfg, E, seed=2), pkg.HipVecEnv(cfg, E, seed=2)
+    A, OBS = env_d.num_agents, env_d.obs_dim
+    dev = pkg.DeviceReplayBuffer(_args(T, E, H, True, True), A, OBS, 4)
+    ref = OracleRolloutBuffer(T, E, A, OBS, 4, 1, H, 0.99, 0.95, True, True)
+    env_d.reset(); obs0 = env_h.reset()
+    act_d, obs_d, rew_d, done_d, _ = env_d.device_tensors()
+    dev.set_slot("obs", 0, obs0); ref.obs[0] = obs0
+    rng = np.random.default_rng(12)
+    zeros_h = np.zeros((E, A, 1, H), dtype=np.float32)
+    zeros_d = torch.zeros((E, A, 1, H), device="cuda:0")
+    for t in range(T):
+        a = rand_actions(rng, E, A)
+        logp, val = rng.normal(size=(E, A, 1)).astype(np.float32), rng.normal(size=(E, A, 1)).astype(np.float32)
+        # device side: actions written in place, step, outputs inserted without leaving HBM
+        act_d.copy_(torch.from_numpy(a))
+        env_d.step_device(act_d.data_ptr()); env_d.sync()
+        masks_d = (1.0 - done_d.float()).contiguous()
+        dev.insert(obs_d, act_d, rew_d, masks_d, torch.from_numpy(logp).cuda(), torch.from_numpy(val).cuda(), zeros_d, zeros_d, on_device=True)
+        # host side: the reference's call sequence (runner/jsbsim_runner.py:116-133)
+        o, r, d, _ = env_h.step(a)
+        ref.insert(o, a, r, (1.0 - d).astype(np.float32), logp, val, zeros_h, zeros_h)
+    nv = rng.normal(size=(E, A, 1)).astype(np.float32)
+    dev.compute_returns(torch.from_numpy(nv).cuda(), on_device=True); ref.compute_returns(nv)
+    for name in ("obs", "actions", "rewards", "masks", "value_preds", "returns"):
+        assert (dev.array(name) == getattr(ref, name)).all(), name     # two handles, same seed, same actions: bit-identical rollouts
+    dev.close(); env_d.close(); env_h.close()
+
+
+def rand_actions(rng, E, A):
+    return np.stack([rng.integers(0, n, size=(E, A)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
