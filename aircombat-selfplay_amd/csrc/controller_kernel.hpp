@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void controller_kernel(ctl::Args a) {
   }
   __syncthreads();
   layer_norm(act1, red, W + D_G3, W + D_BE3, tid);
-  // ---- heads: 153 logits = five column tiles; wave w takes tile w, wave 0 also the fifth
+  // ---- heads: 153 logits = five column tiles; wave w takes tile w and a quarter of the fifth tile's K range
   {
     float A[64];
     load_a<HID>(act1, lane, A);
@@ -281,12 +281,31 @@ __global__ __launch_bounds__(256) void controller_kernel(ctl::Args a) {
     mma_tile<HID>(W + D_WA + w * tile_floats(HID), lane, A, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) lg[(w * 32 + col) * LS + c_row(r, lane)] = acc[r];
-    if (w == 0) {
-      floatx16 acc4 = splat(W[D_BA + 128 + col]);
-      mma_tile<HID>(W + D_WA + 4 * tile_floats(HID), lane, A, acc4);
+    // fifth tile (logits 128 .. 152): its K range is split over the four waves (16 MFMAs each instead of 64 on one wave); the
+    // partial sums go to act0 (free by now) and are added in a fixed order below
+    {
+      floatx16 part = splat(0.0f);
+      const float4* t4 = reinterpret_cast<const float4*>(W + D_WA + 4 * tile_floats(HID)) + lane + (size_t)(4 * w) * 64;
+      float Aw[16];   // this wave's K slice (k = 32 w .. 32 w + 31), read again from LDS: indexing A[] by w would put it in scratch
 #pragma unroll
-      for (int r = 0; r < 16; ++r) lg[(128 + col) * LS + c_row(r, lane)] = acc4[r];
+      for (int t = 0; t < 16; ++t) Aw[t] = act1[(2 * (16 * w + t) + (lane >> 5)) * LS + (lane & 31)];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = t4[g * 64];
+        part = __builtin_amdgcn_mfma_f32_32x32x2f32(Aw[4 * g + 0], b.x, part, 0, 0, 0);
+        part = __builtin_amdgcn_mfma_f32_32x32x2f32(Aw[4 * g + 1], b.y, part, 0, 0, 0);
+        part = __builtin_amdgcn_mfma_f32_32x32x2f32(Aw[4 * g + 2], b.z, part, 0, 0, 0);
+        part = __builtin_amdgcn_mfma_f32_32x32x2f32(Aw[4 * g + 3], b.w, part, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) act0[(w * 32 + col) * LS + c_row(r, lane)] = part[r];
     }
+  }
+  __syncthreads();
+  // logits 128 .. 152 = bias + the four K-partials, summed in a fixed order (25 columns x 32 aircraft over 256 threads)
+  for (int e = tid; e < 25 * 32; e += 256) {
+    const int q = e >> 5, row = e & 31;
+    lg[(128 + q) * LS + row] = (((W[D_BA + 128 + q] + act0[q * LS + row]) + act0[(32 + q) * LS + row]) + act0[(64 + q) * LS + row]) + act0[(96 + q) * LS + row];
   }
   __syncthreads();
   if (tid < 128) {   // thread = (head, aircraft): first maximum, like torch argmax
