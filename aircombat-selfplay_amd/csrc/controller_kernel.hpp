@@ -268,10 +268,17 @@ __global__ __launch_bounds__(256) void controller_kernel(ctl::Args a) {
       const float ng = tanh_f(in_[r] + rg * hn[r]);
       const float hnew = (1.0f - zg) * ng + zg * hbuf[unit * LS + row];
       act1[unit * LS + row] = hnew;
-      if (i0 + row < a.N) a.H[(size_t)unit * a.N + i0 + row] = hnew;
     }
   }
   __syncthreads();
+  {   // the new hidden state goes out row-contiguous (128-byte runs per feature) from LDS; the tile registers above would scatter it
+      // one float per cache line. Thread = (row, 16-feature part): the very elements this thread normalises next.
+    const int row = tid & 31, part = tid >> 5, n = i0 + row;
+    if (n < a.N) {
+#pragma unroll
+      for (int f = 0; f < 16; ++f) a.H[(size_t)(part * 16 + f) * a.N + n] = act1[(part * 16 + f) * LS + row];
+    }
+  }
   layer_norm(act1, red, W + D_G3, W + D_BE3, tid);
   // ---- heads: 153 logits = five column tiles; wave w takes tile w and a quarter of the fifth tile's K range
   {
