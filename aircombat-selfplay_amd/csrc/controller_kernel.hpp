@@ -105,7 +105,18 @@ __device__ __forceinline__ int c_row(int r, int lane) { return (r >> 2) * 8 + (l
 // torch.nn.LayerNorm(128) (eps 1e-5, biased variance) of buf[feature][row] in place; 256 threads: thread = (row, 16-feature part)
 __device__ __forceinline__ void layer_norm(float* buf, float* red, const float* __restrict__ g, const float* __restrict__ b, int tid) {
   const int row = tid & 31, part = tid >> 5;
-  float x[16];
+  float x[16], gg[16], bb[16];
+  // scale / shift from L2 first: their latency then hides behind the two reductions instead of following them
+  {
+    const float4* g4 = reinterpret_cast<const float4*>(g + part * 16);
+    const float4* b4 = reinterpret_cast<const float4*>(b + part * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 gv = g4[q], bv = b4[q];
+      gg[4 * q] = gv.x; gg[4 * q + 1] = gv.y; gg[4 * q + 2] = gv.z; gg[4 * q + 3] = gv.w;
+      bb[4 * q] = bv.x; bb[4 * q + 1] = bv.y; bb[4 * q + 2] = bv.z; bb[4 * q + 3] = bv.w;
+    }
+  }
   float s = 0.0f;
 #pragma unroll
   for (int f = 0; f < 16; ++f) { x[f] = buf[(part * 16 + f) * LS + row]; s += x[f]; }
@@ -125,7 +136,7 @@ __device__ __forceinline__ void layer_norm(float* buf, float* red, const float* 
   for (int p = 0; p < 8; ++p) var += red[(8 + p) * LS + row];
   const float is = rsqrtf(var * (1.0f / HID) + 1e-5f);
 #pragma unroll
-  for (int f = 0; f < 16; ++f) buf[(part * 16 + f) * LS + row] = fmaf((x[f] - m) * is, g[part * 16 + f], b[part * 16 + f]);
+  for (int f = 0; f < 16; ++f) buf[(part * 16 + f) * LS + row] = fmaf((x[f] - m) * is, gg[f], bb[f]);
   __syncthreads();
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
