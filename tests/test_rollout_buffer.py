@@ -197,3 +197,55 @@ def test_env_to_buffer_rollout_stays_on_the_device(pkg):
 
 def rand_actions(rng, E, A):
     return np.stack([rng.integers(0, n, size=(E, A)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
+
+
+@pytest.mark.gpu
+def test_returns_at_training_size_properties(pkg):
+    """The reference's training shape (buffer_size 3000) at the BASELINE batch (8192 columns), checked through properties that do
+    not need the slow reference loop: with gamma = lambda = 1, masks = bad_masks = 1 and V = 0 the GAE return is the suffix sum
+    of the rewards plus the bootstrap value; sampled columns equal the numpy oracle bit for bit with random masks, in both tilings
+    of the kernel (32-column workgroups below 16 384 columns, 64-column workgroups from there)."""
+    import torch
+    from oracle.rollout_buffer import OracleRolloutBuffer
+    T, E, A, H = 3000, 4096, 2, 1
+    g = torch.Generator(device="cuda:0").manual_seed(7)
+    buf = pkg.DeviceReplayBuffer(_args(T, E, H, True, True, gamma=1.0, lam=1.0), A, 1, 1)
+    rew = buf.device_tensor("rewards").normal_(generator=g)
+    buf.device_tensor("value_preds").zero_()
+    nv = torch.randn(E * A, device="cuda:0", generator=g)
+    buf.compute_returns(nv, on_device=True)
+    R = buf.device_tensor("returns")[:T, ..., 0].double()
+    want = torch.flip(torch.cumsum(torch.flip(rew[..., 0].double(), [0]), 0), [0]) + nv.view(E, A).double()
+    assert float((R - want).abs().max()) <= 2e-2        # 3000 float32 additions of N(0,1) terms: |sum| ~ 55, ulp 4e-6, error random-walks
+    buf.close()
+    # random masks / values at gamma 0.99: sampled columns against the oracle, bit for bit
+    buf = pkg.DeviceReplayBuffer(_args(T, E, H, True, True), A, 1, 1)
+    for name in ("rewards", "value_preds"):
+        buf.device_tensor(name).normal_(generator=g)
+    for name in ("masks", "bad_masks"):
+        t = buf.device_tensor(name)
+        t.copy_((torch.rand(t.shape, device="cuda:0", generator=g) > 0.02).float())
+    buf.compute_returns(nv, on_device=True)
+    cols = [0, 1, 31, 32, 63, 64, 4095, 8191]
+    ref = OracleRolloutBuffer(T, len(cols), 1, 1, 1, 1, H, 0.99, 0.95, True, True)
+    pick = lambda name: buf.device_tensor(name).view(-1, E * A, 1)[:, cols].cpu().numpy().reshape(-1, len(cols), 1, 1)
+    ref.rewards[:], ref.value_preds[:], ref.masks[:], ref.bad_masks[:] = pick("rewards"), pick("value_preds"), pick("masks"), pick("bad_masks")
+    ref.compute_returns(nv[cols].cpu().numpy().reshape(len(cols), 1, 1))
+    assert (pick("returns") == ref.returns).all()
+    buf.close()
+    # 16 384 columns select the kernel's other tiling (64-column workgroups, 64-step tiles): same check on a shorter buffer
+    T2, E2 = 200, 8192
+    buf = pkg.DeviceReplayBuffer(_args(T2, E2, H, False, True), A, 1, 1)
+    for name in ("rewards", "value_preds"):
+        buf.device_tensor(name).normal_(generator=g)
+    t = buf.device_tensor("masks")
+    t.copy_((torch.rand(t.shape, device="cuda:0", generator=g) > 0.05).float())
+    nv2 = torch.randn(E2 * A, device="cuda:0", generator=g)
+    buf.compute_returns(nv2, on_device=True)
+    cols = [0, 63, 64, 8191, 8192, 16383]
+    ref = OracleRolloutBuffer(T2, len(cols), 1, 1, 1, 1, H, 0.99, 0.95, True, False)
+    pick = lambda name: buf.device_tensor(name).view(-1, E2 * A, 1)[:, cols].cpu().numpy().reshape(-1, len(cols), 1, 1)
+    ref.rewards[:], ref.value_preds[:], ref.masks[:] = pick("rewards"), pick("value_preds"), pick("masks")
+    ref.compute_returns(nv2[cols].cpu().numpy().reshape(len(cols), 1, 1))
+    assert (pick("returns") == ref.returns).all()
+    buf.close()
