@@ -8,10 +8,10 @@ or through the repo-root alias module ``aircombat_selfplay_amd``.
 """
 from .capi import AcConfig, AcInitState, Lib, load_library, library_path, HipExtensionMissing  # noqa: F401
 from .config import config_from_yaml, default_config, default_nvn_config, TASK_IDS  # noqa: F401
-from .vec_env import HipVecEnv, HipShareVecEnv, make_env  # noqa: F401
+from .vec_env import HipVecEnv, HipShareVecEnv, MultiDeviceVecEnv, make_env  # noqa: F401
 from .rollout_buffer import DeviceReplayBuffer, DeviceSharedReplayBuffer  # noqa: F401
 from . import sharding  # noqa: F401
 
 __all__ = ["AcConfig", "AcInitState", "Lib", "load_library", "library_path", "HipExtensionMissing",
-           "config_from_yaml", "default_config", "default_nvn_config", "TASK_IDS", "HipVecEnv", "HipShareVecEnv", "make_env",
+           "config_from_yaml", "default_config", "default_nvn_config", "TASK_IDS", "HipVecEnv", "HipShareVecEnv", "MultiDeviceVecEnv", "make_env",
            "DeviceReplayBuffer", "DeviceSharedReplayBuffer"]

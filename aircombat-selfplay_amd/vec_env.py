@@ -370,6 +370,67 @@ class HipShareVecEnv(HipVecEnv):
         return obs, self._share(obs), rew, done, infos
 
 
+class MultiDeviceVecEnv:
+    """One VecEnv over several GPUs from a single process: a contiguous block of envs per device
+    (sharding.env_block), one handle, stream and pinned host slab per device, no collective; the caller sees one
+    ``[E, A, ...]`` array. ``step`` runs the per-device ``ac_step`` calls concurrently (one thread per handle; ctypes releases the
+    GIL for the duration of the call). Env ``i`` keeps the seed ``seed + 1000 i`` of a single-handle VecEnv (heading task).
+    The multi-process form (one process per GPU, bench.py --gpus N) needs none of this."""
+
+    def __init__(self, config, num_envs, device_ids, seed=0, share=None):
+        from concurrent.futures import ThreadPoolExecutor
+        from .sharding import env_block
+        if not device_ids:
+            raise ValueError("device_ids must name at least one GPU")
+        share = (config.task in (AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO_NVN)) if share is None else share
+        cls = HipShareVecEnv if share else HipVecEnv
+        self.blocks = [env_block(r, len(device_ids), num_envs) for r in range(len(device_ids))]
+        if min(c for _, c in self.blocks) < 1:
+            raise ValueError("fewer envs than devices")
+        self.parts = [cls(config, count, device_id=dev, seed=seed + 1000 * start) for dev, (start, count) in zip(device_ids, self.blocks)]
+        self.share = share
+        self.num_envs, self.num_agents = int(num_envs), self.parts[0].num_agents
+        self.obs_dim, self.act_dim = self.parts[0].obs_dim, self.parts[0].act_dim
+        self.observation_space, self.action_space = self.parts[0].observation_space, self.parts[0].action_space
+        if share:
+            self.share_observation_space = self.parts[0].share_observation_space
+        self._pool = ThreadPoolExecutor(max_workers=len(self.parts))
+        self._pending = None
+
+    def _cat(self, results):
+        cols = list(zip(*results))
+        out = [np.concatenate(c, axis=0) for c in cols[:-1]]
+        return tuple(out) + (LazyInfos(np.concatenate([i._codes for i in cols[-1]], axis=0)),)
+
+    def reset(self):
+        res = [p.reset() for p in self.parts]
+        if self.share:
+            return tuple(np.concatenate(c, axis=0) for c in zip(*res))
+        return np.concatenate(res, axis=0)
+
+    def step_async(self, actions):
+        a = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.num_agents, self.act_dim)
+        self._pending = [self._pool.submit(p.step, a[s:s + c]) for p, (s, c) in zip(self.parts, self.blocks)]
+
+    def step_wait(self):
+        res, self._pending = [f.result() for f in self._pending], None
+        return self._cat(res)
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def seed(self, seed=None):
+        if seed is not None:
+            for p, (s, _) in zip(self.parts, self.blocks):
+                p.seed(seed + 1000 * s)
+
+    def close(self):
+        for p in self.parts:
+            p.close()
+        self._pool.shutdown(wait=True)
+
+
 def make_env(scenario=None, num_envs=1, task=None, device_id=0, seed=0):
     """``scenario``: path of a scenario YAML (reference format) or None for the 1v1 block of WVR_selfplay.yaml."""
     cfg = config_from_yaml(scenario, task=task) if scenario else default_config(task or "singlecombat")

@@ -780,3 +780,26 @@ def test_shot_down_aircraft_freezes_while_its_missile_flies(pkg):
                 assert any(env.get_missile(0, 0, k)[0] == 0 for k in range(4)), step   # a launched missile keeps the env alive
     assert killed_at is not None and done.all() and step > killed_at + 3
     env.close()
+
+
+@pytest.mark.parametrize("task", ["singlecombat", "heading", "multiplecombat"])
+def test_multi_device_vec_env_matches_one_handle(pkg, task):
+    """SURVEY 8e's single-process form: env blocks on several devices behind one VecEnv. Rehearsed here with two handles on the
+    same GPU (uneven blocks: 37 envs -> 19 + 18): it must return exactly what one handle over all 37 envs returns."""
+    cfg = pkg.default_config(task)
+    A, E = cfg.n_agents, 37
+    share = task == "multiplecombat"
+    one = (pkg.HipShareVecEnv if share else pkg.HipVecEnv)(cfg, E, seed=5)
+    many = pkg.MultiDeviceVecEnv(cfg, E, device_ids=[0, 0], seed=5)
+    assert [c for _, c in many.blocks] == [19, 18]
+    r1, r2 = one.reset(), many.reset()
+    for a, b in zip(r1 if share else (r1,), r2 if share else (r2,)):
+        assert a.shape == b.shape and (a == b).all()
+    rng = np.random.default_rng(1)
+    for step in range(25):
+        act = rand_actions(rng, E, A, 4)
+        o1, o2 = one.step(act), many.step(act)
+        for a, b in zip(o1[:-1], o2[:-1]):
+            assert a.shape == b.shape and (a == b).all(), step
+        assert list(o1[-1]) == list(o2[-1])
+    one.close(); many.close()
