@@ -174,3 +174,23 @@ def test_shipped_yamls_resolve_to_device_tasks():
         if name not in ("heading.yaml", "approach.yaml"):
             assert cfg.hierarchical == 1, name        # every shipped combat task takes the [3,5,3] action
     assert ok == 34
+
+
+def test_lazy_infos_equal_the_reference_info_dicts(pkg):
+    """`infos` of VecEnv.step builds its dicts on access: element by element it must equal what the workers' dicts hold
+    (env_wrappers.py:276-282): current_step always, done_condition on an episode end, heading_turn_counts with UnreachHeading."""
+    import importlib
+    import numpy as np
+    ve = importlib.import_module("aircombat-selfplay_amd.vec_env")
+    codes = np.array([[3, 0, 0, 0], [7, 8, 2, 1], [9, 1, 0, 1], [12, 7, 0, 1]], dtype=np.int32)
+    infos = ve.LazyInfos(codes)
+    assert len(infos) == 4 and infos.shape == (4,)
+    assert infos[0] == {"current_step": 3}
+    assert infos[1] == {"current_step": 7, "done_condition": ve.DONE_MESSAGES[8], "heading_turn_counts": 2}
+    assert infos[-1]["done_condition"] == ve.DONE_MESSAGES[7] and "heading_turn_counts" not in infos[-1]
+    assert [i for i in infos if "heading_turn_counts" in i] == [infos[1]]          # runner/jsbsim_runner.py:55-57
+    arr = np.asarray(infos)
+    assert arr.dtype == object and arr.shape == (4,) and arr[2] == infos[2]
+    assert infos[1:3] == [infos[1], infos[2]]
+    with pytest.raises(IndexError):
+        infos[4]
