@@ -1,0 +1,19 @@
+#!/bin/bash
+# LDS behaviour of the step kernel (one SQ pass): instructions, bank-conflict cycles, active cycles
+set -e
+out=gpurun_out/${1:-lds}
+mkdir -p $out
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/pmc -o pmc -- python3 bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-saturating ${@:2} > $out/bench.json 2> $out/err.txt
+python3 - <<PY
+import csv,glob,collections
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for p in glob.glob("$out/pmc/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(p)):
+        if "step_kernel" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k,d in acc.items():
+    print(k)
+    for c,v in sorted(d.items()):
+        print("   %-24s avg per dispatch %14.1f  (n=%d)" % (c, sum(v)/len(v), len(v)))
+PY
