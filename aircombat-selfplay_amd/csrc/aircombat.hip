@@ -105,6 +105,7 @@ struct DevCfg {
   int num_missiles[AC_MAX_AGENTS];
   // battle-field origin for pymap3d-style geodetic <-> NED (metres, WGS84)
   double P0x, P0y, P0z, sLat0, cLat0, sLon0, cLon0;
+  float rm0, rn0, h0;         // meridional / prime-vertical radius of curvature at the battle-field centre (+ its height), that height
   unsigned long long chaff_seed;  // base of the keyed decoy draw (the env index is added on the device)
 };
 
@@ -317,6 +318,14 @@ __device__ __forceinline__ double neu_height64(double n, double e, double u, con
   return ((rxy * cc + s0 * s1 - a * sqrt(ec2 * s12 + cc2)) / norm);
 }
 __device__ __forceinline__ float neu_height(float n, float e, float u, const DevCfg& c) { return (float)neu_height64(n, e, u, c); }
+// The fp32 missiles (AIM-9L of the 1v1 tasks, 300 m fuse) only use their geodetic height for the air density exp(-h / 9300): the
+// local-curvature form h0 + u + n^2 / 2(M0 + h) + e^2 / 2(N0 + h) is within 4 cm of the exact reduction over +-60 km (3.5 mm within
+// 40 km; density error < 5e-6) and costs eight fp32 operations instead of ~160 fp64 ones with four square roots. The fp64 munitions
+// of the scenario tasks (5 m fuse, bang-bang terminal guidance) keep the exact form.
+__device__ __forceinline__ float missile_height(float n, float e, float u, const DevCfg& c) {
+  return c.h0 + u + n * n / (2.0f * (c.rm0 + u)) + e * e / (2.0f * (c.rn0 + u));
+}
+__device__ __forceinline__ double missile_height(double n, double e, double u, const DevCfg& c) { return neu_height64(n, e, u, c); }
 // MissileSimulator.run (simulatior.py:520-533) with _guidance (:556-576) and _state_trans (:578-608).
 __device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
@@ -355,7 +364,7 @@ __device__ __forceinline__ void missile_run(MslT<R>& m, const MslParam& P, R tx,
     m.status = MSL_MISS;
   } else {
     m.px += dt * m.vx; m.py += dt * m.vy; m.pz += dt * m.vz;
-    R alt = (R)neu_height64(m.px, m.py, m.pz, c);
+    R alt = missile_height(m.px, m.py, m.pz, c);
     R Isp = burning ? (R)P.Isp : (R)0;
     R Tt = g * Isp * (R)P.dm;
     R sd = m_sin(m.dth), sp = m_sin(m.dph);
@@ -1415,6 +1424,12 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   for (int i = 0; i < AC_MAX_AGENTS; ++i) c.num_missiles[i] = cfg->num_missiles[i];
   geodetic2ecef_m(cfg->center_lat, cfg->center_lon, cfg->center_alt, &c.P0x, &c.P0y, &c.P0z);
   c.sLat0 = sin(cfg->center_lat * M_PI / 180.0); c.cLat0 = cos(cfg->center_lat * M_PI / 180.0);
+  {
+    const double a = 6378137.0, f = 1.0 / 298.257223563, e2 = f * (2.0 - f), w2 = 1.0 - e2 * c.sLat0 * c.sLat0;
+    c.rn0 = (float)(a / sqrt(w2) + cfg->center_alt);
+    c.rm0 = (float)(a * (1.0 - e2) / (w2 * sqrt(w2)) + cfg->center_alt);
+    c.h0 = (float)cfg->center_alt;
+  }
   c.sLon0 = sin(cfg->center_lon * M_PI / 180.0); c.cLon0 = cos(cfg->center_lon * M_PI / 180.0);
 
   HIP_OK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
