@@ -600,12 +600,15 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
     if (split_helper_wave(s, t, T, L, l, c.substeps)) return;
   }
   Msl ms[MSLOTS];
-  int nslots = 0;
+  int nslots = 0, msl_was_active = 0;
   if (HAS_MSL) {
     nslots = min(c.num_missiles[slot], MSLOTS);
 #pragma unroll
     for (int k = 0; k < MSLOTS; ++k) {
-      if (k < nslots) load_msl(P.MF, P.MI, N, nn, k, ms[k]);
+      // a slot that has not been launched since the last reset holds zeros and MSL_INACTIVE (reset_all_kernel, the reset branch
+      // below): only its status is read, and it is written back only once it has been launched or reset
+      const int st = (k < nslots) ? P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn] : MSL_INACTIVE;
+      if (st != MSL_INACTIVE) { load_msl(P.MF, P.MI, N, nn, k, ms[k]); msl_was_active |= 1 << k; }
       else { ms[k] = Msl{}; ms[k].status = MSL_INACTIVE; }
     }
   }
@@ -833,7 +836,8 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
     store_state(P.F, P.I, P.D, N, n, s, t);
     if (HAS_MSL) {
 #pragma unroll
-      for (int k = 0; k < MSLOTS; ++k) if (k < nslots) store_msl(P.MF, P.MI, N, n, k, ms[k]);
+      for (int k = 0; k < MSLOTS; ++k)
+        if (k < nslots && (ms[k].status != MSL_INACTIVE || ((msl_was_active >> k) & 1))) store_msl(P.MF, P.MI, N, n, k, ms[k]);
     }
     float* o = P.obs + (size_t)n * OBS;
 #pragma unroll
