@@ -318,14 +318,16 @@ __device__ __forceinline__ double neu_height64(double n, double e, double u, con
   return ((rxy * cc + s0 * s1 - a * sqrt(ec2 * s12 + cc2)) / norm);
 }
 __device__ __forceinline__ float neu_height(float n, float e, float u, const DevCfg& c) { return (float)neu_height64(n, e, u, c); }
-// The fp32 missiles (AIM-9L of the 1v1 tasks, 300 m fuse) only use their geodetic height for the air density exp(-h / 9300): the
-// local-curvature form h0 + u + n^2 / 2(M0 + h) + e^2 / 2(N0 + h) is within 4 cm of the exact reduction over +-60 km (3.5 mm within
-// 40 km; density error < 5e-6) and costs eight fp32 operations instead of ~160 fp64 ones with four square roots. The fp64 munitions
-// of the scenario tasks (5 m fuse, bang-bang terminal guidance) keep the exact form.
+// A missile only uses its geodetic height for the air density 1.225 exp(-h / 9300): the local-curvature form
+// h0 + u + n^2 / 2(M0 + h) + e^2 / 2(N0 + h) is within 4 cm of the exact reduction over +-60 km of the battle-field centre (3.5 mm
+// within 40 km), i.e. a density error below 5e-6 -- smaller than what the fp32 flight model's centimetres of target position do to
+// an intercept -- and costs a handful of operations instead of ~160 fp64 ones with four square roots (neu_height64 above).
 __device__ __forceinline__ float missile_height(float n, float e, float u, const DevCfg& c) {
   return c.h0 + u + n * n / (2.0f * (c.rm0 + u)) + e * e / (2.0f * (c.rn0 + u));
 }
-__device__ __forceinline__ double missile_height(double n, double e, double u, const DevCfg& c) { return neu_height64(n, e, u, c); }
+__device__ __forceinline__ double missile_height(double n, double e, double u, const DevCfg& c) {
+  return (double)c.h0 + u + n * n / (2.0 * ((double)c.rm0 + u)) + e * e / (2.0 * ((double)c.rn0 + u));
+}
 // MissileSimulator.run (simulatior.py:520-533) with _guidance (:556-576) and _state_trans (:578-608).
 __device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
@@ -423,7 +425,7 @@ __device__ __forceinline__ void missile_run(MslD& m, const MslParam& P, double t
     m.status = MSL_MISS;
   } else {
     m.px += dt * m.vx; m.py += dt * m.vy; m.pz += dt * m.vz;
-    const double alt = neu_height64(m.px, m.py, m.pz, c);
+    const double alt = missile_height(m.px, m.py, m.pz, c);
     const double Tt = burning ? g * (double)P.Isp * (double)P.dm : 0.0;
     const double sd = sin(m.dth), sp = sin(m.dph);
     const double D0 = P.Diameter, L0 = P.Length;
