@@ -803,3 +803,31 @@ def test_multi_device_vec_env_matches_one_handle(pkg, task):
             assert a.shape == b.shape and (a == b).all(), step
         assert list(o1[-1]) == list(o2[-1])
     one.close(); many.close()
+
+
+@pytest.mark.parametrize("substeps", [1, 3, 12])
+def test_kernel_forms_agree_for_other_interaction_steps(pkg, monkeypatch, substeps):
+    """Every shipped YAML steps the FDM 6 times per env step; the three-wave form's tick-ahead hand-over is double-buffered by tick
+    parity, so other counts (one tick, an odd count, more ticks than buffers) are checked against the one-wave form here."""
+    cfg = pkg.default_config("singlecombat")
+    cfg.agent_interaction_steps = substeps
+    E = 40
+    envs = []
+    for form in ("0", "1"):
+        monkeypatch.setenv("AIRCOMBAT_SPLIT", form)
+        envs.append(pkg.HipVecEnv(cfg, E, seed=3))
+    o0, o1 = envs[0].reset(), envs[1].reset()
+    assert (o0 == o1).all()
+    rng = np.random.default_rng(21)
+    for step in range(20):
+        act = rand_actions(rng, E, 2, 4)
+        o0, r0, d0, i0 = envs[0].step(act)
+        o1, r1, d1, i1 = envs[1].step(act)
+        assert (d0 == d1).all(), step
+        assert obs_close(o0, o1, 0.25).all(), (step, np.abs(o0 - o1).max())
+        assert (np.abs(r0 - r1) <= 1e-3 + 2.5e-4 * np.abs(r1)).all(), step
+    names = envs[0].lib.state_field_names()
+    ticks = names.index("ticks")
+    assert envs[0].get_state(0, 0)[ticks] == envs[1].get_state(0, 0)[ticks] == 20 * substeps
+    for env in envs:
+        env.close()
