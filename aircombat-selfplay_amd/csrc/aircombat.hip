@@ -256,7 +256,11 @@ __device__ __forceinline__ Geo ao_ta_r(float ex, float ey, float ez, float evx, 
 }
 // posture_reward.py:58-75 (orientation v2, range v3)
 __device__ __forceinline__ float posture_fn(float AO, float TA, float Rkm) {
-  float x = 1.0f - fmaxf(2.0f * TA / f16::kPi, 1e-4f);
+  // TA = pi exactly (the target flying straight away along the line of sight) cannot happen in the reference: its float64 cosine
+  // stays above -1 by the 1e-8 in the denominator (utils.py:74-76) and atanh bottoms out near -8.5. In fp32 the cosine does round
+  // to -1 once the true angle is within 3.5e-4 rad of pi, and atanh(-1) would be -inf: the argument is kept one ulp inside
+  // (atanh = -8.66, the reference's own floor), so a reward is never infinite.
+  float x = fmaxf(1.0f - fmaxf(2.0f * TA / f16::kPi, 1e-4f), -0.99999994f);
   float orn = 1.0f / (50.0f * AO / f16::kPi + 2.0f) + 0.5f + fminf(atanhf(x) / (2.0f * f16::kPi), 0.0f) + 0.5f;
   float rng = (Rkm < 5.0f ? 1.0f : 0.0f) + (Rkm >= 5.0f ? clampf(0.0f, -0.032f * Rkm * Rkm + 0.284f * Rkm + 0.38f, 1.0f) : 0.0f) +
               clampf(0.0f, __expf(-0.16f * Rkm), 0.2f);

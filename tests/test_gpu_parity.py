@@ -831,3 +831,28 @@ def test_kernel_forms_agree_for_other_interaction_steps(pkg, monkeypatch, subste
     assert envs[0].get_state(0, 0)[ticks] == envs[1].get_state(0, 0)[ticks] == 20 * substeps
     for env in envs:
         env.close()
+
+
+@pytest.mark.parametrize("task", ["singlecombat", "singlecombat_shoot", "scenario1", "scenario_nvn", "multiplecombat", "heading"])
+def test_long_random_rollouts_stay_finite(pkg, task):
+    """Soak: 1500 env steps of random actions (crashes, shoot-downs, auto-resets, munitions) on 256 envs; every observation and
+    reward stays finite and inside the observation box where the task clips, step counters stay within the episode length."""
+    cfg = pkg.default_config(task)
+    A, E = cfg.n_agents, 256
+    # (the shipped NvN geometry is exactly head-on, TA = pi: PostureReward's atanh sits at its floor there; fp32 used to return -inf
+    #  at that point and, once in ~1e6 agent-steps, in flight -- which is how this test earned its place)
+    env = (pkg.HipShareVecEnv if A > 2 else pkg.HipVecEnv)(cfg, E, seed=9)
+    env.reset()
+    rng = np.random.default_rng(33)
+    pool = [rand_actions(rng, E, A, env.act_dim) for _ in range(16)]
+    ends = 0
+    for step in range(1500):
+        res = env.step(pool[step % 16])
+        obs, rew, done, infos = res[0], res[-3], res[-2], res[-1]
+        assert np.isfinite(obs).all() and np.isfinite(rew).all(), step
+        if task in ("singlecombat", "multiplecombat", "heading"):
+            assert np.abs(obs).max() <= 10.0
+        ends += int(done.all(axis=(1, 2)).sum())
+    assert ends > E // 4                                   # episodes really ended and restarted
+    assert max(i["current_step"] for i in infos) <= cfg.max_steps
+    env.close()
