@@ -833,7 +833,8 @@ def test_kernel_forms_agree_for_other_interaction_steps(pkg, monkeypatch, subste
         env.close()
 
 
-@pytest.mark.parametrize("task", ["singlecombat", "singlecombat_shoot", "scenario1", "scenario_nvn", "multiplecombat", "heading"])
+@pytest.mark.parametrize("task", ["singlecombat", "singlecombat_shoot", "singlecombat_dodge_missile", "scenario1", "scenario_nvn", "scenario3_nvn",
+                                  "multiplecombat", "wvr_lowlevel", "maneuver_lowlevel", "heading", "approach"])
 def test_long_random_rollouts_stay_finite(pkg, task):
     """Soak: 1500 env steps of random actions (crashes, shoot-downs, auto-resets, munitions) on 256 envs; every observation and
     reward stays finite and inside the observation box where the task clips, step counters stay within the episode length."""
@@ -850,9 +851,30 @@ def test_long_random_rollouts_stay_finite(pkg, task):
         res = env.step(pool[step % 16])
         obs, rew, done, infos = res[0], res[-3], res[-2], res[-1]
         assert np.isfinite(obs).all() and np.isfinite(rew).all(), step
-        if task in ("singlecombat", "multiplecombat", "heading"):
+        if task in ("singlecombat", "multiplecombat", "heading", "approach", "wvr_lowlevel", "maneuver_lowlevel"):
             assert np.abs(obs).max() <= 10.0
         ends += int(done.all(axis=(1, 2)).sum())
     assert ends > E // 4                                   # episodes really ended and restarted
     assert max(i["current_step"] for i in infos) <= cfg.max_steps
+    env.close()
+
+
+@pytest.mark.parametrize("task", ["hierarchical_singlecombat", "scenario1", "scenario_nvn"])
+def test_long_hierarchical_rollouts_stay_finite(pkg, task):
+    """The same soak through the as-shipped action space ([3,5,3] (+ weapon bits) -> controller_kernel -> step): 600 steps."""
+    cfg = pkg.default_config(task, hierarchical=True)
+    A, E = cfg.n_agents, 128
+    env = (pkg.HipShareVecEnv if A > 2 else pkg.HipVecEnv)(cfg, E, seed=4)
+    env.reset()
+    rng = np.random.default_rng(35)
+    ends = 0
+    for step in range(600):
+        hi = np.stack([rng.integers(0, n, size=(E, A)) for n in (3, 5, 3)], axis=-1).astype(np.float32)
+        act = hi if env.act_dim == 3 else np.concatenate([hi, (rng.random((E, A, env.act_dim - 3)) < 0.2).astype(np.float32)], axis=-1)
+        res = env.step(act)
+        obs, rew, done = res[0], res[-3], res[-2]
+        assert np.isfinite(obs).all() and np.isfinite(rew).all(), step
+        ends += int(done.all(axis=(1, 2)).sum())
+    hid, low = env.get_controller_state(0, 0)
+    assert np.isfinite(hid).all() and (0 <= low[:4]).all() and (low[:3] <= 40).all() and low[3] <= 29
     env.close()
