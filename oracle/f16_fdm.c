@@ -111,16 +111,23 @@ static double atm_reng(void) {
 }
 static double atm_lapse[8], atm_pb[9], atm_db[9];
 static int atm_ready = 0;
+/* CalculatePressureBreakpoints (FGStandardAtmosphere.cpp:461-481) for a temperature bias (SetTemperatureBias, :344-354; the
+ * reference never sets one: bias = 0 gives StdPressureBreakpoints). The biased form exists so that the reference's own
+ * TestDensityAltitude / TestPressureAltitude tables (delta-T = +-27 R rows) can pin the layer formulas. */
+static void atm_breakpoints(double bias, double* pb) {
+  double R = atm_reng();
+  pb[0] = ATM_SLP;
+  for (int b = 0; b < 8; b++) {
+    double Tmb = ATM_T[b] + bias, dH = ATM_H[b + 1] - ATM_H[b], L = atm_lapse[b];
+    if (L != 0.0) pb[b + 1] = pb[b] * pow(Tmb / (Tmb + L * dH), G0_FT / (R * L));
+    else pb[b + 1] = pb[b] * exp(-G0_FT * dH / (R * Tmb));
+  }
+}
 static void atm_init(void) {
   if (atm_ready) return;
   double R = atm_reng();
   for (int b = 0; b < 8; b++) atm_lapse[b] = (ATM_T[b + 1] - ATM_T[b]) / (ATM_H[b + 1] - ATM_H[b]);
-  atm_pb[0] = ATM_SLP;
-  for (int b = 0; b < 8; b++) {
-    double Tmb = ATM_T[b], dH = ATM_H[b + 1] - ATM_H[b], L = atm_lapse[b];
-    if (L != 0.0) atm_pb[b + 1] = atm_pb[b] * pow(Tmb / (Tmb + L * dH), G0_FT / (R * L));
-    else atm_pb[b + 1] = atm_pb[b] * exp(-G0_FT * dH / (R * Tmb));
-  }
+  atm_breakpoints(0.0, atm_pb);
   for (int b = 0; b < 9; b++) atm_db[b] = atm_pb[b] / (R * ATM_T[b]);
   atm_ready = 1;
 }
@@ -134,11 +141,16 @@ static double atm_temp_geopot(double gp) {
   if (f > 1.0) f = 1.0;
   return f * (ATM_T[r] - ATM_T[r - 1]) + ATM_T[r - 1];
 }
-void f16_atmosphere(double h, double* T, double* P, double* rho, double* snd, double* dens_alt) {
+/* GetTemperature (:232-256), GetPressure (:186-214), Density = P / (Reng T) (FGAtmosphere.cpp:107-131, dry air),
+ * CalculateDensityAltitude (:494-521), CalculatePressureAltitude (:525-553); `bias` = atmosphere/delta-T [R] */
+void f16_atmosphere_bias(double h, double bias, double* T, double* P, double* rho, double* snd, double* dens_alt, double* press_alt) {
   atm_init();
   double R = atm_reng();
+  double pbs[9];
+  const double* pb = atm_pb;
+  if (bias != 0.0) { atm_breakpoints(bias, pbs); pb = pbs; }
   double gp = h * ATM_EARTH_R / (ATM_EARTH_R + h);
-  *T = atm_temp_geopot(gp);
+  *T = atm_temp_geopot(gp) + bias;
   double base = ATM_H[0];
   int b;
   for (b = 0; b < 7; ++b) {
@@ -146,18 +158,29 @@ void f16_atmosphere(double h, double* T, double* P, double* rho, double* snd, do
     if (gp < test) break;
     base = test;
   }
-  double Tmb = atm_temp_geopot(base), dH = gp - base, L = atm_lapse[b];
-  if (L != 0.0) *P = atm_pb[b] * pow(Tmb / (Tmb + L * dH), G0_FT / (R * L));
-  else *P = atm_pb[b] * exp(-G0_FT * dH / (R * Tmb));
+  double Tmb = atm_temp_geopot(base) + bias, dH = gp - base, L = atm_lapse[b];
+  if (L != 0.0) *P = pb[b] * pow(Tmb / (Tmb + L * dH), G0_FT / (R * L));
+  else *P = pb[b] * exp(-G0_FT * dH / (R * Tmb));
   *rho = *P / (R * *T);
   *snd = sqrt(1.4 * R * *T);
-  /* CalculateDensityAltitude */
+  /* CalculateDensityAltitude: inverted on the STANDARD day's breakpoints */
   int k = 0;
   for (; k < 7; k++) if (*rho >= atm_db[k + 1]) break;
   double Tk = ATM_T[k], Hk = ATM_H[k], Lk = atm_lapse[k], pk = atm_db[k], da;
   if (Lk != 0.0) da = Hk + (Tk / Lk) * (pow(*rho / pk, -1.0 / (1.0 + G0_FT / (R * Lk))) - 1.0);
   else da = Hk + (-R * Tk / G0_FT) * log(*rho / pk);
   *dens_alt = da * ATM_EARTH_R / (ATM_EARTH_R - da);
+  if (press_alt) {
+    int j = 0;
+    for (; j < 7; j++) if (*P >= atm_pb[j + 1]) break;
+    double Tj = ATM_T[j], Hj = ATM_H[j], Lj = atm_lapse[j], Pj = atm_pb[j], pa;
+    if (Lj != 0.0) pa = Hj + (Tj / Lj) * (pow(*P / Pj, -R * Lj / G0_FT) - 1.0);
+    else pa = Hj + (-R * Tj / G0_FT) * log(*P / Pj);
+    *press_alt = pa * ATM_EARTH_R / (ATM_EARTH_R - pa);
+  }
+}
+void f16_atmosphere(double h, double* T, double* P, double* rho, double* snd, double* dens_alt) {
+  f16_atmosphere_bias(h, 0.0, T, P, rho, snd, dens_alt, 0);
 }
 
 /* S/FGJSBBase.cpp:245-296 */
@@ -612,6 +635,20 @@ static double turbine_calculate(F16State* s, double dt) {
   s->thrust = thrust;
   return thrust;
 }
+/* test hook: ONE FGTurbine::Run pass in phase Run from (n1, n2, n2norm) with the throttle position and density ratio given,
+ * through the very turbine_calculate() the tick uses. Pinned by the reference's TestTurbine.py (seek, default spool-up law,
+ * N1 / N2 spool-down factors 2.4 / 3.0). io = {n1, n2, n2norm} in and out. */
+void f16_test_turbine_run(double* io, double throttle_pos, double sigma, double dt) {
+  F16State s;
+  memset(&s, 0, sizeof s);
+  s.phase = TP_RUN; s.running = 1;
+  s.n1 = io[0]; s.n2 = io[1]; s.n2norm = io[2];
+  s.throttle_pos = throttle_pos;
+  s.T = 518.67; s.rho = sigma * (ATM_SLP / (atm_reng() * 518.67));
+  s.tank[0] = s.tank[1] = 1000.0;
+  turbine_calculate(&s, dt);
+  io[0] = s.n1; io[1] = s.n2; io[2] = s.n2norm;
+}
 /* FGPropulsion::Run + ConsumeFuel (S/models/FGPropulsion.cpp:113-258), FGTank::Drain (S/models/propulsion/FGTank.cpp:281-294) */
 static void propulsion_run(F16State* s, double dt) {
   double thrust = turbine_calculate(s, dt);
@@ -634,7 +671,8 @@ static void propulsion_run(F16State* s, double dt) {
 }
 
 /* ------------------------------------------------------------------ FGAerodynamics::Run (S/models/FGAerodynamics.cpp:132-300), f16.xml:994-1925 */
-static void aerodynamics_run(F16State* s) {
+/* the six axis sums (DRAG, SIDE, LIFT wind axes; ROLL, PITCH, YAW body axes), each function = product of its properties and table */
+static void aero_axis_sums(const F16State* s, double* o) {
   const double Sw = F16_WINGAREA, bw = F16_WINGSPAN, cbar = F16_CHORD;
   double twovel = 2 * s->vt, bi2vel = 0.0, ci2vel = 0.0;
   if (twovel != 0) { bi2vel = bw / twovel; ci2vel = cbar / twovel; }
@@ -684,6 +722,12 @@ static void aerodynamics_run(F16State* s) {
   n += qS * bw * da * TAB2(CNDA, a, b);
   n += qS * bw * dr * TAB2(CNDR, a, b);
   n += qS * bw * a * dr * TAB1(CNDR_M, M);
+  o[0] = D; o[1] = Y; o[2] = L; o[3] = l; o[4] = m; o[5] = n;
+}
+static void aerodynamics_run(F16State* s) {
+  double o[6];
+  aero_axis_sums(s, o);
+  const double D = o[0], Y = o[1], L = o[2], l = o[3], m = o[4], n = o[5];
   /* wind axes: drag and lift sign-flipped, rotated by Tw2b (:205-212) */
   double fw[3] = {-D, Y, -L};
   mv3(s->Tw2b, fw, s->f_aero);
@@ -694,6 +738,19 @@ static void aerodynamics_run(F16State* s) {
   s->m_aero[0] = l + mx[0]; s->m_aero[1] = m + mx[1]; s->m_aero[2] = n + mx[2];
 }
 
+/* test hook: the axis sums for given property values, in the order of tests/golden/make_f16_aero_check.py's PROPS (alpha, beta,
+ * mach, qbar, bi2vel, ci2vel, p, q, r aero, elevator, aileron, rudder, lef, flaperon-mix, speedbrake [rad], gear, h/b) */
+void f16_test_aero_sums(const double* in, double* out6) {
+  F16State s;
+  memset(&s, 0, sizeof s);
+  s.alpha = in[0]; s.beta = in[1]; s.mach = in[2]; s.qbar = in[3];
+  /* aerodynamics_run derives bi2vel = b / 2Vt and ci2vel = cbar / 2Vt from vt: hand it the vt that gives in[4], and check in[5] agrees */
+  s.vt = F16_WINGSPAN / (2.0 * in[4]);
+  s.aero_pqr[0] = in[6]; s.aero_pqr[1] = in[7]; s.aero_pqr[2] = in[8];
+  s.elevator_pos_rad = in[9]; s.aileron_pos_rad = in[10]; s.rudder_pos_rad = in[11]; s.lef_pos_rad = in[12];
+  s.flaperon_mix_rad = in[13]; s.speedbrake_pos_rad = in[14]; s.gear_pos_norm = in[15]; s.h_b_mac = in[16];
+  aero_axis_sums(&s, out6);
+}
 /* ------------------------------------------------------------------ FGAccelerations::Run (S/models/FGAccelerations.cpp:138-208) */
 static void accelerations_run(F16State* s) {
   double F[3], Mo[3];

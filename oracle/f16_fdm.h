@@ -88,10 +88,16 @@ void f16_refresh_derived(F16State* s);
 double f16_tab1(int off, int nr, double key);
 double f16_tab2(int off, int nr, int nc, double rkey, double ckey);
 void f16_atmosphere(double h_ft, double* T, double* P, double* rho, double* snd, double* dens_alt);
+/* the same with atmosphere/delta-T [R] (tests only: pins the layer formulas on the reference's TestDensityAltitude / TestPressureAltitude tables) */
+void f16_atmosphere_bias(double h_ft, double bias_R, double* T, double* P, double* rho, double* snd, double* dens_alt, double* press_alt);
 double f16_vcas_from_mach(double mach, double p);
 double f16_pitot_qc(double mach, double p);   /* impact pressure pt - p */
 double f16_vcas_from_qc(double qc);
 void f16_geodetic_from_ecef(const double r[3], double* lon, double* lat_gc, double* lat_geod, double* h_geod, double* radius);
+/* one FGTurbine::Run pass in phase Run (tests only); io = {n1, n2, n2norm} */
+void f16_test_turbine_run(double* io, double throttle_pos, double sigma, double dt);
+/* FGAerodynamics axis sums for given property values (tests only; order: tests/golden/make_f16_aero_check.py PROPS) */
+void f16_test_aero_sums(const double* in17, double* out6);
 double f16_kinemat(double out, double in, const double* detents, const double* times, int n, double dt);
 
 #ifdef __cplusplus

@@ -96,6 +96,9 @@ def lib():
         L.or_lla2neu.argtypes = [C.c_double] * 6 + [dp]
         L.or_neu2lla.argtypes = [C.c_double] * 6 + [dp]
         L.f16_atmosphere.argtypes = [C.c_double] + [dp] * 5
+        L.f16_atmosphere_bias.argtypes = [C.c_double, C.c_double] + [dp] * 6
+        L.f16_test_aero_sums.argtypes = [dp, dp]
+        L.f16_test_turbine_run.argtypes = [dp, C.c_double, C.c_double, C.c_double]
         L.f16_tab1.argtypes = [C.c_int, C.c_int, C.c_double]
         L.f16_tab1.restype = C.c_double
         L.f16_tab2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]

@@ -1,0 +1,162 @@
+"""The FDM oracle against what the reference itself holds for the generic JSBSim blocks it restates (the F-16 trajectory is
+unpinned, these blocks are not): the expectations of the reference's JSBSim unit tests (tests/golden/jsbsim_blocks.npz, written by
+make_jsbsim_blocks.py) and an independent reading of f16.xml / F100-PW-229.xml (tests/golden/f16_aero_check.npz, make_f16_aero_check.py)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def blocks():
+    return np.load(os.path.join(GOLD, "jsbsim_blocks.npz"))
+
+
+@pytest.fixture(scope="module")
+def aero():
+    return np.load(os.path.join(GOLD, "f16_aero_check.npz"))
+
+
+def atmosphere(L, h, bias):
+    o = [C.c_double() for _ in range(6)]
+    L.f16_atmosphere_bias(float(h), float(bias), *[C.byref(v) for v in o])
+    return dict(zip(("T", "P", "rho", "a", "density_alt", "pressure_alt"), (v.value for v in o)))
+
+
+def test_isa_walk_of_TestStdAtmosphere(oracle, blocks):
+    """TestStdAtmosphere.py check_temperature / check_pressure on the standard day and with delta-T = 15 K: T and P at every ISA
+    breakpoint, half way between them, at 91 / 100 km and at -1.5 km; the test's own criterion (ratio to 7 places)."""
+    L = oracle.lib()
+    for h, dT, T in blocks["isa_T"]:
+        assert abs(atmosphere(L, h, dT)["T"] / T - 1.0) < 5e-8, (h, dT)
+    for h, dT, P in blocks["isa_P"]:
+        assert abs(atmosphere(L, h, dT)["P"] / P - 1.0) < 5e-8, (h, dT)
+    T0, P0, rho0, a0 = blocks["isa_sl"]
+    sl = atmosphere(L, 0.0, 0.0)
+    assert abs(sl["T"] / T0 - 1) < 5e-8 and abs(sl["P"] / P0 - 1) < 5e-8 and abs(sl["rho"] - rho0) < 5e-8 and abs(sl["a"] / a0 - 1) < 5e-8
+
+
+def test_density_altitude_table_of_TestDensityAltitude(oracle, blocks):
+    """All 42 rows (0 .. 320 000 ft, delta-T in {0, -27, +27} R): every atmosphere layer of the pressure law and of the inversion."""
+    L = oracle.lib()
+    for h, dT, want in blocks["density_altitude"]:
+        got = atmosphere(L, h, dT)["density_alt"]
+        assert (abs(got) < 5e-8) if abs(want) < 1e-9 else (abs(got / want - 1.0) < 5e-8), (h, dT, got, want)
+
+
+def test_pressure_altitude_table_of_TestPressureAltitude(oracle, blocks):
+    L = oracle.lib()
+    for h, dT, want in blocks["pressure_altitude"]:
+        got = atmosphere(L, h, dT)["pressure_alt"]
+        assert abs(got - want) < 1e-7 * max(1.0, abs(want)) + 2e-7, (h, dT, got, want)    # the test's delta = 1e-7 on ~1e5 ft values is below fp64 noise of the 1.1.x build; relative here
+
+
+def test_standard_day_is_what_the_tick_uses(oracle):
+    """f16_atmosphere (called by the tick) IS f16_atmosphere_bias(bias = 0)."""
+    L = oracle.lib()
+    o = [C.c_double() for _ in range(5)]
+    for h in (0.0, 12345.6, 36100.0, 70000.0):
+        L.f16_atmosphere(h, *[C.byref(v) for v in o])
+        a = atmosphere(L, h, 0.0)
+        assert [v.value for v in o] == [a["T"], a["P"], a["rho"], a["a"], a["density_alt"]]
+
+
+def test_kinematic_sequence_of_TestKinematic(oracle, blocks):
+    """TestKinematic.testKinematicTiming: the c172r four-detent flap kinematic (0/10/20/30 deg in 0/2/1/1 s) through the command
+    sequence 1.5 (clamped), 0.25 (stops between detents), -1 (clamped), frame by frame at 1/120 s: 1200 expected angles."""
+    L = oracle.lib()
+    det, tt = blocks["kin_detents"], blocks["kin_times"]
+    n = len(det)
+    d = (C.c_double * n)(*det)
+    t = (C.c_double * n)(*tt)
+    dt = float(blocks["kin_dt"])
+    cmd = blocks["kin_cmd_by_frame"]
+    pos = np.zeros(len(cmd) + 1)
+    for k in range(len(cmd)):
+        pos[k + 1] = L.f16_kinemat(pos[k], float(cmd[k]), d, t, n, dt)
+    for frame, want in zip(blocks["kin_frame"], blocks["kin_expected"]):
+        assert abs(pos[frame] - want) < 5e-8, (frame, pos[frame], want)   # assertAlmostEqual: 7 places
+
+
+def test_turbine_spool_of_TestTurbine(oracle, blocks):
+    """TestTurbine.py: seek(), the default spool-up law delay / (1 + 3 (1 - n)^3 + (1 - sigma)) and the frame-by-frame N1 / N2 the
+    test predicts for the F100-PW-229 from idle to 100 % and back (N1 spools down 2.4x, N2 3x as fast), at two density ratios,
+    through the oracle's own turbine_calculate()."""
+    L = oracle.lib()
+    idleN1, maxN1, idleN2, maxN2, bpr = blocks["engine_consts"]
+    dt = float(blocks["spool_dt"])
+    io = (C.c_double * 3)()
+    for sigma, thr, n1, n2, n2norm, n1_next, n2_next in blocks["spool_traj"]:
+        io[0], io[1], io[2] = n1, n2, n2norm
+        L.f16_test_turbine_run(io, float(thr), float(sigma), dt)
+        assert abs(io[0] - n1_next) < 5e-8 and abs(io[1] - n2_next) < 5e-8, (sigma, thr, n1, n2)
+        assert abs(io[2] - (n2_next - idleN2) / (maxN2 - idleN2)) < 1e-12
+    # the law itself on a grid, seen through one spool-up step from idle-side states (target far above: the step IS the rate)
+    for n2norm, sigma, rate in blocks["spool_grid"]:
+        n2 = 60.0
+        io[0], io[1], io[2] = 50.0, n2, n2norm
+        L.f16_test_turbine_run(io, 1.0, float(sigma), dt)
+        assert abs((io[1] - n2) - rate) < 1e-10, (n2norm, sigma)
+
+
+def header_tables(path):
+    txt = open(path).read()
+    blob = np.array([float(v) for v in re.search(r"F16_TAB\[F16_TAB_LEN\] = \{(.*?)\};", txt, re.S).group(1).replace("\n", " ").split(",") if v.strip()])
+    tabs = {}
+    for m in re.finditer(r"#define T_(\w+)_OFF (\d+)\n#define T_\w+_NR (\d+)\n#define T_\w+_NC (\d+)", txt):
+        name, off, nr, nc = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))
+        if nc == 0:
+            tabs[name] = (blob[off:off + nr], np.zeros(0), blob[off + nr:off + 2 * nr], off, nr, nc)
+        else:
+            tabs[name] = (blob[off:off + nr], blob[off + nr:off + nr + nc], blob[off + nr + nc:off + nr + nc + nr * nc].reshape(nr, nc), off, nr, nc)
+    return tabs
+
+
+def xml_to_header_name(xml_name, engine):
+    base = xml_name.split("/")[-1].replace("-", "_").upper()
+    return ("ENG_" + base) if engine else base
+
+
+@pytest.mark.parametrize("header", ["oracle/f16_tables.h", "aircombat-selfplay_amd/csrc/f16_tables.h"])
+def test_every_table_against_the_independent_reading(aero, header):
+    """All 43 tables (35 aerodynamic incl. the 12x13 Clb / Cnb, 5 FCS schedules, 3 engine tables) of both generated headers, value
+    by value, against make_f16_aero_check.py's own tokenizer of the XML files."""
+    tabs = header_tables(os.path.join(ROOT, header))
+    names = [str(n) for n in aero["table_names"]]
+    assert len(names) == 43
+    seen = set()
+    for nm in names:
+        rk, ck, v = aero[f"tab|{nm}|rows"], aero[f"tab|{nm}|cols"], aero[f"tab|{nm}|vals"]
+        engine = nm in ("IdleThrust", "MilThrust", "AugThrust")
+        cands = [xml_to_header_name(nm, engine), "FCS_" + xml_to_header_name(nm, False)]
+        key = next(c for c in cands if c in tabs)
+        seen.add(key)
+        hrk, hck, hv = tabs[key][:3]
+        assert np.array_equal(hrk, rk) and np.array_equal(hck, ck) and np.array_equal(hv, v), nm
+    assert seen == set(tabs), set(tabs) - seen
+
+
+def test_aero_axis_sums_against_a_generic_reading_of_f16_xml(oracle, aero):
+    """FGAerodynamics::Run's per-axis summation: oracle/f16_fdm.c hard-codes which properties multiply which table; the fixture was
+    produced by interpreting the <aerodynamics> section generically. 400 random property sets, incl. beyond every table axis."""
+    L = oracle.lib()
+    X, Y = aero["aero_inputs"], aero["aero_sums"]
+    out = (C.c_double * 6)()
+    for x, y in zip(X, Y):
+        L.f16_test_aero_sums((C.c_double * len(x))(*x), out)
+        got = np.array(out[:])
+        assert np.all(np.abs(got - y) <= 1e-9 * np.maximum(1.0, np.abs(y))), (x, got, y)
+
+
+def test_engine_tables_through_the_oracle_lookup(oracle, aero):
+    L = oracle.lib()
+    tabs = header_tables(os.path.join(ROOT, "oracle", "f16_tables.h"))
+    for xml_name, key in (("IdleThrust", "ENG_IDLETHRUST"), ("MilThrust", "ENG_MILTHRUST"), ("AugThrust", "ENG_AUGTHRUST")):
+        off, nr, nc = tabs[key][3:]
+        for (m, h), want in zip(aero["eng_inputs"], aero["eng|" + xml_name]):
+            assert abs(L.f16_tab2(off, nr, nc, float(m), float(h)) - want) < 1e-12, (xml_name, m, h)
