@@ -318,18 +318,28 @@ double f16_kinemat(double out, double in, const double* det, const double* tt, i
   return out;
 }
 /* FGPID::Run (S/models/flight_control/FGPID.cpp:154-204); <ki> without type => Adams-Bashforth-2 (:84-98) */
-static double pid_run(OrPid* p, double in, double trigger, double kp, double ki, double kd, int clip) {
-  double dval = (in - p->in_prev) / FCS_DT;
+static double pid_run_dt(OrPid* p, double in, double trigger, double kp, double ki, double kd, int clip, double dt) {
+  double dval = (in - p->in_prev) / dt;
   double i_delta = 0.0;
   if (fabs(trigger) < 0.000001) i_delta = 1.5 * in - 0.5 * p->in_prev;
   if (trigger < 0.0) p->i_total = 0.0;
-  p->i_total += ki * FCS_DT * i_delta;
+  p->i_total += ki * dt * i_delta;
   double out = kp * in + p->i_total + kd * dval;
   p->in_prev2 = trigger < 0.0 ? 0.0 : p->in_prev;
   p->in_prev = in;
   if (clip) out = clampd(-1.0, out, 1.0);
   p->out = out;
   return out;
+}
+static double pid_run(OrPid* p, double in, double trigger, double kp, double ki, double kd, int clip) {
+  return pid_run_dt(p, in, trigger, kp, ki, kd, clip, FCS_DT);
+}
+/* test hook: one FGPID::Run at a given dt (the reference's TestIntegrators.py runs its <pid> blocks at 0.005 s); st = {in_prev, in_prev2, i_total, out} */
+double f16_test_pid(double* st, double in, double trigger, double kp, double ki, double kd, double dt) {
+  OrPid p = {st[0], st[1], st[2], st[3]};
+  double o = pid_run_dt(&p, in, trigger, kp, ki, kd, 0, dt);
+  st[0] = p.in_prev; st[1] = p.in_prev2; st[2] = p.i_total; st[3] = p.out;
+  return o;
 }
 
 /* f16.xml:317-992, channels in document order (S/models/FGFCS.cpp:153-178) */

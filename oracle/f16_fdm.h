@@ -98,6 +98,8 @@ void f16_geodetic_from_ecef(const double r[3], double* lon, double* lat_gc, doub
 void f16_test_turbine_run(double* io, double throttle_pos, double sigma, double dt);
 /* FGAerodynamics axis sums for given property values (tests only; order: tests/golden/make_f16_aero_check.py PROPS) */
 void f16_test_aero_sums(const double* in17, double* out6);
+/* one FGPID::Run at a given dt (tests only); st = {in_prev, in_prev2, i_total, out} */
+double f16_test_pid(double* st, double in, double trigger, double kp, double ki, double kd, double dt);
 double f16_kinemat(double out, double in, const double* detents, const double* times, int n, double dt);
 
 #ifdef __cplusplus

