@@ -83,6 +83,11 @@ SIGNATURES = {
     "ac_num_agents": (C.c_int, [_p]),
     "ac_reset": (C.c_int, [_p, _p]),
     "ac_step": (C.c_int, [_p, _p, _p, _p, _p, _p]),
+    "ac_host_buffers": (C.c_int, [_p, C.c_int32, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
+    "ac_step_host_async": (C.c_int, [_p, C.c_int32]),
+    "ac_step_host_wait": (C.c_int, [_p]),
+    "ac_order_after": (C.c_int, [_p, _p]),
+    "ac_order_before": (C.c_int, [_p, _p]),
     "ac_step_async_device": (C.c_int, [_p, _p]),
     "ac_device_buffers": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
     "ac_stream": (_p, [_p]),

@@ -118,7 +118,9 @@ struct DevPtrs {
   const float* tF; const int* tI; const double* tD;  // reset template, [field][A]
   const float* tab;                      // F16_PACK as fp32 in HBM (staged to LDS per workgroup)
   const float* actions;                  // [N][act_dim]
-  float* obs; float* rew; uint8_t* done; int* info;
+  float* obs; float* rew; uint8_t* done; int* info;        // outputs, rows padded to whole workgroups (64 aircraft)
+  float* obs2; float* rew2; uint8_t* done2; int* info2;    // second copy of the outputs (pinned host memory mapped into the device:
+                                                           // ac_step_host), or null
 };
 
 // ------------------------------------------------------------------------------------------------ device helpers
@@ -507,6 +509,54 @@ __device__ __forceinline__ void stage_tables(float* lds, const float* __restrict
   __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------ step outputs
+// The outputs of the 64 aircraft of a workgroup, written by ONE wave with every lane active. A lane's observation row is `ow`
+// floats (60-260 B): storing it lane by lane gives 64 partial-line writes per field, which the L2 merges for HBM but which cross
+// PCIe one by one when the destination is mapped host memory (ac_step_host) -- so the rows go through LDS and leave as contiguous
+// 16-byte vectors (the block's 64 * ow floats are contiguous in [N][ow]); done flags leave as 16 dwords built from a ballot, the
+// info row of an env as one 16-byte store. Output arrays are padded to whole workgroups, so the tail lanes of the last block
+// (which shadow the last env) write their copy into the padding: no bounds logic here.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int NOB>
+__device__ __forceinline__ void emit_outputs(const DevPtrs& P, float* lds /* [64 * ow], 16-byte aligned */, int ow, int lane, const float (&ob)[NOB],
+                                             float reward, bool done, int A, int i0, int i1, int i2, int i3) {
+  float* row = lds + lane * ow;
+#pragma unroll
+  for (int k = 0; k < NOB; ++k) if (k < ow) row[k] = ob[k];
+  for (int k = NOB; k < ow; ++k) row[k] = 0.0f;             // reserved slots of the *_RWR variants
+  wave_lds_fence();
+  const size_t blk = blockIdx.x;
+  const int nvec = 16 * ow;                                 // float4 count of the block's rows
+  const float4* l4 = reinterpret_cast<const float4*>(lds);
+  const unsigned long long dmask = __ballot(done);
+  unsigned dword = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) dword |= (unsigned)((dmask >> (4 * (lane & 15) + b)) & 1ull) << (8 * b);
+  const int4 inf = make_int4(i0, i1, i2, i3);
+  const size_t n = blk * 64 + lane;
+#pragma unroll
+  for (int set = 0; set < 2; ++set) {
+    float* obs = set ? P.obs2 : P.obs; float* rew = set ? P.rew2 : P.rew; uint8_t* dn = set ? P.done2 : P.done; int* info = set ? P.info2 : P.info;
+    if (!obs) continue;
+    float4* o4 = reinterpret_cast<float4*>(obs + blk * 64 * (size_t)ow);
+    for (int i = lane; i < nvec; i += 64) o4[i] = l4[i];
+    rew[n] = reward;
+    if (lane < 16) reinterpret_cast<unsigned*>(dn + blk * 64)[lane] = dword;
+    if (lane % A == 0) *reinterpret_cast<int4*>(info + (n / A) * 4) = inf;
+  }
+  wave_lds_fence();
+}
+// the four control indices of an aircraft's action row: one 16-byte load where the row width allows it (a row read from mapped
+// host memory then crosses PCIe as one request per 4 lanes instead of four)
+__device__ __forceinline__ float4 load_controls(const float* act, int act_dim) {
+  if ((act_dim & 3) == 0) return *reinterpret_cast<const float4*>(act);
+  return make_float4(act[0], act[1], act[2], act[3]);
+}
+
 // ------------------------------------------------------------------------------------------------ 1v1 observation
 // singlecombat_task.py:88-139 (15 values, 2-D AO/TA, clipped to +-10) and
 // singlecombat_with_missile_task.py:31-99 (21 values, 3-D AO/TA, unclipped, missile-warning block).
@@ -576,6 +626,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
   constexpr int OBS = TT::OBS;
   AC_CLK(0);
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
+  __shared__ __attribute__((aligned(16))) float lds_out[64 * OBS];
   __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : 16];
   SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
   const Tab T{lds_tab};
@@ -598,11 +649,11 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
   }
   AC_CLK(1);
   if (SPLIT) {   // helper waves: decode the commands they integrate, run their part of every substep, done
-    const float* act = P.actions + (size_t)nn * c.act_dim;
-    s.da = clampf(-1.0f, act[0] / 20.0f - 1.0f, 1.0f);
-    s.de = clampf(-1.0f, act[1] / 20.0f - 1.0f, 1.0f);
-    s.dr = clampf(-1.0f, act[2] / 20.0f - 1.0f, 1.0f);
-    s.thr = clampf(0.0f, act[3] / 58.0f + 0.4f, 0.9f);
+    const float4 a4 = load_controls(P.actions + (size_t)nn * c.act_dim, c.act_dim);
+    s.da = clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);
+    s.de = clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
+    s.dr = clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);
+    s.thr = clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
     if (split_helper_wave(s, t, T, L, l, c.substeps)) return;
   }
   Msl ms[MSLOTS];
@@ -621,11 +672,12 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
 
   // ---- apply actions (normalize_action, singlecombat_task.py:141-153; property bounds catalog.py:189-197)
   const float* act = P.actions + (size_t)nn * c.act_dim;
+  const float4 a4 = load_controls(act, c.act_dim);
   t.cur_step += 1;
-  s.da = clampf(-1.0f, act[0] / 20.0f - 1.0f, 1.0f);
-  s.de = clampf(-1.0f, act[1] / 20.0f - 1.0f, 1.0f);
-  s.dr = clampf(-1.0f, act[2] / 20.0f - 1.0f, 1.0f);
-  s.thr = clampf(0.0f, act[3] / 58.0f + 0.4f, 0.9f);
+  s.da = clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);
+  s.de = clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
+  s.dr = clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);
+  s.thr = clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
   if (TASK == AC_TASK_SHOOT_MISSILE) t.shoot_action = (act[4] != 0.0f) ? 1 : 0;  // singlecombat_with_missile_task.py:182-184
 
   // ---- substeps (env_base.py:139-154): every aircraft, then every missile against this substep's aircraft poses
@@ -845,19 +897,9 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
       for (int k = 0; k < MSLOTS; ++k)
         if (k < nslots && (ms[k].status != MSL_INACTIVE || ((msl_was_active >> k) & 1))) store_msl(P.MF, P.MI, N, n, k, ms[k]);
     }
-    float* o = P.obs + (size_t)n * OBS;
-#pragma unroll
-    for (int k = 0; k < OBS; ++k) o[k] = ob[k];
-    P.rew[n] = reward;
-    P.done[n] = done ? 1 : 0;
-    if (slot == 0) {
-      int* inf = P.info + (size_t)(n >> 1) * 4;
-      inf[0] = step_out;
-      inf[1] = other_code ? other_code : code;  // info['done_condition'] keeps the last agent's message
-      inf[2] = 0;
-      inf[3] = all_done ? 1 : 0;
-    }
   }
+  // info['done_condition'] keeps the last agent's message
+  emit_outputs(P, lds_out, OBS, l, ob, reward, done, 2, step_out, other_code ? other_code : code, 0, all_done ? 1 : 0);
   AC_CLK(54);
 }
 
@@ -932,6 +974,7 @@ template <int A, int WPE, bool SPLIT = false>
 __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs P, DevCfg c) {
   constexpr int OBS = 9 + 6 * (A - 1);
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
+  __shared__ __attribute__((aligned(16))) float lds_out[64 * OBS];
   __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : 16];
   SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
   stage_tables<SPLIT ? 192 : 64>(lds_tab, P.tab);
@@ -947,12 +990,12 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
 
   State s; Task t; Derived d; Props pr;
   load_state(P.F, P.I, P.D, N, nn, s, t);
-  const float* act = P.actions + (size_t)nn * c.act_dim;
+  const float4 a4 = load_controls(P.actions + (size_t)nn * c.act_dim, c.act_dim);
   t.cur_step += 1;
-  s.da = clampf(-1.0f, act[0] / 20.0f - 1.0f, 1.0f);   // multiplecombat_task.py:137-145
-  s.de = clampf(-1.0f, act[1] / 20.0f - 1.0f, 1.0f);
-  s.dr = clampf(-1.0f, act[2] / 20.0f - 1.0f, 1.0f);
-  s.thr = clampf(0.0f, act[3] / 58.0f + 0.4f, 0.9f);
+  s.da = clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);   // multiplecombat_task.py:137-145
+  s.de = clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
+  s.dr = clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);
+  s.thr = clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
   if (SPLIT && split_helper_wave(s, t, T, L, l, c.substeps)) return;
   bool have_pose = false;
   int nrun_split = 0;
@@ -1040,17 +1083,9 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
   }
   if (live) {
     store_state(P.F, P.I, P.D, N, n, s, t);
-    const int ow = c.legacy_obs ? 21 : OBS;    // (the template keeps the kernel's own OBS stride)
-    float* o = P.obs + (size_t)n * ow;
-#pragma unroll
-    for (int k = 0; k < OBS; ++k) if (k < ow) o[k] = ob[k];
-    P.rew[n] = reward;
-    P.done[n] = done ? 1 : 0;
-    if (slot == 0) {
-      int* inf = P.info + (size_t)(n / A) * 4;
-      inf[0] = step_out; inf[1] = last_code; inf[2] = 0; inf[3] = all_done ? 1 : 0;
-    }
   }
+  // (the template keeps the kernel's own OBS stride; hierarchical_multiplecombat_shoot puts out the first 21 values)
+  emit_outputs(P, lds_out, c.legacy_obs ? 21 : OBS, l, ob, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------ initial conditions
@@ -1247,6 +1282,10 @@ struct ac_env {
   HeadingPtrs hp; HeadingCfg hc;         // HeadingTask: targets, check clock, numpy-PCG64 state per env
   int act_low;                           // width of the low-level action the step kernels decode
   hipEvent_t ev0, ev1;
+  hipEvent_t ev_order;                   // stream-ordering hand-shake with the caller's streams (ac_order_after / ac_order_before)
+  // ac_step_host: two library-owned sets of pinned host buffers mapped into the device (actions in; obs, rewards, dones, info out)
+  struct HostSet { float* act; float* obs; float* rew; uint8_t* done; int* info; } hs[2];
+  bool have_hs;
   bool timing;
   bool split_waves;                      // SingleCombat below one wave per SIMD: three waves per 64 aircraft (step_kernel_1v1<.., SPLIT>)
 };
@@ -1260,9 +1299,13 @@ static void geodetic2ecef_m(double lat_deg, double lon_deg, double alt, double* 
   *z = (Nn * (b / a) * (b / a) + alt) * sin(lat);
 }
 
-static int launch_step(ac_env* h, const float* d_actions) {
+static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
   DevPtrs p = h->dp;
   p.actions = d_actions ? d_actions : h->d_actions;
+  if (host_set >= 0) {   // actions read from, and a second copy of every output written to, mapped host memory
+    const ac_env::HostSet& hs = h->hs[host_set];
+    p.actions = hs.act; p.obs2 = hs.obs; p.rew2 = hs.rew; p.done2 = hs.done; p.info2 = hs.info;
+  }
   dim3 block(64), grid((h->N + 63) / 64);
   if (h->cfg.hierarchical) {   // [3,5,3] (+ weapon bits) -> control indices, then the ordinary step on those
     if (!h->d_ctlW) return fail("hierarchical task: ac_load_controller has not been called");
@@ -1445,6 +1488,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   HIP_OK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIP_OK(hipEventCreate(&h->ev0));
   HIP_OK(hipEventCreate(&h->ev1));
+  HIP_OK(hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming));
   const size_t N = (size_t)h->N;
   DevPtrs& p = h->dp;
   HIP_OK(hipMalloc(&p.F, sizeof(float) * NF * N));
@@ -1455,10 +1499,13 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   p.MD = nullptr;
   if (scenario) HIP_OK(hipMalloc(&p.MD, sizeof(double) * ms * NMF * N));
   HIP_OK(hipMalloc(&p.MI, sizeof(int) * ms * NMI * N));
-  HIP_OK(hipMalloc(&p.obs, sizeof(float) * N * h->obs_dim));
-  HIP_OK(hipMalloc(&p.rew, sizeof(float) * N));
-  HIP_OK(hipMalloc(&p.done, N));
-  HIP_OK(hipMalloc(&p.info, sizeof(int) * 4 * h->E));
+  // outputs: rows padded to whole workgroups (emit_outputs stores whole blocks)
+  const size_t Npad = (N + 63) / 64 * 64;
+  HIP_OK(hipMalloc(&p.obs, sizeof(float) * Npad * h->obs_dim));
+  HIP_OK(hipMalloc(&p.rew, sizeof(float) * Npad));
+  HIP_OK(hipMalloc(&p.done, Npad));
+  HIP_OK(hipMalloc(&p.info, sizeof(int) * 4 * (Npad / h->A)));
+  p.obs2 = nullptr; p.rew2 = nullptr; p.done2 = nullptr; p.info2 = nullptr;
   HIP_OK(hipMalloc(&h->d_actions, sizeof(float) * N * h->act_dim));
   HIP_OK(hipMemset(h->d_actions, 0, sizeof(float) * N * h->act_dim));
   std::vector<float> tab(F16_PACK_LEN);
@@ -1538,7 +1585,9 @@ int ac_destroy(ac_env_t* h) {
   void* bufs[] = {h->dp.F, h->dp.I, h->dp.D, h->dp.MF, h->dp.MD, h->dp.MI, h->dp.obs, h->dp.rew, h->dp.done, h->dp.info,
                   h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_scripted, h->d_ctlW, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
   for (void* b : bufs) (void)hipFree(b);
-  (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1);
+  if (h->have_hs)
+    for (auto& hs : h->hs) { (void)hipHostFree(hs.act); (void)hipHostFree(hs.obs); (void)hipHostFree(hs.rew); (void)hipHostFree(hs.done); (void)hipHostFree(hs.info); }
+  (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); (void)hipEventDestroy(h->ev_order);
   (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -1568,6 +1617,67 @@ int ac_step(ac_env_t* h, const float* actions, float* obs, float* rewards, uint8
   if (dones) HIP_OK(hipMemcpyAsync(dones, h->dp.done, N, hipMemcpyDeviceToHost, h->stream));
   if (info) HIP_OK(hipMemcpyAsync(info, h->dp.info, sizeof(int) * 4 * h->E, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ---- zero-copy host boundary. The step kernel reads the actions straight from pinned host memory mapped into the device and
+// writes a second copy of its outputs there (whole 16-byte vectors, emit_outputs): no H2D / D2H copy commands, no staging, one
+// launch and one completion wait per step. Two buffer sets, so the arrays of step t stay untouched while step t+1 runs.
+int ac_host_buffers(ac_env_t* h, int32_t set, float** actions, float** obs, float** rewards, uint8_t** dones, int32_t** info) {
+  if (!h || set < 0 || set > 1) return fail("ac_host_buffers: bad argument");
+  HIP_OK(hipSetDevice(h->device));
+  if (!h->have_hs) {
+    const size_t Npad = ((size_t)h->N + 63) / 64 * 64;
+    for (auto& hs : h->hs) {
+      // hipHostMallocDefault: page-locked, mapped into the device's address space, coherent (kernel stores are visible to the host
+      // once the kernel has completed)
+      HIP_OK(hipHostMalloc((void**)&hs.act, sizeof(float) * Npad * h->act_dim, hipHostMallocDefault));
+      HIP_OK(hipHostMalloc((void**)&hs.obs, sizeof(float) * Npad * h->obs_dim, hipHostMallocDefault));
+      HIP_OK(hipHostMalloc((void**)&hs.rew, sizeof(float) * Npad, hipHostMallocDefault));
+      HIP_OK(hipHostMalloc((void**)&hs.done, Npad, hipHostMallocDefault));
+      HIP_OK(hipHostMalloc((void**)&hs.info, sizeof(int) * 4 * (Npad / h->A), hipHostMallocDefault));
+      memset(hs.act, 0, sizeof(float) * Npad * h->act_dim); memset(hs.obs, 0, sizeof(float) * Npad * h->obs_dim);
+      memset(hs.rew, 0, sizeof(float) * Npad); memset(hs.done, 0, Npad); memset(hs.info, 0, sizeof(int) * 4 * (Npad / h->A));
+    }
+    h->have_hs = true;
+  }
+  const ac_env::HostSet& hs = h->hs[set];
+  if (actions) *actions = hs.act;
+  if (obs) *obs = hs.obs;
+  if (rewards) *rewards = hs.rew;
+  if (dones) *dones = hs.done;
+  if (info) *info = hs.info;
+  return 0;
+}
+int ac_step_host_async(ac_env_t* h, int32_t set) {
+  if (!h || set < 0 || set > 1) return fail("ac_step_host_async: bad argument");
+  if (!h->have_hs) return fail("ac_step_host_async: call ac_host_buffers first");
+  HIP_OK(hipSetDevice(h->device));
+  return launch_step(h, nullptr, set);
+}
+int ac_step_host_wait(ac_env_t* h) {
+  if (!h) return fail("ac_step_host_wait: null handle");
+  // busy-poll the stream: the step is tens of microseconds, a blocking wait's wake-up would be a sizeable part of it
+  hipError_t e;
+  while ((e = hipStreamQuery(h->stream)) == hipErrorNotReady) __builtin_ia32_pause();
+  if (e != hipSuccess) return fail(std::string("ac_step_host_wait: ") + hipGetErrorString(e));
+  return 0;
+}
+
+// ---- stream ordering for the device-resident path: the handle's stream is non-blocking, so work on the caller's streams (a torch
+// policy writing the actions, a buffer reading the observations) is not ordered against the step kernel unless asked for.
+int ac_order_after(ac_env_t* h, void* producer_stream) {   // the next step waits for everything queued on producer_stream so far
+  if (!h) return fail("ac_order_after: null handle");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipEventRecord(h->ev_order, (hipStream_t)producer_stream));
+  HIP_OK(hipStreamWaitEvent(h->stream, h->ev_order, 0));
+  return 0;
+}
+int ac_order_before(ac_env_t* h, void* consumer_stream) {  // consumer_stream waits for every step queued so far
+  if (!h) return fail("ac_order_before: null handle");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipEventRecord(h->ev_order, h->stream));
+  HIP_OK(hipStreamWaitEvent((hipStream_t)consumer_stream, h->ev_order, 0));
   return 0;
 }
 

@@ -120,6 +120,7 @@ __device__ void heading_reset(const HeadingCfg& hc, const DevCfg& c, const Tab& 
 template <bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 192 : 64, SPLIT ? 1 : 2) void step_kernel_heading(DevPtrs P, DevCfg c, HeadingPtrs H, HeadingCfg hc, int reset_only) {
   constexpr int OBS = 12;
+  __shared__ __attribute__((aligned(16))) float lds_out[64 * OBS];
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
   __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : 16];
   SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
@@ -138,21 +139,18 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, SPLIT ? 1 : 2) void step_kernel_h
     if (live) {
       store_state(P.F, P.I, P.D, N, n, s, t);
       store_heading(H, N, n, x);
-      for (int k = 0; k < OBS; ++k) P.obs[(size_t)n * OBS + k] = ob[k];
-      P.rew[n] = 0.0f; P.done[n] = 0;
-      int* inf = P.info + (size_t)n * 4;
-      inf[0] = 0; inf[1] = 0; inf[2] = 0; inf[3] = 0;
     }
+    emit_outputs(P, lds_out, OBS, l, ob, 0.0f, false, 1, 0, 0, 0, 0);
     return;
   }
   load_state(P.F, P.I, P.D, N, nn, s, t);
-  const float* act = P.actions + (size_t)nn * c.act_dim;
+  const float4 a4 = load_controls(P.actions + (size_t)nn * c.act_dim, c.act_dim);
   t.cur_step += 1;
   // heading_task.py:102-110: a * 2 / (41 - 1) - 1 and a * 0.5 / (30 - 1) + 0.4, then the property bounds (catalog.py:189-197)
-  s.da = clampf(-1.0f, act[0] * (2.0f / 40.0f) - 1.0f, 1.0f);
-  s.de = clampf(-1.0f, act[1] * (2.0f / 40.0f) - 1.0f, 1.0f);
-  s.dr = clampf(-1.0f, act[2] * (2.0f / 40.0f) - 1.0f, 1.0f);
-  s.thr = clampf(0.0f, act[3] * (0.5f / 29.0f) + 0.4f, 0.9f);
+  s.da = clampf(-1.0f, a4.x * (2.0f / 40.0f) - 1.0f, 1.0f);
+  s.de = clampf(-1.0f, a4.y * (2.0f / 40.0f) - 1.0f, 1.0f);
+  s.dr = clampf(-1.0f, a4.z * (2.0f / 40.0f) - 1.0f, 1.0f);
+  s.thr = clampf(0.0f, a4.w * (0.5f / 29.0f) + 0.4f, 0.9f);
   if (SPLIT && split_helper_wave(s, t, T, L, l, c.substeps)) return;
   bool have_pose = false;
   int nrun_split = 0;
@@ -228,12 +226,6 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, SPLIT ? 1 : 2) void step_kernel_h
   if (live) {
     store_state(P.F, P.I, P.D, N, n, s, t);
     store_heading(H, N, n, x);
-    float* o = P.obs + (size_t)n * OBS;
-#pragma unroll
-    for (int k = 0; k < OBS; ++k) o[k] = ob[k];
-    P.rew[n] = reward;
-    P.done[n] = done ? 1 : 0;
-    int* inf = P.info + (size_t)n * 4;
-    inf[0] = step_out; inf[1] = code; inf[2] = turns_out; inf[3] = done ? 1 : 0;
   }
+  emit_outputs(P, lds_out, OBS, l, ob, reward, done, 1, step_out, code, turns_out, done ? 1 : 0);
 }

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_scenario(De
   constexpr int NE = SD::NE;
   constexpr int MS = 2;  // munition slots (uids) per aircraft
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
+  __shared__ __attribute__((aligned(16))) float lds_out[64 * (OBS + 2)];
   __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : 16];
   SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
   stage_tables<SPLIT ? 192 : 64>(lds_tab, P.tab);
@@ -117,16 +118,20 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_scenario(De
   // ---- actions: 4 control indices + [gun, AIM-9M, AIM-120B, chaff] (scenario1_task.py:33-48: Scenario1 only refreshes the ego
   // team's bits, its other team flies the scripted baseline with bits 0; scenario2_task.py:58-61 refreshes both teams)
   const float* act = P.actions + (size_t)nn * c.act_dim;
+  const float4 a4 = load_controls(act, c.act_dim);
   t.cur_step += 1;
-  s.da = clampf(-1.0f, act[0] / 20.0f - 1.0f, 1.0f);
-  s.de = clampf(-1.0f, act[1] / 20.0f - 1.0f, 1.0f);
-  s.dr = clampf(-1.0f, act[2] / 20.0f - 1.0f, 1.0f);
-  s.thr = clampf(0.0f, act[3] / 58.0f + 0.4f, 0.9f);
+  s.da = clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);
+  s.de = clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
+  s.dr = clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);
+  s.thr = clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
   const bool maneuver = !MULTI && c.task == AC_TASK_MANEUVER;   // Maneuver_curriculum (singlecombat_task.py:264-359)
   const bool gun_only = !MULTI && (c.task == AC_TASK_WVR || maneuver);   // WVRTask (WVR_task.py:10-90) / Maneuver_curriculum: no weapon bits
   const bool wvr = gun_only && !maneuver;
   if (!gun_only && (MULTI || team == 0))
-    x.bits = (act[4] != 0.0f ? 1 : 0) | (act[5] != 0.0f ? 2 : 0) | (act[6] != 0.0f ? 4 : 0) | (act[7] != 0.0f ? 8 : 0);
+  {
+    const float4 b4 = load_controls(act + 4, c.act_dim);   // (act_dim is 8 for every task with weapon bits)
+    x.bits = (b4.x != 0.0f ? 1 : 0) | (b4.y != 0.0f ? 2 : 0) | (b4.z != 0.0f ? 4 : 0) | (b4.w != 0.0f ? 8 : 0);
+  }
 
   const MslParam MP = aim120b();
   bool have_pose = false;
@@ -529,17 +534,9 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_scenario(De
     store_ext(XF, XI, N, n, x);
 #pragma unroll
     for (int k = 0; k < MS; ++k) store_msl(P.MD, P.MI, N, n, k, ms[k]);
-    float* o = P.obs + (size_t)n * c.obs_dim;
-#pragma unroll
-    for (int k = 0; k < OBS; ++k) if (k < c.obs_dim) o[k] = ob[k];   // (WVR uses the first 15 of the 21 slots)
-    for (int k = OBS; k < c.obs_dim; ++k) o[k] = 0.0f;   // the two reserved slots of the *_RWR variants
-    P.rew[n] = reward;
-    P.done[n] = done ? 1 : 0;
-    if (slot == 0) {
-      int* inf = P.info + (size_t)(n / A) * 4;
-      inf[0] = step_out; inf[1] = last_code; inf[2] = 0; inf[3] = all_done ? 1 : 0;
-    }
   }
+  // (WVR uses the first 15 of the 21 slots; the *_RWR variants append two reserved zero slots)
+  emit_outputs(P, lds_out, c.obs_dim, lane, ob, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);
 }
 
 // reset template for the scenario tasks: same initial-condition pass, scenario observation layout, potential seeds

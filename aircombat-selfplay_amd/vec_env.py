@@ -157,17 +157,28 @@ class HipVecEnv:
         else:
             self.action_space = MultiDiscrete([41, 41, 41, 30])
         E, A = self.num_envs, self.num_agents
-        # reusable host buffers; returned arrays are views that stay valid until the next step()/reset()
-        self._actions = np.zeros((E, A, self.act_dim), dtype=np.float32)
-        self._obs = np.zeros((E, A, self.obs_dim), dtype=np.float32)
-        self._rew = np.zeros((E, A, 1), dtype=np.float32)
-        self._done = np.zeros((E, A, 1), dtype=np.uint8)
-        self._info = np.zeros((E, 4), dtype=np.int32)
-        # page-lock the reusable buffers: H2D / D2H then run as direct DMA
-        self._pinned = []
-        for buf in (self._actions, self._obs, self._rew, self._done, self._info):
-            if self.lib.ac_pin_host_buffer(self._h, buf.ctypes.data, buf.nbytes) == 0:
-                self._pinned.append(buf)
+        # Two sets of page-locked host buffers owned by the library and mapped into the device (ac_host_buffers): the step kernel
+        # reads the actions from, and writes observations / rewards / dones / info into, the set of the step. step() alternates the
+        # sets, so what it returns stays untouched while the next step runs (the reference returns fresh arrays,
+        # env_wrappers.py:276-282, and its callers copy them into their buffers right away, runner/jsbsim_runner.py:104).
+        self._sets = []
+        for k in range(2):
+            ptrs = [C.c_void_p() for _ in range(5)]
+            self.lib.check(self.lib.ac_host_buffers(self._h, k, *[C.byref(p) for p in ptrs]), "ac_host_buffers")
+
+            def arr(ptr, shape, ctype):
+                n = int(np.prod(shape))
+                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).reshape(shape)
+
+            self._sets.append({
+                "actions": arr(ptrs[0], (E, A, self.act_dim), C.c_float),
+                "obs": arr(ptrs[1], (E, A, self.obs_dim), C.c_float),
+                "rew": arr(ptrs[2], (E, A, 1), C.c_float),
+                "done": arr(ptrs[3], (E, A, 1), C.c_uint8).view(np.bool_),     # the kernel writes 0 / 1
+                "info": arr(ptrs[4], (E, 4), C.c_int32),
+            })
+        self._cur = 0
+        self._actions = self._sets[0]["actions"]
 
     # ---- reference surface
     def seed(self, seed=None):
@@ -186,27 +197,30 @@ class HipVecEnv:
 
     def reset(self):
         self._assert_not_closed()
-        self.lib.check(self.lib.ac_reset(self._h, self._obs.ctypes.data), "ac_reset")
-        return self._obs.copy()
+        obs = self._sets[self._cur]["obs"]
+        self.lib.check(self.lib.ac_reset(self._h, obs.ctypes.data), "ac_reset")
+        return obs.copy()
 
     def step_async(self, actions):
+        """SubprocVecEnv.step_async (env_wrappers.py:269-273): hand the actions over and start the step."""
         self._assert_not_closed()
-        a = np.asarray(actions, dtype=np.float32)
-        if a.shape != self._actions.shape:
-            a = a.reshape(self._actions.shape)  # nested lists [E][A][act_dim] from the runners
-        np.copyto(self._actions, a)
+        self._cur ^= 1
+        dst = self._sets[self._cur]["actions"]
+        a = actions if isinstance(actions, np.ndarray) else np.asarray(actions, dtype=np.float32)
+        if a.shape != dst.shape:
+            a = a.reshape(dst.shape)  # nested lists [E][A][act_dim] from the runners
+        np.copyto(dst, a)             # into the mapped buffer the kernel reads
+        self.lib.check(self.lib.ac_step_host_async(self._h, self._cur), "ac_step_host_async")
         self.waiting = True
 
     def step_wait(self):
+        """SubprocVecEnv.step_wait (env_wrappers.py:275-282). The returned arrays are views of the step's buffer set: valid until
+        the step after next overwrites it (float32; the buffers cast on insert, algorithms/utils/buffer.py:52-58)."""
         self._assert_not_closed()
-        self.lib.check(self.lib.ac_step(self._h, self._actions.ctypes.data, self._obs.ctypes.data, self._rew.ctypes.data,
-                                        self._done.ctypes.data, self._info.ctypes.data), "ac_step")
+        self.lib.check(self.lib.ac_step_host_wait(self._h), "ac_step_host_wait")
         self.waiting = False
-        return self._obs.copy(), self._rew.copy(), self._done.astype(bool), self._infos()
-
-    def _infos(self):
-        """The workers' info dicts (env_wrappers.py:276-282), one per env, built when read: see LazyInfos."""
-        return LazyInfos(self._info.copy())
+        st = self._sets[self._cur]
+        return st["obs"], st["rew"], st["done"], LazyInfos(st["info"])
 
     def step(self, actions):
         self.step_async(actions)
@@ -254,9 +268,8 @@ class HipVecEnv:
     def close(self):
         if self.closed:
             return
-        for buf in self._pinned:
-            self.lib.ac_unpin_host_buffer(self._h, buf.ctypes.data)
-        self._pinned = []
+        self._sets = []           # views of library-owned memory: dropped before the handle frees it
+        self._actions = None
         self.lib.ac_destroy(self._h)
         self._h = None
         self.closed = True
@@ -291,9 +304,19 @@ class HipVecEnv:
         info = view(ptrs[4], (E, 4), "<i4")
         return act, obs, rew, done, info
 
-    def step_device(self, d_actions_ptr=None):
-        """Asynchronous step on device-resident actions; results stay in the device buffers."""
+    def step_device(self, d_actions_ptr=None, stream=None):
+        """Asynchronous step on device-resident actions; results stay in the device buffers.
+
+        The handle's stream is non-blocking, i.e. NOT ordered against torch's streams. ``stream`` (a ``torch.cuda.Stream``, a raw
+        ``hipStream_t`` value, or 0 for the default stream) names the stream that produced the actions and will consume the
+        outputs: the step then waits for the work queued on it so far, and it waits for the step, without any host sync. With
+        ``stream=None`` no ordering is added: the caller synchronises itself (``env.sync()`` / ``torch.cuda.synchronize()``)."""
+        if stream is not None:
+            raw = getattr(stream, "cuda_stream", stream)
+            self.lib.check(self.lib.ac_order_after(self._h, raw), "ac_order_after")
         self.lib.check(self.lib.ac_step_async_device(self._h, d_actions_ptr), "ac_step_async_device")
+        if stream is not None:
+            self.lib.check(self.lib.ac_order_before(self._h, raw), "ac_order_before")
 
     def sync(self):
         self.lib.check(self.lib.ac_sync(self._h), "ac_sync")

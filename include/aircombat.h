@@ -110,12 +110,27 @@ int ac_reset(ac_env_t* h, float* obs);
  * terminal reward/done, like worker() does (env_wrappers.py:191-204). */
 int ac_step(ac_env_t* h, const float* actions, float* obs, float* rewards, uint8_t* dones, int32_t* info);
 
+/* Zero-copy form of the same step for the VecEnv shim: the library owns two sets of page-locked host buffers that are mapped into
+ * the device (rows padded to a multiple of 64 aircraft); the step kernel reads the actions of set `set` straight from host memory
+ * and writes obs / rewards / dones / info of the step into the same set -- no copy commands. The caller fills the action buffer,
+ * calls ac_step_host_async (= SubprocVecEnv.step_async, R/envs/env_wrappers.py:269-273) and ac_step_host_wait (= step_wait,
+ * :275-282); alternating the two sets keeps the arrays of one step valid while the next one runs. The device buffers of
+ * ac_device_buffers are written as well. ac_reset(h, obs) may be pointed at a set's obs buffer. */
+int ac_host_buffers(ac_env_t* h, int32_t set, float** actions, float** obs, float** rewards, uint8_t** dones, int32_t** info);
+int ac_step_host_async(ac_env_t* h, int32_t set);
+int ac_step_host_wait(ac_env_t* h);
+
 /* Device-resident variant of the same step: d_actions is a DEVICE pointer (or NULL to use the
  * handle's own action buffer); results stay in the handle's device buffers; asynchronous on the handle's stream. */
 int ac_step_async_device(ac_env_t* h, const float* d_actions);
 int ac_device_buffers(ac_env_t* h, float** d_actions, float** d_obs, float** d_rewards, uint8_t** d_dones, int32_t** d_info);
-void* ac_stream(ac_env_t* h);   /* hipStream_t the kernels are launched on */
+void* ac_stream(ac_env_t* h);   /* hipStream_t the kernels are launched on (created non-blocking: NOT ordered against other streams) */
 int ac_sync(ac_env_t* h);
+/* Ordering against the caller's streams without a host sync: ac_order_after makes the steps launched from now on wait for the work
+ * already queued on `producer_stream` (the policy that wrote the actions); ac_order_before makes `consumer_stream` wait for the
+ * steps launched so far (whoever reads obs / rewards / dones next). NULL = the device's default stream. */
+int ac_order_after(ac_env_t* h, void* producer_stream);
+int ac_order_before(ac_env_t* h, void* consumer_stream);
 
 /* test/render access, mirrors env.agents[uid] property reads and env.agents[uid].crash() (R/tests/test_jsbsim.py:147-186) */
 int ac_get_state(ac_env_t* h, int32_t env, int32_t agent, double* out /* [AC_STATE_LEN] */);

@@ -284,12 +284,13 @@ class OracleEnv:
 class OracleVecEnv:
     """E oracle envs behind the reference's VecEnv semantics (auto-reset when every agent is done)."""
 
-    def __init__(self, cfg, num_envs, chaff_seed=None):
+    def __init__(self, cfg, num_envs, chaff_seed=None, env_ids=None):
+        """``env_ids``: which envs of a larger batch these are (a sample of a full-size product batch replayed here)."""
         self.envs = []
         for e in range(num_envs):
             if chaff_seed is not None:   # the product keys its decoy draws with seed + env index
                 cfg = copy_config(cfg)
-                cfg.chaff_seed = chaff_seed + e
+                cfg.chaff_seed = chaff_seed + (env_ids[e] if env_ids is not None else e)
             self.envs.append(OracleEnv(cfg))
         self.num_envs = num_envs
         self.num_agents = cfg.n_aircraft

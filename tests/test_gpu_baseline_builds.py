@@ -1,0 +1,116 @@
+"""Every kernel build a BASELINE config launches, against the oracle.
+
+ac_create picks the kernel build from the grid size and the task, so a small-batch parity test only ever sees the small-grid build
+of a task. These tests run the BASELINE shapes themselves -- C3 (1v1 with munitions), C4 (2v2) and C5 (4v4) at 4096 envs per GPU --
+and a > 1024-workgroup batch, replay a sample of envs on the oracle, and hold them to per-element tolerances (no aggregate pass
+criteria). The flight state of the sampled envs is re-synchronised from the oracle before every step (fp32 vs fp64 open-loop
+divergence through the discontinuous FCS is not a kernel error); munitions, chaff, decoy draws and all weapon bookkeeping run
+open-loop on both sides."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from parity_util import TASK_FIELDS, RewardBound, assert_obs, team_max
+
+
+def make_cfg(pkg, task, per_side):
+    if per_side == 1:
+        cfg = pkg.default_config(task)
+        if task != "singlecombat":          # close and nose-on: munitions fly during the comparison
+            cfg.init[1].lon_deg, cfg.init[1].lat_geod_deg, cfg.init[1].psi_deg = 120.02, 60.06, 171.0
+            cfg.init[0].psi_deg = 9.0
+        return cfg
+    cfg = pkg.default_nvn_config(per_side, task=task)
+    for i in range(2 * per_side):           # off the shipped exactly-head-on geometry (PostureReward's atanh is singular at TA = pi)
+        cfg.init[i].lon_deg += 0.013 * (i % 3) + (0.02 if i >= per_side else 0.0)
+        cfg.init[i].psi_deg = (7.0 + 3.0 * i) if i < per_side else (171.0 + 2.0 * i)
+        cfg.init[i].h_sl_ft += 300.0 * i
+        if i >= per_side and task == "scenario_nvn":
+            cfg.init[i].lat_geod_deg = 60.06
+    return cfg
+
+
+def actions_for(rng, E, A, act_dim, gentle):
+    a = np.stack([rng.integers(0, n, size=(E, A)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
+    if gentle:
+        a = (np.array([20, 18.6, 20, 15], dtype=np.float32) + rng.integers(-2, 3, size=(E, A, 4))).astype(np.float32)
+    if act_dim > 4:
+        a = np.concatenate([a, (rng.random((E, A, act_dim - 4)) < (0.6 if gentle else 0.3)).astype(np.float32)], axis=-1)
+    return a
+
+
+def run_sampled(pkg, oracle, task, per_side, E, sample, steps, seed=77, expect_kernel=None):
+    cfg = make_cfg(pkg, task, per_side)
+    A = cfg.n_agents
+    cls = pkg.HipShareVecEnv if A > 2 else pkg.HipVecEnv
+    env = cls(cfg, E, seed=seed)
+    ocfg = oracle.config_from_ac(cfg)
+    ref = oracle.OracleVecEnv(ocfg, len(sample), chaff_seed=seed, env_ids=sample)
+    out = env.reset()
+    obs = out[0] if A > 2 else out
+    robs = ref.reset()
+    assert_obs(obs[sample], robs, 1.0, "reset")
+    names = env.lib.state_field_names()
+    ix = {nm: k for k, nm in enumerate(names) if nm}
+    fdm_fields = np.array([k for k, nm in enumerate(names) if nm and not nm.startswith("x_") and nm not in TASK_FIELDS])
+    weapons = task not in ("singlecombat", "multiplecombat")
+    nvn_order = A > 2
+    # where the enemies' geometry blocks sit in the oracle's observation (for the reward conditioning)
+    n_en = max(1, A // 2)
+    en_from = 9 + 6 * (A // 2 - 1) if (A > 2 and not cfg.legacy_obs) else 9
+    rng = np.random.default_rng(seed)
+    launched = 0
+    bound = RewardBound(cfg.posture_scale, en_from, n_en, 10.0 if weapons else 1.0)
+    for step in range(steps):
+        for k, e in enumerate(sample):
+            for a in range(A):
+                v = env.get_state(e, a)
+                v[fdm_fields] = ref.envs[k].export_state(a)[fdm_fields]
+                env.set_state(e, a, v)
+        act = actions_for(rng, E, A, env.act_dim, gentle=weapons)
+        res = env.step(act)
+        obs, rew, done = (res[0], res[2], res[3]) if A > 2 else (res[0], res[1], res[2])
+        robs, rrew, rdone, rinfo = ref.step(act[sample])
+        assert (done[sample] == rdone).all(), (task, step, done[sample][..., 0], rdone[..., 0])
+        sc = 10.0 if weapons else 1.0      # munition poses integrate open-loop in fp64 against fp32 target poses
+        assert_obs(obs[sample], robs, sc, (task, step))
+        rt = bound(rrew, robs)
+        if nvn_order:
+            rt = team_max(rt, A)
+        bad = np.abs(rew[sample] - rrew) > rt
+        assert not bad.any(), (task, step, np.argwhere(bad)[:4].tolist(), rew[sample][bad][:4], rrew[bad][:4], rt[bad][:4])
+        if weapons:
+            launched = max(launched, max(len(r.missiles()) for r in ref.envs))
+    if weapons:
+        assert launched >= 1, "no munition flew during the comparison"
+    env.close()
+
+
+SAMPLE_4096 = [0, 1, 7, 8, 2047, 2048, 4094, 4095]     # first / last env, workgroup edges
+
+
+@pytest.mark.parametrize("task,per_side", [("singlecombat_shoot", 1), ("scenario1", 1), ("singlecombat_dodge_missile", 1),
+                                           ("multiplecombat", 2), ("scenario_nvn", 2),
+                                           ("multiplecombat", 4), ("scenario_nvn", 4)])
+def test_baseline_shapes_sampled_envs_match_oracle(pkg, oracle, task, per_side):
+    """C3 (4096 envs x 2 aircraft with missiles), C4 (4096 envs x 4) and C5 (4096 envs x 8: 512 workgroups) as the driver's bench
+    launches them: 8 sampled envs on the oracle, 40 steps, per-element bounds."""
+    run_sampled(pkg, oracle, task, per_side, 4096, SAMPLE_4096, 100 if task == "singlecombat_dodge_missile" else 40)
+
+
+@pytest.mark.parametrize("task,per_side", [("singlecombat", 1), ("singlecombat_shoot", 1), ("scenario1", 1), ("multiplecombat", 4), ("scenario_nvn", 2), ("scenario_nvn", 4)])
+def test_saturating_grid_builds_sampled_envs_match_oracle(pkg, oracle, task, per_side):
+    """> 1024 workgroups (70 000 aircraft): the two-waves-per-SIMD builds, sampled envs on the oracle."""
+    A = 2 * per_side
+    E = 70000 // A
+    run_sampled(pkg, oracle, task, per_side, E, [0, 1, E // 2, E - 2, E - 1], 25)
+
+
+@pytest.mark.parametrize("task,per_side", [("singlecombat_shoot", 1), ("scenario1", 1), ("scenario_nvn", 4), ("multiplecombat", 4)])
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_small_batch_both_kernel_forms_match_oracle(pkg, oracle, monkeypatch, task, per_side, split):
+    """AIRCOMBAT_SPLIT pins the one-wave (0) or the cooperative multi-wave (1) form at a small batch: both against the oracle for the
+    munition tasks and A = 8, every env compared."""
+    monkeypatch.setenv("AIRCOMBAT_SPLIT", split)
+    run_sampled(pkg, oracle, task, per_side, 6, list(range(6)), 60)
