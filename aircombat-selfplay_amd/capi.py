@@ -86,6 +86,7 @@ SIGNATURES = {
     "ac_host_buffers": (C.c_int, [_p, C.c_int32, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
     "ac_step_host_async": (C.c_int, [_p, C.c_int32]),
     "ac_step_host_wait": (C.c_int, [_p]),
+    "ac_step_host": (C.c_int, [_p, C.c_int32]),
     "ac_order_after": (C.c_int, [_p, _p]),
     "ac_order_before": (C.c_int, [_p, _p]),
     "ac_step_async_device": (C.c_int, [_p, _p]),

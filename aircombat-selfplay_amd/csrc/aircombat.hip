@@ -85,6 +85,9 @@ template <typename R>
 struct MslT {
   R px, py, pz, vx, vy, vz, theta, psi, t, m, dth, dph, dprev;
   int status, recede, order;
+  int dpos;   // position of the munition's uid in env._tempsims (the dict is walked in insertion order, and a uid that is launched again
+              // keeps its place): (env step << 4 | agent) of the FIRST launch into this slot since the reset; kept in the upper bits of
+              // the `recede` word in HBM
 };
 using Msl = MslT<float>;
 using MslD = MslT<double>;
@@ -130,33 +133,49 @@ struct DevPtrs {
 #define AC_LANE_INDEX(n) const unsigned un_ = (unsigned)(n), uN_ = (unsigned)N
 #define AC_AT(base, f) \
   (*(decltype(base))((char*)(base) + (size_t)((unsigned)(f) * (uN_ * (unsigned)sizeof(*(base))) + un_ * (unsigned)sizeof(*(base)))))
-__device__ __forceinline__ void load_state(const float* F, const int* I, const double* D, int N, int n, State& s, Task& t) {
+// the flight-dynamics part of an aircraft's state (what the FDM tick reads and writes) ...
+__device__ __forceinline__ void load_flight(const float* F, const int* I, const double* D, int N, int n, State& s) {
   AC_LANE_INDEX(n);
 #define X(f) s.f = AC_AT(F, FF_##f);
   AC_F_FIELDS(X)
 #undef X
-#define X(f) t.f = AC_AT(F, FF_##f);
-  AC_TF_FIELDS(X)
-#undef X
   s.eng = AC_AT(I, FI_eng); s.ticks = AC_AT(I, FI_ticks);
-#define X(f) t.f = AC_AT(I, FI_##f);
-  AC_TI_FIELDS(X)
-#undef X
   s.rx = AC_AT(D, 0); s.ry = AC_AT(D, 1); s.rz = AC_AT(D, 2);
 }
-__device__ __forceinline__ void store_state(float* F, int* I, double* D, int N, int n, const State& s, const Task& t) {
+__device__ __forceinline__ void store_flight(float* F, int* I, double* D, int N, int n, const State& s) {
   AC_LANE_INDEX(n);
 #define X(f) AC_AT(F, FF_##f) = s.f;
   AC_F_FIELDS(X)
 #undef X
+  AC_AT(I, FI_eng) = s.eng; AC_AT(I, FI_ticks) = s.ticks;
+  AC_AT(D, 0) = s.rx; AC_AT(D, 1) = s.ry; AC_AT(D, 2) = s.rz;
+}
+// ... and the task bookkeeping (what the environment layer reads and writes)
+__device__ __forceinline__ void load_task(const float* F, const int* I, int N, int n, Task& t) {
+  AC_LANE_INDEX(n);
+#define X(f) t.f = AC_AT(F, FF_##f);
+  AC_TF_FIELDS(X)
+#undef X
+#define X(f) t.f = AC_AT(I, FI_##f);
+  AC_TI_FIELDS(X)
+#undef X
+}
+__device__ __forceinline__ void store_task(float* F, int* I, int N, int n, const Task& t) {
+  AC_LANE_INDEX(n);
 #define X(f) AC_AT(F, FF_##f) = t.f;
   AC_TF_FIELDS(X)
 #undef X
-  AC_AT(I, FI_eng) = s.eng; AC_AT(I, FI_ticks) = s.ticks;
 #define X(f) AC_AT(I, FI_##f) = t.f;
   AC_TI_FIELDS(X)
 #undef X
-  AC_AT(D, 0) = s.rx; AC_AT(D, 1) = s.ry; AC_AT(D, 2) = s.rz;
+}
+__device__ __forceinline__ void load_state(const float* F, const int* I, const double* D, int N, int n, State& s, Task& t) {
+  load_flight(F, I, D, N, n, s);
+  load_task(F, I, N, n, t);
+}
+__device__ __forceinline__ void store_state(float* F, int* I, double* D, int N, int n, const State& s, const Task& t) {
+  store_flight(F, I, D, N, n, s);
+  store_task(F, I, N, n, t);
 }
 template <typename R>
 __device__ __forceinline__ void load_msl(const R* MF, const int* MI, int N, int n, int slot, MslT<R>& m) {
@@ -167,7 +186,9 @@ __device__ __forceinline__ void load_msl(const R* MF, const int* MI, int N, int 
   m.vx = AC_AT(f, MF_vx); m.vy = AC_AT(f, MF_vy); m.vz = AC_AT(f, MF_vz);
   m.theta = AC_AT(f, MF_theta); m.psi = AC_AT(f, MF_psi); m.t = AC_AT(f, MF_t); m.m = AC_AT(f, MF_m);
   m.dth = AC_AT(f, MF_dth); m.dph = AC_AT(f, MF_dph); m.dprev = AC_AT(f, MF_dprev);
-  m.status = AC_AT(i, MI_status); m.recede = AC_AT(i, MI_recede); m.order = AC_AT(i, MI_order);
+  m.status = AC_AT(i, MI_status); m.order = AC_AT(i, MI_order);
+  const int rw = AC_AT(i, MI_recede);
+  m.recede = rw & 511; m.dpos = rw >> 9;
 }
 template <typename R>
 __device__ __forceinline__ void store_msl(R* MF, int* MI, int N, int n, int slot, const MslT<R>& m) {
@@ -178,7 +199,7 @@ __device__ __forceinline__ void store_msl(R* MF, int* MI, int N, int n, int slot
   AC_AT(f, MF_vx) = m.vx; AC_AT(f, MF_vy) = m.vy; AC_AT(f, MF_vz) = m.vz;
   AC_AT(f, MF_theta) = m.theta; AC_AT(f, MF_psi) = m.psi; AC_AT(f, MF_t) = m.t; AC_AT(f, MF_m) = m.m;
   AC_AT(f, MF_dth) = m.dth; AC_AT(f, MF_dph) = m.dph; AC_AT(f, MF_dprev) = m.dprev;
-  AC_AT(i, MI_status) = m.status; AC_AT(i, MI_recede) = m.recede; AC_AT(i, MI_order) = m.order;
+  AC_AT(i, MI_status) = m.status; AC_AT(i, MI_recede) = (m.dpos << 9) | m.recede; AC_AT(i, MI_order) = m.order;
 }
 
 // task.reset() of the hierarchical tasks clears _inner_rnn_states (singlecombat_task.py:258-262)
@@ -202,22 +223,26 @@ struct Props {
 };
 __device__ __forceinline__ float mps(float fps) { return clampf(-700.0f, fps * f16::kFt2M, 700.0f); }
 
-__device__ __forceinline__ void make_props(const State& s, const Derived& d, const DevCfg& c, Props& p) {
+// the part a munition's guidance reads: NEU position (fp64 and rounded), NED velocity, altitude
+__device__ __forceinline__ void make_pose(const Derived& d, const DevCfg& c, Props& p) {
   p.alt_m = clampf(-500.0f, d.h_sl_ft * f16::kFt2M, 26000.0f);
   p.vn = mps(d.vn); p.ve = mps(d.ve); p.vd = mps(d.vd);
-  p.ub = mps(d.u); p.vb = mps(d.v); p.wb = mps(d.w);
-  p.vc = clampf(0.0f, f16::vcas_from_impact_pressure(s.qc) * f16::kFt2M, 1400.0f);
   // LLA2NEU(lon, lat_geod, h_sl_m): the reference feeds the sea-level altitude to pymap3d.geodetic2ned as if it
   // were ellipsoidal height (simulatior.py:240-245, utils.py:30-41). fp64: differences of 6.4e6 m ECEF coordinates.
   const double a = 6378137.0, b = 6356752.314245179;  // pymap3d WGS84: a, a*(1-1/298.257223563)
   double sl = d.sLat64, cl = d.cLat64, so = d.sLon64, co = d.cLon64;
-  double Nn = a * a / sqrt(a * a * cl * cl + b * b * sl * sl);
+  double Nn = a * a * fx::rsqrt(a * a * cl * cl + b * b * sl * sl);
   double h = (double)p.alt_m;
   double x = (Nn + h) * cl * co, y = (Nn + h) * cl * so, z = (Nn * (b / a) * (b / a) + h) * sl;
   double dx = x - c.P0x, dy = y - c.P0y, dz = z - c.P0z;
   double t = c.cLon0 * dx + c.sLon0 * dy;
   p.e64 = -c.sLon0 * dx + c.cLon0 * dy; p.u64 = c.cLat0 * t + c.sLat0 * dz; p.n64 = -c.sLat0 * t + c.cLat0 * dz;
   p.e = (float)p.e64; p.u = (float)p.u64; p.n = (float)p.n64;
+}
+__device__ __forceinline__ void make_props(const State& s, const Derived& d, const DevCfg& c, Props& p) {
+  make_pose(d, c, p);
+  p.ub = mps(d.u); p.vb = mps(d.v); p.wb = mps(d.w);
+  p.vc = clampf(0.0f, f16::vcas_from_impact_pressure(s.qc) * f16::kFt2M, 1400.0f);
   // Euler sines/cosines from Tl2b = Ti2b * Ti2l^T  (only the five entries GetEuler reads)
   const float* T = d.T;
   float m13 = T[0] * d.d_eci[0] + T[1] * d.d_eci[1] + T[2] * d.d_eci[2];
@@ -332,7 +357,7 @@ __device__ __forceinline__ float missile_height(float n, float e, float u, const
   return c.h0 + u + n * n / (2.0f * (c.rm0 + u)) + e * e / (2.0f * (c.rn0 + u));
 }
 __device__ __forceinline__ double missile_height(double n, double e, double u, const DevCfg& c) {
-  return (double)c.h0 + u + n * n / (2.0 * ((double)c.rm0 + u)) + e * e / (2.0 * ((double)c.rn0 + u));
+  return (double)c.h0 + u + n * n * fx::rcp(2.0 * ((double)c.rm0 + u)) + e * e * fx::rcp(2.0 * ((double)c.rn0 + u));
 }
 // MissileSimulator.run (simulatior.py:520-533) with _guidance (:556-576) and _state_trans (:578-608).
 __device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
@@ -364,7 +389,7 @@ __device__ __forceinline__ void missile_run(MslT<R>& m, const MslParam& P, R tx,
   R K = fmax((R)P.K * (t_max - m.t) / t_max, (R)0);
   R ny = m_clamp(-nyz_max, K * vm / g * cth * dbeta, nyz_max);
   R nz = m_clamp(-nyz_max, K * vm / g * deps + cth, nyz_max);
-  m.recede = (Rxyz > m.dprev) ? m.recede + 1 : 0;
+  m.recede = (Rxyz > m.dprev) ? min(m.recede + 1, P.recede_max) : 0;   // (300 in a row decide; the count saturates there)
   m.dprev = Rxyz;
   if (Rxyz < (R)P.Rc && target_alive && m.status != MSL_MISS) {
     m.status = MSL_HIT;
@@ -412,18 +437,18 @@ __device__ __forceinline__ void missile_run(MslD& m, const MslParam& P, double t
   const bool burning = k < P.k_burnout;
   const double g = P.g, t_max = P.t_max, nyz_max = P.nyz_max;
   const double hxy2 = m.vx * m.vx + m.vy * m.vy;
-  const double vm = sqrt(hxy2 + m.vz * m.vz);
-  const double ivm = 1.0 / vm;
-  const double cth = sqrt(fmax(0.0, 1.0 - (m.vz * ivm) * (m.vz * ivm)));  // cos(asin(dz/v))
+  const double vm = fx::sqrt(hxy2 + m.vz * m.vz);
+  const double ivm = fx::rcp(vm);
+  const double cth = fx::sqrt(fmax(0.0, 1.0 - (m.vz * ivm) * (m.vz * ivm)));  // cos(asin(dz/v))
   const double ddx = tx - m.px, ddy = ty - m.py, ddz = tz - m.pz;
-  const double Rxy2 = ddx * ddx + ddy * ddy, Rxy = sqrt(Rxy2);
-  const double R2 = Rxy2 + ddz * ddz, Rxyz = sqrt(R2);
-  const double dbeta = ((tvy - m.vy) * ddx - (tvx - m.vx) * ddy) / Rxy2;
-  const double deps = ((tvz - m.vz) * Rxy2 - ddz * (ddx * (tvx - m.vx) + ddy * (tvy - m.vy))) / (R2 * Rxy);
-  const double K = fmax((double)P.K * (t_max - m.t) / t_max, 0.0);
-  const double ny = m_clamp(-nyz_max, K * vm / g * cth * dbeta, nyz_max);
-  const double nz = m_clamp(-nyz_max, K * vm / g * deps + cth, nyz_max);
-  m.recede = (Rxyz > m.dprev) ? m.recede + 1 : 0;
+  const double Rxy2 = ddx * ddx + ddy * ddy, Rxy = fx::sqrt(Rxy2);
+  const double R2 = Rxy2 + ddz * ddz, Rxyz = fx::sqrt(R2);
+  const double dbeta = ((tvy - m.vy) * ddx - (tvx - m.vx) * ddy) * fx::rcp(Rxy2);
+  const double deps = ((tvz - m.vz) * Rxy2 - ddz * (ddx * (tvx - m.vx) + ddy * (tvy - m.vy))) * fx::rcp(R2 * Rxy);
+  const double K = fmax((double)P.K * (t_max - m.t) * (1.0 / t_max), 0.0);
+  const double ny = m_clamp(-nyz_max, K * vm * (1.0 / g) * cth * dbeta, nyz_max);
+  const double nz = m_clamp(-nyz_max, K * vm * (1.0 / g) * deps + cth, nyz_max);
+  m.recede = (Rxyz > m.dprev) ? min(m.recede + 1, P.recede_max) : 0;   // (300 in a row decide; the count saturates there)
   m.dprev = Rxyz;
   if (Rxyz < (double)P.Rc && target_alive && m.status != MSL_MISS) {
     m.status = MSL_HIT;
@@ -433,20 +458,20 @@ __device__ __forceinline__ void missile_run(MslD& m, const MslParam& P, double t
     m.px += dt * m.vx; m.py += dt * m.vy; m.pz += dt * m.vz;
     const double alt = missile_height(m.px, m.py, m.pz, c);
     const double Tt = burning ? g * (double)P.Isp * (double)P.dm : 0.0;
-    const double sd = sin(m.dth), sp = sin(m.dph);
+    const double sd = fx::sin(m.dth), sp = fx::sin(m.dph);
     const double D0 = P.Diameter, L0 = P.Length;
-    const double S = 3.14159265358979323846 * 0.25 * D0 * D0 + sqrt(sd * sd + sp * sp) * D0 * L0;
-    const double rho = 1.225 * exp(-alt / 9300.0);
+    const double S = 3.14159265358979323846 * 0.25 * D0 * D0 + fx::sqrt(sd * sd + sp * sp) * D0 * L0;
+    const double rho = 1.225 * fx::exp(-alt * (1.0 / 9300.0));
     const double D = 0.5 * (double)P.cD * S * rho * vm * vm;
-    const double nx = (Tt - D) / (m.m * g);
+    const double nx = (Tt - D) * fx::rcp(m.m * g);
     double st, ct, sps, cps;   // of the CURRENT theta, psi
     if (k == 1) { sincos(m.theta, &st, &ct); sincos(m.psi, &sps, &cps); }
     else {
-      const double hxy = sqrt(hxy2), ih = 1.0 / hxy;
+      const double hxy = fx::sqrt(hxy2), ih = fx::rcp(hxy);
       st = m.vz * ivm; ct = hxy * ivm; cps = m.vx * ih; sps = m.vy * ih;
     }
     const double dv = g * (nx - st);
-    m.dph = g * ivm * (ny / ct);
+    m.dph = g * ivm * (ny * fx::rcp(ct));
     m.dth = g * ivm * (nz - ct);
     const double v = vm + dt * dv;
     const double dps = dt * m.dph, dts = dt * m.dth;
@@ -616,19 +641,23 @@ struct TaskTraits {
 // waves share a SIMD and fill its 2-cycle issue rate: +38 % throughput once there are more waves than SIMDs. WPE = 1 keeps
 // everything in registers (269 incl. accumulation VGPRs): 5 % less latency when each SIMD has at most one wave (E*A <= 65536).
 #include "split_kernel.hpp"
+#include "pair_kernel.hpp"
 
-// SPLIT: the three-wave form (split_kernel.hpp) for the task without munitions at small grids.
-template <int TASK, int WPE, bool SPLIT = false>
-__global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) {
+// FORM: 0 = one wave per 64 aircraft, 1 = the three-wave form (split_kernel.hpp) for the task without munitions at small grids,
+// 2 = the pair form (pair_kernel.hpp: flight wave + environment wave) for the tasks with missiles.
+template <int TASK, int WPE, int FORM = 0>
+__global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) {
   using TT = TaskTraits<TASK>;
+  constexpr bool SPLIT = FORM == 1, PAIR = FORM == 2;
   constexpr bool HAS_MSL = TT::HAS_MSL;
   constexpr int MSLOTS = TT::MSLOTS;
   constexpr int OBS = TT::OBS;
   AC_CLK(0);
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
   __shared__ __attribute__((aligned(16))) float lds_out[64 * OBS];
-  __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : 16];
+  __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : (PAIR ? sizeof(PairLds) : 16)];
   SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
+  PairLds& LP = *reinterpret_cast<PairLds*>(split_lds);
   const Tab T{lds_tab};
   const int N = c.N;
   const int l = threadIdx.x & 63;
@@ -643,6 +672,12 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
     tc.issue(P.tab);
     load_state(P.F, P.I, P.D, N, nn, s, t);
     tc.commit(lds_tab);
+  } else if (PAIR) {
+    stage_tables<128>(lds_tab, P.tab);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1) { pair_flight_wave(P, c, T, LP, l, nn, n, live); return; }
+    s = State{};   // the environment wave owns the task bookkeeping; of the flight state it only needs the tick count
+    load_task(P.F, P.I, N, nn, t);
+    s.ticks = P.I[(size_t)FI_ticks * N + nn];
   } else {
     stage_tables<64>(lds_tab, P.tab);
     load_state(P.F, P.I, P.D, N, nn, s, t);
@@ -684,8 +719,26 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
   const MslParam MP = aim9l();
   bool have_pose = false;
   int last_tick = -1;   // three-wave form: the last substep this aircraft flew
+  int ticks_now = s.ticks;   // pair form: the executive tick count of the posted pose
+  // pair form: with no missile entry in the env there is nothing to fly between the ticks, and only the last substep's pose is needed
+  bool env_has_missiles = false;
+  if (PAIR) {
+    bool mine = false;
+#pragma unroll
+    for (int k = 0; k < MSLOTS; ++k) mine = mine || ms[k].status != MSL_INACTIVE;
+    env_has_missiles = mine || (bool)__shfl_xor((int)mine, 1);
+  }
+  bool located = false;
   for (int sub = 0; sub < c.substeps; ++sub) {
-    if (SPLIT) {        // the FDM tick over three waves; what follows in the substep (munitions) stays on this wave
+    if (PAIR) {
+      if (pair_substep(t, LP, l)) ticks_now += 1;
+      if (!env_has_missiles) continue;
+      pair_read_pose(LP, l, ticks_now, s);
+      f16::locate(s, d);
+      ned_velocity(s, d);
+      make_pose(d, c, pr);
+      located = sub + 1 == c.substeps;
+    } else if (SPLIT) {        // the FDM tick over three waves; what follows in the substep (munitions) stays on this wave
       if (dynamics_wave_tick(s, t, d, T, L, l, sub)) { have_pose = true; last_tick = sub; }
     } else if (t.status == AC_ALIVE) {
       if (t.bloods <= 0.0f) t.status = AC_SHOTDOWN;  // simulatior.py:220-222: this tick still integrates
@@ -693,9 +746,11 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
       have_pose = true;
     }
     if (HAS_MSL) {
+      if (!PAIR) {
       f16::locate(s, d);                                       // fp64 geodetic reduction for the NEU pose of this substep
       if (!have_pose) { f16::body_frame(s, d); have_pose = true; }  // frozen pose of a dead aircraft
       make_props(s, d, c, pr);
+      }
       float tx = __shfl_xor(pr.n, 1), ty = __shfl_xor(pr.e, 1), tz = __shfl_xor(pr.u, 1);
       float tvx = __shfl_xor(pr.vn, 1), tvy = __shfl_xor(pr.ve, 1), tvz = __shfl_xor(pr.vd, 1);
       bool talive = __shfl_xor(t.status, 1) == AC_ALIVE;
@@ -711,7 +766,16 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
     }
   }
   const bool split_located = SPLIT && dynamics_wave_finish(s, d, L, l, last_tick, c.substeps);   // (+ the helper waves' fields)
-  if (!HAS_MSL || c.substeps == 0) {
+  if (PAIR) {
+    wg_sync();                                     // the flight wave has posted its final values and stored the flight state
+    if (!located) {
+      pair_read_pose(LP, l, ticks_now, s);
+      f16::locate(s, d);
+      ned_velocity(s, d);
+    }
+    pair_read_final(LP, l, s, d);
+    make_props(s, d, c, pr);
+  } else if (!HAS_MSL || c.substeps == 0) {
     if (!split_located) f16::locate(s, d);
     if (!have_pose) f16::body_frame(s, d);
     make_props(s, d, c, pr);
@@ -891,7 +955,11 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_1v1(DevPtrs
   }
   AC_CLK(53);
   if (live) {
-    store_state(P.F, P.I, P.D, N, n, s, t);
+    if (!PAIR) store_state(P.F, P.I, P.D, N, n, s, t);
+    else {   // the flight wave has stored the flown state (ordered before this by the barrier): an episode reset overwrites it
+      if (all_done) store_flight(P.F, P.I, P.D, N, n, s);
+      store_task(P.F, P.I, N, n, t);
+    }
     if (HAS_MSL) {
 #pragma unroll
       for (int k = 0; k < MSLOTS; ++k)
@@ -1327,17 +1395,21 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
     HIP_OK(hipGetLastError());
     return 0;
   }
-  if (h->cfg.task == AC_TASK_SCENARIO1 || h->cfg.task == AC_TASK_SCENARIO_NVN || h->cfg.task == AC_TASK_WVR || h->cfg.task == AC_TASK_MANEUVER) {
-#define AC_LAUNCH_SCN(AA)                                                                                                        \
-  do {                                                                                                                           \
-    if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_scenario<AA, 1>), grid, block, 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr); \
-    else hipLaunchKernelGGL((step_kernel_scenario<AA, 2>), grid, block, 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);                  \
+  // pair form (every task with munitions): two waves per workgroup, so one wave per SIMD up to 512 workgroups
+  const bool pair_wpe1 = grid.x <= 512;
+  const bool gun_only = h->cfg.task == AC_TASK_WVR || h->cfg.task == AC_TASK_MANEUVER;
+  if (gun_only) {   // the scenario kernel family without munitions: ticks only between the env steps
+    if (h->split_waves) hipLaunchKernelGGL((step_kernel_scenario<2, 1, FORM_SPLIT>), grid, dim3(192), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
+    else if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_scenario<2, 1, FORM_ONE>), grid, block, 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
+    else hipLaunchKernelGGL((step_kernel_scenario<2, 2, FORM_ONE>), grid, block, 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
+  } else if (h->cfg.task == AC_TASK_SCENARIO1 || h->cfg.task == AC_TASK_SCENARIO_NVN) {
+#define AC_LAUNCH_PAIR(AA)                                                                                                                                \
+  do {                                                                                                                                                    \
+    if (pair_wpe1) hipLaunchKernelGGL((step_kernel_scenario<AA, 1, FORM_PAIR>), grid, dim3(128), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr); \
+    else hipLaunchKernelGGL((step_kernel_scenario<AA, 2, FORM_PAIR>), grid, dim3(128), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);          \
   } while (0)
-#define AC_LAUNCH_SCN3(AA) hipLaunchKernelGGL((step_kernel_scenario<AA, 1, true>), grid, dim3(192), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr)
-    if (h->split_waves) { if (h->A == 2) AC_LAUNCH_SCN3(2); else if (h->A == 4) AC_LAUNCH_SCN3(4); else AC_LAUNCH_SCN3(8); }
-    else if (h->A == 2) AC_LAUNCH_SCN(2); else if (h->A == 4) AC_LAUNCH_SCN(4); else AC_LAUNCH_SCN(8);
-#undef AC_LAUNCH_SCN3
-#undef AC_LAUNCH_SCN
+    if (h->A == 2) AC_LAUNCH_PAIR(2); else if (h->A == 4) AC_LAUNCH_PAIR(4); else AC_LAUNCH_PAIR(8);
+#undef AC_LAUNCH_PAIR
   } else if (h->cfg.task == AC_TASK_MULTICOMBAT) {
     if (h->split_waves) {
       if (h->A == 4) hipLaunchKernelGGL((step_kernel_nvn<4, 1, true>), grid, dim3(192), 0, h->stream, p, h->dc);
@@ -1350,16 +1422,15 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
       else hipLaunchKernelGGL((step_kernel_nvn<8, 2>), grid, block, 0, h->stream, p, h->dc);
     }
   } else if (h->cfg.task == AC_TASK_SINGLECOMBAT) {
-    if (h->split_waves) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 1, true>), grid, dim3(192), 0, h->stream, p, h->dc);
-    else if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 1>), grid, block, 0, h->stream, p, h->dc);
-    else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 2>), grid, block, 0, h->stream, p, h->dc);
+    if (h->split_waves) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 1, 1>), grid, dim3(192), 0, h->stream, p, h->dc);
+    else if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 1, 0>), grid, block, 0, h->stream, p, h->dc);
+    else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 2, 0>), grid, block, 0, h->stream, p, h->dc);
   } else if (h->cfg.task == AC_TASK_DODGE_MISSILE) {
-    if (h->split_waves) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_DODGE_MISSILE, 1, true>), grid, dim3(192), 0, h->stream, p, h->dc);
-    else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_DODGE_MISSILE, 2>), grid, block, 0, h->stream, p, h->dc);
+    if (pair_wpe1) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_DODGE_MISSILE, 1, 2>), grid, dim3(128), 0, h->stream, p, h->dc);
+    else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_DODGE_MISSILE, 2, 2>), grid, dim3(128), 0, h->stream, p, h->dc);
   } else {
-    if (h->split_waves) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 1, true>), grid, dim3(192), 0, h->stream, p, h->dc);
-    else if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 1>), grid, block, 0, h->stream, p, h->dc);
-    else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 2>), grid, block, 0, h->stream, p, h->dc);
+    if (pair_wpe1) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 1, 2>), grid, dim3(128), 0, h->stream, p, h->dc);
+    else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 2, 2>), grid, dim3(128), 0, h->stream, p, h->dc);
   }
   HIP_OK(hipGetLastError());
   return 0;
@@ -1435,15 +1506,15 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   ac_env* h = new ac_env();
   memset(h, 0, sizeof *h);
   h->cfg = *cfg; h->E = n_envs; h->A = cfg->n_agents; h->N = n_envs * cfg->n_agents; h->device = device_id;
-  {  // Three waves per 64 aircraft (split_kernel.hpp) while the chip has SIMDs to spare. Tasks whose substeps are the FDM tick alone:
-     // up to 512 workgroups (1536 waves on 256 CUs x 4 SIMDs; measured faster than one wave per 64 aircraft up to there, slower from
-     // 768 on). Tasks with munitions, whose dynamics wave also flies the missiles between ticks: while every wave still gets a SIMD
-     // of its own (341 workgroups; at 512 the 4v4 scenario measured 159 us against 111). AIRCOMBAT_SPLIT=0/1 overrides.
+  {  // Kernel form. Tasks whose substeps are the FDM tick alone: three waves per 64 aircraft (split_kernel.hpp) while the chip has
+     // SIMDs to spare -- up to 512 workgroups (1536 waves on 256 CUs x 4 SIMDs; measured faster than one wave per 64 aircraft up to
+     // there, slower from 768 on); AIRCOMBAT_SPLIT=0/1 overrides that choice. Tasks with munitions always run the pair form
+     // (pair_kernel.hpp: a flight wave and an environment wave per 64 aircraft).
     const char* e = getenv("AIRCOMBAT_SPLIT");
     const int wgs = (h->N + 63) / 64;
     const bool ticks_only = cfg->task == AC_TASK_SINGLECOMBAT || cfg->task == AC_TASK_MULTICOMBAT || cfg->task == AC_TASK_HEADING ||
                             cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER;
-    h->split_waves = e ? (e[0] == '1') : (wgs <= (ticks_only ? 512 : 341));
+    h->split_waves = ticks_only && (e ? (e[0] == '1') : (wgs <= 512));
   }
   h->obs_dim = heading ? 12 : (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
@@ -1657,11 +1728,14 @@ int ac_step_host_async(ac_env_t* h, int32_t set) {
 }
 int ac_step_host_wait(ac_env_t* h) {
   if (!h) return fail("ac_step_host_wait: null handle");
-  // busy-poll the stream: the step is tens of microseconds, a blocking wait's wake-up would be a sizeable part of it
-  hipError_t e;
-  while ((e = hipStreamQuery(h->stream)) == hipErrorNotReady) __builtin_ia32_pause();
-  if (e != hipSuccess) return fail(std::string("ac_step_host_wait: ") + hipGetErrorString(e));
+  // (hipStreamSynchronize spins on the completion signal itself; polling hipStreamQuery measured 5 us slower per step,
+  //  tools/micro/host_io.hip)
+  HIP_OK(hipStreamSynchronize(h->stream));
   return 0;
+}
+int ac_step_host(ac_env_t* h, int32_t set) {   // step_async + step_wait in one call (VecEnv.step, env_wrappers.py:30-42)
+  if (ac_step_host_async(h, set)) return -1;
+  return ac_step_host_wait(h);
 }
 
 // ---- stream ordering for the device-resident path: the handle's stream is non-blocking, so work on the caller's streams (a torch

@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "f16_tables.h"
+#include "fp64_fast.hpp"
 
 namespace f16 {
 
@@ -280,20 +281,20 @@ __device__ __forceinline__ void locate(const State& s, Derived& d) {
   double X = ce * s.rx + se * s.ry, Y = -se * s.rx + ce * s.ry, Z = s.rz;
   d.X = X; d.Y = Y; d.Z = Z;
   double rxy2 = X * X + Y * Y;
-  double rxy = sqrt(rxy2), rad = sqrt(rxy2 + Z * Z);
+  double rxy = fx::sqrt(rxy2), rad = fx::sqrt(rxy2 + Z * Z);
   const double ec = kB / kA, ec2 = ec * ec, ee = 1.0 - ec2, c = kA * ee;
   double s0 = fabs(Z), zc = ec * s0, c0 = ec * rxy, c02 = c0 * c0, s02 = s0 * s0, a02 = c02 + s02;
-  double a0 = sqrt(a02), a03 = a02 * a0;
+  double a0 = fx::sqrt(a02), a03 = a02 * a0;
   double s1 = zc * a03 + c * s02 * s0, c1 = rxy * a03 - c * c02 * c0, cs = c * c0 * s0;
   double b0 = 1.5 * cs * ((rxy * s0 - zc * c0) * a0 - cs);
   s1 = s1 * a03 - b0 * s0;
   double cc = ec * (c1 * a03 - b0 * c0);
-  double inv = 1.0 / sqrt(s1 * s1 + cc * cc);
+  double inv = fx::rsqrt(s1 * s1 + cc * cc);
   double sinLat = (Z >= 0.0 ? s1 : -s1) * inv, cosLat = cc * inv;
-  double cgc = rxy / rad;
-  double slr = kA * ec / sqrt(1.0 - ee * cgc * cgc);
+  double cgc = rxy * fx::rcp(rad);
+  double slr = kA * ec * fx::rsqrt(1.0 - ee * cgc * cgc);
   d.h_sl_ft = (float)(rad - slr);
-  double irxy = 1.0 / rxy;
+  double irxy = fx::rcp(rxy);
   double cosLon = X * irxy, sinLon = Y * irxy;
   d.sLat64 = sinLat; d.cLat64 = cosLat; d.sLon64 = sinLon; d.cLon64 = cosLon;
   // local unit vectors in ECEF, rotated back by the Earth angle into ECI
@@ -339,36 +340,37 @@ __device__ __forceinline__ void engine_factors(const Tab& T, float mach, float h
   idle_f = e.x; mil_f = e.y; aug_f = e.z;
 }
 
-// One executive tick. DT_ZERO = true reproduces the two "integration suspended" passes of FGFDMExec::RunIC
-// (data/src/FGFDMExec.cpp:636-669): nothing integrates, the turbine runs its Trim() branch, the FCS still steps.
-// TANK_ARM_ORIGIN = true is the very first of those passes: FGMassBalance has not run yet, so the tank inertia the
-// executive loads for it (FGFDMExec.cpp:572 before FGMassBalance::Run) is taken about the structural origin; that pass's
-// angular acceleration reaches the FCS of the first real tick through the pilot-station load factor.
+// The integration step of FGPropagate (FGPropagate.cpp:218-290, :336-360): attitude and inertial rates by rectangular Euler,
+// inertial position by Adams-Bashforth 3, inertial velocity by Adams-Bashforth 2 -- all explicit in the derivatives the LAST
+// tick left in the state, so the pose after this tick is known before any of this tick's forces are (the cooperative kernel forms
+// hand it to the weapons wave at this point).
+__device__ __forceinline__ void propagate(State& s) {
+  constexpr float dt = 1.0f / 60.0f;
+  float qd0 = -0.5f * (s.q1 * s.wp + s.q2 * s.wq + s.q3 * s.wr);
+  float qd1 = 0.5f * (s.q0 * s.wp - s.q3 * s.wq + s.q2 * s.wr);
+  float qd2 = 0.5f * (s.q3 * s.wp + s.q0 * s.wq - s.q1 * s.wr);
+  float qd3 = 0.5f * (-s.q2 * s.wp + s.q1 * s.wq + s.q0 * s.wr);
+  float a0 = fmaf(dt, qd0, s.q0), a1 = fmaf(dt, qd1, s.q1), a2 = fmaf(dt, qd2, s.q2), a3 = fmaf(dt, qd3, s.q3);
+  float rn = rsqrtf(a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3);
+  s.q0 = a0 * rn; s.q1 = a1 * rn; s.q2 = a2 * rn; s.q3 = a3 * rn;
+  s.wp = fmaf(dt, s.wdx, s.wp); s.wq = fmaf(dt, s.wdy, s.wq); s.wr = fmaf(dt, s.wdz, s.wr);
+  const float k = dt / 12.0f;
+  s.rx += (double)(k * (23.0f * s.vx - 16.0f * s.hv1x + 5.0f * s.hv2x));
+  s.ry += (double)(k * (23.0f * s.vy - 16.0f * s.hv1y + 5.0f * s.hv2y));
+  s.rz += (double)(k * (23.0f * s.vz - 16.0f * s.hv1z + 5.0f * s.hv2z));
+  s.hv2x = s.hv1x; s.hv2y = s.hv1y; s.hv2z = s.hv1z;
+  s.hv1x = s.vx; s.hv1y = s.vy; s.hv1z = s.vz;
+  s.vx += dt * (1.5f * s.aix - 0.5f * s.ha1x);
+  s.vy += dt * (1.5f * s.aiy - 0.5f * s.ha1y);
+  s.vz += dt * (1.5f * s.aiz - 0.5f * s.ha1z);
+  s.ha1x = s.aix; s.ha1y = s.aiy; s.ha1z = s.aiz;
+  s.ticks += 1;
+}
+
+// The rest of the tick, from the frames of the (new) pose to the accelerations the next tick integrates.
 template <bool DT_ZERO, bool TANK_ARM_ORIGIN = false>
-__device__ __forceinline__ void tick(State& s, Derived& d, const Tab& T) {
+__device__ __forceinline__ void tick_after_propagate(State& s, Derived& d, const Tab& T) {
   constexpr float dt = DT_ZERO ? 0.0f : (1.0f / 60.0f);
-  // ---------------- Propagate (FGPropagate.cpp:218-290, :336-360)
-  if (!DT_ZERO) {
-    float qd0 = -0.5f * (s.q1 * s.wp + s.q2 * s.wq + s.q3 * s.wr);
-    float qd1 = 0.5f * (s.q0 * s.wp - s.q3 * s.wq + s.q2 * s.wr);
-    float qd2 = 0.5f * (s.q3 * s.wp + s.q0 * s.wq - s.q1 * s.wr);
-    float qd3 = 0.5f * (-s.q2 * s.wp + s.q1 * s.wq + s.q0 * s.wr);
-    float a0 = fmaf(dt, qd0, s.q0), a1 = fmaf(dt, qd1, s.q1), a2 = fmaf(dt, qd2, s.q2), a3 = fmaf(dt, qd3, s.q3);
-    float rn = rsqrtf(a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3);
-    s.q0 = a0 * rn; s.q1 = a1 * rn; s.q2 = a2 * rn; s.q3 = a3 * rn;
-    s.wp = fmaf(dt, s.wdx, s.wp); s.wq = fmaf(dt, s.wdy, s.wq); s.wr = fmaf(dt, s.wdz, s.wr);
-    const float k = dt / 12.0f;
-    s.rx += (double)(k * (23.0f * s.vx - 16.0f * s.hv1x + 5.0f * s.hv2x));
-    s.ry += (double)(k * (23.0f * s.vy - 16.0f * s.hv1y + 5.0f * s.hv2y));
-    s.rz += (double)(k * (23.0f * s.vz - 16.0f * s.hv1z + 5.0f * s.hv2z));
-    s.hv2x = s.hv1x; s.hv2y = s.hv1y; s.hv2z = s.hv1z;
-    s.hv1x = s.vx; s.hv1y = s.vy; s.hv1z = s.vz;
-    s.vx += dt * (1.5f * s.aix - 0.5f * s.ha1x);
-    s.vy += dt * (1.5f * s.aiy - 0.5f * s.ha1y);
-    s.vz += dt * (1.5f * s.aiz - 0.5f * s.ha1z);
-    s.ha1x = s.aix; s.ha1y = s.aiy; s.ha1z = s.aiz;
-    s.ticks += 1;
-  }
   locate_fast(s, d);
   body_frame(s, d);
   const float* Tb = d.T;
@@ -648,6 +650,17 @@ __device__ __forceinline__ void tick(State& s, Derived& d, const Tab& T) {
   s.alpha = alpha; s.mach = mach; s.qc = qc; s.vg = vg;
   s.ap = d.p; s.aq = d.q; s.ar = d.r;
   s.npx = npx; s.npy = npy; s.npz = npz;
+}
+
+// One executive tick. DT_ZERO = true reproduces the two "integration suspended" passes of FGFDMExec::RunIC
+// (data/src/FGFDMExec.cpp:636-669): nothing integrates, the turbine runs its Trim() branch, the FCS still steps.
+// TANK_ARM_ORIGIN = true is the very first of those passes: FGMassBalance has not run yet, so the tank inertia the
+// executive loads for it (FGFDMExec.cpp:572 before FGMassBalance::Run) is taken about the structural origin; that pass's
+// angular acceleration reaches the FCS of the first real tick through the pilot-station load factor.
+template <bool DT_ZERO, bool TANK_ARM_ORIGIN = false>
+__device__ __forceinline__ void tick(State& s, Derived& d, const Tab& T) {
+  if (!DT_ZERO) propagate(s);
+  tick_after_propagate<DT_ZERO, TANK_ARM_ORIGIN>(s, d, T);
 }
 
 }  // namespace f16

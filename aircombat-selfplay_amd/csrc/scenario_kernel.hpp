@@ -83,19 +83,24 @@ struct ScenarioDims {
 // Relative-geometry quantities of every reward term towards the enemies of this lane, in enemy order.
 struct EnemyGeo { float AO, TA, R; };
 
-// SPLIT: the FDM ticks in the three-wave form (split_kernel.hpp); the munitions of a substep stay on the dynamics wave.
-template <int A, int WPE, bool SPLIT = false>
-__global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_scenario(DevPtrs P, DevCfg c, float* XF, int* XI, const float* tXF, const int* tXI) {
+// FORM: FORM_ONE = one wave per 64 aircraft does everything; FORM_SPLIT = the FDM ticks in the three-wave form (split_kernel.hpp; used
+// for the gun-only tasks, which have nothing to fly between ticks); FORM_PAIR = a flight wave and an environment wave
+// (pair_kernel.hpp; every task with munitions, at every batch size).
+enum { FORM_ONE = 0, FORM_SPLIT = 1, FORM_PAIR = 2 };
+template <int A, int WPE, int FORM = FORM_ONE>
+__global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128 : 64), WPE) void step_kernel_scenario(DevPtrs P, DevCfg c, float* XF, int* XI, const float* tXF, const int* tXI) {
   using SD = ScenarioDims<A>;
+  constexpr bool SPLIT = FORM == FORM_SPLIT, PAIR = FORM == FORM_PAIR;
   constexpr bool MULTI = SD::MULTI;
   constexpr int OBS = SD::OBS;
   constexpr int NE = SD::NE;
   constexpr int MS = 2;  // munition slots (uids) per aircraft
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
   __shared__ __attribute__((aligned(16))) float lds_out[64 * (OBS + 2)];
-  __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : 16];
+  __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : (PAIR ? sizeof(PairLds) : 16)];
   SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
-  stage_tables<SPLIT ? 192 : 64>(lds_tab, P.tab);
+  PairLds& LP = *reinterpret_cast<PairLds*>(split_lds);
+  stage_tables<SPLIT ? 192 : (PAIR ? 128 : 64)>(lds_tab, P.tab);
   const Tab T{lds_tab};
   const int N = c.N;
   const int lane = threadIdx.x & 63;
@@ -107,13 +112,27 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_scenario(De
   const int n_ego = c.n_ego;
   const int team = slot < n_ego ? 0 : 1;
   const int e_first = team == 0 ? n_ego : 0;   // my enemies are slots e_first .. e_first + NE - 1
+  if (PAIR && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1) { pair_flight_wave(P, c, T, LP, lane, nn, n, live); return; }
 
   State s; Task t; Derived d; Props pr; Ext x;
-  load_state(P.F, P.I, P.D, N, nn, s, t);
+  if (PAIR) {   // the environment wave owns the task bookkeeping; of the flight state it only needs the tick count (Earth angle)
+    s = State{};
+    load_task(P.F, P.I, N, nn, t);
+    s.ticks = P.I[(size_t)FI_ticks * N + nn];
+  } else load_state(P.F, P.I, P.D, N, nn, s, t);
   load_ext(XF, XI, N, nn, x);
   MslD ms[MS];
 #pragma unroll
-  for (int k = 0; k < MS; ++k) load_msl(P.MD, P.MI, N, nn, k, ms[k]);
+  for (int k = 0; k < MS; ++k) {
+    // a slot that has not been used since the last reset holds zeros and MSL_INACTIVE: only its status word is read, and it is written
+    // back only once it has been launched or reset
+    const int st = P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn];
+    if (st != MSL_INACTIVE) load_msl(P.MD, P.MI, N, nn, k, ms[k]);
+    else { ms[k] = MslD{}; ms[k].status = MSL_INACTIVE; }
+  }
+  int msl_was_active = 0;
+#pragma unroll
+  for (int k = 0; k < MS; ++k) msl_was_active |= (ms[k].status != MSL_INACTIVE) << k;
 
   // ---- actions: 4 control indices + [gun, AIM-9M, AIM-120B, chaff] (scenario1_task.py:33-48: Scenario1 only refreshes the ego
   // team's bits, its other team flies the scripted baseline with bits 0; scenario2_task.py:58-61 refreshes both teams)
@@ -145,7 +164,18 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_scenario(De
   const bool env_has_munitions = (__ballot(mine) & env_mask) != 0;
   if (SPLIT && split_helper_wave(s, t, T, L, lane, c.substeps)) return;
   int last_tick = -1;   // three-wave form: the last substep this aircraft flew
+  int ticks_now = s.ticks;   // pair form: the executive tick count of the posted pose (Earth angle of the geodetic reduction)
+  bool located = false;      // pair form: d / pr hold the pose of the step's last substep already
   for (int sub = 0; sub < c.substeps; ++sub) {
+    if (PAIR) {
+      if (pair_substep(t, LP, lane)) ticks_now += 1;
+      if (!env_has_munitions) continue;     // nothing to fly: the pose is only needed after the last substep
+      pair_read_pose(LP, lane, ticks_now, s);
+      f16::locate(s, d);
+      ned_velocity(s, d);
+      make_pose(d, c, pr);
+      located = sub + 1 == c.substeps;
+    } else {
     if (SPLIT) {
       if (dynamics_wave_tick(s, t, d, T, L, lane, sub)) { have_pose = true; last_tick = sub; }
     } else if (t.status == AC_ALIVE) {
@@ -159,21 +189,55 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_scenario(De
     f16::locate(s, d);
     if (!have_pose) { f16::body_frame(s, d); have_pose = true; }
     make_props(s, d, c, pr);
+    }
     const int tick_id = (t.cur_step - 1) * c.substeps + sub + 1;
     // ---- missiles: every dict entry is run(), finished ones included (env_base.py:142-143)
     int hit_tgt[MS];
+    double tx[MS], ty[MS], tz[MS], tvx[MS], tvy[MS], tvz[MS];
+    bool talive[MS];
+    int hit_pos[MS];   // dict position of a missile that is inside its fuse radius of a live target this substep (else INT_MAX)
 #pragma unroll
     for (int k = 0; k < MS; ++k) {
-      hit_tgt[k] = -1;
       const int tg = ms[k].order & 15;               // target slot lives in the low bits of `order`
       const bool used = ms[k].status != MSL_INACTIVE;
       const int src = base + (used ? tg : slot);
-      double tx = __shfl(pr.n64, src), ty = __shfl(pr.e64, src), tz = __shfl(pr.u64, src);
-      double tvx = (double)__shfl(pr.vn, src), tvy = (double)__shfl(pr.ve, src), tvz = (double)__shfl(pr.vd, src);
-      bool talive = __shfl(t.status, src) == AC_ALIVE;
-      if (used) {
-        missile_run(ms[k], MP, tx, ty, tz, tvx, tvy, tvz, talive, c);
-        if (ms[k].status == MSL_HIT && talive) hit_tgt[k] = tg;
+      tx[k] = __shfl(pr.n64, src); ty[k] = __shfl(pr.e64, src); tz[k] = __shfl(pr.u64, src);
+      tvx[k] = (double)__shfl(pr.vn, src); tvy[k] = (double)__shfl(pr.ve, src); tvz[k] = (double)__shfl(pr.vd, src);
+      talive[k] = __shfl(t.status, src) == AC_ALIVE;
+      hit_pos[k] = 0x7fffffff;
+      if (MULTI && used && talive[k] && ms[k].status != MSL_MISS) {   // the fuse test of run(), exactly as missile_run makes it
+        const double ddx = tx[k] - ms[k].px, ddy = ty[k] - ms[k].py, ddz = tz[k] - ms[k].pz;
+        const double Rxy2 = ddx * ddx + ddy * ddy, R2 = Rxy2 + ddz * ddz;
+        if (fx::sqrt(R2) < (double)MP.Rc) hit_pos[k] = ms[k].dpos;
+      }
+    }
+    if (MULTI) {
+      // env._tempsims is walked ONCE per substep in dict order (env_base.py:142-143) and a hit kills its target on the spot
+      // (simulatior.py:525-527): every missile later in the dict aimed at the same aircraft already sees a dead target in this
+      // substep -- it turns MISS without moving, and it cannot hit as well. Only the earliest hitter of a target counts.
+      const bool any_hit = hit_pos[0] != 0x7fffffff || hit_pos[1] != 0x7fffffff;
+      if (__ballot(any_hit) & env_mask) {
+        int first_on_me = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < A; ++j)
+#pragma unroll
+          for (int k = 0; k < MS; ++k) {
+            const int hp = __shfl(hit_pos[k], base + j), htg = __shfl(ms[k].order & 15, base + j);
+            if (hp != 0x7fffffff && htg == slot && hp < first_on_me) first_on_me = hp;
+          }
+#pragma unroll
+        for (int k = 0; k < MS; ++k) {
+          const int fp = __shfl(first_on_me, base + (ms[k].order & 15));
+          if (ms[k].status != MSL_INACTIVE && fp < ms[k].dpos) talive[k] = false;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MS; ++k) {
+      hit_tgt[k] = -1;
+      if (ms[k].status != MSL_INACTIVE) {
+        missile_run(ms[k], MP, tx[k], ty[k], tz[k], tvx[k], tvy[k], tvz[k], talive[k], c);
+        if (ms[k].status == MSL_HIT && talive[k]) hit_tgt[k] = ms[k].order & 15;
       }
     }
 #pragma unroll
@@ -211,7 +275,16 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_scenario(De
     }
   }
   const bool split_located = SPLIT && dynamics_wave_finish(s, d, L, lane, last_tick, c.substeps);   // (+ the helper waves' fields)
-  if (c.substeps == 0) { f16::locate(s, d); f16::body_frame(s, d); make_props(s, d, c, pr); }
+  if (PAIR) {
+    wg_sync();                                     // the flight wave has posted its final values and stored the flight state
+    if (!located) {
+      pair_read_pose(LP, lane, ticks_now, s);
+      f16::locate(s, d);
+      ned_velocity(s, d);
+    }
+    pair_read_final(LP, lane, s, d);
+    make_props(s, d, c, pr);
+  } else if (c.substeps == 0) { f16::locate(s, d); f16::body_frame(s, d); make_props(s, d, c, pr); }
   else if (SPLIT && !env_has_munitions) {
     if (!split_located) f16::locate(s, d);
     if (!have_pose) { f16::body_frame(s, d); have_pose = true; }
@@ -260,6 +333,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_scenario(De
           for (int q = 0; q < MS; ++q)
             if (q == k) {
               if (ms[q].status == MSL_HIT) x.orphan_hits += 1;   // a replaced entry that was HIT stays is_success forever (never run again)
+              if (ms[q].status == MSL_INACTIVE) ms[q].dpos = (t.cur_step << 4) | i;   // a uid launched again keeps its place in the dict
               ms[q].px = pr.n64; ms[q].py = pr.e64; ms[q].pz = pr.u64; ms[q].vx = pr.vn; ms[q].vy = pr.ve; ms[q].vz = pr.vd;
               ms[q].theta = tht; ms[q].psi = psi; ms[q].t = 0.0; ms[q].m = MP.m0; ms[q].dth = 0.0; ms[q].dph = 0.0;
               ms[q].dprev = INFINITY; ms[q].recede = 0; ms[q].status = MSL_LAUNCHED;
@@ -530,10 +604,15 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_scenario(De
     for (int k = 0; k < OBS; ++k) ob[k] = tobs[k];
   }
   if (live) {
-    store_state(P.F, P.I, P.D, N, n, s, t);
+    if (!PAIR) store_state(P.F, P.I, P.D, N, n, s, t);
+    else {   // the flight wave has stored the flown state (ordered before this by the barrier): an episode reset overwrites it
+      if (all_done) store_flight(P.F, P.I, P.D, N, n, s);
+      store_task(P.F, P.I, N, n, t);
+    }
     store_ext(XF, XI, N, n, x);
 #pragma unroll
-    for (int k = 0; k < MS; ++k) store_msl(P.MD, P.MI, N, n, k, ms[k]);
+    for (int k = 0; k < MS; ++k)
+      if (ms[k].status != MSL_INACTIVE || ((msl_was_active >> k) & 1)) store_msl(P.MD, P.MI, N, n, k, ms[k]);
   }
   // (WVR uses the first 15 of the 21 slots; the *_RWR variants append two reserved zero slots)
   emit_outputs(P, lds_out, c.obs_dim, lane, ob, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);

@@ -219,12 +219,23 @@ class HipVecEnv:
         self._assert_not_closed()
         self.lib.check(self.lib.ac_step_host_wait(self._h), "ac_step_host_wait")
         self.waiting = False
-        st = self._sets[self._cur]
+        return self._result(self._sets[self._cur])
+
+    def _result(self, st):
         return st["obs"], st["rew"], st["done"], LazyInfos(st["info"])
 
     def step(self, actions):
-        self.step_async(actions)
-        return self.step_wait()
+        """VecEnv.step = step_async + step_wait (env_wrappers.py:30-42), through one library call."""
+        self._cur ^= 1
+        st = self._sets[self._cur]
+        dst = st["actions"]
+        a = actions if isinstance(actions, np.ndarray) else np.asarray(actions, dtype=np.float32)
+        if a.shape != dst.shape:
+            a = a.reshape(dst.shape)
+        np.copyto(dst, a)
+        if self.lib.ac_step_host(self._h, self._cur) != 0:
+            self.lib.check(-1, "ac_step_host")
+        return self._result(st)
 
     def render(self, mode="txt", filepath="./JSBSimRecording.txt.acmi", env=0):
         """BaseEnv.render (env_base.py:207-250) for one env (the reference renders through DummyVecEnv, i.e. env 0): appends one
@@ -388,9 +399,9 @@ class HipShareVecEnv(HipVecEnv):
         obs = super().reset()
         return obs, self._share(obs)
 
-    def step_wait(self):
-        obs, rew, done, infos = super().step_wait()
-        return obs, self._share(obs), rew, done, infos
+    def _result(self, st):
+        obs = st["obs"]
+        return obs, self._share(obs), st["rew"], st["done"], LazyInfos(st["info"])
 
 
 class MultiDeviceVecEnv:

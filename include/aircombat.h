@@ -119,6 +119,7 @@ int ac_step(ac_env_t* h, const float* actions, float* obs, float* rewards, uint8
 int ac_host_buffers(ac_env_t* h, int32_t set, float** actions, float** obs, float** rewards, uint8_t** dones, int32_t** info);
 int ac_step_host_async(ac_env_t* h, int32_t set);
 int ac_step_host_wait(ac_env_t* h);
+int ac_step_host(ac_env_t* h, int32_t set);   /* both in one call: VecEnv.step (env_wrappers.py:30-42) */
 
 /* Device-resident variant of the same step: d_actions is a DEVICE pointer (or NULL to use the
  * handle's own action buffer); results stay in the handle's device buffers; asynchronous on the handle's stream. */

@@ -44,3 +44,45 @@ long or_bench_run(const OrEnvConfig* cfg, int n_envs, int steps, uint64_t seed, 
   free(envs); free(obs); free(act);
   return (long)steps * n_envs * A;
 }
+
+/* A block of envs stepped by one call (the unit a worker process of oracle/subproc_vec_env.py owns): VecEnv semantics with
+ * float32 arrays in the product's layout -- actions [n][A][act_dim], obs [n][A][obs_dim], rewards [n][A], dones [n][A],
+ * info [n][4] -- and the worker's auto-reset (envs/env_wrappers.py:191-204). */
+typedef struct { int n, A, od, ad; OrEnvConfig cfg; OrEnv* envs; double* obs; double* act; } OrBlock;
+
+OrBlock* or_block_create(const OrEnvConfig* cfg, int n_envs, uint64_t chaff_seed0) {
+  OrBlock* b = (OrBlock*)calloc(1, sizeof(OrBlock));
+  if (!b) return 0;
+  b->n = n_envs; b->A = cfg->n_aircraft; b->cfg = *cfg;
+  b->envs = (OrEnv*)malloc(sizeof(OrEnv) * (size_t)n_envs);
+  for (int e = 0; e < n_envs; e++) {
+    OrEnvConfig c = *cfg;
+    c.chaff_seed = chaff_seed0 + (uint64_t)e;
+    or_env_init(&b->envs[e], &c);
+  }
+  b->od = b->envs[0].obs_dim; b->ad = b->envs[0].act_dim;
+  b->obs = (double*)malloc(sizeof(double) * b->A * b->od);
+  b->act = (double*)malloc(sizeof(double) * b->A * b->ad);
+  return b;
+}
+void or_block_destroy(OrBlock* b) { if (b) { free(b->envs); free(b->obs); free(b->act); free(b); } }
+int or_block_obs_dim(const OrBlock* b) { return b->od; }
+int or_block_act_dim(const OrBlock* b) { return b->ad; }
+void or_block_reset(OrBlock* b, float* obs) {
+  const int row = b->A * b->od;
+  for (int e = 0; e < b->n; e++) {
+    or_env_reset(&b->envs[e], b->obs);
+    for (int k = 0; k < row; k++) obs[(size_t)e * row + k] = (float)b->obs[k];
+  }
+}
+void or_block_step(OrBlock* b, const float* actions, float* obs, float* rew, uint8_t* done, int32_t* info) {
+  const int A = b->A, row = A * b->od, arow = A * b->ad;
+  double r[OR_MAX_AC]; uint8_t d[OR_MAX_AC];
+  for (int e = 0; e < b->n; e++) {
+    for (int k = 0; k < arow; k++) b->act[k] = (double)actions[(size_t)e * arow + k];
+    or_env_step(&b->envs[e], b->act, b->obs, r, d, &info[(size_t)e * 4]);
+    if (info[(size_t)e * 4 + 3]) or_env_reset(&b->envs[e], b->obs);
+    for (int k = 0; k < row; k++) obs[(size_t)e * row + k] = (float)b->obs[k];
+    for (int i = 0; i < A; i++) { rew[(size_t)e * A + i] = (float)r[i]; done[(size_t)e * A + i] = d[i]; }
+  }
+}

@@ -25,9 +25,15 @@ def rep(txt, old, new):
 
 def generate():
     s = open(SRC).read()
-    a = s.index("template <bool DT_ZERO, bool TANK_ARM_ORIGIN = false>\n__device__ __forceinline__ void tick(State& s, Derived& d, const Tab& T) {")
-    body = s[a:s.index("}  // namespace f16")]
-    prop = cut(body, "  // ---------------- Propagate", "  // ---------------- Inertial")
+    a = s.index("template <bool DT_ZERO, bool TANK_ARM_ORIGIN = false>\n__device__ __forceinline__ void tick_after_propagate(State& s, Derived& d, const Tab& T) {")
+    body = s[a:s.index("template <bool DT_ZERO, bool TANK_ARM_ORIGIN = false>\n__device__ __forceinline__ void tick(State& s")]
+    # the integration step lives in propagate(); together with the frame calls that open tick_after_propagate() it is the
+    # "Propagate" section the pieces below are cut from
+    pb = cut(s, "__device__ __forceinline__ void propagate(State& s) {\n", "\n}\n")
+    pb = pb[pb.index("\n") + 1:]
+    pb = rep(pb, "  constexpr float dt = 1.0f / 60.0f;\n", "")
+    frames = cut(body, "  locate_fast(s, d);", "  // ---------------- Inertial")
+    prop = "  // ---------------- Propagate (FGPropagate.cpp:218-290, :336-360)\n  if (!DT_ZERO) {\n" + "\n".join("  " + l if l.strip() else l for l in pb.split("\n")) + "\n  }\n" + frames
     grav = cut(body, "  // ---------------- Inertial", "  // ---------------- Atmosphere")
     fcs = cut(body, "  // ---------------- FCS", "  // ---------------- MassBalance")
     mass = cut(body, "  // ---------------- MassBalance", "  // ---------------- Auxiliary")
