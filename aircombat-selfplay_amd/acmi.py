@@ -30,20 +30,33 @@ def neu_to_lla(n, e, u, lon0, lat0, alt0):
     return math.degrees(math.atan2(y, x)), math.degrees(lat), p / math.cos(lat) - Nn
 
 
+MISSILE_MODELS = {0: "AIM-9L", 1: "AIM-120B", 2: "AIM-9M"}   # ac_get_missile's model code -> MissileSimulator.model
+
+
 def aircraft_record(uid, color, entity, model="f16"):
-    """BaseSimulator.log: `entity` = ac_get_entity's lon, lat (deg), alt (m), roll, pitch, yaw (rad), ..."""
+    """BaseSimulator.log (simulatior.py:73-79): `entity` = ac_get_entity's lon, lat (deg), alt (m), roll, pitch, yaw (rad), ..."""
     lon, lat, alt, roll, pitch, yaw = entity[:6]
-    return (f"{uid},T={lon}|{lat}|{alt}|{math.degrees(roll)}|{math.degrees(pitch)}|{math.degrees(yaw)},"
+    deg = lambda x: x * 180 / math.pi           # get_rpy() * 180 / np.pi, in the reference's operation order
+    return (f"{uid},T={lon}|{lat}|{alt}|{deg(roll)}|{deg(pitch)}|{deg(yaw)},"
             f"Name={model.upper()},Color={color}")
 
 
 def missile_records(uid, color, status, neu, theta, psi, center, exploded, radius, model="AIM-9L"):
-    """MissileSimulator.log: alive -> a position record; first frame after it is done -> removal + explosion; later -> removal.
-    Returns (text or None, exploded_flag)."""
+    """MissileSimulator.log (simulatior.py:535-551): alive -> a position record; first frame after it is done -> removal + explosion;
+    later -> removal (the reference's removal message carries its own newline, so the file shows an empty line after it).
+    Returns (text, exploded_flag)."""
     lon, lat, alt = neu_to_lla(neu[0], neu[1], neu[2], *center)
-    pose = f"T={lon}|{lat}|{alt}|0.0|{math.degrees(theta)}|{math.degrees(psi)}"
+    pose = f"T={lon}|{lat}|{alt}|0.0|{theta * 180 / math.pi}|{psi * 180 / math.pi}"
     if status == 0:
         return f"{uid},{pose},Name={model.upper()},Color={color}", exploded
     if not exploded:
         return f"-{uid}\n{uid}F,{pose},Type=Misc+Explosion,Color={color},Radius={radius}", True
-    return f"-{uid}", exploded
+    return f"-{uid}\n", exploded
+
+
+def chaff_record(uid, color, alive, pose, model="CHF"):
+    """ChaffSimulator.log (simulatior.py:383-388): the cloud keeps the geodetic position and attitude its parent had at the release
+    (`pose` = lon, lat, alt, roll, pitch, yaw) while it is effective; afterwards the removal message."""
+    if alive:
+        return aircraft_record(uid, color, pose, model)
+    return f"-{uid}\n"

@@ -28,11 +28,17 @@ TASK_IDS = {
     # missile variant of MultipleCombat an env can select. Its step() launches nothing, so it is MultipleCombat with the 21-value
     # paired-enemy observation and a [3,5,3] + shoot-bit action whose bit is ignored.
     "hierarchical_multiplecombat_shoot": AC_TASK_MULTICOMBAT,
+    # HierarchicalSingleCombatShootTask / HierarchicalSingleCombatDodgeMissileTask (singlecombat_with_missile_task.py:126-145,206-238):
+    # the 1v1 missile tasks behind the low-level controller. No env of the reference selects them (singlecombat_env.py:19-36); the
+    # names are this package's own.
+    "hierarchical_singlecombat_shoot": AC_TASK_SHOOT_MISSILE,
+    "hierarchical_singlecombat_dodge_missile": AC_TASK_DODGE_MISSILE,
 }
 # task names whose reference class takes the [3,5,3] (+ weapon bits) action through the low-level controller. The scenario tasks
 # are hierarchical in the reference (scenario1_task.py:11, scenario2_task.py:14); config_from_yaml follows that, while
 # default_config() keeps the control-index form unless asked (tests drive the weapon rules with explicit controls).
-ALWAYS_HIERARCHICAL = ("hierarchical_singlecombat", "hierarchical_multiplecombat", "hierarchical_multiplecombat_shoot")
+ALWAYS_HIERARCHICAL = ("hierarchical_singlecombat", "hierarchical_multiplecombat", "hierarchical_multiplecombat_shoot",
+                       "hierarchical_singlecombat_shoot", "hierarchical_singlecombat_dodge_missile")
 HIERARCHICAL_IN_REFERENCE = ALWAYS_HIERARCHICAL + ("scenario1", "scenario2_nvn", "scenario3_nvn", "scenario1_curriculum",
                                                    "scenario2_nvn_curriculum", "scenario3_nvn_curriculum", "scenario1_rwr",
                                                    "scenario2_rwr", "scenario3_rwr", "scenario1_rwr_curriculum",

@@ -88,6 +88,7 @@ struct MslT {
   int dpos;   // position of the munition's uid in env._tempsims (the dict is walked in insertion order, and a uid that is launched again
               // keeps its place): (env step << 4 | agent) of the FIRST launch into this slot since the reset; kept in the upper bits of
               // the `recede` word in HBM
+  int model;  // 0 = AIM-120B (or the 1v1 tasks' AIM-9L), 1 = AIM-9M: the same parameter set, a different name in the ACMI record
 };
 using Msl = MslT<float>;
 using MslD = MslT<double>;
@@ -188,7 +189,7 @@ __device__ __forceinline__ void load_msl(const R* MF, const int* MI, int N, int 
   m.dth = AC_AT(f, MF_dth); m.dph = AC_AT(f, MF_dph); m.dprev = AC_AT(f, MF_dprev);
   m.status = AC_AT(i, MI_status); m.order = AC_AT(i, MI_order);
   const int rw = AC_AT(i, MI_recede);
-  m.recede = rw & 511; m.dpos = rw >> 9;
+  m.recede = rw & 511; m.model = (rw >> 9) & 1; m.dpos = rw >> 10;
 }
 template <typename R>
 __device__ __forceinline__ void store_msl(R* MF, int* MI, int N, int n, int slot, const MslT<R>& m) {
@@ -199,7 +200,7 @@ __device__ __forceinline__ void store_msl(R* MF, int* MI, int N, int n, int slot
   AC_AT(f, MF_vx) = m.vx; AC_AT(f, MF_vy) = m.vy; AC_AT(f, MF_vz) = m.vz;
   AC_AT(f, MF_theta) = m.theta; AC_AT(f, MF_psi) = m.psi; AC_AT(f, MF_t) = m.t; AC_AT(f, MF_m) = m.m;
   AC_AT(f, MF_dth) = m.dth; AC_AT(f, MF_dph) = m.dph; AC_AT(f, MF_dprev) = m.dprev;
-  AC_AT(i, MI_status) = m.status; AC_AT(i, MI_recede) = (m.dpos << 9) | m.recede; AC_AT(i, MI_order) = m.order;
+  AC_AT(i, MI_status) = m.status; AC_AT(i, MI_recede) = (m.dpos << 10) | (m.model << 9) | m.recede; AC_AT(i, MI_order) = m.order;
 }
 
 // task.reset() of the hierarchical tasks clears _inner_rnn_states (singlecombat_task.py:258-262)
@@ -1483,8 +1484,6 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   } else if (!heading && (cfg->n_agents != 2 || cfg->n_ego != 1)) return fail("ac_create: 1v1 tasks need n_agents == 2 and n_ego == 1");
   if (cfg->use_baseline && (!cfg->hierarchical || cfg->use_baseline < 0 || cfg->use_baseline > 2 || cfg->n_ego * 2 != cfg->n_agents))
     return fail("ac_create: use_baseline (1 pursue, 2 maneuver) needs the hierarchical form and equal teams (enemy k is flown by scripted agent k)");
-  if (cfg->hierarchical && (cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE))
-    return fail("ac_create: the hierarchical form is available for AC_TASK_SINGLECOMBAT, AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN");
   if ((cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER) && (cfg->n_agents != 2 || cfg->n_ego != 1 || cfg->rwr))
     return fail("ac_create: AC_TASK_WVR / AC_TASK_MANEUVER are 1v1 tasks");
   if (cfg->legacy_obs && ((cfg->task != AC_TASK_SCENARIO_NVN && cfg->task != AC_TASK_MULTICOMBAT) || cfg->rwr))
@@ -1525,7 +1524,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   const bool weapon_bits = scenario && !gun_only;
   h->act_low = weapon_bits ? 8 : ((cfg->task == AC_TASK_SHOOT_MISSILE) ? 5 : 4);
   // hierarchical tasks (HierarchicalSingleCombatTask and everything built on it): [3,5,3] (+ the four weapon bits)
-  h->act_dim = cfg->hierarchical ? (weapon_bits ? 7 : 3) : h->act_low;
+  // (HierarchicalSingleCombatShootTask: Tuple([3,5,3], Discrete(2)), singlecombat_with_missile_task.py:221-223; the Dodge variant: [3,5,3])
+  h->act_dim = cfg->hierarchical ? (weapon_bits ? 7 : (cfg->task == AC_TASK_SHOOT_MISSILE ? 4 : 3)) : h->act_low;
   // hierarchical_multiplecombat_shoot: Tuple([3,5,3], Discrete(2)); the shoot bit is stored and never used (the task's step() launches nothing)
   if (cfg->hierarchical && cfg->task == AC_TASK_MULTICOMBAT && cfg->legacy_obs) h->act_dim = 4;
   DevCfg& c = h->dc;
@@ -1997,7 +1997,11 @@ int ac_get_missile(ac_env_t* h, int32_t env, int32_t agent, int32_t k, double ou
       out[1 + i] = v;
     }
   }
-  out[11] = 0.0;
+  {   // which munition the slot holds (ACMI name): 0 AIM-9L (the 1v1 missile tasks), 1 AIM-120B, 2 AIM-9M
+    int rw;
+    HIP_OK(hipMemcpy(&rw, h->dp.MI + ((size_t)k * NMI + MI_recede) * N + n, sizeof rw, hipMemcpyDeviceToHost));
+    out[11] = h->dp.MD ? (double)(1 + ((rw >> 9) & 1)) : 0.0;
+  }
   return 0;
 }
 

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
           for (int k = 0; k < MS; ++k) if (k == t.last_missile) dn = ms[k].status == MSL_HIT || ms[k].status == MSL_MISS;
           return dn;
         };
-        auto launch = [&](int k) {   // MissileSimulator.launch (:497-514) into the dict entry of uid "agent + (MS - k)"
+        auto launch = [&](int k, int model) {   // MissileSimulator.launch (:497-514) into the dict entry of uid "agent + (MS - k)"
           float tht = asinf(pr.stht);
           float psi = atan2f(pr.m12, pr.m11);
           if (psi < 0.0f) psi += 2.0f * f16::kPi;
@@ -334,6 +334,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
             if (q == k) {
               if (ms[q].status == MSL_HIT) x.orphan_hits += 1;   // a replaced entry that was HIT stays is_success forever (never run again)
               if (ms[q].status == MSL_INACTIVE) ms[q].dpos = (t.cur_step << 4) | i;   // a uid launched again keeps its place in the dict
+              ms[q].model = model;
               ms[q].px = pr.n64; ms[q].py = pr.e64; ms[q].pz = pr.u64; ms[q].vx = pr.vn; ms[q].vy = pr.ve; ms[q].vz = pr.vd;
               ms[q].theta = tht; ms[q].psi = psi; ms[q].t = 0.0; ms[q].m = MP.m0; ms[q].dth = 0.0; ms[q].dph = 0.0;
               ms[q].dprev = INFINITY; ms[q].recede = 0; ms[q].status = MSL_LAUNCHED;
@@ -343,8 +344,8 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
           launched = true;
         };
         if ((x.bits & 1) && x.rem_gun > 0 && last_done() && av_gun) { gun_dmg = 5.0f; gun_tgt = tg; x.rem_gun -= 1; }
-        if ((x.bits & 4) && x.rem_120b > 0 && last_done() && av_120) { launch(MS - x.rem_120b); x.rem_120b -= 1; }
-        if ((x.bits & 2) && x.rem_9m > 0 && last_done() && av_9m) { launch(MS - x.rem_9m); x.rem_9m -= 1; }
+        if ((x.bits & 4) && x.rem_120b > 0 && last_done() && av_120) { launch(MS - x.rem_120b, 0); x.rem_120b -= 1; }
+        if ((x.bits & 2) && x.rem_9m > 0 && last_done() && av_9m) { launch(MS - x.rem_9m, 1); x.rem_9m -= 1; }
       }
       (void)launched;
       // gun damage lands on the target's blood right away (:70-73)

@@ -145,8 +145,8 @@ class HipVecEnv:
             self.lib.check(self.lib.ac_load_controller(self._h, w.ctypes.data, int(w.size)), "ac_load_controller")
         if self.hierarchical and config.task in (AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN):
             self.action_space = Tuple([MultiDiscrete([3, 5, 3]), MultiDiscrete([2, 2, 2, 2])])     # scenario1_task.py:29-31
-        elif self.hierarchical and config.legacy_obs:
-            self.action_space = Tuple([MultiDiscrete([3, 5, 3]), Discrete(2)])                     # multiplecombat_with_missile_task.py:221-223
+        elif self.hierarchical and (config.legacy_obs or config.task == AC_TASK_SHOOT_MISSILE):
+            self.action_space = Tuple([MultiDiscrete([3, 5, 3]), Discrete(2)])                     # *_with_missile_task.py:221-223
         elif self.hierarchical:
             self.action_space = MultiDiscrete([3, 5, 3])                                           # singlecombat_task.py:221-222
         elif config.task == AC_TASK_SHOOT_MISSILE:
@@ -239,37 +239,74 @@ class HipVecEnv:
 
     def render(self, mode="txt", filepath="./JSBSimRecording.txt.acmi", env=0):
         """BaseEnv.render (env_base.py:207-250) for one env (the reference renders through DummyVecEnv, i.e. env 0): appends one
-        Tacview ACMI frame — every aircraft, every launched missile, explosions once — to `filepath`."""
+        Tacview ACMI frame to `filepath` -- every aircraft (env._jsbsims), every munition that has been launched (env._tempsims: a
+        position record while it flies, removal + explosion once, then removal) and every chaff cloud (env._chaffsims), in the
+        reference's order and text. A chaff record carries the pose its parent had at the release: the release happens at the end
+        of an env step, so the frame rendered after that step still sees that pose (call render() after every step, as the
+        reference's render loop does)."""
         from . import acmi
         if mode != "txt":
             raise NotImplementedError
         self._assert_not_closed()
+        cfg = self.config
+        step = int(self.get_state(env, 0)[self._ix("cur_step")])
         if not getattr(self, "_acmi_started", False):
             with open(filepath, mode="w", encoding="utf-8-sig") as f:
                 f.write(acmi.HEADER)
-            self._acmi_started, self._acmi_exploded = True, set()
-        cfg = self.config
+            self._acmi_started, self._acmi_exploded, self._acmi_chaff, self._acmi_first, self._acmi_step = True, set(), {}, {}, -1
+        if step <= self._acmi_step:      # the episode was reset: env.reset() clears _tempsims / _chaffsims (env_base.py:98-113)
+            self._acmi_exploded, self._acmi_chaff, self._acmi_first = set(), {}, {}
+        self._acmi_step = step
         center = (cfg.center_lon, cfg.center_lat, cfg.center_alt)
         uids = getattr(cfg, "uids", None) or [f"{'A' if a < cfg.n_ego else 'B'}0{(a if a < cfg.n_ego else a - cfg.n_ego) + 1}00" for a in range(self.num_agents)]
-        step = int(self.get_state(env, 0)[self._ix("cur_step")])
-        lines = [f"#{step * cfg.agent_interaction_steps / cfg.sim_freq:.2f}"]
+        color = lambda a: "Blue" if a < cfg.n_ego else "Red"
+        msgs = []
+        entities = [self.get_entity(env, a) for a in range(self.num_agents)]
         for a in range(self.num_agents):
-            lines.append(acmi.aircraft_record(uids[a], "Blue" if a < cfg.n_ego else "Red", self.get_entity(env, a)))
+            msgs.append(acmi.aircraft_record(uids[a], color(a), entities[a]))
         slots = {AC_TASK_SHOOT_MISSILE: 4, 2: 4, AC_TASK_SCENARIO1: 2, AC_TASK_SCENARIO_NVN: 2}.get(cfg.task, 0)
+        # env._tempsims in dict order = first-launch order of the uids; a slot's uid is "agent + remaining count at the launch"
+        # (scenario1_task.py:83,92; singlecombat_with_missile_task.py:199): slots are consumed from the highest count down
+        flying = []
         for a in range(self.num_agents):
-            for k in range(slots):
+            nmis = min(int(cfg.num_missiles[a]), slots) if slots == 4 else slots
+            for k in range(nmis):
                 m = self.get_missile(env, a, k)
                 if m[0] < 0:
                     self._acmi_exploded.discard((a, k))
                     continue
-                uid = f"{uids[a]}{k + 1}"
-                rec, boom = acmi.missile_records(uid, "Blue" if a < cfg.n_ego else "Red", int(m[0]), m[1:4], m[7], m[8], center,
-                                                 (a, k) in self._acmi_exploded, 300 if slots == 4 else 5)
-                if boom:
-                    self._acmi_exploded.add((a, k))
-                lines.append(rec)
+                flying.append((0.0, a, k, m, nmis))
+        for _, a, k, _m, _n in flying:
+            self._acmi_first.setdefault((a, k), (step, a))      # dict position of the uid: its first launch (step, agent order)
+        flying.sort(key=lambda r: self._acmi_first[(r[1], r[2])])
+        for _, a, k, m, nmis in flying:
+            uid = f"{uids[a]}{nmis - k}"
+            rec, boom = acmi.missile_records(uid, color(a), int(m[0]), m[1:4], m[7], m[8], center, (a, k) in self._acmi_exploded,
+                                             300 if slots == 4 else 5, acmi.MISSILE_MODELS[int(m[11])])
+            if boom:
+                self._acmi_exploded.add((a, k))
+            msgs.append(rec)
+        # env._chaffsims: one ChaffSimulator per qualifying incoming missile of a release event, uid "agent + (remaining + 10)"
+        if cfg.task in (AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN):
+            for a in range(self.num_agents):
+                st = self.get_state(env, a)
+                n_ch = int(st[self._ix("x_n_ch")])
+                rem = int(cfg.num_missiles[a])
+                for q in range(min(n_ch, 2)):
+                    mult = int(st[self._ix(f"x_ch_mult{q}")])
+                    alive = int(st[self._ix(f"x_ch_status{q}")]) == 0
+                    for j in range(mult):
+                        uid = f"{uids[a]}{rem + 10}"
+                        rem -= 1
+                        if uid not in self._acmi_chaff:
+                            self._acmi_chaff[uid] = {"color": color(a), "pose": tuple(entities[a][:6])}
+                        self._acmi_chaff[uid]["alive"] = alive
+            for uid, ch in self._acmi_chaff.items():
+                msgs.append(acmi.chaff_record(uid, ch["color"], ch["alive"], ch["pose"]))
         with open(filepath, mode="a", encoding="utf-8-sig") as f:
-            f.write("\n".join(lines) + "\n")
+            f.write(f"#{step * cfg.agent_interaction_steps / cfg.sim_freq:.2f}\n")
+            for msg in msgs:
+                f.write(msg + "\n")
 
     def _ix(self, name):
         if not hasattr(self, "_names"):

@@ -139,7 +139,7 @@ int ac_set_state(ac_env_t* h, int32_t env, int32_t agent, const double* in /* [A
 int ac_set_status(ac_env_t* h, int32_t env, int32_t agent, int32_t status);
 /* lon deg, lat deg, alt m, roll, pitch, yaw rad, vN, vE, vDown m/s, N, E, U m  (BaseSimulator getters, simulatior.py:47-61) */
 int ac_get_entity(ac_env_t* h, int32_t env, int32_t agent, double out[12]);
-/* missile k of an agent: status, N,E,U, vN,vE,vU, theta, psi, t, mass (MissileSimulator, simulatior.py:393-608) */
+/* missile k of an agent: status, N,E,U, vN,vE,vU, theta, psi, t, mass, model (0 AIM-9L, 1 AIM-120B, 2 AIM-9M) (MissileSimulator, simulatior.py:393-608) */
 int ac_get_missile(ac_env_t* h, int32_t env, int32_t agent, int32_t k, double out[12]);
 
 /* Order-independent 64-bit digest of all aircraft states on the device (sum over aircraft of a per-field hash): E envs in the

@@ -69,6 +69,7 @@ void or_baseline_observation(const OrAircraft* a, const double dv[3], double x[1
 /* hierarchical action spaces: MultiDiscrete [3,5,3] (singlecombat_task.py:221-222), + [2,2,2,2] weapon bits for the scenario tasks */
 int or_env_act_dim_h(int task, int hierarchical) {
   if (!hierarchical) return or_env_act_dim(task);
+  if (task == OR_TASK_SHOOT_MISSILE) return 4;   /* HierarchicalSingleCombatShootTask: Tuple([3,5,3], Discrete(2)) (singlecombat_with_missile_task.py:221-223) */
   return (task == OR_TASK_SCENARIO1 || task == OR_TASK_SCENARIO_NVN) ? 7 : 3;
 }
 int or_env_act_dim(int task) {
@@ -984,6 +985,7 @@ void or_env_step(OrEnv* e, const double* actions, double* obs, double* rew, uint
       if (scripted) { for (int k = 0; k < 4; k++) e->ac[i].shoot4[k] = c->use_artillery ? 1 : 0; }
       else if (c->task == OR_TASK_SCENARIO_NVN || (c->task == OR_TASK_SCENARIO1 && e->ac[i].team == 0))
         for (int k = 0; k < 4; k++) e->ac[i].shoot4[k] = act[3 + k] != 0;
+      if (c->task == OR_TASK_SHOOT_MISSILE) e->ac[i].shoot_action = act[3] != 0;   /* self._shoot_action[agent_id] = action[-1] (:228) */
       decode_action(e, i, low, u);
       f16_set_controls(&e->ac[i].fdm, u[0], u[1], u[2], u[3]);
       continue;

@@ -1067,10 +1067,59 @@ def gen_rollout_buffer(rng):
     np.savez_compressed(os.path.join(OUT, "rollout_buffer.npz"), **out)
 
 
+def gen_acmi_records():
+    """The reference's own Tacview records for a scripted sequence: BaseSimulator.log for two aircraft,
+    MissileSimulator.log for an AIM-120B flown by the reference's missile engine until it is done (position records, then removal +
+    explosion once, then removal), ChaffSimulator.log for a cloud released on frame 1 (alive, then removed after 20 s), the frame
+    layout of BaseEnv.render (env_base.py:207-250). Stored: the inputs of every frame and the text the reference produced."""
+    from envs.JSBSim.core.simulatior import AIM_120B, BaseSimulator, ChaffSimulator
+    a, b = FakeAircraft("A0100", "Blue"), FakeAircraft("B0100", "Red")
+    a.model = b.model = "f16"
+    a.set_pose(120.0, 60.0, 6000.0, (0.1, 0.05, 0.3), (240.0, 60.0, -5.0))
+    b.set_pose(120.01, 60.02, 6100.0, (-0.2, 0.02, 3.3), (-250.0, -20.0, 1.0))
+    m = AIM_120B.create(a, b, "A01002", "AIM-120B")
+    chaff = None
+    frames, inputs = [], []
+    tpos = b._position.copy()
+    done_frames = 0
+    for f in range(200):
+        for _ in range(6):                                  # agent_interaction_steps substeps of 1/60 s
+            tpos += a.dt * np.array([b._velocity[0], b._velocity[1], -b._velocity[2]])
+            b._position[:] = tpos
+            m.run()
+            if chaff is not None:
+                chaff.run()
+        from envs.JSBSim.utils.utils import NEU2LLA
+        b._geodetic[:] = NEU2LLA(*b._position, b.lon0, b.lat0, b.alt0)   # (AircraftSimulator.run refreshes the cache every substep)
+        if f == 1:                                           # task.step releases chaff after the substeps (scenario1_task.py:97-103)
+            chaff = ChaffSimulator.create(parent=b, uid="B010012", chaff_model="CHF")
+        if f == 30 and chaff is not None:
+            chaff._t = 25.0                                  # past its 20 s life: the next run() ends it
+        lines = [f"#{(f + 1) * 0.1:.2f}"]
+        for sim in (a, b):                                   # env._jsbsims, then _tempsims, then _chaffsims
+            lines.append(BaseSimulator.log(sim))
+        msg = m.log()
+        if msg is not None:
+            lines.append(msg)
+        if chaff is not None:
+            lines.append(chaff.log())
+        frames.append("\n".join(lines) + "\n")             # render() writes log_msg + "\n" per simulator
+        inputs.append(np.concatenate([a._geodetic, a._posture, b._geodetic, b._posture, [m._MissileSimulator__status], m.get_position(),
+                                      m.get_rpy(), [0 if chaff is None else (1 if chaff.is_alive else 2)]]))
+        done_frames += 1 if m.is_done else 0
+        if done_frames >= 3 and f > 34:
+            break
+    np.savez_compressed(os.path.join(OUT, "acmi_records.npz"), frames=np.array(frames), inputs=np.array(inputs),
+                        center=np.array([a.lon0, a.lat0, a.alt0]), missile_radius=np.array([m._Rc]))
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit(f"{REF} not present: golden vectors are generated in the build container only")
     install_standins()
+    if len(sys.argv) > 1 and sys.argv[1] == "acmi":         # this fixture alone
+        gen_acmi_records()
+        return
     rng = np.random.default_rng(20250321)
     gen_geometry(rng)
     gen_reward_functions(rng)
@@ -1088,6 +1137,7 @@ def main():
     gen_wvr_sequences(np.random.default_rng(83), which="maneuver")
     gen_rollout_buffer(np.random.default_rng(84))
     gen_approach(np.random.default_rng(85))
+    gen_acmi_records()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -150,7 +150,7 @@ def test_acmi_records_and_neu_inverse():
     r, boom = acmi.missile_records("A01001", "Blue", 1, (100.0, 50.0, 6000.0), 0.0, 0.5, (120.0, 60.0, 0.0), False, 300)
     assert boom and r.startswith("-A01001\nA01001F,T=") and "Type=Misc+Explosion" in r
     r2, boom2 = acmi.missile_records("A01001", "Blue", 1, (100.0, 50.0, 6000.0), 0.0, 0.5, (120.0, 60.0, 0.0), True, 300)
-    assert r2 == "-A01001" and boom2
+    assert r2 == "-A01001\n" and boom2          # the reference's removal message carries its own newline (simulatior.py:547-548)
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/envs/JSBSim/configs"), reason="the reference tree only exists in the build container")
@@ -194,3 +194,47 @@ def test_lazy_infos_equal_the_reference_info_dicts(pkg):
     assert infos[1:3] == [infos[1], infos[2]]
     with pytest.raises(IndexError):
         infos[4]
+
+
+def test_acmi_records_match_the_reference_log_text(pkg):
+    """the Tacview records against the text the reference's own log() methods produced for a scripted sequence
+    (tests/golden/acmi_records.npz, written by make_golden.py from BaseSimulator / MissileSimulator / ChaffSimulator.log): aircraft and
+    chaff records must be the same strings (same float64 inputs, same formatting); a missile record is rebuilt from its NEU position
+    through NEU2LLA, so its numbers are compared to 1e-9 deg / 1e-6 m and everything else as text. Frame layout of BaseEnv.render."""
+    import importlib
+    import numpy as np
+    acmi = importlib.import_module(pkg.__name__ + ".acmi")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "acmi_records.npz"))
+    center = tuple(z["center"])
+    radius = int(z["missile_radius"][0])
+    exploded = False
+    chaff_pose = None
+    seen_explosion = seen_removed_chaff = False
+    for f, (text, row) in enumerate(zip(z["frames"], z["inputs"])):
+        want = str(text).split("\n")
+        assert want[0] == f"#{(f + 1) * 0.1:.2f}"
+        got = [want[0]]
+        a_pose, b_pose = row[0:6], row[6:12]
+        got.append(acmi.aircraft_record("A0100", "Blue", a_pose))
+        got.append(acmi.aircraft_record("B0100", "Red", b_pose))
+        status, neu, rpy, chaff_state = int(row[12]), row[13:16], row[16:19], int(row[19])
+        rec, exploded = acmi.missile_records("A01002", "Blue", status, neu, rpy[1], rpy[2], center, exploded, radius, "AIM-120B")
+        got.append(rec)
+        if chaff_state:
+            if chaff_pose is None:
+                chaff_pose = tuple(b_pose)          # the release happened at the end of this frame's env step
+            got.append(acmi.chaff_record("B010012", "Red", chaff_state == 1, chaff_pose))
+        got_text = "\n".join(got) + "\n"
+        glines, wlines = got_text.split("\n"), str(text).split("\n")
+        assert len(glines) == len(wlines), (f, got_text, str(text))
+        for g, w in zip(glines, wlines):
+            if g == w:
+                continue
+            # a missile record: same fields, position rebuilt from NEU
+            gp, wp = g.split(","), w.split(",")
+            assert gp[0] == wp[0] and gp[2:] == wp[2:], (f, g, w)
+            gv, wv = [float(v) for v in gp[1][2:].split("|")], [float(v) for v in wp[1][2:].split("|")]
+            assert abs(gv[0] - wv[0]) < 1e-9 and abs(gv[1] - wv[1]) < 1e-9 and abs(gv[2] - wv[2]) < 1e-6 and gv[3:] == wv[3:], (f, g, w)
+        seen_explosion |= "Type=Misc+Explosion" in got_text
+        seen_removed_chaff |= "-B010012" in got_text
+    assert seen_explosion and seen_removed_chaff and exploded

@@ -447,14 +447,15 @@ def test_dodge_missile_rule_based_launch(pkg, oracle):
 
 @pytest.mark.parametrize("task,baseline", [("hierarchical_singlecombat", 0), ("scenario1", 0), ("scenario_nvn", 0),
                                            ("scenario1", 1), ("scenario_nvn", 1), ("hierarchical_singlecombat", 2),
-                                           ("hierarchical_multiplecombat_shoot", 0)])
+                                           ("hierarchical_multiplecombat_shoot", 0),
+                                           ("hierarchical_singlecombat_shoot", 0), ("hierarchical_singlecombat_dodge_missile", 0)])
 def test_hierarchical_tasks_lowlevel_controller(pkg, oracle, task, baseline):
     """The as-shipped action space: MultiDiscrete [3,5,3] (+ four weapon bits) -> BaselineActor (MLP + GRU + four argmax
     heads) -> control indices -> step. Each step both sides start from the oracle's flight state and GRU state; compared are the
     controller's argmax indices (identical except where the oracle's own top-two logits tie to fp32 accuracy: < 0.2 % of
     calls), the new GRU state (fp32 GEMV accuracy) and, where the indices agree, everything the step returns."""
     cfg = pkg.default_config(task, hierarchical=True)
-    if task == "scenario1":
+    if task in ("scenario1", "hierarchical_singlecombat_shoot", "hierarchical_singlecombat_dodge_missile"):
         cfg.init[1].lon_deg, cfg.init[1].lat_geod_deg, cfg.init[1].psi_deg = 120.02, 60.06, 171.0
         cfg.init[0].psi_deg = 9.0
     if task == "hierarchical_multiplecombat_shoot":   # off the shipped head-on geometry, where PostureReward's atanh is singular
@@ -470,7 +471,8 @@ def test_hierarchical_tasks_lowlevel_controller(pkg, oracle, task, baseline):
     obs = out[0] if A > 2 else out
     robs = ref.reset()
     assert obs.shape == robs.shape
-    assert env.act_dim == {"hierarchical_singlecombat": 3, "hierarchical_multiplecombat_shoot": 4}.get(task, 7)
+    assert env.act_dim == {"hierarchical_singlecombat": 3, "hierarchical_multiplecombat_shoot": 4, "hierarchical_singlecombat_shoot": 4,
+                           "hierarchical_singlecombat_dodge_missile": 3}.get(task, 7)
     if task == "hierarchical_multiplecombat_shoot":   # the only MultipleCombat missile variant an env can select: 21-value paired-enemy
         assert obs.shape == (E, 4, 21)                 # observation, [3,5,3] + a shoot bit that the task stores and never uses
     names = env.lib.state_field_names()
@@ -668,7 +670,38 @@ def test_render_writes_acmi_frames(pkg, tmp_path):
     assert len(a0) == 3 and a0[0].endswith("Name=F16,Color=Blue")
     lon, lat, alt = (float(v) for v in a0[0].split("T=")[1].split(",")[0].split("|")[:3])
     assert abs(lon - 120.0) < 1e-2 and abs(lat - 60.0) < 1e-2 and abs(alt - 6096) < 5
-    assert any(l.startswith("A01001,T=") and "Name=AIM-9L" in l for l in text)   # the shoot bit launched a missile
+    # the shoot bit launched a missile: uid = agent + remaining count at the launch (singlecombat_with_missile_task.py:199)
+    first = f"A0100{int(cfg.num_missiles[0])}"
+    assert any(l.startswith(first + ",T=") and "Name=AIM-9L" in l for l in text)
+    env.close()
+
+
+def test_render_scenario_munitions_and_chaff(pkg, tmp_path):
+    """Scenario tasks in the ACMI file: munitions under their own names (AIM-120B / AIM-9M share a parameter set, not a name), the
+    removal + explosion record with the 5 m fuse radius, and the chaff clouds (ChaffSimulator.log: Name=CHF at the releasing
+    aircraft's pose, uid = agent + (remaining + 10))."""
+    cfg = pkg.default_nvn_config(2, task="scenario_nvn")
+    for i in range(4):
+        cfg.init[i].lon_deg += 0.013 * (i % 3) + (0.02 if i >= 2 else 0.0)
+        cfg.init[i].psi_deg = (7.0 + 3.0 * i) if i < 2 else (171.0 + 2.0 * i)
+        if i >= 2:
+            cfg.init[i].lat_geod_deg = 60.06
+    env = pkg.HipShareVecEnv(cfg, 2, seed=3)
+    env.reset()
+    path = str(tmp_path / "scn.txt.acmi")
+    rng = np.random.default_rng(2)
+    for step in range(140):
+        act = np.zeros((2, 4, 8), dtype=np.float32)
+        act[..., :4] = np.array([20, 18.6, 20, 15], dtype=np.float32) + rng.integers(-1, 2, size=(2, 4, 4))
+        act[..., 4:] = rng.random((2, 4, 4)) < 0.7
+        env.step(act)
+        env.render(filepath=path)
+    text = open(path, encoding="utf-8-sig").read().splitlines()
+    assert any("Name=AIM-120B" in l for l in text)
+    assert any(",Name=CHF,Color=" in l and l.split(",")[0][-2:] in ("12", "11") for l in text)
+    assert any("Type=Misc+Explosion" in l and l.endswith("Radius=5") for l in text)
+    frames = [l for l in text if l.startswith("#")]
+    assert len(frames) == 140 and frames[0] == "#0.10"
     env.close()
 
 
@@ -793,13 +826,15 @@ def test_shot_down_aircraft_freezes_while_its_missile_flies(pkg):
 
 @pytest.mark.parametrize("task", ["singlecombat", "heading", "multiplecombat"])
 def test_multi_device_vec_env_matches_one_handle(pkg, task):
-    """SURVEY 8e's single-process form: env blocks on several devices behind one VecEnv. Rehearsed here with two handles on the
-    same GPU (uneven blocks: 37 envs -> 19 + 18): it must return exactly what one handle over all 37 envs returns."""
+    """SURVEY 8e's single-process form: env blocks on several devices behind one VecEnv (uneven blocks: 37 envs -> 19 + 18): it must
+    return exactly what one handle over all 37 envs returns. On a box with two or more GPUs the two blocks live on devices 0 and 1;
+    on a one-GPU box both handles share device 0."""
+    import torch
     cfg = pkg.default_config(task)
     A, E = cfg.n_agents, 37
     share = task == "multiplecombat"
     one = (pkg.HipShareVecEnv if share else pkg.HipVecEnv)(cfg, E, seed=5)
-    many = pkg.MultiDeviceVecEnv(cfg, E, device_ids=[0, 0], seed=5)
+    many = pkg.MultiDeviceVecEnv(cfg, E, device_ids=[0, 1] if torch.cuda.device_count() >= 2 else [0, 0], seed=5)
     assert [c for _, c in many.blocks] == [19, 18]
     r1, r2 = one.reset(), many.reset()
     for a, b in zip(r1 if share else (r1,), r2 if share else (r2,)):

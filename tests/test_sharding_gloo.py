@@ -63,3 +63,42 @@ def test_env_block_partition(pkg):
             for (s0, c0), (s1, _) in zip(blocks, blocks[1:]):
                 assert s0 + c0 == s1
             assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
+
+
+def test_bench_control_flow_two_ranks_under_torchrun(tmp_path):
+    """bench.py's multi-rank control flow exactly as the driver launches it (python -m torch.distributed.run, two ranks, gloo instead
+    of RCCL, a stand-in env handle instead of a GPU): barrier, W untimed + exactly K timed steps per rank, max-over-ranks, ONE JSON
+    line from rank 0, whole-job value, and a distinct seed block per rank (env i of the job keeps seed + 1000 i)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5", "--envs", "64", "--stub-env"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout          # rank 0 alone prints
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 30 and r["warmup"] == 5 and r["scaling"] == "weak" and r["higher_is_better"] is True
+    assert r["stub"]["steps_taken"] == 35 and r["stub"]["seed"] == 1                     # rank 0: envs 0 .. 63
+    assert abs(r["value"] - 2 * 64 * 2 * 30 / (r["ms_per_step"] * 1e-3 * 30)) < 1e-6 * r["value"]   # whole-job agent-steps / max-over-ranks time
+    assert r["ms_per_step"] >= 0.2                                                        # the stand-in sleeps 0.2 ms per step
+    assert "stub" in r["data"]
+
+
+def test_bench_rank_seed_blocks_do_not_overlap(pkg):
+    """Rank r of an N-rank bench owns envs [r E, (r + 1) E) of the job and seeds its handle with 1 + 1000 r E, so env i of the job keeps
+    the reference's seed + 1000 i (scripts/train/train_jsbsim.py:33) whatever N is: no two ranks share a stream."""
+    E = 4096
+    for world in (2, 8):
+        seeds = set()
+        for rank in range(world):
+            start, count = pkg.sharding.env_block(rank, world, world * E)
+            assert (start, count) == (rank * E, E)
+            block = {1 + 1000 * start + 1000 * i for i in range(count)}
+            assert not (seeds & block)
+            seeds |= block
