@@ -260,7 +260,16 @@ __device__ __forceinline__ void make_props(const State& s, const Derived& d, con
 }
 
 // utils.py:58-103. v = (vN, vE, vDOWN) against an (N, E, UP) position, exactly as the reference mixes them.
-struct Geo { float AO, TA, R, side; };
+struct Geo { float AO, TA, R, side, cAO, cTA; };   // (cAO / cTA: the clipped cosines the angles were taken from)
+// acos for an argument already clipped to [-1, 1]: atan2(sqrt((1 - x)(1 + x)), x) on the polynomial atan2 (8e-8 rad); the product
+// form keeps the sine exact to an ulp where the angle is ill-conditioned (x -> +-1)
+__device__ __forceinline__ float acos_fast(float x) { return f16::atan2_fast(sqrtf((1.0f - x) * (1.0f + x)), x); }
+// tanh on the transcendental unit (|error| < 1e-6 absolute), atanh for x in (-1, 1)
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float t = __expf(2.0f * clampf(-10.0f, x, 10.0f));
+  return (t - 1.0f) / (t + 1.0f);
+}
+__device__ __forceinline__ float atanh_fast(float x) { return 0.5f * __logf((1.0f + x) / (1.0f - x)); }
 template <bool TWO_D>
 __device__ __forceinline__ Geo ao_ta_r(float ex, float ey, float ez, float evx, float evy, float evz,
                                        float nx, float ny, float nz, float nvx, float nvy, float nvz) {
@@ -275,8 +284,10 @@ __device__ __forceinline__ Geo ao_ta_r(float ex, float ey, float ez, float evx, 
     pe = dx * evx + dy * evy + dz * evz; pn = dx * nvx + dy * nvy + dz * nvz;
   }
   Geo g;
-  g.AO = acosf(clampf(-1.0f, pe / (R * ev + 1e-8f), 1.0f));
-  g.TA = acosf(clampf(-1.0f, pn / (R * nv + 1e-8f), 1.0f));
+  g.cAO = clampf(-1.0f, pe / (R * ev + 1e-8f), 1.0f);
+  g.cTA = clampf(-1.0f, pn / (R * nv + 1e-8f), 1.0f);
+  g.AO = acos_fast(g.cAO);
+  g.TA = acos_fast(g.cTA);
   g.R = R;
   float cr = evx * dy - evy * dx;
   g.side = (cr > 0.0f) ? 1.0f : ((cr < 0.0f) ? -1.0f : 0.0f);
@@ -289,7 +300,7 @@ __device__ __forceinline__ float posture_fn(float AO, float TA, float Rkm) {
   // to -1 once the true angle is within 3.5e-4 rad of pi, and atanh(-1) would be -inf: the argument is kept one ulp inside
   // (atanh = -8.66, the reference's own floor), so a reward is never infinite.
   float x = fmaxf(1.0f - fmaxf(2.0f * TA / f16::kPi, 1e-4f), -0.99999994f);
-  float orn = 1.0f / (50.0f * AO / f16::kPi + 2.0f) + 0.5f + fminf(atanhf(x) / (2.0f * f16::kPi), 0.0f) + 0.5f;
+  float orn = 1.0f / (50.0f * AO / f16::kPi + 2.0f) + 0.5f + fminf(atanh_fast(x) / (2.0f * f16::kPi), 0.0f) + 0.5f;
   float rng = (Rkm < 5.0f ? 1.0f : 0.0f) + (Rkm >= 5.0f ? clampf(0.0f, -0.032f * Rkm * Rkm + 0.284f * Rkm + 0.38f, 1.0f) : 0.0f) +
               clampf(0.0f, __expf(-0.16f * Rkm), 0.2f);
   return orn * rng;
@@ -547,6 +558,9 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// (the observation rows are already in LDS: lds[lane * ow + k], written by the lane itself)
+__device__ __forceinline__ void emit_rows(const DevPtrs& P, float* lds /* [64 * ow], 16-byte aligned */, int ow, int lane,
+                                          float reward, bool done, int A, int i0, int i1, int i2, int i3);
 template <int NOB>
 __device__ __forceinline__ void emit_outputs(const DevPtrs& P, float* lds /* [64 * ow], 16-byte aligned */, int ow, int lane, const float (&ob)[NOB],
                                              float reward, bool done, int A, int i0, int i1, int i2, int i3) {
@@ -554,6 +568,9 @@ __device__ __forceinline__ void emit_outputs(const DevPtrs& P, float* lds /* [64
 #pragma unroll
   for (int k = 0; k < NOB; ++k) if (k < ow) row[k] = ob[k];
   for (int k = NOB; k < ow; ++k) row[k] = 0.0f;             // reserved slots of the *_RWR variants
+  emit_rows(P, lds, ow, lane, reward, done, A, i0, i1, i2, i3);
+}
+__device__ __forceinline__ void emit_rows(const DevPtrs& P, float* lds, int ow, int lane, float reward, bool done, int A, int i0, int i1, int i2, int i3) {
   wave_lds_fence();
   const size_t blk = blockIdx.x;
   const int nvec = 16 * ow;                                 // float4 count of the block's rows
@@ -569,7 +586,12 @@ __device__ __forceinline__ void emit_outputs(const DevPtrs& P, float* lds /* [64
     float* obs = set ? P.obs2 : P.obs; float* rew = set ? P.rew2 : P.rew; uint8_t* dn = set ? P.done2 : P.done; int* info = set ? P.info2 : P.info;
     if (!obs) continue;
     float4* o4 = reinterpret_cast<float4*>(obs + blk * 64 * (size_t)ow);
-    for (int i = lane; i < nvec; i += 64) o4[i] = l4[i];
+    int i = lane;
+    for (; i + 192 < nvec; i += 256) {     // four rows of the copy in flight at a time
+      const float4 v0 = l4[i], v1 = l4[i + 64], v2 = l4[i + 128], v3 = l4[i + 192];
+      o4[i] = v0; o4[i + 64] = v1; o4[i + 128] = v2; o4[i + 192] = v3;
+    }
+    for (; i < nvec; i += 64) o4[i] = l4[i];
     rew[n] = reward;
     if (lane < 16) reinterpret_cast<unsigned*>(dn + blk * 64)[lane] = dword;
     if (lane % A == 0) *reinterpret_cast<int4*>(info + (n / A) * 4) = inf;
@@ -668,17 +690,23 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
   const int slot = nn & 1;
 
   State s; Task t; Derived d; Props pr;
+  int pre_st[MSLOTS];
+#pragma unroll
+  for (int k = 0; k < MSLOTS; ++k) pre_st[k] = MSL_INACTIVE;
   if (SPLIT) {   // table loads, then state loads behind them, then the LDS copy: one HBM round trip for both
     TableCopy<192> tc;
     tc.issue(P.tab);
     load_state(P.F, P.I, P.D, N, nn, s, t);
     tc.commit(lds_tab);
   } else if (PAIR) {
+    const bool flight_role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1;
+    if (!flight_role) {   // the environment wave owns the task bookkeeping; the status word of every missile slot comes with it
+      s = State{}; s.ticks = P.I[(size_t)FI_ticks * N + nn]; load_task(P.F, P.I, N, nn, t);
+#pragma unroll
+      for (int k = 0; k < MSLOTS; ++k) pre_st[k] = P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn];
+    }
     stage_tables<128>(lds_tab, P.tab);
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1) { pair_flight_wave(P, c, T, LP, l, nn, n, live); return; }
-    s = State{};   // the environment wave owns the task bookkeeping; of the flight state it only needs the tick count
-    load_task(P.F, P.I, N, nn, t);
-    s.ticks = P.I[(size_t)FI_ticks * N + nn];
+    if (flight_role) { pair_flight_wave(P, c, T, LP, l, nn, n, live); return; }
   } else {
     stage_tables<64>(lds_tab, P.tab);
     load_state(P.F, P.I, P.D, N, nn, s, t);
@@ -700,7 +728,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
     for (int k = 0; k < MSLOTS; ++k) {
       // a slot that has not been launched since the last reset holds zeros and MSL_INACTIVE (reset_all_kernel, the reset branch
       // below): only its status is read, and it is written back only once it has been launched or reset
-      const int st = (k < nslots) ? P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn] : MSL_INACTIVE;
+      const int st = (k < nslots) ? (PAIR ? pre_st[k] : P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn]) : MSL_INACTIVE;
       if (st != MSL_INACTIVE) { load_msl(P.MF, P.MI, N, nn, k, ms[k]); msl_was_active |= 1 << k; }
       else { ms[k] = Msl{}; ms[k].status = MSL_INACTIVE; }
     }
@@ -727,7 +755,8 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
     bool mine = false;
 #pragma unroll
     for (int k = 0; k < MSLOTS; ++k) mine = mine || ms[k].status != MSL_INACTIVE;
-    env_has_missiles = mine || (bool)__shfl_xor((int)mine, 1);
+    const int other = __shfl_xor((int)mine, 1);   // (fetched first: a shuffle on the right of || is skipped by the lanes that short-circuit)
+    env_has_missiles = mine || (bool)other;
   }
   bool located = false;
   for (int sub = 0; sub < c.substeps; ++sub) {

@@ -37,14 +37,19 @@ __device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg&
   s.dr = f16::clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);
   s.thr = f16::clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
   bool flew = false;
+  AC_CLKW(1, 128);
   for (int sub = 0; sub < c.substeps; ++sub) {
     wg_sync();                                              // the environment wave has posted who flies this tick
+    AC_CLKW(1, 129 + 4 * sub);
     const bool run = L.RUNF[l] != 0.0f;
     if (run) f16::propagate(s);
     L.R[0][l] = s.rx; L.R[1][l] = s.ry; L.R[2][l] = s.rz;  // (a grounded aircraft keeps posting its frozen pose)
     L.V[0][l] = s.vx; L.V[1][l] = s.vy; L.V[2][l] = s.vz;
+    AC_CLKW(1, 130 + 4 * sub);
     wg_sync();                                              // poses posted
+    AC_CLKW(1, 131 + 4 * sub);
     if (run) { f16::tick_after_propagate<false>(s, d, T); flew = true; }
+    AC_CLKW(1, 132 + 4 * sub);
   }
   if (!flew) { f16::locate_fast(s, d); f16::body_frame(s, d); }   // never flew this step: the body-frame quantities of the stored pose
 #pragma unroll
@@ -54,6 +59,7 @@ __device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg&
   L.FIN[FIN_QC][l] = s.qc; L.FIN[FIN_NPX][l] = s.npx; L.FIN[FIN_NPY][l] = s.npy; L.FIN[FIN_NPZ][l] = s.npz;
   L.FIN[FIN_TICKS][l] = __int_as_float(s.ticks); L.FIN[FIN_FLEW][l] = flew ? 1.0f : 0.0f;
   if (live) store_flight(P.F, P.I, P.D, c.N, n, s);
+  AC_CLKW(1, 160);
   wg_sync();   // final values posted, flight state stored (the release half of the barrier waits for the stores: an episode reset by
                // the environment wave overwrites them afterwards)
 }

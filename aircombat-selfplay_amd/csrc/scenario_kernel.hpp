@@ -81,7 +81,7 @@ struct ScenarioDims {
 };
 
 // Relative-geometry quantities of every reward term towards the enemies of this lane, in enemy order.
-struct EnemyGeo { float AO, TA, R; };
+struct EnemyGeo { float AO, TA, R, cAO, cTA; };
 
 // FORM: FORM_ONE = one wave per 64 aircraft does everything; FORM_SPLIT = the FDM ticks in the three-wave form (split_kernel.hpp; used
 // for the gun-only tasks, which have nothing to fly between ticks); FORM_PAIR = a flight wave and an environment wave
@@ -100,7 +100,6 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : (PAIR ? sizeof(PairLds) : 16)];
   SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
   PairLds& LP = *reinterpret_cast<PairLds*>(split_lds);
-  stage_tables<SPLIT ? 192 : (PAIR ? 128 : 64)>(lds_tab, P.tab);
   const Tab T{lds_tab};
   const int N = c.N;
   const int lane = threadIdx.x & 63;
@@ -112,22 +111,34 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   const int n_ego = c.n_ego;
   const int team = slot < n_ego ? 0 : 1;
   const int e_first = team == 0 ? n_ego : 0;   // my enemies are slots e_first .. e_first + NE - 1
-  if (PAIR && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1) { pair_flight_wave(P, c, T, LP, lane, nn, n, live); return; }
-
+  // The environment wave's loads are two dependent round trips to HBM: (1) with the table pack, everything it can ask for up front --
+  // the action row, the tick count and the status word of every munition slot; (2) the task bookkeeping and the munition slots that
+  // are in use, in one batch.
+  const bool flight_role = PAIR && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1;
+  const float* act = P.actions + (size_t)nn * c.act_dim;
   State s; Task t; Derived d; Props pr; Ext x;
-  if (PAIR) {   // the environment wave owns the task bookkeeping; of the flight state it only needs the tick count (Earth angle)
-    s = State{};
-    load_task(P.F, P.I, N, nn, t);
-    s.ticks = P.I[(size_t)FI_ticks * N + nn];
-  } else load_state(P.F, P.I, P.D, N, nn, s, t);
+  float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
+  int mst[MS] = {MSL_INACTIVE, MSL_INACTIVE};
+  if (!flight_role) {
+    a4 = load_controls(act, c.act_dim);
+    if (c.act_dim == 8) b4 = load_controls(act + 4, c.act_dim);
+#pragma unroll
+    for (int k = 0; k < MS; ++k) mst[k] = P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn];
+    if (PAIR) { s = State{}; s.ticks = P.I[(size_t)FI_ticks * N + nn]; }
+  }
+  stage_tables<SPLIT ? 192 : (PAIR ? 128 : 64)>(lds_tab, P.tab);
+  AC_CLK(0);
+  if (flight_role) { pair_flight_wave(P, c, T, LP, lane, nn, n, live); return; }   // (it waits for the environment wave's first flags anyway: its state load hides there)
+
+  if (PAIR) load_task(P.F, P.I, N, nn, t);   // the environment wave owns the task bookkeeping; of the flight state it only needs the tick count (Earth angle)
+  else load_state(P.F, P.I, P.D, N, nn, s, t);
   load_ext(XF, XI, N, nn, x);
   MslD ms[MS];
 #pragma unroll
   for (int k = 0; k < MS; ++k) {
     // a slot that has not been used since the last reset holds zeros and MSL_INACTIVE: only its status word is read, and it is written
     // back only once it has been launched or reset
-    const int st = P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn];
-    if (st != MSL_INACTIVE) load_msl(P.MD, P.MI, N, nn, k, ms[k]);
+    if (mst[k] != MSL_INACTIVE) load_msl(P.MD, P.MI, N, nn, k, ms[k]);
     else { ms[k] = MslD{}; ms[k].status = MSL_INACTIVE; }
   }
   int msl_was_active = 0;
@@ -136,8 +147,6 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
 
   // ---- actions: 4 control indices + [gun, AIM-9M, AIM-120B, chaff] (scenario1_task.py:33-48: Scenario1 only refreshes the ego
   // team's bits, its other team flies the scripted baseline with bits 0; scenario2_task.py:58-61 refreshes both teams)
-  const float* act = P.actions + (size_t)nn * c.act_dim;
-  const float4 a4 = load_controls(act, c.act_dim);
   t.cur_step += 1;
   s.da = clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);
   s.de = clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
@@ -148,7 +157,6 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   const bool wvr = gun_only && !maneuver;
   if (!gun_only && (MULTI || team == 0))
   {
-    const float4 b4 = load_controls(act + 4, c.act_dim);   // (act_dim is 8 for every task with weapon bits)
     x.bits = (b4.x != 0.0f ? 1 : 0) | (b4.y != 0.0f ? 2 : 0) | (b4.z != 0.0f ? 4 : 0) | (b4.w != 0.0f ? 8 : 0);
   }
 
@@ -166,15 +174,19 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   int last_tick = -1;   // three-wave form: the last substep this aircraft flew
   int ticks_now = s.ticks;   // pair form: the executive tick count of the posted pose (Earth angle of the geodetic reduction)
   bool located = false;      // pair form: d / pr hold the pose of the step's last substep already
+  AC_CLK(1);
   for (int sub = 0; sub < c.substeps; ++sub) {
+    AC_CLK(2 + 8 * sub);
     if (PAIR) {
       if (pair_substep(t, LP, lane)) ticks_now += 1;
+      AC_CLK(3 + 8 * sub);
       if (!env_has_munitions) continue;     // nothing to fly: the pose is only needed after the last substep
       pair_read_pose(LP, lane, ticks_now, s);
       f16::locate(s, d);
       ned_velocity(s, d);
       make_pose(d, c, pr);
       located = sub + 1 == c.substeps;
+      AC_CLK(4 + 8 * sub);
     } else {
     if (SPLIT) {
       if (dynamics_wave_tick(s, t, d, T, L, lane, sub)) { have_pose = true; last_tick = sub; }
@@ -240,6 +252,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
         if (ms[k].status == MSL_HIT && talive[k]) hit_tgt[k] = ms[k].order & 15;
       }
     }
+    AC_CLK(5 + 8 * sub);
 #pragma unroll
     for (int j = 0; j < A; ++j)
 #pragma unroll
@@ -247,6 +260,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
         int h = __shfl(hit_tgt[k], base + j);
         if (h == slot && t.status == AC_ALIVE) t.status = AC_SHOTDOWN;
       }
+    AC_CLK(6 + 8 * sub);
     // ---- chaff clouds age (ChaffSimulator.run, simulatior.py:377-381), then the decoy test (env_base.py:146-154)
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -260,7 +274,8 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
           const int src = base + j;
           int cst = __shfl(x.ch_status[q], src), cm = __shfl(x.ch_mult[q], src), cn = __shfl(x.n_ch, src);
           float cxx = __shfl(x.cx[q], src), cyy = __shfl(x.cy[q], src), czz = __shfl(x.cz[q], src);
-          int cbase = (q == 0) ? 0 : __shfl(x.ch_mult[0], src);   // release index of the first chaff of this event
+          const int m0 = __shfl(x.ch_mult[0], src);
+          const int cbase = (q == 0) ? 0 : m0;   // release index of the first chaff of this event
           if (q >= cn || cst != 0) continue;
 #pragma unroll
           for (int k = 0; k < MS; ++k) {
@@ -274,9 +289,11 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
         }
     }
   }
+  AC_CLK(60);
   const bool split_located = SPLIT && dynamics_wave_finish(s, d, L, lane, last_tick, c.substeps);   // (+ the helper waves' fields)
   if (PAIR) {
     wg_sync();                                     // the flight wave has posted its final values and stored the flight state
+    AC_CLK(61);
     if (!located) {
       pair_read_pose(LP, lane, ticks_now, s);
       f16::locate(s, d);
@@ -291,7 +308,11 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     make_props(s, d, c, pr);
   }
 
-  // ---- weapons (scenario1_task.py:61-103): agents act one after another in env order
+  AC_CLK(62);
+  // ---- weapons (scenario1_task.py:61-103). The reference walks the agents one after another in env order; what an agent decides
+  // depends on the others only through the chaff rule, which counts the dict's missiles aimed at it (so it sees the launches of the
+  // agents before it, and entries those launches replaced are gone). Gun damage lands on bloods, which nobody reads until the next
+  // substep. So every lane decides gun / missiles for itself at once, and the chaff count reconstructs the dict as agent `slot` saw it.
   {
     const float hv = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve + pr.vd * pr.vd);
     // farthest enemy (get_target, :139-145): poses and statuses do not change while the weapons are evaluated
@@ -304,82 +325,99 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
       float dd = sqrtf(ex * ex + ey * ey + ez * ez);
       if (dd > bd) { bd = dd; tg = e_first + q; tdx = ex; tdy = ey; tdz = ez; tg_status = est; }
     }
+    const float ang = 57.29577951f * acos_fast(clampf(-1.0f, (tdx * pr.vn + tdy * pr.ve + tdz * pr.vd) / (bd * hv + 1e-8f), 1.0f));
+    // my dict entries before this step's launches (what an agent that acts before me still sees of them)
+    int old_st[MS], old_tg[MS]; float old_x[MS], old_y[MS], old_z[MS];
 #pragma unroll
-    for (int i = 0; i < A; ++i) {
-      float gun_dmg = 0.0f; int gun_tgt = -1;
-      bool launched = false;
-      if (gun_only) {
-        // WVR_task.py:62-76 / singlecombat_task.py:290-297: every aircraft, dead or alive, drains 5 blood from its farthest enemy inside 3 km and 5 deg, every step
-        const float ang = 57.29577951f * acosf(clampf(-1.0f, (tdx * pr.vn + tdy * pr.ve + tdz * pr.vd) / (bd * hv + 1e-8f), 1.0f));
-        if (slot == i && bd * 0.001f < 3.0f && ang < 5.0f) { gun_dmg = 5.0f; gun_tgt = tg; }
-      } else if (slot == i && t.status == AC_ALIVE) {
-        const float ang = 57.29577951f * acosf(clampf(-1.0f, (tdx * pr.vn + tdy * pr.ve + tdz * pr.vd) / (bd * hv + 1e-8f), 1.0f));
-        const bool talive = tg_status == AC_ALIVE;
-        const bool av_gun = talive && bd * 0.001f < 3.0f && ang < 5.0f;
-        const bool av_120 = talive && bd * 0.001f < 37.0f && ang < 90.0f;
-        const bool av_9m = talive && bd * 0.001f < 7.0f && ang < 90.0f;
-        auto last_done = [&]() {
-          if (t.last_missile < 0) return true;
-          bool dn = true;
+    for (int k = 0; k < MS; ++k) {
+      old_st[k] = ms[k].status; old_tg[k] = ms[k].order & 15;
+      old_x[k] = (float)ms[k].px; old_y[k] = (float)ms[k].py; old_z[k] = (float)ms[k].pz;
+    }
+    float gun_dmg = 0.0f; int gun_tgt = -1;
+    int launched_k = -1;   // the slot this aircraft launched into this step (one launch per step at most: the second rule needs the first missile done)
+    if (gun_only) {
+      // WVR_task.py:62-76 / singlecombat_task.py:290-297: every aircraft, dead or alive, drains 5 blood from its farthest enemy inside 3 km and 5 deg, every step
+      if (bd * 0.001f < 3.0f && ang < 5.0f) { gun_dmg = 5.0f; gun_tgt = tg; }
+    } else if (t.status == AC_ALIVE) {
+      const bool talive = tg_status == AC_ALIVE;
+      const bool av_gun = talive && bd * 0.001f < 3.0f && ang < 5.0f;
+      const bool av_120 = talive && bd * 0.001f < 37.0f && ang < 90.0f;
+      const bool av_9m = talive && bd * 0.001f < 7.0f && ang < 90.0f;
+      auto last_done = [&]() {
+        if (t.last_missile < 0) return true;
+        bool dn = true;
 #pragma unroll
-          for (int k = 0; k < MS; ++k) if (k == t.last_missile) dn = ms[k].status == MSL_HIT || ms[k].status == MSL_MISS;
-          return dn;
-        };
-        auto launch = [&](int k, int model) {   // MissileSimulator.launch (:497-514) into the dict entry of uid "agent + (MS - k)"
-          float tht = asinf(pr.stht);
-          float psi = atan2f(pr.m12, pr.m11);
-          if (psi < 0.0f) psi += 2.0f * f16::kPi;
+        for (int k = 0; k < MS; ++k) if (k == t.last_missile) dn = ms[k].status == MSL_HIT || ms[k].status == MSL_MISS;
+        return dn;
+      };
+      int want_k = -1, want_model = 0;
+      if ((x.bits & 1) && x.rem_gun > 0 && last_done() && av_gun) { gun_dmg = 5.0f; gun_tgt = tg; x.rem_gun -= 1; }
+      if ((x.bits & 4) && x.rem_120b > 0 && last_done() && av_120) { want_k = MS - x.rem_120b; want_model = 0; x.rem_120b -= 1; }
+      else if ((x.bits & 2) && x.rem_9m > 0 && last_done() && av_9m) { want_k = MS - x.rem_9m; want_model = 1; x.rem_9m -= 1; }   // (after an AIM-120B launch the last missile is in flight: no AIM-9M in the same step)
+      if (want_k >= 0) {   // MissileSimulator.launch (:497-514) into the dict entry of uid "agent + (MS - k)"
+        float tht = asinf(pr.stht);
+        float psi = atan2f(pr.m12, pr.m11);
+        if (psi < 0.0f) psi += 2.0f * f16::kPi;
 #pragma unroll
-          for (int q = 0; q < MS; ++q)
-            if (q == k) {
-              if (ms[q].status == MSL_HIT) x.orphan_hits += 1;   // a replaced entry that was HIT stays is_success forever (never run again)
-              if (ms[q].status == MSL_INACTIVE) ms[q].dpos = (t.cur_step << 4) | i;   // a uid launched again keeps its place in the dict
-              ms[q].model = model;
-              ms[q].px = pr.n64; ms[q].py = pr.e64; ms[q].pz = pr.u64; ms[q].vx = pr.vn; ms[q].vy = pr.ve; ms[q].vz = pr.vd;
-              ms[q].theta = tht; ms[q].psi = psi; ms[q].t = 0.0; ms[q].m = MP.m0; ms[q].dth = 0.0; ms[q].dph = 0.0;
-              ms[q].dprev = INFINITY; ms[q].recede = 0; ms[q].status = MSL_LAUNCHED;
-              ms[q].order = (t.cur_step << 8) | (i << 4) | tg;    // launch order (step, agent) and target slot
-            }
-          t.last_missile = k;
-          launched = true;
-        };
-        if ((x.bits & 1) && x.rem_gun > 0 && last_done() && av_gun) { gun_dmg = 5.0f; gun_tgt = tg; x.rem_gun -= 1; }
-        if ((x.bits & 4) && x.rem_120b > 0 && last_done() && av_120) { launch(MS - x.rem_120b, 0); x.rem_120b -= 1; }
-        if ((x.bits & 2) && x.rem_9m > 0 && last_done() && av_9m) { launch(MS - x.rem_9m, 1); x.rem_9m -= 1; }
+        for (int q = 0; q < MS; ++q)
+          if (q == want_k) {
+            if (ms[q].status == MSL_HIT) x.orphan_hits += 1;   // a replaced entry that was HIT stays is_success forever (never run again)
+            if (ms[q].status == MSL_INACTIVE) ms[q].dpos = (t.cur_step << 4) | slot;   // a uid launched again keeps its place in the dict
+            ms[q].model = want_model;
+            ms[q].px = pr.n64; ms[q].py = pr.e64; ms[q].pz = pr.u64; ms[q].vx = pr.vn; ms[q].vy = pr.ve; ms[q].vz = pr.vd;
+            ms[q].theta = tht; ms[q].psi = psi; ms[q].t = 0.0; ms[q].m = MP.m0; ms[q].dth = 0.0; ms[q].dph = 0.0;
+            ms[q].dprev = INFINITY; ms[q].recede = 0; ms[q].status = MSL_LAUNCHED;
+            ms[q].order = (t.cur_step << 8) | (slot << 4) | tg;    // launch order (step, agent) and target slot
+          }
+        t.last_missile = want_k;
+        launched_k = want_k;
       }
-      (void)launched;
-      // gun damage lands on the target's blood right away (:70-73)
-      {
-        int gt = __shfl(gun_tgt, base + i);
-        float gd = __shfl(gun_dmg, base + i);
-        if (gt == slot) t.bloods -= gd;
-      }
-      // chaff (:97-103): one release per dict missile (done ones included) aimed at agent i within 1000 m
-      {
-        int n_rel = 0;
-        const bool can = slot == i && t.status == AC_ALIVE && (x.bits & 8) && x.rem_chaff > 0 &&
-                         (x.last_chaff < 0 || x.ch_status[x.last_chaff & 1] == 1);
+    }
+    // gun damage lands on the target's blood right away (:70-73)
 #pragma unroll
-        for (int j = 0; j < A; ++j)
+    for (int j = 0; j < A; ++j) {
+      const int gt = __shfl(gun_tgt, base + j);
+      const float gd = __shfl(gun_dmg, base + j);
+      if (gt == slot) t.bloods -= gd;
+    }
+    // chaff (:97-103): one release per dict missile (done ones included) aimed at this agent within 1000 m, as the dict stands when
+    // the agent acts: entries of agents up to and including itself already hold this step's launches
+    if (!gun_only) {
+      const int lc_status = (x.last_chaff & 1) ? x.ch_status[1] : x.ch_status[0];
+      const bool can = t.status == AC_ALIVE && (x.bits & 8) && x.rem_chaff > 0 && (x.last_chaff < 0 || lc_status == 1);
+      int n_rel = 0;
+      if (__ballot(can) & env_mask) {
+#pragma unroll
+        for (int j = 0; j < A; ++j) {
+          const int src = base + j;
+          const int lk = __shfl(launched_k, src), ntg = __shfl(tg, src);
+          const float lx = __shfl(pr.n, src), ly = __shfl(pr.e, src), lz = __shfl(pr.u, src);
 #pragma unroll
           for (int k = 0; k < MS; ++k) {
-            const int src = base + j;
-            int mst = __shfl(ms[k].status, src), mtg = __shfl(ms[k].order, src) & 15;
-            float mx = __shfl((float)ms[k].px, src), my = __shfl((float)ms[k].py, src), mz = __shfl((float)ms[k].pz, src);
-            if (can && mst != MSL_INACTIVE && mtg == slot) {
-              float dx = pr.n - mx, dy = pr.e - my, dz = pr.u - mz;
+            const int ost = __shfl(old_st[k], src), otg = __shfl(old_tg[k], src);
+            const float ox = __shfl(old_x[k], src), oy = __shfl(old_y[k], src), oz = __shfl(old_z[k], src);
+            const bool fresh = lk == k && j <= slot;           // launched this step by an agent that acted before me (or by me)
+            const int st = fresh ? MSL_LAUNCHED : ost, mtg = fresh ? ntg : otg;
+            const float mx = fresh ? lx : ox, my = fresh ? ly : oy, mz = fresh ? lz : oz;
+            if (can && st != MSL_INACTIVE && mtg == slot) {
+              const float dx = pr.n - mx, dy = pr.e - my, dz = pr.u - mz;
               if (sqrtf(dx * dx + dy * dy + dz * dz) < 1000.0f) n_rel += 1;
             }
           }
-        if (n_rel > 0 && x.n_ch < 2) {
-          const int q = x.n_ch;
-          x.cx[q] = pr.n; x.cy[q] = pr.e; x.cz[q] = pr.u; x.ct[q] = 0.0f; x.ch_status[q] = 0; x.ch_mult[q] = n_rel;
-          x.last_chaff = q; x.n_ch += 1; x.rem_chaff -= n_rel;
         }
+      }
+      if (n_rel > 0 && x.n_ch < 2) {
+        const bool second = x.n_ch == 1;
+        x.cx[0] = second ? x.cx[0] : pr.n; x.cy[0] = second ? x.cy[0] : pr.e; x.cz[0] = second ? x.cz[0] : pr.u;
+        x.ct[0] = second ? x.ct[0] : 0.0f; x.ch_status[0] = second ? x.ch_status[0] : 0; x.ch_mult[0] = second ? x.ch_mult[0] : n_rel;
+        x.cx[1] = second ? pr.n : x.cx[1]; x.cy[1] = second ? pr.e : x.cy[1]; x.cz[1] = second ? pr.u : x.cz[1];
+        x.ct[1] = second ? 0.0f : x.ct[1]; x.ch_status[1] = second ? 0 : x.ch_status[1]; x.ch_mult[1] = second ? n_rel : x.ch_mult[1];
+        x.last_chaff = x.n_ch; x.n_ch += 1; x.rem_chaff -= n_rel;
       }
     }
   }
 
+  AC_CLK(63);
   // ---- geometry towards my enemies (every reward term iterates agent.enemies in env order)
   EnemyGeo eg[NE];
   float e_u0 = 0.0f;
@@ -387,31 +425,40 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   for (int q = 0; q < NE; ++q) {
     Enemy E = gather_pose(pr, base + e_first + q);
     Geo g = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd);
-    eg[q].AO = g.AO; eg[q].TA = g.TA; eg[q].R = g.R;
+    eg[q].AO = g.AO; eg[q].TA = g.TA; eg[q].R = g.R; eg[q].cAO = g.cAO; eg[q].cTA = g.cTA;
     if (q == 0) e_u0 = E.u;
   }
   // ---- my first alive incoming missile in launch order (check_missile_warning), and whether any is alive
   Incoming inc{false, 0, 0, 0, 0, 0, 0};
   int inc_id = 0;    // 1 + launcher*MS + slot of that missile
   {
-    int best = 0x7fffffff;
+    // one word per entry finds it (launch order and target sit in `order`), then its six floats come from that one lane
+    int key[MS];
+#pragma unroll
+    for (int k = 0; k < MS; ++k) key[k] = ms[k].status == MSL_LAUNCHED ? ms[k].order : 0x7fffffff;
+    int best = 0x7fffffff, bj = 0, bk = -1;
 #pragma unroll
     for (int j = 0; j < A; ++j)
 #pragma unroll
       for (int k = 0; k < MS; ++k) {
-        const int src = base + j;
-        int mst = __shfl(ms[k].status, src), mo = __shfl(ms[k].order, src);
-        float a0 = __shfl((float)ms[k].px, src), a1 = __shfl((float)ms[k].py, src), a2 = __shfl((float)ms[k].pz, src);
-        float a3 = __shfl((float)ms[k].vx, src), a4 = __shfl((float)ms[k].vy, src), a5 = __shfl((float)ms[k].vz, src);
-        if (mst == MSL_LAUNCHED && (mo & 15) == slot && (mo >> 4) < best) {
-          best = mo >> 4; inc.any = true; inc.px = a0; inc.py = a1; inc.pz = a2; inc.vx = a3; inc.vy = a4; inc.vz = a5; inc_id = 1 + j * MS + k;
-        }
+        const int kk = __shfl(key[k], base + j);
+        if (kk != 0x7fffffff && (kk & 15) == slot && (kk >> 4) < best) { best = kk >> 4; bj = j; bk = k; }
       }
+#pragma unroll
+    for (int k = 0; k < MS; ++k) {
+      const int src = base + bj;
+      const float a0 = __shfl((float)ms[k].px, src), a1 = __shfl((float)ms[k].py, src), a2 = __shfl((float)ms[k].pz, src);
+      const float a3 = __shfl((float)ms[k].vx, src), a4 = __shfl((float)ms[k].vy, src), a5 = __shfl((float)ms[k].vz, src);
+      if (k == bk) { inc.px = a0; inc.py = a1; inc.pz = a2; inc.vx = a3; inc.vy = a4; inc.vz = a5; }
+    }
+    inc.any = bk >= 0;
+    inc_id = bk >= 0 ? 1 + bj * MS + bk : 0;
   }
   int my_hits = x.orphan_hits;
 #pragma unroll
   for (int k = 0; k < MS; ++k) if (ms[k].status == MSL_HIT) my_hits += 1;
 
+  AC_CLK(64);
   // ---- observation
   float ob[OBS];
   if (!MULTI) {
@@ -427,12 +474,14 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     Enemy E = gather_pose(pr, base + e_first + (slot - (team == 0 ? 0 : n_ego)));
     observe_1v1<AC_TASK_SHOOT_MISSILE>(pr, E, inc, ob);
   } else {
-    // scenario2_task.py:256-316: ego 9, partners, enemies, then the missile block directly after them; not clipped
-#pragma unroll
-    for (int k = 0; k < OBS; ++k) ob[k] = 0.0f;
-    ob[0] = pr.alt_m / 5000.0f;
-    ob[1] = pr.sphi; ob[2] = pr.cphi; ob[3] = pr.stht; ob[4] = pr.ctht;
-    ob[5] = pr.ub / 340.0f; ob[6] = pr.vb / 340.0f; ob[7] = pr.wb / 340.0f; ob[8] = pr.vc / 340.0f;
+    // scenario2_task.py:256-316: ego 9, partners, enemies, then the missile block directly after them; not clipped. Written straight
+    // into this lane's row of the output staging buffer (a block's place in the row is a run-time index: an LDS address, not a
+    // select chain over 63 registers)
+    float* orow = lds_out + lane * c.obs_dim;
+    for (int k = 0; k < c.obs_dim; ++k) orow[k] = 0.0f;
+    orow[0] = pr.alt_m / 5000.0f;
+    orow[1] = pr.sphi; orow[2] = pr.cphi; orow[3] = pr.stht; orow[4] = pr.ctht;
+    orow[5] = pr.ub / 340.0f; orow[6] = pr.vb / 340.0f; orow[7] = pr.wb / 340.0f; orow[8] = pr.vc / 340.0f;
     const int n_mine = team == 0 ? n_ego : A - n_ego;
 #pragma unroll
     for (int j = 0; j < A; ++j) {
@@ -440,24 +489,22 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
       if (j == slot) continue;
       Geo g = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd);
       const int team_j = j < n_ego ? 0 : 1;
-      int idx = (team_j == team) ? (j - (team == 0 ? 0 : n_ego)) - (j > slot ? 1 : 0) : (n_mine - 1) + (j - e_first);
-      const float v[6] = {(E.ub - pr.ub) / 340.0f, (E.alt - pr.alt_m) / 1000.0f, g.AO, g.TA, g.R / 10000.0f, g.side};
-#pragma unroll
-      for (int q = 0; q < A - 1; ++q)
-        if (q == idx) {
-#pragma unroll
-          for (int m = 0; m < 6; ++m) ob[9 + q * 6 + m] = v[m];
-        }
+      const int idx = (team_j == team) ? (j - (team == 0 ? 0 : n_ego)) - (j > slot ? 1 : 0) : (n_mine - 1) + (j - e_first);
+      float* blk = orow + 9 + idx * 6;
+      blk[0] = (E.ub - pr.ub) / 340.0f; blk[1] = (E.alt - pr.alt_m) / 1000.0f; blk[2] = g.AO; blk[3] = g.TA; blk[4] = g.R / 10000.0f; blk[5] = g.side;
     }
     if (inc.any) {
       Geo gm = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, inc.px, inc.py, inc.pz, inc.vx, inc.vy, inc.vz);
-      const int o = 9 + 6 * (A - 1);
-      ob[o + 0] = (sqrtf(inc.vx * inc.vx + inc.vy * inc.vy + inc.vz * inc.vz) - pr.ub) / 340.0f;
-      ob[o + 1] = (inc.pz - pr.alt_m) / 1000.0f;
-      ob[o + 2] = gm.AO; ob[o + 3] = gm.TA; ob[o + 4] = gm.R / 10000.0f; ob[o + 5] = gm.side;
+      float* blk = orow + 9 + 6 * (A - 1);
+      blk[0] = (sqrtf(inc.vx * inc.vx + inc.vy * inc.vy + inc.vz * inc.vz) - pr.ub) / 340.0f;
+      blk[1] = (inc.pz - pr.alt_m) / 1000.0f;
+      blk[2] = gm.AO; blk[3] = gm.TA; blk[4] = gm.R / 10000.0f; blk[5] = gm.side;
     }
   }
+  constexpr bool OBS_IN_LDS = MULTI;   // (the legacy 21-value form of the NvN tasks still goes through ob[] below)
+  const bool row_direct = OBS_IN_LDS && !c.legacy_obs;
 
+  AC_CLK(65);
   // ---- terminations of the 1v1 family come BEFORE the rewards (env_base.py:159-171)
   bool done = false;
   int code = AC_DONE_NONE, last_code = AC_DONE_NONE;
@@ -515,7 +562,8 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
 #pragma unroll
   for (int q = 0; q < NE; ++q) {
     const float R = eg[q].R, r3 = 3000.0f * kFt2M, r5 = 5000.0f * kFt2M;
-    float sA, cA, sT, cT; sincosf(eg[q].AO, &sA, &cA); sincosf(eg[q].TA, &sT, &cT);
+    // sin / cos of the two angles: the angles are acos of these very cosines (utils.py:74-77)
+    const float cA = eg[q].cAO, cT = eg[q].cTA, sA = sqrtf((1.0f - cA) * (1.0f + cA)), sT = sqrtf((1.0f - cT) * (1.0f + cT));
     dwez[q] = (R >= 500.0f * kFt2M && R <= r3) ? R * sA : sqrtf(R * R + r3 * r3 - 2.0f * R * r3 * cA);
     dtail[q] = (R >= r3 && R <= r5) ? R * sT : ((R <= r3) ? sqrtf(R * R + r3 * r3 - 2.0f * R * r3 * cT) : sqrtf(R * R + r5 * r5 - 2.0f * R * r5 * cT));
   }
@@ -523,7 +571,9 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     x.cg_AO = __shfl(eg[0].AO, first_lane); x.cg_TA = __shfl(eg[0].TA, first_lane);
 #pragma unroll
     for (int q = 0; q < NE; ++q) {
-      float w = __shfl(q == 0 ? dwez[0] : dwez[q - 1], first_lane), tl = __shfl(q == 0 ? dtail[0] : dtail[q - 1], first_lane);
+      const float w_src = dwez[q == 0 ? 0 : q - 1], t_src = dtail[q == 0 ? 0 : q - 1];
+      const float w = __shfl(w_src, first_lane);
+      const float tl = __shfl(t_src, first_lane);
       x.wez[q] = w; x.tail[q] = tl;
     }
     x.ref_set = 7;
@@ -571,8 +621,8 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
       if (band && eg[q].AO >= 179.0f * f16::kPi / 180.0f) behit += -5.0f;
       if (band && eg[q].AO <= f16::kPi / 180.0f) wez += 5.0f + 5.0f * (3000.0f * kFt2M - R) / (2500.0f * kFt2M);
       float isr = rsqrtf(R);
-      tailr += -(1.0f / 60.0f) * tanhf((dtail[q] - x.tail[q]) * isr);
-      wezdot += -(1.0f / 60.0f) * tanhf((dwez[q] - x.wez[q]) * isr);
+      tailr += -(1.0f / 60.0f) * tanh_fast((dtail[q] - x.tail[q]) * isr);
+      wezdot += -(1.0f / 60.0f) * tanh_fast((dwez[q] - x.wez[q]) * isr);
       posture += posture_fn(eg[q].AO, eg[q].TA, R * 0.001f);
     }
     float ev = ((t.status != AC_ALIVE) ? -200.0f : 0.0f) + 200.0f * (float)my_hits;
@@ -590,6 +640,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     terminations();
   }
 
+  AC_CLK(66);
   bool all_done = true;
 #pragma unroll
   for (int j = 0; j < A; ++j) { const int dj = __shfl((int)done, base + j); all_done = all_done && (bool)dj; }
@@ -601,8 +652,11 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
 #pragma unroll
     for (int k = 0; k < MS; ++k) { ms[k] = MslD{}; ms[k].status = MSL_INACTIVE; }
     const float* tobs = P.tF + (size_t)NF * A + slot * OBS;
+    if (row_direct) { float* orow = lds_out + lane * c.obs_dim; for (int k = 0; k < OBS; ++k) orow[k] = tobs[k]; }
+    else {
 #pragma unroll
-    for (int k = 0; k < OBS; ++k) ob[k] = tobs[k];
+      for (int k = 0; k < OBS; ++k) ob[k] = tobs[k];
+    }
   }
   if (live) {
     if (!PAIR) store_state(P.F, P.I, P.D, N, n, s, t);
@@ -615,8 +669,11 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     for (int k = 0; k < MS; ++k)
       if (ms[k].status != MSL_INACTIVE || ((msl_was_active >> k) & 1)) store_msl(P.MD, P.MI, N, n, k, ms[k]);
   }
+  AC_CLK(67);
   // (WVR uses the first 15 of the 21 slots; the *_RWR variants append two reserved zero slots)
-  emit_outputs(P, lds_out, c.obs_dim, lane, ob, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);
+  if (row_direct) emit_rows(P, lds_out, c.obs_dim, lane, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);
+  else emit_outputs(P, lds_out, c.obs_dim, lane, ob, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);
+  AC_CLK(68);
 }
 
 // reset template for the scenario tasks: same initial-condition pass, scenario observation layout, potential seeds

@@ -64,11 +64,13 @@ __device__ __forceinline__ void fetch_mass(float (*M)[64], int l, f16::DynVars& 
   k.c00 = v[10]; k.c01 = v[11]; k.c02 = v[12]; k.c11 = v[13]; k.c12 = v[14]; k.c22 = v[15]; k.idet = v[16]; k.im_ = v[17];
 }
 #ifdef AC_SPLIT_TIMING   // scratch builds only (variants/): cycle stamps of workgroup 0's dynamics wave
-__device__ unsigned long long g_clk[64];
+__device__ unsigned long long g_clk[256];
 #define AC_CLK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_clk[i] = __builtin_readcyclecounter(); } while (0)
+#define AC_CLKW(w, i) do { if (blockIdx.x == 0 && threadIdx.x == 64 * (w)) g_clk[i] = __builtin_readcyclecounter(); } while (0)   // wave w of workgroup 0
 extern "C" void ac_debug_clocks(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk), sizeof g_clk); }
 #else
 #define AC_CLK(i) do {} while (0)
+#define AC_CLKW(w, i) do {} while (0)
 #endif
 __device__ __forceinline__ void wg_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

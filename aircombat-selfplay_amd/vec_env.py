@@ -226,6 +226,7 @@ class HipVecEnv:
 
     def step(self, actions):
         """VecEnv.step = step_async + step_wait (env_wrappers.py:30-42), through one library call."""
+        self._assert_not_closed()
         self._cur ^= 1
         st = self._sets[self._cur]
         dst = st["actions"]

@@ -174,15 +174,15 @@ def cpu_baseline(np, cfg, envs, agents, seconds_target=8.0):
     k1, s1 = timed(one, actions(32), seconds_target * 0.4)
     one.close()
     cores = os.cpu_count() or 1
-    workers = max(1, min(cores, 64))
+    workers = max(1, min(cores, 16))     # a one-GPU box's CPU share is 16 cores (os.cpu_count() reports the whole host)
     sub = OracleSubprocVecEnv(ocfg, envs, workers)
     kw, sw = timed(sub, actions(envs), seconds_target * 0.6)
     sub.close()
     return {"value": envs * agents * kw / sw, "unit": "agent-steps/s", "cores": workers, "kind": "port", "host_cpu_count": cores,
             "single_thread": {"value": 32 * agents * k1 / s1, "unit": "agent-steps/s", "envs": 32, "cores": 1,
                               "sample": f"32 envs x {agents} aircraft x {k1} env steps in {s1:.1f} s, one process, one thread"},
-            "sample": f"{envs} envs x {agents} aircraft x {kw} env steps in {sw:.1f} s: {workers} worker processes (one per host core of "
-                      f"os.cpu_count() = {cores}), each stepping its block of envs per ('step', actions) message over a pipe, pickled "
+            "sample": f"{envs} envs x {agents} aircraft x {kw} env steps in {sw:.1f} s: {workers} worker processes (one per core of this box's "
+                      f"16-core share; os.cpu_count() = {cores} is the whole host), each stepping its block of envs per ('step', actions) message over a pipe, pickled "
                       f"numpy arrays both ways, auto-reset in the worker, parent concatenates (shape of envs/env_wrappers.py:182-320); "
                       f"uniform random actions, oracle/ = f64 C restatement of the JSBSim + Python path"}
 
@@ -254,7 +254,7 @@ def main():
     else:
         if args.task == "heading":
             cfg = pkg.default_config("heading")
-        elif args.per_side:
+        elif args.per_side and args.per_side > 1:
             cfg = pkg.default_nvn_config(args.per_side, task=args.task, hierarchical=args.hierarchical)
         else:
             cfg = pkg.default_config(args.task, hierarchical=args.hierarchical)

@@ -5,11 +5,12 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this.
  * The shipped product (aircombat-selfplay_amd/) never links or calls it.
  *
- * PARITY STATUS: "parity unpinned" for the FDM. The reference runs the third-party wheel
- * jsbsim==1.1.6 (README.md:10); it is not installed here, its vendored sources under
- * envs/JSBSim/data/src have no headers and cannot be compiled, and the reference's tests hold
- * no F-16 golden trajectory. This file restates the published algorithm from those sources
- * (file:line cited at each function) with the aircraft data of aircraft/f16/f16.xml.
+ * PARITY STATUS: "parity unpinned" for the F-16 trajectory. The reference runs the third-party wheel jsbsim==1.1.6
+ * (README.md:10); it is not installed here, its vendored sources under envs/JSBSim/data/src have no headers and cannot be
+ * compiled, and the reference's tests hold no F-16 golden trajectory. This file restates the published algorithm from those
+ * sources (file:line cited at each function) with the aircraft data of aircraft/f16/f16.xml. The generic blocks it is built from
+ * ARE pinned by what the reference holds (tests/test_oracle_jsbsim_blocks.py): atmosphere, density / pressure altitude, the
+ * <kinematic> and <pid> components, the turbine spool law, every table and the aerodynamic summation.
  */
 #ifndef ORACLE_F16_FDM_H
 #define ORACLE_F16_FDM_H
