@@ -701,7 +701,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
   } else if (PAIR) {
     const bool flight_role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1;
     if (!flight_role) {   // the environment wave owns the task bookkeeping; the status word of every missile slot comes with it
-      s = State{}; s.ticks = P.I[(size_t)FI_ticks * N + nn]; load_task(P.F, P.I, N, nn, t);
+      s = State{}; load_task(P.F, P.I, N, nn, t);
 #pragma unroll
       for (int k = 0; k < MSLOTS; ++k) pre_st[k] = P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn];
     }
@@ -748,7 +748,6 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
   const MslParam MP = aim9l();
   bool have_pose = false;
   int last_tick = -1;   // three-wave form: the last substep this aircraft flew
-  int ticks_now = s.ticks;   // pair form: the executive tick count of the posted pose
   // pair form: with no missile entry in the env there is nothing to fly between the ticks, and only the last substep's pose is needed
   bool env_has_missiles = false;
   if (PAIR) {
@@ -758,16 +757,10 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
     const int other = __shfl_xor((int)mine, 1);   // (fetched first: a shuffle on the right of || is skipped by the lanes that short-circuit)
     env_has_missiles = mine || (bool)other;
   }
-  bool located = false;
   for (int sub = 0; sub < c.substeps; ++sub) {
     if (PAIR) {
-      if (pair_substep(t, LP, l)) ticks_now += 1;
+      pair_substep(t, LP, l, sub, env_has_missiles, pr);
       if (!env_has_missiles) continue;
-      pair_read_pose(LP, l, ticks_now, s);
-      f16::locate(s, d);
-      ned_velocity(s, d);
-      make_pose(d, c, pr);
-      located = sub + 1 == c.substeps;
     } else if (SPLIT) {        // the FDM tick over three waves; what follows in the substep (munitions) stays on this wave
       if (dynamics_wave_tick(s, t, d, T, L, l, sub)) { have_pose = true; last_tick = sub; }
     } else if (t.status == AC_ALIVE) {
@@ -798,13 +791,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
   const bool split_located = SPLIT && dynamics_wave_finish(s, d, L, l, last_tick, c.substeps);   // (+ the helper waves' fields)
   if (PAIR) {
     wg_sync();                                     // the flight wave has posted its final values and stored the flight state
-    if (!located) {
-      pair_read_pose(LP, l, ticks_now, s);
-      f16::locate(s, d);
-      ned_velocity(s, d);
-    }
-    pair_read_final(LP, l, s, d);
-    make_props(s, d, c, pr);
+    pair_read_final(LP, l, s, d, pr);
   } else if (!HAS_MSL || c.substeps == 0) {
     if (!split_located) f16::locate(s, d);
     if (!have_pose) f16::body_frame(s, d);
@@ -1430,8 +1417,8 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
   const bool gun_only = h->cfg.task == AC_TASK_WVR || h->cfg.task == AC_TASK_MANEUVER;
   if (gun_only) {   // the scenario kernel family without munitions: ticks only between the env steps
     if (h->split_waves) hipLaunchKernelGGL((step_kernel_scenario<2, 1, FORM_SPLIT>), grid, dim3(192), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
-    else if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_scenario<2, 1, FORM_ONE>), grid, block, 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
-    else hipLaunchKernelGGL((step_kernel_scenario<2, 2, FORM_ONE>), grid, block, 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
+    else if (pair_wpe1) hipLaunchKernelGGL((step_kernel_scenario<2, 1, FORM_PAIR>), grid, dim3(128), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
+    else hipLaunchKernelGGL((step_kernel_scenario<2, 2, FORM_PAIR>), grid, dim3(128), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
   } else if (h->cfg.task == AC_TASK_SCENARIO1 || h->cfg.task == AC_TASK_SCENARIO_NVN) {
 #define AC_LAUNCH_PAIR(AA)                                                                                                                                \
   do {                                                                                                                                                    \

@@ -1,85 +1,36 @@
 // The pair form of the step kernels for the tasks with munitions (included by aircombat.hip after split_kernel.hpp).
 //
 // A workgroup is TWO waves over the same 64 aircraft, each on a SIMD of its own:
-//   wave 1, "flight": JSBSim's part -- the six FDM ticks of the step, nothing else. It loads and stores the flight state.
+//   wave 1, "flight": JSBSim's part -- the six FDM ticks of the step and the aircraft's pose in the battle-field frame (what
+//            AircraftSimulator caches after every tick, simulatior.py:238-258). It loads and stores the flight state.
 //   wave 0, "environment": the reference's Python part -- AircraftSimulator's status / blood bookkeeping, the munitions, chaff and decoy
 //            test of every substep, the weapon rules, observations, rewards, terminations, the episode reset. It loads and stores the task
 //            bookkeeping, the munition slots and the step's outputs.
-// The integrators of FGPropagate are explicit (f16::propagate): an aircraft's pose after tick k is fixed by what tick k-1 left in
-// the state, so the flight wave posts it at the START of tick k and the environment wave flies the substep's munitions against it
-// (fp64 geodetic reduction, proportional navigation, fuse, decoys) WHILE the flight wave works through the tick's aerodynamics. What
-// comes back is one flag per aircraft -- does it fly the next tick (a hit grounds the target from the next substep on,
-// simulatior.py:220-229). Two workgroup barriers per substep: "run flags posted" and "poses posted".
+// The integrators of FGPropagate are explicit (f16::propagate): an aircraft's position and velocity after tick k are fixed by what
+// tick k-1 left in the state. So the flight wave posts the pose of tick k BEFORE the tick (the fp64 geodetic reduction and the NEU
+// offset included), and the environment wave flies the substep's munitions against it -- proportional navigation, fuse, decoys --
+// WHILE the flight wave works through the tick's aerodynamics. What comes back is one flag per aircraft: does it fly the next tick
+// (a hit grounds the target from the next substep on, simulatior.py:220-229). An aircraft that turns out not to fly tick k keeps the
+// pose the environment wave already holds. One workgroup barrier per substep; the mailboxes are double-buffered by substep parity.
 //
-// Against the one-wave form this halves the length of the longest instruction stream of a munition task (the munitions took more
-// than half of a substep) and splits the register file demand in two: neither wave spills (the one-wave scenario kernels kept 100-1160
-// values in scratch).
+// Against the one-wave form this takes the munitions (more than half of a substep there) off the critical path and splits the
+// register file demand in two: neither wave spills (the one-wave scenario kernels kept 100-1160 values in scratch).
 #pragma once
 
 namespace pair {
-enum { FIN_T = 0, FIN_U = 9, FIN_V, FIN_W, FIN_P, FIN_Q, FIN_R, FIN_VECI, FIN_QC, FIN_NPX, FIN_NPY, FIN_NPZ, FIN_TICKS, FIN_FLEW, NFIN };
+enum { FIN_VN, FIN_VE, FIN_VD, FIN_ALT, FIN_UB, FIN_VB, FIN_WB, FIN_VC, FIN_SPHI, FIN_CPHI, FIN_STHT, FIN_CTHT, FIN_M11, FIN_M12,
+       FIN_P, FIN_Q, FIN_R, FIN_VECI, FIN_HSL, FIN_NPX, FIN_NPY, FIN_NPZ, FIN_TICKS, NFIN };
+enum { RUN_FLY = 1, RUN_NEED_POSE = 2 };
 }
 struct PairLds {
-  double R[3][64];            // flight -> environment: ECI position after the substep's propagate step
-  float V[3][64];             //                        ECI velocity
-  float RUNF[64];             // environment -> flight: this aircraft flies the coming tick
-  float FIN[pair::NFIN][64];  // flight -> environment after the last tick: what the observation / termination code reads off the FDM
+  double P64[2][3][64];       // flight -> environment: NEU position after the substep's integration step, by substep parity
+  float PV[2][4][64];         //                        NED velocity (clipped like the catalogue does) and altitude
+  int RUNF[2][64];            // environment -> flight: pair::RUN_* bits for the coming tick, by substep parity
+  double F64[3][64];          // flight -> environment after the last tick: the final pose ...
+  float FIN[pair::NFIN][64];  // ... and everything else the observation / reward / termination code reads off the aircraft
 };
 
-// The flight wave. Returns when its part of the step is done (the caller returns).
-__device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg& c, const f16::Tab& T, PairLds& L, int l, int nn, int n, bool live) {
-  using namespace pair;
-  f16::State s; f16::Derived d;
-  load_flight(P.F, P.I, P.D, c.N, nn, s);
-  const float4 a4 = load_controls(P.actions + (size_t)nn * c.act_dim, c.act_dim);
-  s.da = f16::clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);   // normalize_action (singlecombat_task.py:141-153), property bounds catalog.py:189-197
-  s.de = f16::clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
-  s.dr = f16::clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);
-  s.thr = f16::clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
-  bool flew = false;
-  AC_CLKW(1, 128);
-  for (int sub = 0; sub < c.substeps; ++sub) {
-    wg_sync();                                              // the environment wave has posted who flies this tick
-    AC_CLKW(1, 129 + 4 * sub);
-    const bool run = L.RUNF[l] != 0.0f;
-    if (run) f16::propagate(s);
-    L.R[0][l] = s.rx; L.R[1][l] = s.ry; L.R[2][l] = s.rz;  // (a grounded aircraft keeps posting its frozen pose)
-    L.V[0][l] = s.vx; L.V[1][l] = s.vy; L.V[2][l] = s.vz;
-    AC_CLKW(1, 130 + 4 * sub);
-    wg_sync();                                              // poses posted
-    AC_CLKW(1, 131 + 4 * sub);
-    if (run) { f16::tick_after_propagate<false>(s, d, T); flew = true; }
-    AC_CLKW(1, 132 + 4 * sub);
-  }
-  if (!flew) { f16::locate_fast(s, d); f16::body_frame(s, d); }   // never flew this step: the body-frame quantities of the stored pose
-#pragma unroll
-  for (int i = 0; i < 9; ++i) L.FIN[FIN_T + i][l] = d.T[i];
-  L.FIN[FIN_U][l] = d.u; L.FIN[FIN_V][l] = d.v; L.FIN[FIN_W][l] = d.w;
-  L.FIN[FIN_P][l] = d.p; L.FIN[FIN_Q][l] = d.q; L.FIN[FIN_R][l] = d.r; L.FIN[FIN_VECI][l] = d.veci;
-  L.FIN[FIN_QC][l] = s.qc; L.FIN[FIN_NPX][l] = s.npx; L.FIN[FIN_NPY][l] = s.npy; L.FIN[FIN_NPZ][l] = s.npz;
-  L.FIN[FIN_TICKS][l] = __int_as_float(s.ticks); L.FIN[FIN_FLEW][l] = flew ? 1.0f : 0.0f;
-  if (live) store_flight(P.F, P.I, P.D, c.N, n, s);
-  AC_CLKW(1, 160);
-  wg_sync();   // final values posted, flight state stored (the release half of the barrier waits for the stores: an episode reset by
-               // the environment wave overwrites them afterwards)
-}
-
-// Environment wave, one substep: post who flies, wait for the poses. Returns whether this aircraft flew the tick.
-__device__ __forceinline__ bool pair_substep(Task& t, PairLds& L, int l) {
-  const bool run = t.status == AC_ALIVE;
-  if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;      // simulatior.py:220-222: this tick still integrates
-  L.RUNF[l] = run ? 1.0f : 0.0f;
-  wg_sync();
-  wg_sync();
-  return run;
-}
-// the posted pose as the fields of State the geodetic reduction and the NED velocity read
-__device__ __forceinline__ void pair_read_pose(const PairLds& L, int l, int ticks, f16::State& s) {
-  s.rx = L.R[0][l]; s.ry = L.R[1][l]; s.rz = L.R[2][l];
-  s.vx = L.V[0][l]; s.vy = L.V[1][l]; s.vz = L.V[2][l];
-  s.ticks = ticks;
-}
-// local NED velocity from the ECI velocity and the frame of f16::locate (the part of f16::body_frame the munitions need)
+// local NED velocity from the ECI velocity and the frame of f16::locate (the part of f16::body_frame the pose needs)
 __device__ __forceinline__ void ned_velocity(const f16::State& s, f16::Derived& d) {
   const float om = (float)f16::kOmega;
   const float rvx = s.vx + om * (float)s.ry, rvy = s.vy - om * (float)s.rx, rvz = s.vz;
@@ -87,13 +38,103 @@ __device__ __forceinline__ void ned_velocity(const f16::State& s, f16::Derived& 
   d.ve = d.e_eci[0] * rvx + d.e_eci[1] * rvy;
   d.vd = d.d_eci[0] * rvx + d.d_eci[1] * rvy + d.d_eci[2] * rvz;
 }
-// after the last substep: wait for the flight wave's final values and read them
-__device__ __forceinline__ void pair_read_final(const PairLds& L, int l, f16::State& s, f16::Derived& d) {
+
+// The flight wave. Returns when its part of the step is done (the caller returns).
+__device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg& c, const f16::Tab& T, PairLds& L, int l, int nn, int n, bool live) {
   using namespace pair;
+  f16::State s; f16::Derived d;
+  load_flight(P.F, P.I, P.D, c.N, nn, s);
+  const int status0 = P.I[(size_t)FI_status * c.N + nn];   // (only to know whether tick 0 flies: the environment wave owns the field)
+  const float4 a4 = load_controls(P.actions + (size_t)nn * c.act_dim, c.act_dim);
+  s.da = f16::clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);   // normalize_action (singlecombat_task.py:141-153), property bounds catalog.py:189-197
+  s.de = f16::clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
+  s.dr = f16::clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);
+  s.thr = f16::clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
+  // pose after the coming tick (or of the stored state when the aircraft does not fly it), posted under parity `par`
+  f16::Derived dp; Props pp;
+  auto post_pose = [&](int par, bool flies) {
+    f16::State sp = s;
+    if (flies) {   // the position / velocity part of f16::propagate, without committing it
+      constexpr float dt = 1.0f / 60.0f, k = dt / 12.0f;
+      sp.rx = s.rx + (double)(k * (23.0f * s.vx - 16.0f * s.hv1x + 5.0f * s.hv2x));
+      sp.ry = s.ry + (double)(k * (23.0f * s.vy - 16.0f * s.hv1y + 5.0f * s.hv2y));
+      sp.rz = s.rz + (double)(k * (23.0f * s.vz - 16.0f * s.hv1z + 5.0f * s.hv2z));
+      sp.vx = s.vx + dt * (1.5f * s.aix - 0.5f * s.ha1x);
+      sp.vy = s.vy + dt * (1.5f * s.aiy - 0.5f * s.ha1y);
+      sp.vz = s.vz + dt * (1.5f * s.aiz - 0.5f * s.ha1z);
+      sp.ticks = s.ticks + 1;
+    }
+    f16::locate(sp, dp);
+    ned_velocity(sp, dp);
+    make_pose(dp, c, pp);
+    L.P64[par][0][l] = pp.n64; L.P64[par][1][l] = pp.e64; L.P64[par][2][l] = pp.u64;
+    L.PV[par][0][l] = pp.vn; L.PV[par][1][l] = pp.ve; L.PV[par][2][l] = pp.vd; L.PV[par][3][l] = pp.alt_m;
+  };
+  bool flew = false, need = true, pose_is_final = false;
+  AC_CLKW(1, 128);
+  post_pose(0, status0 == AC_ALIVE);
+  for (int sub = 0; sub < c.substeps; ++sub) {
+    wg_sync();                                              // the environment wave has posted who flies this tick; tick `sub`'s pose is posted
+    AC_CLKW(1, 129 + 4 * sub);
+    const int rf = L.RUNF[sub & 1][l];
+    const bool run = rf & RUN_FLY;
+    need = rf & RUN_NEED_POSE;
+    if (run) { f16::propagate(s); f16::tick_after_propagate<false>(s, d, T); flew = true; }
+    pose_is_final = sub + 1 == c.substeps && run;           // the pose posted for this (last) tick is the step's final pose
+    AC_CLKW(1, 131 + 4 * sub);
+    // the next tick's pose: needed when something flies between the ticks, and in any case for the step's last tick
+    if (sub + 1 < c.substeps && (need || sub + 2 == c.substeps)) post_pose((sub + 1) & 1, true);
+    AC_CLKW(1, 132 + 4 * sub);
+  }
+  // ---- final values: the pose of the stored state (that of the last tick flown, which is already in dp / pp if that was the step's
+  // last tick) and what the wrapper reads off the FDM (catalog.py:292-338, 386-416)
+  if (!pose_is_final) { f16::locate(s, dp); ned_velocity(s, dp); }
+  if (!flew) { f16::locate_fast(s, d); f16::body_frame(s, d); }   // never flew this step: the body-frame quantities of the stored pose
+  d.h_sl_ft = dp.h_sl_ft; d.vn = dp.vn; d.ve = dp.ve; d.vd = dp.vd;
+  d.sLat64 = dp.sLat64; d.cLat64 = dp.cLat64; d.sLon64 = dp.sLon64; d.cLon64 = dp.cLon64;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) d.T[i] = L.FIN[FIN_T + i][l];
-  d.u = L.FIN[FIN_U][l]; d.v = L.FIN[FIN_V][l]; d.w = L.FIN[FIN_W][l];
-  d.p = L.FIN[FIN_P][l]; d.q = L.FIN[FIN_Q][l]; d.r = L.FIN[FIN_R][l]; d.veci = L.FIN[FIN_VECI][l];
-  s.qc = L.FIN[FIN_QC][l]; s.npx = L.FIN[FIN_NPX][l]; s.npy = L.FIN[FIN_NPY][l]; s.npz = L.FIN[FIN_NPZ][l];
+  for (int i = 0; i < 3; ++i) { d.n_eci[i] = dp.n_eci[i]; d.e_eci[i] = dp.e_eci[i]; d.d_eci[i] = dp.d_eci[i]; }
+  make_props(s, d, c, pp);
+  L.F64[0][l] = pp.n64; L.F64[1][l] = pp.e64; L.F64[2][l] = pp.u64;
+  L.FIN[FIN_VN][l] = pp.vn; L.FIN[FIN_VE][l] = pp.ve; L.FIN[FIN_VD][l] = pp.vd; L.FIN[FIN_ALT][l] = pp.alt_m;
+  L.FIN[FIN_UB][l] = pp.ub; L.FIN[FIN_VB][l] = pp.vb; L.FIN[FIN_WB][l] = pp.wb; L.FIN[FIN_VC][l] = pp.vc;
+  L.FIN[FIN_SPHI][l] = pp.sphi; L.FIN[FIN_CPHI][l] = pp.cphi; L.FIN[FIN_STHT][l] = pp.stht; L.FIN[FIN_CTHT][l] = pp.ctht;
+  L.FIN[FIN_M11][l] = pp.m11; L.FIN[FIN_M12][l] = pp.m12;
+  L.FIN[FIN_P][l] = d.p; L.FIN[FIN_Q][l] = d.q; L.FIN[FIN_R][l] = d.r; L.FIN[FIN_VECI][l] = d.veci; L.FIN[FIN_HSL][l] = d.h_sl_ft;
+  L.FIN[FIN_NPX][l] = s.npx; L.FIN[FIN_NPY][l] = s.npy; L.FIN[FIN_NPZ][l] = s.npz;
+  L.FIN[FIN_TICKS][l] = __int_as_float(s.ticks);
+  if (live) store_flight(P.F, P.I, P.D, c.N, n, s);
+  AC_CLKW(1, 160);
+  wg_sync();   // final values posted, flight state stored (the release half of the barrier waits for the stores: an episode reset by
+               // the environment wave overwrites them afterwards)
+}
+
+// Environment wave, one substep: post who flies (and whether poses are wanted between the ticks), meet the flight wave, take the
+// pose of this substep. Returns whether this aircraft flew the tick.
+__device__ __forceinline__ bool pair_substep(Task& t, PairLds& L, int l, int sub, bool need_pose, Props& pr) {
+  using namespace pair;
+  const bool run = t.status == AC_ALIVE;
+  if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;      // simulatior.py:220-222: this tick still integrates
+  L.RUNF[sub & 1][l] = (run ? RUN_FLY : 0) | (need_pose ? RUN_NEED_POSE : 0);
+  wg_sync();
+  if (need_pose && (run || sub == 0)) {                     // (a grounded aircraft keeps the pose it had)
+    const int par = sub & 1;
+    pr.n64 = L.P64[par][0][l]; pr.e64 = L.P64[par][1][l]; pr.u64 = L.P64[par][2][l];
+    pr.n = (float)pr.n64; pr.e = (float)pr.e64; pr.u = (float)pr.u64;
+    pr.vn = L.PV[par][0][l]; pr.ve = L.PV[par][1][l]; pr.vd = L.PV[par][2][l]; pr.alt_m = L.PV[par][3][l];
+  }
+  return run;
+}
+// after the last substep: wait for the flight wave's final values and read them
+__device__ __forceinline__ void pair_read_final(const PairLds& L, int l, f16::State& s, f16::Derived& d, Props& pr) {
+  using namespace pair;
+  pr.n64 = L.F64[0][l]; pr.e64 = L.F64[1][l]; pr.u64 = L.F64[2][l];
+  pr.n = (float)pr.n64; pr.e = (float)pr.e64; pr.u = (float)pr.u64;
+  pr.vn = L.FIN[FIN_VN][l]; pr.ve = L.FIN[FIN_VE][l]; pr.vd = L.FIN[FIN_VD][l]; pr.alt_m = L.FIN[FIN_ALT][l];
+  pr.ub = L.FIN[FIN_UB][l]; pr.vb = L.FIN[FIN_VB][l]; pr.wb = L.FIN[FIN_WB][l]; pr.vc = L.FIN[FIN_VC][l];
+  pr.sphi = L.FIN[FIN_SPHI][l]; pr.cphi = L.FIN[FIN_CPHI][l]; pr.stht = L.FIN[FIN_STHT][l]; pr.ctht = L.FIN[FIN_CTHT][l];
+  pr.m11 = L.FIN[FIN_M11][l]; pr.m12 = L.FIN[FIN_M12][l];
+  d.p = L.FIN[FIN_P][l]; d.q = L.FIN[FIN_Q][l]; d.r = L.FIN[FIN_R][l]; d.veci = L.FIN[FIN_VECI][l]; d.h_sl_ft = L.FIN[FIN_HSL][l];
+  s.npx = L.FIN[FIN_NPX][l]; s.npy = L.FIN[FIN_NPY][l]; s.npz = L.FIN[FIN_NPZ][l];
   s.ticks = __float_as_int(L.FIN[FIN_TICKS][l]);
 }

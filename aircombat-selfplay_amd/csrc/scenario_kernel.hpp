@@ -97,6 +97,8 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   constexpr int MS = 2;  // munition slots (uids) per aircraft
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
   __shared__ __attribute__((aligned(16))) float lds_out[64 * (OBS + 2)];
+  __shared__ float4 cl_pos[64 * 2];   // the chaff clouds of the workgroup's aircraft (position; live flag and multiplicity below)
+  __shared__ int2 cl_meta[64 * 2];
   __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : (PAIR ? sizeof(PairLds) : 16)];
   SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
   PairLds& LP = *reinterpret_cast<PairLds*>(split_lds);
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     if (c.act_dim == 8) b4 = load_controls(act + 4, c.act_dim);
 #pragma unroll
     for (int k = 0; k < MS; ++k) mst[k] = P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn];
-    if (PAIR) { s = State{}; s.ticks = P.I[(size_t)FI_ticks * N + nn]; }
+    if (PAIR) s = State{};
   }
   stage_tables<SPLIT ? 192 : (PAIR ? 128 : 64)>(lds_tab, P.tab);
   AC_CLK(0);
@@ -170,22 +172,20 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
 #pragma unroll
   for (int k = 0; k < MS; ++k) mine = mine || ms[k].status != MSL_INACTIVE;
   const bool env_has_munitions = (__ballot(mine) & env_mask) != 0;
+  const bool env_has_clouds = (__ballot(x.n_ch > 0 && (x.ch_status[0] == 0 || x.ch_status[1] == 0)) & env_mask) != 0;
+  if (env_has_clouds) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) cl_pos[lane * 2 + q] = make_float4(x.cx[q], x.cy[q], x.cz[q], 0.0f);
+  }
   if (SPLIT && split_helper_wave(s, t, T, L, lane, c.substeps)) return;
   int last_tick = -1;   // three-wave form: the last substep this aircraft flew
-  int ticks_now = s.ticks;   // pair form: the executive tick count of the posted pose (Earth angle of the geodetic reduction)
-  bool located = false;      // pair form: d / pr hold the pose of the step's last substep already
   AC_CLK(1);
   for (int sub = 0; sub < c.substeps; ++sub) {
     AC_CLK(2 + 8 * sub);
     if (PAIR) {
-      if (pair_substep(t, LP, lane)) ticks_now += 1;
+      pair_substep(t, LP, lane, sub, env_has_munitions, pr);
       AC_CLK(3 + 8 * sub);
       if (!env_has_munitions) continue;     // nothing to fly: the pose is only needed after the last substep
-      pair_read_pose(LP, lane, ticks_now, s);
-      f16::locate(s, d);
-      ned_velocity(s, d);
-      make_pose(d, c, pr);
-      located = sub + 1 == c.substeps;
       AC_CLK(4 + 8 * sub);
     } else {
     if (SPLIT) {
@@ -261,32 +261,36 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
         if (h == slot && t.status == AC_ALIVE) t.status = AC_SHOTDOWN;
       }
     AC_CLK(6 + 8 * sub);
-    // ---- chaff clouds age (ChaffSimulator.run, simulatior.py:377-381), then the decoy test (env_base.py:146-154)
+    // ---- chaff clouds age (ChaffSimulator.run, simulatior.py:377-381), then the decoy test (env_base.py:146-154). Clouds only come
+    // into being in the weapons stage after the substeps: an env without a live cloud at the start of the step has none during it.
 #pragma unroll
     for (int q = 0; q < 2; ++q)
       if (q < x.n_ch) { x.ct[q] += 1.0f / 60.0f; if (x.ct[q] > 20.0f) x.ch_status[q] = 1; }
-    const unsigned long long any_cloud = __ballot(x.n_ch > 0 && (x.ch_status[0] == 0 || x.ch_status[1] == 0));
-    if (any_cloud & env_mask) {
+    if (env_has_clouds) {
+      // the env's clouds sit in LDS (position once per step, the live flag refreshed as they expire): a missile's test against a cloud
+      // is two LDS reads instead of seven cross-lane shuffles
+#pragma unroll
+      for (int q = 0; q < 2; ++q) cl_meta[lane * 2 + q] = make_int2((q < x.n_ch && x.ch_status[q] == 0) ? 1 : 0, x.ch_mult[q]);
+      wave_lds_fence();
 #pragma unroll
       for (int j = 0; j < A; ++j)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          const int src = base + j;
-          int cst = __shfl(x.ch_status[q], src), cm = __shfl(x.ch_mult[q], src), cn = __shfl(x.n_ch, src);
-          float cxx = __shfl(x.cx[q], src), cyy = __shfl(x.cy[q], src), czz = __shfl(x.cz[q], src);
-          const int m0 = __shfl(x.ch_mult[0], src);
-          const int cbase = (q == 0) ? 0 : m0;   // release index of the first chaff of this event
-          if (q >= cn || cst != 0) continue;
+          const int2 me = cl_meta[(base + j) * 2 + q];
+          if (!me.x) continue;
+          const float4 cp = cl_pos[(base + j) * 2 + q];
+          const int cbase = (q == 0) ? 0 : cl_meta[(base + j) * 2].y;   // release index of the first chaff of this event
 #pragma unroll
           for (int k = 0; k < MS; ++k) {
             if (ms[k].status != MSL_LAUNCHED) continue;
-            float dx = cxx - (float)ms[k].px, dy = cyy - (float)ms[k].py, dz = czz - (float)ms[k].pz;
+            float dx = cp.x - (float)ms[k].px, dy = cp.y - (float)ms[k].py, dz = cp.z - (float)ms[k].pz;
             if (dx * dx + dy * dy + dz * dz <= 300.0f * 300.0f) {
-              for (int m = 0; m < cm; ++m)   // one draw per chaff of the event; the missile stays "not done" only until one succeeds
+              for (int m = 0; m < me.y; ++m)   // one draw per chaff of the event; the missile stays "not done" only until one succeeds
                 if (ms[k].status == MSL_LAUNCHED && decoy_uniform(c.chaff_seed + (unsigned long long)(nn / A), tick_id, slot, MS - k, j, cbase + m) < 0.85f) ms[k].status = MSL_MISS;
             }
           }
         }
+      wave_lds_fence();
     }
   }
   AC_CLK(60);
@@ -294,13 +298,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   if (PAIR) {
     wg_sync();                                     // the flight wave has posted its final values and stored the flight state
     AC_CLK(61);
-    if (!located) {
-      pair_read_pose(LP, lane, ticks_now, s);
-      f16::locate(s, d);
-      ned_velocity(s, d);
-    }
-    pair_read_final(LP, lane, s, d);
-    make_props(s, d, c, pr);
+    pair_read_final(LP, lane, s, d, pr);
   } else if (c.substeps == 0) { f16::locate(s, d); f16::body_frame(s, d); make_props(s, d, c, pr); }
   else if (SPLIT && !env_has_munitions) {
     if (!split_located) f16::locate(s, d);
