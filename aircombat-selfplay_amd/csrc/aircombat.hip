@@ -477,7 +477,7 @@ __device__ __forceinline__ void missile_run(MslD& m, const MslParam& P, double t
     const double D = 0.5 * (double)P.cD * S * rho * vm * vm;
     const double nx = (Tt - D) * fx::rcp(m.m * g);
     double st, ct, sps, cps;   // of the CURRENT theta, psi
-    if (k == 1) { sincos(m.theta, &st, &ct); sincos(m.psi, &sps, &cps); }
+    if (k == 1) { fx::sincos(m.theta, &st, &ct); fx::sincos(m.psi, &sps, &cps); }
     else {
       const double hxy = fx::sqrt(hxy2), ih = fx::rcp(hxy);
       st = m.vz * ivm; ct = hxy * ivm; cps = m.vx * ih; sps = m.vy * ih;
@@ -489,7 +489,7 @@ __device__ __forceinline__ void missile_run(MslD& m, const MslParam& P, double t
     const double dps = dt * m.dph, dts = dt * m.dth;
     m.psi += dps; m.theta += dts;
     double s2, c2, s3, c3;
-    if (fabs(dps) > 0.05 || fabs(dts) > 0.05) { sincos(m.theta, &s2, &c2); sincos(m.psi, &s3, &c3); }   // (never in the guidance envelope)
+    if (fabs(dps) > 0.05 || fabs(dts) > 0.05) { fx::sincos(m.theta, &s2, &c2); fx::sincos(m.psi, &s3, &c3); }   // (never in the guidance envelope)
     else {
       double sa, ca, sb, cb;
       small_sincos(dts, &sa, &ca); small_sincos(dps, &sb, &cb);
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
       for (int k = 0; k < MSLOTS; ++k) pre_st[k] = P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn];
     }
     stage_tables<128>(lds_tab, P.tab);
-    if (flight_role) { pair_flight_wave(P, c, T, LP, l, nn, n, live); return; }
+    if (flight_role) { pair_flight_wave<true>(P, c, T, LP, l, nn, n, live); return; }
   } else {
     stage_tables<64>(lds_tab, P.tab);
     load_state(P.F, P.I, P.D, N, nn, s, t);
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
   }
   for (int sub = 0; sub < c.substeps; ++sub) {
     if (PAIR) {
-      pair_substep(t, LP, l, sub, env_has_missiles, pr);
+      pair_substep<true>(t, LP, l, sub, env_has_missiles, pr, c);
       if (!env_has_missiles) continue;
     } else if (SPLIT) {        // the FDM tick over three waves; what follows in the substep (munitions) stays on this wave
       if (dynamics_wave_tick(s, t, d, T, L, l, sub)) { have_pose = true; last_tick = sub; }

@@ -50,6 +50,35 @@ __device__ __forceinline__ double sin(double x) {
   const double r = fma(-y * t, p, y);
   return ((long long)n & 1) ? -r : r;
 }
+// sin and cos together for |x| up to a few turns (a missile's pitch and heading): reduction by the nearest multiple of pi / 2 in two
+// pieces, Taylor series on [-pi/4, pi/4] (truncation < 1e-17), quadrant swap
+__device__ __forceinline__ void sincos(double x, double* sn, double* cs) {
+  const double n = rint(x * 0.63661977236758134308);
+  double y = fma(-n, 1.5707963267948965580, x);
+  y = fma(-n, 6.1232339957367660e-17, y);
+  const double t = y * y;
+  double ps = 2.8114572543455206e-15;                       //  1/17!
+  ps = fma(ps, t, -7.6471637318198164e-13);                 // -1/15!
+  ps = fma(ps, t, 1.6059043836821613e-10);                  //  1/13!
+  ps = fma(ps, t, -2.5052108385441720e-08);                 // -1/11!
+  ps = fma(ps, t, 2.7557319223985893e-06);                  //  1/9!
+  ps = fma(ps, t, -1.9841269841269841e-04);                 // -1/7!
+  ps = fma(ps, t, 8.3333333333333332e-03);                  //  1/5!
+  ps = fma(ps, t, -1.6666666666666666e-01);                 // -1/3!
+  const double s0 = fma(y * t, ps, y);
+  double pc = -1.1470745597729725e-11;                      // -1/14!  ... (the 1/16! term is below 1e-17 on this range)
+  pc = fma(pc, t, 2.0876756987868100e-09);                  //  1/12!
+  pc = fma(pc, t, -2.7557319223985888e-07);                 // -1/10!
+  pc = fma(pc, t, 2.4801587301587302e-05);                  //  1/8!
+  pc = fma(pc, t, -1.3888888888888889e-03);                 // -1/6!
+  pc = fma(pc, t, 4.1666666666666664e-02);                  //  1/4!
+  pc = fma(pc, t, -0.5);
+  const double c0 = fma(t, pc, 1.0);
+  const long long q = (long long)n & 3;
+  const double s1 = (q & 1) ? c0 : s0, c1 = (q & 1) ? s0 : c0;
+  *sn = (q == 2 || q == 3) ? -s1 : s1;
+  *cs = (q == 1 || q == 2) ? -c1 : c1;
+}
 // exp for moderate arguments (the air-density law exp(-h / 9300): x in [-3, 0.1]): 2^k * exp(r), |r| <= ln2 / 2, Taylor to r^13
 __device__ __forceinline__ double exp(double x) {
   const double k = rint(x * 1.4426950408889634074);

@@ -94,7 +94,7 @@ __device__ __forceinline__ void heading_obs(const Props& pr, const Derived& d, c
 }
 
 // SingleControlEnv.reset (singlecontrol_env.py:24-49) + HeadingTask.reset: three draws, reload, targets, reward memories
-__device__ __attribute__((noinline)) void heading_reset(const HeadingCfg& hc, const DevCfg& c, const Tab& T, State& s, Derived& d, Task& t, Props& pr, HeadingState& x, float* ob) {
+__device__ void heading_reset(const HeadingCfg& hc, const DevCfg& c, const Tab& T, State& s, Derived& d, Task& t, Props& pr, HeadingState& x, float* ob) {
   const double hdg = pcg_uniform(x.rng, 0.0, 180.0), alt = pcg_uniform(x.rng, 14000.0, 30000.0), u = pcg_uniform(x.rng, 400.0, 1200.0);
   ac_init_state_t ic = hc.ic;
   ic.psi_deg = hdg; ic.h_sl_ft = alt; ic.u_fps = u;

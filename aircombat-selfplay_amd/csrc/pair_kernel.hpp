@@ -40,6 +40,9 @@ __device__ __forceinline__ void ned_velocity(const f16::State& s, f16::Derived& 
 }
 
 // The flight wave. Returns when its part of the step is done (the caller returns).
+// RAW_POSE: post the tick's ECI position / velocity as they are and leave the geodetic reduction to the environment wave -- for the 1v1
+// missile tasks, whose fp32 AIM-9L update leaves that wave the slack (there the flight wave is the longer of the two).
+template <bool RAW_POSE = false>
 __device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg& c, const f16::Tab& T, PairLds& L, int l, int nn, int n, bool live) {
   using namespace pair;
   f16::State s; f16::Derived d;
@@ -64,6 +67,11 @@ __device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg&
       sp.vz = s.vz + dt * (1.5f * s.aiz - 0.5f * s.ha1z);
       sp.ticks = s.ticks + 1;
     }
+    if (RAW_POSE) {
+      L.P64[par][0][l] = sp.rx; L.P64[par][1][l] = sp.ry; L.P64[par][2][l] = sp.rz;
+      L.PV[par][0][l] = sp.vx; L.PV[par][1][l] = sp.vy; L.PV[par][2][l] = sp.vz; L.PV[par][3][l] = __int_as_float(sp.ticks);
+      return;
+    }
     f16::locate(sp, dp);
     ned_velocity(sp, dp);
     make_pose(dp, c, pp);
@@ -80,7 +88,7 @@ __device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg&
     const bool run = rf & RUN_FLY;
     need = rf & RUN_NEED_POSE;
     if (run) { f16::propagate(s); f16::tick_after_propagate<false>(s, d, T); flew = true; }
-    pose_is_final = sub + 1 == c.substeps && run;           // the pose posted for this (last) tick is the step's final pose
+    pose_is_final = !RAW_POSE && sub + 1 == c.substeps && run;   // the pose posted for this (last) tick is the step's final pose
     AC_CLKW(1, 131 + 4 * sub);
     // the next tick's pose: needed when something flies between the ticks, and in any case for the step's last tick
     if (sub + 1 < c.substeps && (need || sub + 2 == c.substeps)) post_pose((sub + 1) & 1, true);
@@ -111,7 +119,8 @@ __device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg&
 
 // Environment wave, one substep: post who flies (and whether poses are wanted between the ticks), meet the flight wave, take the
 // pose of this substep. Returns whether this aircraft flew the tick.
-__device__ __forceinline__ bool pair_substep(Task& t, PairLds& L, int l, int sub, bool need_pose, Props& pr) {
+template <bool RAW_POSE = false>
+__device__ __forceinline__ bool pair_substep(Task& t, PairLds& L, int l, int sub, bool need_pose, Props& pr, const DevCfg& c) {
   using namespace pair;
   const bool run = t.status == AC_ALIVE;
   if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;      // simulatior.py:220-222: this tick still integrates
@@ -119,6 +128,15 @@ __device__ __forceinline__ bool pair_substep(Task& t, PairLds& L, int l, int sub
   wg_sync();
   if (need_pose && (run || sub == 0)) {                     // (a grounded aircraft keeps the pose it had)
     const int par = sub & 1;
+    if (RAW_POSE) {                                         // the geodetic reduction of the posted ECI pose happens here
+      f16::State sp{}; f16::Derived dp;
+      sp.rx = L.P64[par][0][l]; sp.ry = L.P64[par][1][l]; sp.rz = L.P64[par][2][l];
+      sp.vx = L.PV[par][0][l]; sp.vy = L.PV[par][1][l]; sp.vz = L.PV[par][2][l]; sp.ticks = __float_as_int(L.PV[par][3][l]);
+      f16::locate(sp, dp);
+      ned_velocity(sp, dp);
+      make_pose(dp, c, pr);
+      return run;
+    }
     pr.n64 = L.P64[par][0][l]; pr.e64 = L.P64[par][1][l]; pr.u64 = L.P64[par][2][l];
     pr.n = (float)pr.n64; pr.e = (float)pr.e64; pr.u = (float)pr.u64;
     pr.vn = L.PV[par][0][l]; pr.ve = L.PV[par][1][l]; pr.vd = L.PV[par][2][l]; pr.alt_m = L.PV[par][3][l];

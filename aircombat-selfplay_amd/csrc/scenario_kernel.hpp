@@ -130,7 +130,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   }
   stage_tables<SPLIT ? 192 : (PAIR ? 128 : 64)>(lds_tab, P.tab);
   AC_CLK(0);
-  if (flight_role) { pair_flight_wave(P, c, T, LP, lane, nn, n, live); return; }   // (it waits for the environment wave's first flags anyway: its state load hides there)
+  if (flight_role) { pair_flight_wave<false>(P, c, T, LP, lane, nn, n, live); return; }   // (it waits for the environment wave's first flags anyway: its state load hides there)
 
   if (PAIR) load_task(P.F, P.I, N, nn, t);   // the environment wave owns the task bookkeeping; of the flight state it only needs the tick count (Earth angle)
   else load_state(P.F, P.I, P.D, N, nn, s, t);
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   for (int sub = 0; sub < c.substeps; ++sub) {
     AC_CLK(2 + 8 * sub);
     if (PAIR) {
-      pair_substep(t, LP, lane, sub, env_has_munitions, pr);
+      pair_substep<false>(t, LP, lane, sub, env_has_munitions, pr, c);
       AC_CLK(3 + 8 * sub);
       if (!env_has_munitions) continue;     // nothing to fly: the pose is only needed after the last substep
       AC_CLK(4 + 8 * sub);
@@ -272,24 +272,35 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
 #pragma unroll
       for (int q = 0; q < 2; ++q) cl_meta[lane * 2 + q] = make_int2((q < x.n_ch && x.ch_status[q] == 0) ? 1 : 0, x.ch_mult[q]);
       wave_lds_fence();
+      int2 me[A * 2];                                        // every cloud record of the env in one batch of LDS reads
 #pragma unroll
-      for (int j = 0; j < A; ++j)
+      for (int i = 0; i < A * 2; ++i) me[i] = cl_meta[base * 2 + i];
+      bool any_live = false;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int2 me = cl_meta[(base + j) * 2 + q];
-          if (!me.x) continue;
-          const float4 cp = cl_pos[(base + j) * 2 + q];
-          const int cbase = (q == 0) ? 0 : cl_meta[(base + j) * 2].y;   // release index of the first chaff of this event
+      for (int i = 0; i < A * 2; ++i) any_live = any_live || me[i].x != 0;
+      bool mine_flying = false;
 #pragma unroll
-          for (int k = 0; k < MS; ++k) {
-            if (ms[k].status != MSL_LAUNCHED) continue;
-            float dx = cp.x - (float)ms[k].px, dy = cp.y - (float)ms[k].py, dz = cp.z - (float)ms[k].pz;
-            if (dx * dx + dy * dy + dz * dz <= 300.0f * 300.0f) {
-              for (int m = 0; m < me.y; ++m)   // one draw per chaff of the event; the missile stays "not done" only until one succeeds
-                if (ms[k].status == MSL_LAUNCHED && decoy_uniform(c.chaff_seed + (unsigned long long)(nn / A), tick_id, slot, MS - k, j, cbase + m) < 0.85f) ms[k].status = MSL_MISS;
+      for (int k = 0; k < MS; ++k) mine_flying = mine_flying || ms[k].status == MSL_LAUNCHED;
+      if (any_live && mine_flying) {
+#pragma unroll
+        for (int j = 0; j < A; ++j)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if (!me[j * 2 + q].x) continue;
+            const float4 cp = cl_pos[(base + j) * 2 + q];
+            const int cm = me[j * 2 + q].y;
+            const int cbase = (q == 0) ? 0 : me[j * 2].y;   // release index of the first chaff of this event
+#pragma unroll
+            for (int k = 0; k < MS; ++k) {
+              if (ms[k].status != MSL_LAUNCHED) continue;
+              float dx = cp.x - (float)ms[k].px, dy = cp.y - (float)ms[k].py, dz = cp.z - (float)ms[k].pz;
+              if (dx * dx + dy * dy + dz * dz <= 300.0f * 300.0f) {
+                for (int m = 0; m < cm; ++m)   // one draw per chaff of the event; the missile stays "not done" only until one succeeds
+                  if (ms[k].status == MSL_LAUNCHED && decoy_uniform(c.chaff_seed + (unsigned long long)(nn / A), tick_id, slot, MS - k, j, cbase + m) < 0.85f) ms[k].status = MSL_MISS;
+              }
             }
           }
-        }
+      }
       wave_lds_fence();
     }
   }

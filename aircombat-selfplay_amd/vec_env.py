@@ -179,6 +179,9 @@ class HipVecEnv:
             })
         self._cur = 0
         self._actions = self._sets[0]["actions"]
+        # what step() hands back for each set, built once: the arrays are views of fixed buffers, and LazyInfos reads its codes when asked
+        self._results = [self._result(st) for st in self._sets]
+        self._step_host = self.lib.ac_step_host
 
     # ---- reference surface
     def seed(self, seed=None):
@@ -219,24 +222,23 @@ class HipVecEnv:
         self._assert_not_closed()
         self.lib.check(self.lib.ac_step_host_wait(self._h), "ac_step_host_wait")
         self.waiting = False
-        return self._result(self._sets[self._cur])
+        return self._results[self._cur]
 
     def _result(self, st):
         return st["obs"], st["rew"], st["done"], LazyInfos(st["info"])
 
     def step(self, actions):
         """VecEnv.step = step_async + step_wait (env_wrappers.py:30-42), through one library call."""
-        self._assert_not_closed()
-        self._cur ^= 1
-        st = self._sets[self._cur]
-        dst = st["actions"]
+        assert not self.closed, "Trying to operate on a HipVecEnv after calling close()"
+        cur = self._cur = self._cur ^ 1
+        dst = self._sets[cur]["actions"]
         a = actions if isinstance(actions, np.ndarray) else np.asarray(actions, dtype=np.float32)
         if a.shape != dst.shape:
             a = a.reshape(dst.shape)
         np.copyto(dst, a)
-        if self.lib.ac_step_host(self._h, self._cur) != 0:
+        if self._step_host(self._h, cur) != 0:
             self.lib.check(-1, "ac_step_host")
-        return self._result(st)
+        return self._results[cur]
 
     def render(self, mode="txt", filepath="./JSBSimRecording.txt.acmi", env=0):
         """BaseEnv.render (env_base.py:207-250) for one env (the reference renders through DummyVecEnv, i.e. env 0): appends one
@@ -317,7 +319,7 @@ class HipVecEnv:
     def close(self):
         if self.closed:
             return
-        self._sets = []           # views of library-owned memory: dropped before the handle frees it
+        self._sets, self._results = [], []           # views of library-owned memory: dropped before the handle frees it
         self._actions = None
         self.lib.ac_destroy(self._h)
         self._h = None
