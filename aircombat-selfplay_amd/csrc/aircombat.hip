@@ -19,6 +19,7 @@
 #include <algorithm>
 #include "../../include/aircombat.h"
 #include "../../include/aircombat_buffer.h"
+#include "clk_stamps.hpp"
 #include "f16_device.hpp"
 #include "f16_split.hpp"
 
@@ -151,6 +152,30 @@ __device__ __forceinline__ void store_flight(float* F, int* I, double* D, int N,
   AC_AT(I, FI_eng) = s.eng; AC_AT(I, FI_ticks) = s.ticks;
   AC_AT(D, 0) = s.rx; AC_AT(D, 1) = s.ry; AC_AT(D, 2) = s.rz;
 }
+// The three-wave form: each wave asks only for what its share of the tick reads (the 64 aircraft's state would otherwise cross the
+// L2 -> CU path three times at the start of every step). ROLE 0 = dynamics wave: everything except the fields the systems wave owns
+// and hands over at the end (dynamics_wave_finish); 1 = systems wave: what sys_mass / sys_fcs / sys_engine read; 2 = kinematics wave:
+// what kin_position / kin_attitude / locate read.
+constexpr bool ac_sys_owned(int f) {
+  return f == FF_tef || f == FF_pin_r || f == FF_pin_p || f == FF_pin_y || f == FF_pi_r || f == FF_pi_p || f == FF_pi_y || f == FF_ail ||
+         f == FF_elev || f == FF_sbdeg || f == FF_n1 || f == FF_n2 || f == FF_n2norm || f == FF_ff || f == FF_tank0 || f == FF_tank1;
+}
+constexpr bool ac_sys_reads(int f) {
+  return ac_sys_owned(f) || f == FF_alpha || f == FF_mach || f == FF_qc || f == FF_vg || f == FF_ap || f == FF_aq || f == FF_ar || f == FF_npy || f == FF_npz;
+}
+constexpr bool ac_kin_reads(int f) {
+  return f == FF_vx || f == FF_vy || f == FF_vz || f == FF_q0 || f == FF_q1 || f == FF_q2 || f == FF_q3 || f == FF_wp || f == FF_wq || f == FF_wr ||
+         f == FF_hv1x || f == FF_hv1y || f == FF_hv1z || f == FF_hv2x || f == FF_hv2y || f == FF_hv2z;
+}
+template <int ROLE>
+__device__ __forceinline__ void load_flight_role(const float* F, const int* I, const double* D, int N, int n, State& s) {
+  AC_LANE_INDEX(n);
+#define X(f) if (ROLE == 0 ? !ac_sys_owned(FF_##f) : (ROLE == 1 ? ac_sys_reads(FF_##f) : ac_kin_reads(FF_##f))) s.f = AC_AT(F, FF_##f);
+  AC_F_FIELDS(X)
+#undef X
+  if (ROLE == 1) s.eng = AC_AT(I, FI_eng);
+  if (ROLE != 1) { s.ticks = AC_AT(I, FI_ticks); s.rx = AC_AT(D, 0); s.ry = AC_AT(D, 1); s.rz = AC_AT(D, 2); }
+}
 // ... and the task bookkeeping (what the environment layer reads and writes)
 __device__ __forceinline__ void load_task(const float* F, const int* I, int N, int n, Task& t) {
   AC_LANE_INDEX(n);
@@ -189,6 +214,23 @@ __device__ __forceinline__ void load_msl(const R* MF, const int* MI, int N, int 
   m.dth = AC_AT(f, MF_dth); m.dph = AC_AT(f, MF_dph); m.dprev = AC_AT(f, MF_dprev);
   m.status = AC_AT(i, MI_status); m.order = AC_AT(i, MI_order);
   const int rw = AC_AT(i, MI_recede);
+  m.recede = rw & 511; m.model = (rw >> 9) & 1; m.dpos = rw >> 10;
+}
+// The same without a branch around the loads: the lanes of a slot that is not in flight read the zero words that follow the arrays
+// (ac_create) - exactly what an unlaunched slot holds - so the loads of every slot are in flight together (one HBM round trip for
+// the lot instead of one per slot) and no missile state is fetched for a slot that has none.
+template <typename R>
+__device__ __forceinline__ void load_msl_masked(const R* MF, const int* MI, int N, int n, int slot, int slots, bool active, int status, MslT<R>& m) {
+  const unsigned un = (unsigned)n, uN = (unsigned)N;
+  const unsigned ftail = (unsigned)slots * NMF * uN * (unsigned)sizeof(R), itail = (unsigned)slots * NMI * uN * 4u;
+  auto F = [&](int f) -> R { return *(const R*)((const char*)MF + (active ? (((unsigned)slot * NMF + (unsigned)f) * uN + un) * (unsigned)sizeof(R) : ftail)); };
+  auto I = [&](int f) -> int { return *(const int*)((const char*)MI + (active ? (((unsigned)slot * NMI + (unsigned)f) * uN + un) * 4u : itail)); };
+  m.px = F(MF_px); m.py = F(MF_py); m.pz = F(MF_pz);
+  m.vx = F(MF_vx); m.vy = F(MF_vy); m.vz = F(MF_vz);
+  m.theta = F(MF_theta); m.psi = F(MF_psi); m.t = F(MF_t); m.m = F(MF_m);
+  m.dth = F(MF_dth); m.dph = F(MF_dph); m.dprev = F(MF_dprev);
+  m.status = status; m.order = I(MI_order);
+  const int rw = I(MI_recede);
   m.recede = rw & 511; m.model = (rw >> 9) & 1; m.dpos = rw >> 10;
 }
 template <typename R>
@@ -570,20 +612,16 @@ __device__ __forceinline__ void emit_outputs(const DevPtrs& P, float* lds /* [64
   for (int k = NOB; k < ow; ++k) row[k] = 0.0f;             // reserved slots of the *_RWR variants
   emit_rows(P, lds, ow, lane, reward, done, A, i0, i1, i2, i3);
 }
-__device__ __forceinline__ void emit_rows(const DevPtrs& P, float* lds, int ow, int lane, float reward, bool done, int A, int i0, int i1, int i2, int i3) {
+// The two halves of the output: the observation rows (the bulk, and ready first) ...
+__device__ __forceinline__ void emit_obs_rows(const DevPtrs& P, float* lds, int ow, int lane) {
   wave_lds_fence();
+  AC_CLK(56);
   const size_t blk = blockIdx.x;
   const int nvec = 16 * ow;                                 // float4 count of the block's rows
   const float4* l4 = reinterpret_cast<const float4*>(lds);
-  const unsigned long long dmask = __ballot(done);
-  unsigned dword = 0;
 #pragma unroll
-  for (int b = 0; b < 4; ++b) dword |= (unsigned)((dmask >> (4 * (lane & 15) + b)) & 1ull) << (8 * b);
-  const int4 inf = make_int4(i0, i1, i2, i3);
-  const size_t n = blk * 64 + lane;
-#pragma unroll
-  for (int set = 0; set < 2; ++set) {
-    float* obs = set ? P.obs2 : P.obs; float* rew = set ? P.rew2 : P.rew; uint8_t* dn = set ? P.done2 : P.done; int* info = set ? P.info2 : P.info;
+  for (int set = 1; set >= 0; --set) {                      // the copy that crosses PCIe first
+    float* obs = set ? P.obs2 : P.obs;
     if (!obs) continue;
     float4* o4 = reinterpret_cast<float4*>(obs + blk * 64 * (size_t)ow);
     int i = lane;
@@ -592,11 +630,31 @@ __device__ __forceinline__ void emit_rows(const DevPtrs& P, float* lds, int ow, 
       o4[i] = v0; o4[i + 64] = v1; o4[i + 128] = v2; o4[i + 192] = v3;
     }
     for (; i < nvec; i += 64) o4[i] = l4[i];
+  }
+  AC_CLK(57);
+  wave_lds_fence();
+}
+// ... and the per-aircraft reward and done flag with the env's info row
+__device__ __forceinline__ void emit_scalars(const DevPtrs& P, int lane, float reward, bool done, int A, int i0, int i1, int i2, int i3) {
+  const size_t blk = blockIdx.x;
+  const unsigned long long dmask = __ballot(done);
+  unsigned dword = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) dword |= (unsigned)((dmask >> (4 * (lane & 15) + b)) & 1ull) << (8 * b);
+  const int4 inf = make_int4(i0, i1, i2, i3);
+  const size_t n = blk * 64 + lane;
+#pragma unroll
+  for (int set = 1; set >= 0; --set) {
+    float* rew = set ? P.rew2 : P.rew; uint8_t* dn = set ? P.done2 : P.done; int* info = set ? P.info2 : P.info;
+    if (!rew) continue;
     rew[n] = reward;
     if (lane < 16) reinterpret_cast<unsigned*>(dn + blk * 64)[lane] = dword;
     if (lane % A == 0) *reinterpret_cast<int4*>(info + (n / A) * 4) = inf;
   }
-  wave_lds_fence();
+}
+__device__ __forceinline__ void emit_rows(const DevPtrs& P, float* lds, int ow, int lane, float reward, bool done, int A, int i0, int i1, int i2, int i3) {
+  emit_obs_rows(P, lds, ow, lane);
+  emit_scalars(P, lane, reward, done, A, i0, i1, i2, i3);
 }
 // the four control indices of an aircraft's action row: one 16-byte load where the row width allows it (a row read from mapped
 // host memory then crosses PCIe as one request per 4 lanes instead of four)
@@ -693,32 +751,54 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
   int pre_st[MSLOTS];
 #pragma unroll
   for (int k = 0; k < MSLOTS; ++k) pre_st[k] = MSL_INACTIVE;
-  if (SPLIT) {   // table loads, then state loads behind them, then the LDS copy: one HBM round trip for both
+  // One HBM round trip for everything a wave can ask for up front: the table loads are issued first, the action row and the state
+  // loads behind them, and the LDS copy of the tables waits (in-order vmcnt) for the table loads alone.
+  const float* act = P.actions + (size_t)nn * c.act_dim;
+  float4 a4;
+  float shoot_raw = 0.0f;
+  if (SPLIT) {
     TableCopy<192> tc;
     tc.issue(P.tab);
-    load_state(P.F, P.I, P.D, N, nn, s, t);
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    s = State{}; t = Task{};
+    if (role == 0) { load_flight_role<0>(P.F, P.I, P.D, N, nn, s); load_task(P.F, P.I, N, nn, t); }
+    else if (role == 1) load_flight_role<1>(P.F, P.I, P.D, N, nn, s);
+    else { load_flight_role<2>(P.F, P.I, P.D, N, nn, s); t.status = P.I[(size_t)FI_status * N + nn]; }
+    a4 = load_controls(act, c.act_dim);   // last: loads return in order, and this one may come from host memory (ac_step_host)
     tc.commit(lds_tab);
   } else if (PAIR) {
     const bool flight_role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1;
+    TableCopy<128> tc;
+    tc.issue(P.tab);
+    PairFlightIn fin;
     if (!flight_role) {   // the environment wave owns the task bookkeeping; the status word of every missile slot comes with it
+      a4 = load_controls(act, c.act_dim);
+      if (TASK == AC_TASK_SHOOT_MISSILE) shoot_raw = act[4];
       s = State{}; load_task(P.F, P.I, N, nn, t);
 #pragma unroll
       for (int k = 0; k < MSLOTS; ++k) pre_st[k] = P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn];
+    } else if (WPE == 1) {
+      pair_flight_load(P, c, nn, fin);
     }
-    stage_tables<128>(lds_tab, P.tab);
-    if (flight_role) { pair_flight_wave<true>(P, c, T, LP, l, nn, n, live); return; }
+    tc.commit(lds_tab);
+    if (flight_role) {
+      // (two waves per SIMD, 256 registers each: the flight state is asked for after the tables have left the registers -- the
+      // neighbouring wave covers the second round trip there)
+      if (WPE != 1) pair_flight_load(P, c, nn, fin);
+      pair_flight_wave<true>(P, c, T, LP, l, n, live, fin);
+      return;
+    }
   } else {
-    stage_tables<64>(lds_tab, P.tab);
+    TableCopy<64> tc;
+    tc.issue(P.tab);
+    a4 = load_controls(act, c.act_dim);
+    if (TASK == AC_TASK_SHOOT_MISSILE) shoot_raw = act[4];
     load_state(P.F, P.I, P.D, N, nn, s, t);
+    tc.commit(lds_tab);
   }
   AC_CLK(1);
-  if (SPLIT) {   // helper waves: decode the commands they integrate, run their part of every substep, done
-    const float4 a4 = load_controls(P.actions + (size_t)nn * c.act_dim, c.act_dim);
-    s.da = clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);
-    s.de = clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
-    s.dr = clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);
-    s.thr = clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
-    if (split_helper_wave(s, t, T, L, l, c.substeps)) return;
+  if (SPLIT) {   // helper waves: run their part of every substep, done (the systems wave decodes the commands it integrates)
+    if (split_helper_wave(s, t, T, L, l, c.substeps, &a4)) return;
   }
   Msl ms[MSLOTS];
   int nslots = 0, msl_was_active = 0;
@@ -729,20 +809,20 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
       // a slot that has not been launched since the last reset holds zeros and MSL_INACTIVE (reset_all_kernel, the reset branch
       // below): only its status is read, and it is written back only once it has been launched or reset
       const int st = (k < nslots) ? (PAIR ? pre_st[k] : P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn]) : MSL_INACTIVE;
-      if (st != MSL_INACTIVE) { load_msl(P.MF, P.MI, N, nn, k, ms[k]); msl_was_active |= 1 << k; }
-      else { ms[k] = Msl{}; ms[k].status = MSL_INACTIVE; }
+      load_msl_masked(P.MF, P.MI, N, nn, k, c.msl_slots, st != MSL_INACTIVE, st, ms[k]);
+      if (st != MSL_INACTIVE) msl_was_active |= 1 << k;
     }
   }
 
   // ---- apply actions (normalize_action, singlecombat_task.py:141-153; property bounds catalog.py:189-197)
-  const float* act = P.actions + (size_t)nn * c.act_dim;
-  const float4 a4 = load_controls(act, c.act_dim);
   t.cur_step += 1;
-  s.da = clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);
-  s.de = clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
-  s.dr = clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);
-  s.thr = clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
-  if (TASK == AC_TASK_SHOOT_MISSILE) t.shoot_action = (act[4] != 0.0f) ? 1 : 0;  // singlecombat_with_missile_task.py:182-184
+  if (!SPLIT) {
+    s.da = clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);
+    s.de = clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
+    s.dr = clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);
+    s.thr = clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
+  }
+  if (TASK == AC_TASK_SHOOT_MISSILE) t.shoot_action = (shoot_raw != 0.0f) ? 1 : 0;  // singlecombat_with_missile_task.py:182-184
 
   // ---- substeps (env_base.py:139-154): every aircraft, then every missile against this substep's aircraft poses
   const MslParam MP = aim9l();
@@ -759,7 +839,9 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
   }
   for (int sub = 0; sub < c.substeps; ++sub) {
     if (PAIR) {
+      AC_CLK(2 + 8 * sub);
       pair_substep<true>(t, LP, l, sub, env_has_missiles, pr, c);
+      AC_CLK(4 + 8 * sub);
       if (!env_has_missiles) continue;
     } else if (SPLIT) {        // the FDM tick over three waves; what follows in the substep (munitions) stays on this wave
       if (dynamics_wave_tick(s, t, d, T, L, l, sub)) { have_pose = true; last_tick = sub; }
@@ -786,9 +868,16 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
         }
       }
       if (__shfl_xor((int)hit_now, 1) && t.status == AC_ALIVE) t.status = AC_SHOTDOWN;
+      AC_CLK(5 + 8 * sub);
     }
   }
   const bool split_located = SPLIT && dynamics_wave_finish(s, d, L, l, last_tick, c.substeps);   // (+ the helper waves' fields)
+  if (SPLIT) {   // the commands, for the stored state (the dynamics wave itself never reads them: it did not wait for the action row)
+    s.da = clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);
+    s.de = clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
+    s.dr = clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);
+    s.thr = clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
+  }
   if (PAIR) {
     wg_sync();                                     // the flight wave has posted its final values and stored the flight state
     pair_read_final(LP, l, s, d, pr);
@@ -875,6 +964,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
   }
   float ob[OBS];
   observe_1v1<TASK>(pr, E, inc, ob);
+  AC_CLK(58);
 
   // ---- terminations (singlecombat_task.py:34-40; first condition that fires wins, task_base.py:88-112).
   // Agents are evaluated in order (env_base.py:159-166): agent 0's SafeReturn sees agent 1's status from before agent 1's
@@ -903,7 +993,26 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
     }
   }
 
+  // ---- episode end: every agent done => the env is reset and its observation replaced (env_wrappers.py:191-204)
+  const int other_done = __shfl_xor((int)done, 1);   // fetched outside the && (a short-circuited shuffle would read a masked-off lane)
+  const bool all_done = done && (bool)other_done;
+  const int other_code = __shfl_xor(code, 1);
+  if (all_done) {
+    const float* tobs = (const float*)(P.tF + (size_t)NF * 2) + slot * OBS;  // template observation follows the template fields
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) ob[k] = tobs[k];
+  }
+  // The observation rows leave now, before the rewards and the state stores: they are nine tenths of what a step writes, and when the
+  // output buffers are host memory (ac_step_host) their trip across PCIe is what the step waits for in the end.
+  {
+    float* row = lds_out + l * OBS;
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) row[k] = ob[k];
+    emit_obs_rows(P, lds_out, OBS, l);
+  }
+
   // ---- rewards (after every termination ran, env_base.py:168-171; die-flag latch singlecombat_task.py:190-195)
+  AC_CLK(59);
   float reward = 0.0f;
   const bool evaluates = !t.die_flag;
   if (evaluates) {
@@ -956,19 +1065,13 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
     reward += r_mp;
   }
 
-  // ---- episode end: every agent done => the env is reset and its observation replaced (env_wrappers.py:191-204)
-  const int other_done = __shfl_xor((int)done, 1);   // fetched outside the && (a short-circuited shuffle would read a masked-off lane)
-  bool all_done = done && (bool)other_done;
-  int other_code = __shfl_xor(code, 1);
+  // ---- the reset itself
   int step_out = t.cur_step;
   if (all_done) {
     load_state(P.tF, P.tI, P.tD, 2, slot, s, t);
     zero_controller_state(P, N, n, live);
 #pragma unroll
     for (int k = 0; k < MSLOTS; ++k) { ms[k] = Msl{}; ms[k].status = MSL_INACTIVE; }
-    const float* tobs = (const float*)(P.tF + (size_t)NF * 2) + slot * OBS;  // template observation follows the template fields
-#pragma unroll
-    for (int k = 0; k < OBS; ++k) ob[k] = tobs[k];
   }
   AC_CLK(53);
   if (live) {
@@ -983,8 +1086,9 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
         if (k < nslots && (ms[k].status != MSL_INACTIVE || ((msl_was_active >> k) & 1))) store_msl(P.MF, P.MI, N, n, k, ms[k]);
     }
   }
+  AC_CLK(55);
   // info['done_condition'] keeps the last agent's message
-  emit_outputs(P, lds_out, OBS, l, ob, reward, done, 2, step_out, other_code ? other_code : code, 0, all_done ? 1 : 0);
+  emit_scalars(P, l, reward, done, 2, step_out, other_code ? other_code : code, 0, all_done ? 1 : 0);
   AC_CLK(54);
 }
 
@@ -1062,7 +1166,6 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
   __shared__ __attribute__((aligned(16))) float lds_out[64 * OBS];
   __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : 16];
   SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
-  stage_tables<SPLIT ? 192 : 64>(lds_tab, P.tab);
   const Tab T{lds_tab};
   const int N = c.N;
   const int l = threadIdx.x & 63;
@@ -1074,8 +1177,11 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
   const int team = slot < c.n_ego ? 0 : 1;
 
   State s; Task t; Derived d; Props pr;
-  load_state(P.F, P.I, P.D, N, nn, s, t);
+  TableCopy<SPLIT ? 192 : 64> tc;               // table loads, the action row and the state behind them: one HBM round trip
+  tc.issue(P.tab);
   const float4 a4 = load_controls(P.actions + (size_t)nn * c.act_dim, c.act_dim);
+  load_state(P.F, P.I, P.D, N, nn, s, t);
+  tc.commit(lds_tab);
   t.cur_step += 1;
   s.da = clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);   // multiplecombat_task.py:137-145
   s.de = clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
@@ -1589,10 +1695,13 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   HIP_OK(hipMalloc(&p.I, sizeof(int) * NI * N));
   HIP_OK(hipMalloc(&p.D, sizeof(double) * ND * N));
   const size_t ms = c.msl_slots > 0 ? (size_t)c.msl_slots : 1;
-  HIP_OK(hipMalloc(&p.MF, sizeof(float) * ms * NMF * N));
+  // (+ 64 zero bytes behind each missile array: what load_msl_masked reads for a slot that is not in flight)
+  HIP_OK(hipMalloc(&p.MF, sizeof(float) * ms * NMF * N + 64));
+  HIP_OK(hipMemset((char*)p.MF + sizeof(float) * ms * NMF * N, 0, 64));
   p.MD = nullptr;
   if (scenario) HIP_OK(hipMalloc(&p.MD, sizeof(double) * ms * NMF * N));
-  HIP_OK(hipMalloc(&p.MI, sizeof(int) * ms * NMI * N));
+  HIP_OK(hipMalloc(&p.MI, sizeof(int) * ms * NMI * N + 64));
+  HIP_OK(hipMemset((char*)p.MI + sizeof(int) * ms * NMI * N, 0, 64));
   // outputs: rows padded to whole workgroups (emit_outputs stores whole blocks)
   const size_t Npad = (N + 63) / 64 * 64;
   HIP_OK(hipMalloc(&p.obs, sizeof(float) * Npad * h->obs_dim));

@@ -56,6 +56,37 @@ __device__ __forceinline__ void mma_tile(const float* __restrict__ tile, int lan
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].w, b.w, acc, 0, 0, 0);
   }
 }
+// One column tile's weights in registers (K = 128: eight 16-byte vectors per lane) so that the NEXT tile's loads are in flight
+// while this tile's 32 MFMAs run: a 16 x 16 tile is only ~1000 cycles of matrix work, about one L2 round trip
+struct BTile { float4 b[8]; };
+__device__ __forceinline__ void load_b(const float* __restrict__ tile, int lane, BTile& B) {
+  const float4* t4 = reinterpret_cast<const float4*>(tile) + lane;
+#pragma unroll
+  for (int g = 0; g < 8; ++g) B.b[g] = t4[g * 64];
+}
+__device__ __forceinline__ void mma_b(const BTile& B, const float4 (&A)[8], floatx4& acc) {
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].x, B.b[g].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].y, B.b[g].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].z, B.b[g].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].w, B.b[g].w, acc, 0, 0, 0);
+  }
+}
+// two independent tiles interleaved (their accumulators do not depend on each other: the matrix pipe never waits for its own result)
+__device__ __forceinline__ void mma_b2(const BTile& B0, const BTile& B1, const float4 (&A)[8], floatx4& acc0, floatx4& acc1) {
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].x, B0.b[g].x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].x, B1.b[g].x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].y, B0.b[g].y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].y, B1.b[g].y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].z, B0.b[g].z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].z, B1.b[g].z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].w, B0.b[g].w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].w, B1.b[g].w, acc1, 0, 0, 0);
+  }
+}
 __device__ __forceinline__ floatx4 splat(float v) { floatx4 a; a[0] = v; a[1] = v; a[2] = v; a[3] = v; return a; }
 __device__ __forceinline__ int c_row(int r, int lane) { return (lane >> 4) * 4 + r; }
 
@@ -163,15 +194,17 @@ __global__ __launch_bounds__(256, 2) void controller16_kernel(ctl::Args a) {
   layer_norm(act1, red, W + E_G1, W + E_BE1, tid);
   // ---- MLP layer 2
   {
+    BTile B0, B1;
+    load_b(W + E_W2 + (2 * w) * tile_floats(HID), lane, B0);
+    load_b(W + E_W2 + (2 * w + 1) * tile_floats(HID), lane, B1);
     float4 A[8];
     load_a<HID>(act1, lane, A);
+    floatx4 acc0 = splat(W[E_B2 + (2 * w) * 16 + col]), acc1 = splat(W[E_B2 + (2 * w + 1) * 16 + col]);
+    mma_b2(B0, B1, A, acc0, acc1);
 #pragma unroll
-    for (int tc = 0; tc < 2; ++tc) {
-      const int c = 2 * w + tc;
-      floatx4 acc = splat(W[E_B2 + c * 16 + col]);
-      mma_tile<HID>(W + E_W2 + c * tile_floats(HID), lane, A, acc);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) act0[act_index(c * 16 + col, c_row(r, lane))] = fmaxf(acc[r], 0.0f);   // act0's inputs were consumed before the last barriers
+    for (int r = 0; r < 4; ++r) {   // act0's inputs were consumed before the last barriers
+      act0[act_index((2 * w) * 16 + col, c_row(r, lane))] = fmaxf(acc0[r], 0.0f);
+      act0[act_index((2 * w + 1) * 16 + col, c_row(r, lane))] = fmaxf(acc1[r], 0.0f);
     }
   }
   __syncthreads();
@@ -186,26 +219,24 @@ __global__ __launch_bounds__(256, 2) void controller16_kernel(ctl::Args a) {
       hr[tc] = splat(W[E_BHH + 0 * 128 + u]); hz[tc] = splat(W[E_BHH + 1 * 128 + u]); hn[tc] = splat(W[E_BHH + 2 * 128 + u]);
     }
     {
-      float4 A[8];
-      load_a<HID>(act0, lane, A);
-#pragma unroll
-      for (int tc = 0; tc < 2; ++tc) {
-        const int c = 2 * w + tc;
-        mma_tile<HID>(W + E_WIH + (0 + c) * tile_floats(HID), lane, A, ir[tc]);
-        mma_tile<HID>(W + E_WIH + (8 + c) * tile_floats(HID), lane, A, iz[tc]);
-        mma_tile<HID>(W + E_WIH + (16 + c) * tile_floats(HID), lane, A, in_[tc]);
-      }
-    }
-    {
-      float4 A[8];
-      load_a<HID>(hbuf, lane, A);
-#pragma unroll
-      for (int tc = 0; tc < 2; ++tc) {
-        const int c = 2 * w + tc;
-        mma_tile<HID>(W + E_WHH + (0 + c) * tile_floats(HID), lane, A, hr[tc]);
-        mma_tile<HID>(W + E_WHH + (8 + c) * tile_floats(HID), lane, A, hz[tc]);
-        mma_tile<HID>(W + E_WHH + (16 + c) * tile_floats(HID), lane, A, hn[tc]);
-      }
+      // twelve tiles in six interleaved pairs (the two unit tiles of a gate), each pair's weights requested while the pair before runs
+      const int c0 = 2 * w, c1 = 2 * w + 1, TF = tile_floats(HID);
+      BTile P0, P1, Q0, Q1;
+      float4 Ai[8], Ah[8];
+      load_b(W + E_WIH + (0 + c0) * TF, lane, P0); load_b(W + E_WIH + (0 + c1) * TF, lane, P1);
+      load_a<HID>(act0, lane, Ai);
+      load_b(W + E_WIH + (8 + c0) * TF, lane, Q0); load_b(W + E_WIH + (8 + c1) * TF, lane, Q1);
+      mma_b2(P0, P1, Ai, ir[0], ir[1]);
+      load_b(W + E_WIH + (16 + c0) * TF, lane, P0); load_b(W + E_WIH + (16 + c1) * TF, lane, P1);
+      mma_b2(Q0, Q1, Ai, iz[0], iz[1]);
+      load_b(W + E_WHH + (0 + c0) * TF, lane, Q0); load_b(W + E_WHH + (0 + c1) * TF, lane, Q1);
+      load_a<HID>(hbuf, lane, Ah);
+      mma_b2(P0, P1, Ai, in_[0], in_[1]);
+      load_b(W + E_WHH + (8 + c0) * TF, lane, P0); load_b(W + E_WHH + (8 + c1) * TF, lane, P1);
+      mma_b2(Q0, Q1, Ah, hr[0], hr[1]);
+      load_b(W + E_WHH + (16 + c0) * TF, lane, Q0); load_b(W + E_WHH + (16 + c1) * TF, lane, Q1);
+      mma_b2(P0, P1, Ah, hz[0], hz[1]);
+      mma_b2(Q0, Q1, Ah, hn[0], hn[1]);
     }
 #pragma unroll
     for (int tc = 0; tc < 2; ++tc)
@@ -229,16 +260,25 @@ __global__ __launch_bounds__(256, 2) void controller16_kernel(ctl::Args a) {
   layer_norm(act1, red, W + E_G3, W + E_BE3, tid);
   // ---- heads: 153 logits = ten column tiles; wave w takes tiles w and 4 + w, and waves 0 / 1 tiles 8 / 9
   {
+    const int TF = tile_floats(HID);
+    BTile B0, B1, B2;
+    load_b(W + E_WA + w * TF, lane, B0);
+    load_b(W + E_WA + (4 + w) * TF, lane, B1);
+    if (w < 2) load_b(W + E_WA + (8 + w) * TF, lane, B2);
     float4 A[8];
     load_a<HID>(act1, lane, A);
+    floatx4 acc0 = splat(W[E_BA + w * 16 + col]), acc1 = splat(W[E_BA + (4 + w) * 16 + col]);
+    mma_b2(B0, B1, A, acc0, acc1);
 #pragma unroll
-    for (int tc = 0; tc < 3; ++tc) {
-      const int c = tc * 4 + w;
-      if (c >= 10) break;
-      floatx4 acc = splat(W[E_BA + c * 16 + col]);
-      mma_tile<HID>(W + E_WA + c * tile_floats(HID), lane, A, acc);
+    for (int r = 0; r < 4; ++r) {
+      lg[(w * 16 + col) * 17 + c_row(r, lane)] = acc0[r];
+      lg[((4 + w) * 16 + col) * 17 + c_row(r, lane)] = acc1[r];
+    }
+    if (w < 2) {
+      floatx4 acc2 = splat(W[E_BA + (8 + w) * 16 + col]);
+      mma_b(B2, A, acc2);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lg[(c * 16 + col) * 17 + c_row(r, lane)] = acc[r];
+      for (int r = 0; r < 4; ++r) lg[((8 + w) * 16 + col) * 17 + c_row(r, lane)] = acc2[r];
     }
   }
   __syncthreads();

@@ -124,7 +124,6 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, SPLIT ? 1 : 2) void step_kernel_h
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
   __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : 16];
   SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
-  stage_tables<SPLIT ? 192 : 64>(lds_tab, P.tab);
   const Tab T{lds_tab};
   const int N = c.N;
   const int l = threadIdx.x & 63;
@@ -133,7 +132,15 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, SPLIT ? 1 : 2) void step_kernel_h
   const int nn = live ? n : N - 1;
   State s; Task t; Derived d; Props pr; HeadingState x;
   float ob[OBS];
+  TableCopy<SPLIT ? 192 : 64> tc;               // table loads, the action row and the state behind them: one HBM round trip
+  tc.issue(P.tab);
+  const float4 a4 = load_controls(P.actions + (size_t)nn * c.act_dim, c.act_dim);   // (a reset never reads it: the row is there all the same)
   load_heading(H, N, nn, x);
+  // (the one-wave form runs two waves per SIMD on 256 registers each: there the state is asked for once the tables have left the
+  // registers, and the neighbouring wave covers the second round trip)
+  if (SPLIT && !reset_only) load_state(P.F, P.I, P.D, N, nn, s, t);
+  tc.commit(lds_tab);
+  if (!SPLIT && !reset_only) load_state(P.F, P.I, P.D, N, nn, s, t);
   if (reset_only) {   // VecEnv.reset(): every env draws a new episode
     heading_reset(hc, c, T, s, d, t, pr, x, ob);
     if (live) {
@@ -143,8 +150,6 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, SPLIT ? 1 : 2) void step_kernel_h
     emit_outputs(P, lds_out, OBS, l, ob, 0.0f, false, 1, 0, 0, 0, 0);
     return;
   }
-  load_state(P.F, P.I, P.D, N, nn, s, t);
-  const float4 a4 = load_controls(P.actions + (size_t)nn * c.act_dim, c.act_dim);
   t.cur_step += 1;
   // heading_task.py:102-110: a * 2 / (41 - 1) - 1 and a * 0.5 / (30 - 1) + 0.4, then the property bounds (catalog.py:189-197)
   s.da = clampf(-1.0f, a4.x * (2.0f / 40.0f) - 1.0f, 1.0f);

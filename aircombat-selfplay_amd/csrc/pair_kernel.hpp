@@ -42,13 +42,20 @@ __device__ __forceinline__ void ned_velocity(const f16::State& s, f16::Derived& 
 // The flight wave. Returns when its part of the step is done (the caller returns).
 // RAW_POSE: post the tick's ECI position / velocity as they are and leave the geodetic reduction to the environment wave -- for the 1v1
 // missile tasks, whose fp32 AIM-9L update leaves that wave the slack (there the flight wave is the longer of the two).
+// What the flight wave reads from HBM: the flight state, the aircraft's status (only to know whether tick 0 flies: the environment
+// wave owns the field) and its action row. Separate from the wave's body so that a kernel can issue the loads behind its table loads.
+struct PairFlightIn { f16::State s; int status0; float4 a4; };
+__device__ __forceinline__ void pair_flight_load(const DevPtrs& P, const DevCfg& c, int nn, PairFlightIn& in) {
+  load_flight(P.F, P.I, P.D, c.N, nn, in.s);
+  in.status0 = P.I[(size_t)FI_status * c.N + nn];
+  in.a4 = load_controls(P.actions + (size_t)nn * c.act_dim, c.act_dim);
+}
 template <bool RAW_POSE = false>
-__device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg& c, const f16::Tab& T, PairLds& L, int l, int nn, int n, bool live) {
+__device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg& c, const f16::Tab& T, PairLds& L, int l, int n, bool live, PairFlightIn& in) {
   using namespace pair;
-  f16::State s; f16::Derived d;
-  load_flight(P.F, P.I, P.D, c.N, nn, s);
-  const int status0 = P.I[(size_t)FI_status * c.N + nn];   // (only to know whether tick 0 flies: the environment wave owns the field)
-  const float4 a4 = load_controls(P.actions + (size_t)nn * c.act_dim, c.act_dim);
+  f16::State& s = in.s; f16::Derived d;
+  const int status0 = in.status0;
+  const float4 a4 = in.a4;
   s.da = f16::clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);   // normalize_action (singlecombat_task.py:141-153), property bounds catalog.py:189-197
   s.de = f16::clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
   s.dr = f16::clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);

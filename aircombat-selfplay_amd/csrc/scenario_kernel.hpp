@@ -130,7 +130,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   }
   stage_tables<SPLIT ? 192 : (PAIR ? 128 : 64)>(lds_tab, P.tab);
   AC_CLK(0);
-  if (flight_role) { pair_flight_wave<false>(P, c, T, LP, lane, nn, n, live); return; }   // (it waits for the environment wave's first flags anyway: its state load hides there)
+  if (flight_role) { PairFlightIn in; pair_flight_load(P, c, nn, in); pair_flight_wave<false>(P, c, T, LP, lane, n, live, in); return; }   // (it waits for the environment wave's first flags anyway: its state load hides there)
 
   if (PAIR) load_task(P.F, P.I, N, nn, t);   // the environment wave owns the task bookkeeping; of the flight state it only needs the tick count (Earth angle)
   else load_state(P.F, P.I, P.D, N, nn, s, t);
