@@ -1425,7 +1425,7 @@ __global__ void init_kernel_nvn(InitArgs ia, DevCfg c, const float* tab, float* 
 
 #include "scenario_kernel.hpp"
 #include "controller_kernel.hpp"
-#include "controller16_kernel.hpp"
+#include "controller_split_kernel.hpp"
 #include "heading_kernel.hpp"
 
 // reset(): every env takes the template (SubprocVecEnv.reset -> env.reset(), env_base.py:98-113)
@@ -1471,7 +1471,7 @@ struct ac_env {
   float* d_XF; int* d_XI;                // scenario-task extension state
   float* d_scripted;                     // [N][12] controller inputs of scripted opponents
   float* d_ctlW; float* d_low;           // hierarchical tasks: controller weights (device layout), low-level action buffer
-  float* d_ctlW16;                       // the same weights tiled for the 16-aircraft controller kernel
+  float* d_ctlWs;                        // the same weights as bf16 pieces (controller_split_kernel)
   HeadingPtrs hp; HeadingCfg hc;         // HeadingTask: targets, check clock, numpy-PCG64 state per env
   int act_low;                           // width of the low-level action the step kernels decode
   hipEvent_t ev0, ev1;
@@ -1480,6 +1480,7 @@ struct ac_env {
   struct HostSet { float* act; float* obs; float* rew; uint8_t* done; int* info; } hs[2];
   bool have_hs;
   bool timing;
+  bool ctl_fp32;                         // hierarchical tasks: controller_kernel (fp32 MFMA) instead of controller_split_kernel (AIRCOMBAT_CTL=fp32 at ac_create)
   bool split_waves;                      // SingleCombat below one wave per SIMD: three waves per 64 aircraft (step_kernel_1v1<.., SPLIT>)
 };
 
@@ -1502,19 +1503,16 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
   dim3 block(64), grid((h->N + 63) / 64);
   if (h->cfg.hierarchical) {   // [3,5,3] (+ weapon bits) -> control indices, then the ordinary step on those
     if (!h->d_ctlW) return fail("hierarchical task: ac_load_controller has not been called");
-    ctl::Args a{h->d_ctlW, h->d_ctlW16, p.actions, p.obs, p.H, h->d_low, h->N, h->obs_dim, h->act_dim, h->act_low,
+    ctl::Args a{h->d_ctlW, h->d_ctlWs, p.actions, p.obs, p.H, h->d_low, h->N, h->obs_dim, h->act_dim, h->act_low,
                 h->cfg.use_baseline, h->A, h->cfg.n_ego, h->cfg.use_artillery,
                 (float)h->cfg.agent_interaction_steps / (float)h->cfg.sim_freq, p.man_step, p.man_h0, p, h->dc, h->d_scripted};
     if (h->cfg.use_baseline) {
       hipLaunchKernelGGL(scripted_inputs_kernel, grid, block, 0, h->stream, a);
       HIP_OK(hipGetLastError());
     }
-    // 16 aircraft per workgroup (two workgroups per CU overlap their MFMA and non-MFMA phases) while that still leaves CUs to fill;
-    // above 2 x 256 x 32 aircraft the 32-aircraft form already has two workgroups per CU and reads the weights half as often
-    static const char* force = getenv("AIRCOMBAT_CTL");
-    const bool use16 = force ? force[0] == '1' : h->N <= 16384;
-    if (use16) hipLaunchKernelGGL(controller16_kernel, dim3((h->N + ctl16::MT - 1) / ctl16::MT), dim3(256), 0, h->stream, a);
-    else hipLaunchKernelGGL(controller_kernel, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
+    // the bf16-piece form (controller_split_kernel.hpp) unless the handle was created under AIRCOMBAT_CTL=fp32 (the fp32 matrix instructions)
+    if (h->ctl_fp32) hipLaunchKernelGGL(controller_kernel, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL(controller_split_kernel, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
     HIP_OK(hipGetLastError());
     p.actions = h->d_low;
   }
@@ -1643,6 +1641,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     const bool ticks_only = cfg->task == AC_TASK_SINGLECOMBAT || cfg->task == AC_TASK_MULTICOMBAT || cfg->task == AC_TASK_HEADING ||
                             cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER;
     h->split_waves = ticks_only && (e ? (e[0] == '1') : (wgs <= 512));
+    const char* ce = getenv("AIRCOMBAT_CTL");
+    h->ctl_fp32 = ce && ce[0] == 'f';
   }
   h->obs_dim = heading ? 12 : (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
@@ -1786,7 +1786,7 @@ int ac_destroy(ac_env_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->dp.F, h->dp.I, h->dp.D, h->dp.MF, h->dp.MD, h->dp.MI, h->dp.obs, h->dp.rew, h->dp.done, h->dp.info,
-                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_scripted, h->d_ctlW, h->d_ctlW16, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
+                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_scripted, h->d_ctlW, h->d_ctlWs, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
   for (void* b : bufs) (void)hipFree(b);
   if (h->have_hs)
     for (auto& hs : h->hs) { (void)hipHostFree(hs.act); (void)hipHostFree(hs.obs); (void)hipHostFree(hs.rew); (void)hipHostFree(hs.done); (void)hipHostFree(hs.info); }
@@ -2089,26 +2089,31 @@ int ac_load_controller(ac_env_t* h, const float* weights, int64_t n) {
   tiles(S_WA, D_WA, NH, 128, 128, 5); copy(S_BA, D_BA, NH);
   if (!h->d_ctlW) HIP_OK(hipMalloc(&h->d_ctlW, sizeof(float) * D_END));
   HIP_OK(hipMemcpy(h->d_ctlW, d.data(), sizeof(float) * D_END, hipMemcpyHostToDevice));
-  {   // B-operand tiles of v_mfma_f32_16x16x4_f32: element (group g, lane, q) of column tile c is W[j = 16 c + lane % 16][k = 16 g + 4 q + lane / 16]
-    using namespace ctl16;
-    std::vector<float> e(E_END, 0.0f);
-    auto tiles16 = [&](int src, int dst, int J, int K, int Kpad, int ntiles) {
+  {   // the same weights as bf16 pieces: tile(c) = K/16 chunks x 3 pieces x 64 lanes x 8 values, element (g, p, lane, i) = piece p of
+      // W[j = 32 c + lane % 32][k = 16 g + 8 (lane / 32) + i]
+    using namespace ctls;
+    std::vector<float> e(B_END, 0.0f);
+    unsigned short* e16 = reinterpret_cast<unsigned short*>(e.data());
+    auto tiles_s = [&](int src, int dst, int J, int K, int Kpad, int ntiles) {
       for (int c = 0; c < ntiles; ++c)
         for (int g = 0; g < Kpad / 16; ++g)
           for (int lane = 0; lane < 64; ++lane)
-            for (int q = 0; q < 4; ++q) {
-              const int k = 16 * g + 4 * q + lane / 16, j = 16 * c + lane % 16;
-              e[dst + ((size_t)(c * (Kpad / 16) + g) * 64 + lane) * 4 + q] = (j < J && k < K) ? weights[src + j * K + k] : 0.0f;
+            for (int i = 0; i < 8; ++i) {
+              const int k = 16 * g + 8 * (lane / 32) + i, j = 32 * c + lane % 32;
+              unsigned pc[3];
+              split3((j < J && k < K) ? weights[src + j * K + k] : 0.0f, pc[0], pc[1], pc[2]);
+              for (int pp = 0; pp < 3; ++pp)
+                e16[(size_t)dst * 2 + ((((size_t)c * (Kpad / 16) + g) * 3 + pp) * 64 + lane) * 8 + i] = (unsigned short)pc[pp];
             }
     };
-    auto copy16 = [&](int src, int dst, int cnt) { for (int i = 0; i < cnt; ++i) e[dst + i] = weights[src + i]; };
-    tiles16(S_W1, E_W1, 128, 12, 16, 8); copy16(S_B1, E_B1, 128); copy16(S_G1, E_G1, 128); copy16(S_BE1, E_BE1, 128);
-    tiles16(S_W2, E_W2, 128, 128, 128, 8); copy16(S_B2, E_B2, 128); copy16(S_G2, E_G2, 128); copy16(S_BE2, E_BE2, 128);
-    tiles16(S_WIH, E_WIH, 384, 128, 128, 24); tiles16(S_WHH, E_WHH, 384, 128, 128, 24); copy16(S_BIH, E_BIH, 384); copy16(S_BHH, E_BHH, 384);
-    copy16(S_G3, E_G3, 128); copy16(S_BE3, E_BE3, 128);
-    tiles16(S_WA, E_WA, NH, 128, 128, 10); copy16(S_BA, E_BA, NH);
-    if (!h->d_ctlW16) HIP_OK(hipMalloc(&h->d_ctlW16, sizeof(float) * E_END));
-    HIP_OK(hipMemcpy(h->d_ctlW16, e.data(), sizeof(float) * E_END, hipMemcpyHostToDevice));
+    auto copy_s = [&](int src, int dst, int cnt) { for (int i = 0; i < cnt; ++i) e[dst + i] = weights[src + i]; };
+    tiles_s(S_W1, B_W1, 128, 12, 16, 4); copy_s(S_B1, B_B1, 128); copy_s(S_G1, B_G1, 128); copy_s(S_BE1, B_BE1, 128);
+    tiles_s(S_W2, B_W2, 128, 128, 128, 4); copy_s(S_B2, B_B2, 128); copy_s(S_G2, B_G2, 128); copy_s(S_BE2, B_BE2, 128);
+    tiles_s(S_WIH, B_WIH, 384, 128, 128, 12); tiles_s(S_WHH, B_WHH, 384, 128, 128, 12); copy_s(S_BIH, B_BIH, 384); copy_s(S_BHH, B_BHH, 384);
+    copy_s(S_G3, B_G3, 128); copy_s(S_BE3, B_BE3, 128);
+    tiles_s(S_WA, B_WA, NH, 128, 128, 5); copy_s(S_BA, B_BA, NH);
+    if (!h->d_ctlWs) HIP_OK(hipMalloc(&h->d_ctlWs, sizeof(float) * B_END));
+    HIP_OK(hipMemcpy(h->d_ctlWs, e.data(), sizeof(float) * B_END, hipMemcpyHostToDevice));
   }
   return 0;
 }

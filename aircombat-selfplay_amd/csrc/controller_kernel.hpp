@@ -44,7 +44,7 @@ enum : int {
 
 struct Args {
   const float* W;          // device blob (layout above)
-  const float* W16;        // the same weights tiled for controller16_kernel (controller16_kernel.hpp)
+  const float* Ws;         // the same weights as bf16 pieces, tiled for controller_split_kernel (controller_split_kernel.hpp)
   const float* hi;         // [N][act_hi]: 3 high-level choices (+ weapon bits passed through)
   const float* obs;        // [N][obs_dim]: observation of the CURRENT state (last step's / the reset's output)
   float* H;                // [128][N] GRU state

@@ -1,0 +1,382 @@
+// The low-level controller (controller_kernel.hpp: same network, same arguments, same outputs) with every fp32 product taken apart into
+// bf16 pieces, so that the GEMMs run on the bf16 matrix path of gfx950 (v_mfma_f32_32x32x16_bf16: 16 k per 32 cycles) instead of the
+// fp32 one (v_mfma_f32_32x32x2_f32: 2 k per 64 cycles).
+//
+// An fp32 value x is exactly hi + mid + lo, three bf16 numbers: hi = x with its low 16 bits cleared, mid = (x - hi) with its low 16
+// bits cleared, lo = x - hi - mid (8 significand bits each, 24 together; both subtractions are exact). A product of two such sums has
+// nine terms; the six that reach 2^-16 of the product are kept -- hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid -- and the three left
+// out (mid*lo, lo*mid, lo*lo) are below 2^-24 of it, the rounding of an fp32 multiply. Every kept term is an exact bf16 x bf16
+// product accumulated in fp32 by the matrix core, like the fp32 instruction accumulates its own. Six bf16 instructions per 16 k are
+// 12 cycles per k against 32: the matrix time of the controller drops from ~13 us to ~5 us at 8192 aircraft. What bounds the GEMM phases
+// then is the L2: every workgroup (32 aircraft, one per CU at 8192) streams all 0.7 MB of weight pieces once per call, 180 MB per
+// call over all CUs, and the GRU's share of that moves at ~21 TB/s aggregate (tools/diag/clk_controller.py) -- a third more matrix
+// rate would need more aircraft per CU than the batch has.
+//
+// Weights are split once on the host (ac_load_controller); activations are split where they are produced -- the LayerNorm epilogue
+// (one thread = 16 features of one aircraft) writes three bf16 planes [aircraft][k] to LDS, so an A operand (8 consecutive k of one
+// aircraft) is one ds_read_b128 per piece.
+#pragma once
+
+namespace ctls {
+using ctl::HID; using ctl::NH; using ctl::NHP; using ctl::MT; using ctl::LS; using ctl::floatx16; using ctl::splat; using ctl::c_row;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int KS = HID + 8;                      // bf16 per plane row (272 bytes: 16 aircraft's 16-byte reads fall on distinct banks)
+constexpr int PLANE = MT * KS;                   // bf16 per plane
+constexpr int RS = HID + 4;                      // floats per row of the fp32 staging buffer [aircraft][k] (LayerNorm reads 16-byte vectors)
+// B-operand tiles: tile(c, K) = K/16 chunks x 3 pieces x 64 lanes x 8 bf16; element (g, p, lane, i) = piece p of W[j = 32c + lane%32][k = 16g + 8(lane/32) + i]
+constexpr int tile_floats(int K) { return (K / 16) * 3 * 64 * 4; }   // in floats (a uint4 = 8 bf16 = 4 floats)
+enum : int {
+  B_W1 = 0,                                  // K = 16 (12 padded), 4 tiles
+  B_W2 = B_W1 + 4 * tile_floats(16),         // K = 128, 4 tiles
+  B_WIH = B_W2 + 4 * tile_floats(128),       // 12 tiles (r0..3, z0..3, n0..3)
+  B_WHH = B_WIH + 12 * tile_floats(128),     // 12 tiles
+  B_WA = B_WHH + 12 * tile_floats(128),      // 5 tiles (columns 153..159 zero)
+  B_B1 = B_WA + 5 * tile_floats(128), B_G1 = B_B1 + 128, B_BE1 = B_G1 + 128,
+  B_B2 = B_BE1 + 128, B_G2 = B_B2 + 128, B_BE2 = B_G2 + 128,
+  B_BIH = B_BE2 + 128, B_BHH = B_BIH + 384, B_G3 = B_BHH + 384, B_BE3 = B_G3 + 128,
+  B_BA = B_BE3 + 128,                        // [160]
+  B_END = B_BA + NHP
+};
+// x = hi + mid + lo (bit patterns of the three bf16, i.e. the high halves of three floats)
+__host__ __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const unsigned xb = __float_as_uint(x);
+  const float h = __uint_as_float(xb & 0xFFFF0000u);
+  const float r1 = x - h;
+  const float m = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+  const float r2 = r1 - m;
+  hi = xb >> 16; mid = __float_as_uint(r1) >> 16; lo = __float_as_uint(r2) >> 16;
+#else
+  unsigned xb; memcpy(&xb, &x, 4);
+  unsigned hb = xb & 0xFFFF0000u; float h; memcpy(&h, &hb, 4);
+  const float r1 = x - h; unsigned r1b; memcpy(&r1b, &r1, 4);
+  unsigned mb = r1b & 0xFFFF0000u; float m; memcpy(&m, &mb, 4);
+  const float r2 = r1 - m; unsigned r2b; memcpy(&r2b, &r2, 4);
+  hi = xb >> 16; mid = r1b >> 16; lo = r2b >> 16;
+#endif
+}
+// 16 consecutive features of one aircraft -> the three planes (two 16-byte LDS stores per plane)
+__device__ __forceinline__ void write_planes(unsigned short* planes, int row, int k0, const float (&v)[16]) {
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3(v[2 * q], h0, m0, l0); split3(v[2 * q + 1], h1, m1, l1);
+    h[q] = h0 | (h1 << 16); m[q] = m0 | (m1 << 16); l[q] = l0 | (l1 << 16);
+  }
+  uint4* ph = reinterpret_cast<uint4*>(planes + 0 * PLANE + row * KS + k0);
+  uint4* pm = reinterpret_cast<uint4*>(planes + 1 * PLANE + row * KS + k0);
+  uint4* pl = reinterpret_cast<uint4*>(planes + 2 * PLANE + row * KS + k0);
+  ph[0] = make_uint4(h[0], h[1], h[2], h[3]); ph[1] = make_uint4(h[4], h[5], h[6], h[7]);
+  pm[0] = make_uint4(m[0], m[1], m[2], m[3]); pm[1] = make_uint4(m[4], m[5], m[6], m[7]);
+  pl[0] = make_uint4(l[0], l[1], l[2], l[3]); pl[1] = make_uint4(l[4], l[5], l[6], l[7]);
+}
+// four consecutive features of one aircraft -> the three planes (one 8-byte LDS store per plane)
+__device__ __forceinline__ void write_planes4(unsigned short* planes, int row, int k0, const float4& v) {
+  unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+  split3(v.x, h0, m0, l0); split3(v.y, h1, m1, l1); split3(v.z, h2, m2, l2); split3(v.w, h3, m3, l3);
+  *reinterpret_cast<uint2*>(planes + 0 * PLANE + row * KS + k0) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+  *reinterpret_cast<uint2*>(planes + 1 * PLANE + row * KS + k0) = make_uint2(m0 | (m1 << 16), m2 | (m3 << 16));
+  *reinterpret_cast<uint2*>(planes + 2 * PLANE + row * KS + k0) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+}
+// A operands of one layer for this lane: piece p, chunk g = planes[p][row = lane % 32][k = 16 g + 8 (lane / 32) .. + 7]
+template <int K>
+struct AOps { uint4 a[3][K / 16]; };
+template <int K>
+__device__ __forceinline__ void load_a(const unsigned short* planes, int lane, AOps<K>& A) {
+  const unsigned short* base = planes + (lane & 31) * KS + 8 * (lane >> 5);
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int g = 0; g < K / 16; ++g) A.a[p][g] = *reinterpret_cast<const uint4*>(base + p * PLANE + 16 * g);
+}
+struct BChunk { uint4 b[3]; };
+__device__ __forceinline__ void load_b(const uint4* __restrict__ t4 /* tile + lane */, int g, BChunk& B) {
+#pragma unroll
+  for (int p = 0; p < 3; ++p) B.b[p] = t4[(g * 3 + p) * 64];
+}
+__device__ __forceinline__ floatx16 mf(const uint4& a, const uint4& b, floatx16 acc) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+// the six kept terms of one 16-k chunk, smallest first
+#define CTLS_CHUNK(acc, A, g, B)                                                                   \
+  do {                                                                                             \
+    acc = mf(A.a[2][g], B.b[0], acc); acc = mf(A.a[0][g], B.b[2], acc); acc = mf(A.a[1][g], B.b[1], acc); \
+    acc = mf(A.a[1][g], B.b[0], acc); acc = mf(A.a[0][g], B.b[1], acc); acc = mf(A.a[0][g], B.b[0], acc); \
+  } while (0)
+// Weight loads run ahead of the matrix instructions that use them: an L2 round trip is ~1200 cycles under this kernel's load, a 16-k
+// chunk of one tile is 192 cycles of matrix work. A whole tile's chunks (K = 128: 24 x 16 bytes per lane) are asked for before the
+// LayerNorm that precedes the layer -- the weights do not depend on the activations -- ...
+template <int K>
+struct BTile { BChunk c[K / 16]; };
+template <int K>
+__device__ __forceinline__ void prefetch_b(const float* __restrict__ tile, int lane, BTile<K>& B) {
+  const uint4* t4 = reinterpret_cast<const uint4*>(tile) + lane;
+#pragma unroll
+  for (int g = 0; g < K / 16; ++g) load_b(t4, g, B.c[g]);
+}
+// ... one tile on three accumulation chains (the matrix pipe does not wait for its own result): the 2^-16 terms, the 2^-8 terms and
+// the leading term with the bias, added smallest first at the end
+template <int K>
+__device__ __forceinline__ floatx16 mma1(const BTile<K>& B, const AOps<K>& A, floatx16 acc) {
+  floatx16 lo = splat(0.0f), mid = splat(0.0f);
+#pragma unroll
+  for (int g = 0; g < K / 16; ++g) {
+    lo = mf(A.a[2][g], B.c[g].b[0], lo); mid = mf(A.a[1][g], B.c[g].b[0], mid); acc = mf(A.a[0][g], B.c[g].b[0], acc);
+    lo = mf(A.a[0][g], B.c[g].b[2], lo); mid = mf(A.a[0][g], B.c[g].b[1], mid); lo = mf(A.a[1][g], B.c[g].b[1], lo);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += mid[r] + lo[r];
+  return acc;
+}
+// ... and the GRU's 6 x 8 chunks (three gate tiles of W_ih, then of W_hh) stream through a ring of three stages, two chunks ahead of
+// the 18 matrix instructions (three independent accumulation chains) that consume a stage.
+struct BRing { BChunk s[3][3]; };   // [stage][gate tile]
+__device__ __forceinline__ void ring_load(const float* __restrict__ W, int w, int lane, int st, BChunk (&dst)[3]) {
+  const int TF = tile_floats(HID);
+  const float* base = W + (st < 8 ? B_WIH : B_WHH);
+#pragma unroll
+  for (int t = 0; t < 3; ++t) load_b(reinterpret_cast<const uint4*>(base + (4 * t + w) * TF) + lane, st & 7, dst[t]);
+}
+#define CTLS_CHUNK3(a0, a1, a2, A, g, B)                                                              \
+  do {                                                                                                \
+    a0 = mf(A.a[2][g], B[0].b[0], a0); a1 = mf(A.a[2][g], B[1].b[0], a1); a2 = mf(A.a[2][g], B[2].b[0], a2); \
+    a0 = mf(A.a[0][g], B[0].b[2], a0); a1 = mf(A.a[0][g], B[1].b[2], a1); a2 = mf(A.a[0][g], B[2].b[2], a2); \
+    a0 = mf(A.a[1][g], B[0].b[1], a0); a1 = mf(A.a[1][g], B[1].b[1], a1); a2 = mf(A.a[1][g], B[2].b[1], a2); \
+    a0 = mf(A.a[1][g], B[0].b[0], a0); a1 = mf(A.a[1][g], B[1].b[0], a1); a2 = mf(A.a[1][g], B[2].b[0], a2); \
+    a0 = mf(A.a[0][g], B[0].b[1], a0); a1 = mf(A.a[0][g], B[1].b[1], a1); a2 = mf(A.a[0][g], B[2].b[1], a2); \
+    a0 = mf(A.a[0][g], B[0].b[0], a0); a1 = mf(A.a[0][g], B[1].b[0], a1); a2 = mf(A.a[0][g], B[2].b[0], a2); \
+  } while (0)
+// torch.nn.LayerNorm(128) (eps 1e-5, biased variance) of buf[row][k] (fp32, row stride RS); the result leaves as the three bf16 planes
+// the next layer's A operands are read from. Thread = (aircraft = tid / 8, part = tid % 8) owns features 4 part + 32 q + {0..3}: its
+// 16-byte reads tile the 32 LDS banks, and the eight parts of an aircraft sit in adjacent lanes, so mean and variance are three
+// butterfly steps each -- no partial sums through LDS, no barrier until the planes are complete.
+__device__ __forceinline__ float group8_sum(float v) {
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+  return v;
+}
+__device__ __forceinline__ void layer_norm_planes(const float* buf, unsigned short* planes, const float* __restrict__ g, const float* __restrict__ b, int tid) {
+  const int row = tid >> 3, part = tid & 7;
+  float4 x[4], gg[4], bb[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {   // scale / shift from L2 first: their latency hides behind the reductions
+    gg[q] = *reinterpret_cast<const float4*>(g + 4 * part + 32 * q);
+    bb[q] = *reinterpret_cast<const float4*>(b + 4 * part + 32 * q);
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    x[q] = *reinterpret_cast<const float4*>(buf + row * RS + 4 * part + 32 * q);
+    s += (x[q].x + x[q].y) + (x[q].z + x[q].w);
+  }
+  const float m = group8_sum(s) * (1.0f / HID);
+  float v = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    x[q].x -= m; x[q].y -= m; x[q].z -= m; x[q].w -= m;
+    v = fmaf(x[q].x, x[q].x, v); v = fmaf(x[q].y, x[q].y, v); v = fmaf(x[q].z, x[q].z, v); v = fmaf(x[q].w, x[q].w, v);
+  }
+  const float is = rsqrtf(group8_sum(v) * (1.0f / HID) + 1e-5f);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 y = make_float4(fmaf(x[q].x * is, gg[q].x, bb[q].x), fmaf(x[q].y * is, gg[q].y, bb[q].y),
+                                 fmaf(x[q].z * is, gg[q].z, bb[q].z), fmaf(x[q].w * is, gg[q].w, bb[q].w));
+    write_planes4(planes, row, 4 * part + 32 * q, y);
+  }
+  __syncthreads();
+}
+}  // namespace ctls
+
+__global__ __launch_bounds__(256) void controller_split_kernel(ctl::Args a) {
+  using namespace ctls;
+  using ctl::sigmoid_f; using ctl::tanh_f;
+  __shared__ __attribute__((aligned(16))) unsigned short PA[3 * PLANE];   // activations as bf16 planes [piece][aircraft][k]
+  __shared__ __attribute__((aligned(16))) unsigned short PH[3 * PLANE];   // the GRU state likewise; the head logits (fp32 [160][LS]) later
+  __shared__ __attribute__((aligned(16))) float stg[HID * LS];   // a layer's fp32 outputs [aircraft][k] (row stride RS) on their way to LayerNorm
+  __shared__ float hbuf[HID * LS];   // GRU state of the 32 aircraft, fp32 (gate algebra)
+  static_assert(MT * RS <= HID * LS, "staging rows fit");
+  static_assert(sizeof(unsigned short) * 3 * PLANE >= sizeof(float) * NHP * LS, "the logits reuse the GRU-state planes");
+  float* lg = reinterpret_cast<float*>(PH);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i0 = blockIdx.x * MT;
+  const float* __restrict__ W = a.Ws;
+  const int col = lane & 31;
+
+  // ---- stage. Loads return in the order they were asked for: the 12 controller inputs first (layer 1 waits for nothing else), then
+  // layer 1's weights, the GRU state (first needed by the GRU) and layer 2's weights.
+  AC_CLK(200);
+  BTile<16> b1;
+  BTile<HID> b2;
+  const int srow = tid & 31, spart = tid >> 5;   // staging: thread = (aircraft, 16-feature part)
+  const int sn = min(i0 + srow, a.N - 1);
+  float x[16];
+  if (spart == 0) {
+    const float* hi = a.hi + (size_t)sn * a.act_hi;
+    const float* ob = a.obs + (size_t)sn * a.obs_dim;
+    const int slot = sn % a.A;
+    if (a.use_baseline && slot >= a.n_ego) {
+      // the enemy team is flown by BaselineAgent k: its 12 inputs were prepared by scripted_inputs_kernel
+#pragma unroll
+      for (int k = 0; k < 12; ++k) x[k] = a.scripted[(size_t)sn * 12 + k];
+    } else {
+      const int c0 = (int)hi[0], c1 = (int)hi[1], c2 = (int)hi[2];
+      // singlecombat_task.py:217-219, 235-241: below 3500 m the altitude choice is overridden by "climb"
+      x[0] = (ob[0] * 5000.0f < 3500.0f) ? 0.1f : (c0 == 0 ? 0.1f : (c0 == 1 ? 0.0f : -0.1f));
+      x[1] = (float)(c1 - 2) * 0.26179938779914943f;   // {-pi/6, -pi/12, 0, pi/12, pi/6}
+      x[2] = c2 == 0 ? 0.05f : (c2 == 1 ? 0.0f : -0.05f);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) x[3 + k] = ob[k];
+    }
+    x[12] = 0.0f; x[13] = 0.0f; x[14] = 0.0f; x[15] = 0.0f;   // (k 12..15 of the one 16-k chunk)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  prefetch_b<16>(W + B_W1 + w * tile_floats(16), lane, b1);
+  float hv[16];
+#pragma unroll
+  for (int f = 0; f < 16; ++f) hv[f] = a.H[(size_t)(spart * 16 + f) * a.N + sn];
+  prefetch_b<HID>(W + B_W2 + w * tile_floats(HID), lane, b2);
+  __builtin_amdgcn_sched_barrier(0);
+  if (spart == 0) write_planes(PA, srow, 0, x);
+  __syncthreads();
+
+  AC_CLK(201);
+  // ---- MLP layer 1: Linear(12, 128) + ReLU + LayerNorm; wave w owns output columns 32 w .. 32 w + 31
+  {
+    AOps<16> A;
+    load_a<16>(PA, lane, A);
+    const floatx16 acc = mma1<16>(b1, A, splat(W[B_B1 + w * 32 + col]));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stg[c_row(r, lane) * RS + w * 32 + col] = fmaxf(acc[r], 0.0f);
+  }
+  {   // the GRU state has arrived behind layer 1: fp32 for the gate algebra, bf16 planes for the products
+#pragma unroll
+    for (int f = 0; f < 16; ++f) hbuf[(spart * 16 + f) * LS + srow] = hv[f];
+    write_planes(PH, srow, spart * 16, hv);
+  }
+  __syncthreads();
+  AC_CLK(202);
+  layer_norm_planes(stg, PA, W + B_G1, W + B_BE1, tid);
+  AC_CLK(203);
+  // ---- MLP layer 2
+  {
+    AOps<HID> A;
+    load_a<HID>(PA, lane, A);
+    const floatx16 acc = mma1<HID>(b2, A, splat(W[B_B2 + w * 32 + col]));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stg[c_row(r, lane) * RS + w * 32 + col] = fmaxf(acc[r], 0.0f);
+  }
+  BRing ring;   // the GRU's first two chunks, behind LayerNorm 2
+  ring_load(W, w, lane, 0, ring.s[0]);
+  ring_load(W, w, lane, 1, ring.s[1]);
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  AC_CLK(204);
+  layer_norm_planes(stg, PA, W + B_G2, W + B_BE2, tid);
+  AC_CLK(205);
+  // ---- GRU cell (torch gate order r, z, n): wave w owns hidden units 32 w .. 32 w + 31, i.e. gate tiles w, 4 + w, 8 + w
+  BTile<HID> bh;
+  BChunk b5a, b5b;
+  {
+    floatx16 ir = splat(W[B_BIH + 0 * 128 + w * 32 + col]), iz = splat(W[B_BIH + 1 * 128 + w * 32 + col]), in_ = splat(W[B_BIH + 2 * 128 + w * 32 + col]);
+    floatx16 hr = splat(W[B_BHH + 0 * 128 + w * 32 + col]), hz = splat(W[B_BHH + 1 * 128 + w * 32 + col]), hn = splat(W[B_BHH + 2 * 128 + w * 32 + col]);
+    {
+      AOps<HID> A;
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {
+        // (the scheduling fences keep the loads where they are written: left alone, the machine scheduler sinks every weight load
+        // to just in front of its first use to save registers, which serialises an L2 round trip with every chunk)
+        if (st + 2 < 16) ring_load(W, w, lane, st + 2, ring.s[(st + 2) % 3]);
+        if (st == 0) load_a<HID>(PA, lane, A);
+        if (st == 8) load_a<HID>(PH, lane, A);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st < 8) CTLS_CHUNK3(ir, iz, in_, A, st & 7, ring.s[st % 3]);
+        else CTLS_CHUNK3(hr, hz, hn, A, st & 7, ring.s[st % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // the heads' weights (this wave's tile and its two chunks of the fifth), behind the gate algebra and LayerNorm 3
+    prefetch_b<HID>(W + B_WA + w * tile_floats(HID), lane, bh);
+    {
+      const uint4* t4 = reinterpret_cast<const uint4*>(W + B_WA + 4 * tile_floats(HID)) + lane;
+      load_b(t4, 2 * w, b5a); load_b(t4, 2 * w + 1, b5b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    AC_CLK(206);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = c_row(r, lane), unit = w * 32 + col;
+      const float rg = sigmoid_f(ir[r] + hr[r]);
+      const float zg = sigmoid_f(iz[r] + hz[r]);
+      const float ng = tanh_f(in_[r] + rg * hn[r]);
+      const float hnew = (1.0f - zg) * ng + zg * hbuf[unit * LS + row];
+      stg[row * RS + unit] = hnew;
+    }
+  }
+  __syncthreads();
+  AC_CLK(207);
+  {   // the new hidden state goes out row-contiguous (128-byte runs per feature) from LDS; thread = (row, 16-feature part): the very
+      // elements this thread normalises next
+    const int row = tid & 31, part = tid >> 5, n = i0 + row;
+    if (n < a.N) {
+#pragma unroll
+      for (int f = 0; f < 16; ++f) a.H[(size_t)(part * 16 + f) * a.N + n] = stg[row * RS + part * 16 + f];
+    }
+  }
+  AC_CLK(208);
+  layer_norm_planes(stg, PA, W + B_G3, W + B_BE3, tid);
+  AC_CLK(209);
+  // ---- heads: 153 logits = five column tiles; wave w takes tile w and a quarter of the fifth tile's K range
+  {
+    AOps<HID> A;
+    load_a<HID>(PA, lane, A);
+    const floatx16 acc = mma1<HID>(bh, A, splat(W[B_BA + w * 32 + col]));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lg[(w * 32 + col) * LS + c_row(r, lane)] = acc[r];   // (the GRU-state planes under lg were last read before two barriers)
+    // fifth tile (logits 128 .. 152): its K range is split over the four waves (chunks 2 w, 2 w + 1); the partial sums go to stg
+    // (free by now) and are added in a fixed order below
+    {
+      floatx16 part = splat(0.0f);
+      // this wave's K slice read again from LDS: indexing A by w would put it in scratch
+      AOps<32> Aw;
+      const unsigned short* base = PA + (lane & 31) * KS + 8 * (lane >> 5) + 32 * w;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) Aw.a[p][g] = *reinterpret_cast<const uint4*>(base + p * PLANE + 16 * g);
+      CTLS_CHUNK(part, Aw, 0, b5a);
+      CTLS_CHUNK(part, Aw, 1, b5b);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stg[(w * 32 + col) * LS + c_row(r, lane)] = part[r];
+    }
+  }
+  __syncthreads();
+  AC_CLK(210);
+  // logits 128 .. 152 = bias + the four K-partials, summed in a fixed order (25 columns x 32 aircraft over 256 threads)
+  for (int e = tid; e < 25 * 32; e += 256) {
+    const int q = e >> 5, row = e & 31;
+    lg[(128 + q) * LS + row] = (((W[B_BA + 128 + q] + stg[q * LS + row]) + stg[(32 + q) * LS + row]) + stg[(64 + q) * LS + row]) + stg[(96 + q) * LS + row];
+  }
+  __syncthreads();
+  AC_CLK(211);
+  if (tid < 128) {   // thread = (head, aircraft): first maximum, like torch argmax
+    const int head = tid >> 5, row = tid & 31;
+    const int off = head * 41, cnt = (head == 3) ? 30 : 41;
+    float best = lg[off * LS + row];
+    int bi = 0;
+    for (int j = 1; j < cnt; ++j) {
+      const float v = lg[(off + j) * LS + row];
+      if (v > best) { best = v; bi = j; }
+    }
+    if (i0 + row < a.N) a.low[(size_t)(i0 + row) * a.act_low + head] = (float)bi;
+  } else if (tid < 160) {   // weapon bits ride along unchanged
+    const int row = tid & 31;
+    if (i0 + row < a.N) {
+      const int nn = i0 + row;
+      const bool scripted = a.use_baseline && (nn % a.A) >= a.n_ego;   // scenario1_task.py:42-48: bits [0,0,0,0], or all ones with artillery
+      for (int k = 4; k < a.act_low; ++k)
+        a.low[(size_t)nn * a.act_low + k] = scripted ? (a.use_artillery ? 1.0f : 0.0f) : a.hi[(size_t)nn * a.act_hi + (k - 1)];
+    }
+  }
+  AC_CLK(212);
+}

@@ -450,6 +450,17 @@ def test_dodge_missile_rule_based_launch(pkg, oracle):
                                            ("hierarchical_multiplecombat_shoot", 0),
                                            ("hierarchical_singlecombat_shoot", 0), ("hierarchical_singlecombat_dodge_missile", 0)])
 def test_hierarchical_tasks_lowlevel_controller(pkg, oracle, task, baseline):
+    _lowlevel_controller_parity(pkg, oracle, task, baseline)
+
+
+def test_lowlevel_controller_fp32_matrix_form(pkg, oracle, monkeypatch):
+    """The same check with the controller on the fp32 matrix instructions (controller_kernel, AIRCOMBAT_CTL=fp32 when the handle is
+    created) instead of the default bf16-piece form (controller_split_kernel): both forms are held to the same bounds."""
+    monkeypatch.setenv("AIRCOMBAT_CTL", "fp32")
+    _lowlevel_controller_parity(pkg, oracle, "hierarchical_singlecombat", 0)
+
+
+def _lowlevel_controller_parity(pkg, oracle, task, baseline):
     """The as-shipped action space: MultiDiscrete [3,5,3] (+ four weapon bits) -> BaselineActor (MLP + GRU + four argmax
     heads) -> control indices -> step. Each step both sides start from the oracle's flight state and GRU state; compared are the
     controller's argmax indices (identical except where the oracle's own top-two logits tie to fp32 accuracy: < 0.2 % of
