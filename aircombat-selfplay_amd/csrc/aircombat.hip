@@ -216,23 +216,6 @@ __device__ __forceinline__ void load_msl(const R* MF, const int* MI, int N, int 
   const int rw = AC_AT(i, MI_recede);
   m.recede = rw & 511; m.model = (rw >> 9) & 1; m.dpos = rw >> 10;
 }
-// The same without a branch around the loads: the lanes of a slot that is not in flight read the zero words that follow the arrays
-// (ac_create) - exactly what an unlaunched slot holds - so the loads of every slot are in flight together (one HBM round trip for
-// the lot instead of one per slot) and no missile state is fetched for a slot that has none.
-template <typename R>
-__device__ __forceinline__ void load_msl_masked(const R* MF, const int* MI, int N, int n, int slot, int slots, bool active, int status, MslT<R>& m) {
-  const unsigned un = (unsigned)n, uN = (unsigned)N;
-  const unsigned ftail = (unsigned)slots * NMF * uN * (unsigned)sizeof(R), itail = (unsigned)slots * NMI * uN * 4u;
-  auto F = [&](int f) -> R { return *(const R*)((const char*)MF + (active ? (((unsigned)slot * NMF + (unsigned)f) * uN + un) * (unsigned)sizeof(R) : ftail)); };
-  auto I = [&](int f) -> int { return *(const int*)((const char*)MI + (active ? (((unsigned)slot * NMI + (unsigned)f) * uN + un) * 4u : itail)); };
-  m.px = F(MF_px); m.py = F(MF_py); m.pz = F(MF_pz);
-  m.vx = F(MF_vx); m.vy = F(MF_vy); m.vz = F(MF_vz);
-  m.theta = F(MF_theta); m.psi = F(MF_psi); m.t = F(MF_t); m.m = F(MF_m);
-  m.dth = F(MF_dth); m.dph = F(MF_dph); m.dprev = F(MF_dprev);
-  m.status = status; m.order = I(MI_order);
-  const int rw = I(MI_recede);
-  m.recede = rw & 511; m.model = (rw >> 9) & 1; m.dpos = rw >> 10;
-}
 template <typename R>
 __device__ __forceinline__ void store_msl(R* MF, int* MI, int N, int n, int slot, const MslT<R>& m) {
   AC_LANE_INDEX(n);
@@ -768,8 +751,6 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
     tc.commit(lds_tab);
   } else if (PAIR) {
     const bool flight_role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1;
-    TableCopy<128> tc;
-    tc.issue(P.tab);
     PairFlightIn fin;
     if (!flight_role) {   // the environment wave owns the task bookkeeping; the status word of every missile slot comes with it
       a4 = load_controls(act, c.act_dim);
@@ -777,14 +758,12 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
       s = State{}; load_task(P.F, P.I, N, nn, t);
 #pragma unroll
       for (int k = 0; k < MSLOTS; ++k) pre_st[k] = P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn];
-    } else if (WPE == 1) {
-      pair_flight_load(P, c, nn, fin);
     }
-    tc.commit(lds_tab);
+    // (the flight wave asks for its state behind the table copy: issuing it in front -- one round trip for both -- measured 0.3 us
+    // slower per step here, the environment wave's longer prologue covers the second round trip anyway)
+    stage_tables<128>(lds_tab, P.tab);
     if (flight_role) {
-      // (two waves per SIMD, 256 registers each: the flight state is asked for after the tables have left the registers -- the
-      // neighbouring wave covers the second round trip there)
-      if (WPE != 1) pair_flight_load(P, c, nn, fin);
+      pair_flight_load(P, c, nn, fin);
       pair_flight_wave<true>(P, c, T, LP, l, n, live, fin);
       return;
     }
@@ -809,8 +788,8 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
       // a slot that has not been launched since the last reset holds zeros and MSL_INACTIVE (reset_all_kernel, the reset branch
       // below): only its status is read, and it is written back only once it has been launched or reset
       const int st = (k < nslots) ? (PAIR ? pre_st[k] : P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn]) : MSL_INACTIVE;
-      load_msl_masked(P.MF, P.MI, N, nn, k, c.msl_slots, st != MSL_INACTIVE, st, ms[k]);
-      if (st != MSL_INACTIVE) msl_was_active |= 1 << k;
+      if (st != MSL_INACTIVE) { load_msl(P.MF, P.MI, N, nn, k, ms[k]); msl_was_active |= 1 << k; }
+      else { ms[k] = Msl{}; ms[k].status = MSL_INACTIVE; }
     }
   }
 
@@ -1002,14 +981,6 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
 #pragma unroll
     for (int k = 0; k < OBS; ++k) ob[k] = tobs[k];
   }
-  // The observation rows leave now, before the rewards and the state stores: they are nine tenths of what a step writes, and when the
-  // output buffers are host memory (ac_step_host) their trip across PCIe is what the step waits for in the end.
-  {
-    float* row = lds_out + l * OBS;
-#pragma unroll
-    for (int k = 0; k < OBS; ++k) row[k] = ob[k];
-    emit_obs_rows(P, lds_out, OBS, l);
-  }
 
   // ---- rewards (after every termination ran, env_base.py:168-171; die-flag latch singlecombat_task.py:190-195)
   AC_CLK(59);
@@ -1088,7 +1059,9 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
   }
   AC_CLK(55);
   // info['done_condition'] keeps the last agent's message
-  emit_scalars(P, l, reward, done, 2, step_out, other_code ? other_code : code, 0, all_done ? 1 : 0);
+  // (sending the observation rows ahead of the rewards and the state stores was tried for the host-boundary path, where their trip
+  // across PCIe is what the step waits for in the end: 0.5 us slower, not faster)
+  emit_outputs(P, lds_out, OBS, l, ob, reward, done, 2, step_out, other_code ? other_code : code, 0, all_done ? 1 : 0);
   AC_CLK(54);
 }
 
@@ -1695,13 +1668,10 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   HIP_OK(hipMalloc(&p.I, sizeof(int) * NI * N));
   HIP_OK(hipMalloc(&p.D, sizeof(double) * ND * N));
   const size_t ms = c.msl_slots > 0 ? (size_t)c.msl_slots : 1;
-  // (+ 64 zero bytes behind each missile array: what load_msl_masked reads for a slot that is not in flight)
-  HIP_OK(hipMalloc(&p.MF, sizeof(float) * ms * NMF * N + 64));
-  HIP_OK(hipMemset((char*)p.MF + sizeof(float) * ms * NMF * N, 0, 64));
+  HIP_OK(hipMalloc(&p.MF, sizeof(float) * ms * NMF * N));
   p.MD = nullptr;
   if (scenario) HIP_OK(hipMalloc(&p.MD, sizeof(double) * ms * NMF * N));
-  HIP_OK(hipMalloc(&p.MI, sizeof(int) * ms * NMI * N + 64));
-  HIP_OK(hipMemset((char*)p.MI + sizeof(int) * ms * NMI * N, 0, 64));
+  HIP_OK(hipMalloc(&p.MI, sizeof(int) * ms * NMI * N));
   // outputs: rows padded to whole workgroups (emit_outputs stores whole blocks)
   const size_t Npad = (N + 63) / 64 * 64;
   HIP_OK(hipMalloc(&p.obs, sizeof(float) * Npad * h->obs_dim));
