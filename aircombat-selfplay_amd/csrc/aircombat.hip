@@ -710,18 +710,19 @@ struct TaskTraits {
 // FORM: 0 = one wave per 64 aircraft, 1 = the three-wave form (split_kernel.hpp) for the task without munitions at small grids,
 // 2 = the pair form (pair_kernel.hpp: flight wave + environment wave) for the tasks with missiles.
 template <int TASK, int WPE, int FORM = 0>
-__global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) {
+__global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 256 : 64)), WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) {
   using TT = TaskTraits<TASK>;
-  constexpr bool SPLIT = FORM == 1, PAIR = FORM == 2;
+  constexpr bool SPLIT = FORM == 1, QUAD = FORM == 3, PAIR = FORM == 2 || QUAD;   // (the quad form's environment wave runs the pair form's code)
   constexpr bool HAS_MSL = TT::HAS_MSL;
   constexpr int MSLOTS = TT::MSLOTS;
   constexpr int OBS = TT::OBS;
   AC_CLK(0);
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
   __shared__ __attribute__((aligned(16))) float lds_out[64 * OBS];
-  __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : (PAIR ? sizeof(PairLds) : 16)];
+  __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : (QUAD ? sizeof(QuadLds) : (PAIR ? sizeof(PairLds) : 16))];
   SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
-  PairLds& LP = *reinterpret_cast<PairLds*>(split_lds);
+  QuadLds& LQ = *reinterpret_cast<QuadLds*>(split_lds);
+  PairLds& LP = QUAD ? LQ.P : *reinterpret_cast<PairLds*>(split_lds);
   const Tab T{lds_tab};
   const int N = c.N;
   const int l = threadIdx.x & 63;
@@ -749,6 +750,25 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
     else { load_flight_role<2>(P.F, P.I, P.D, N, nn, s); t.status = P.I[(size_t)FI_status * N + nn]; }
     a4 = load_controls(act, c.act_dim);   // last: loads return in order, and this one may come from host memory (ac_step_host)
     tc.commit(lds_tab);
+  } else if (QUAD) {
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 dynamics, 1 systems, 2 kinematics, 3 environment
+    TableCopy<256> tc;
+    tc.issue(P.tab);
+    s = State{}; t = Task{};
+    if (role == 0) { load_flight_role<0>(P.F, P.I, P.D, N, nn, s); t.status = P.I[(size_t)FI_status * N + nn]; }
+    else if (role == 1) load_flight_role<1>(P.F, P.I, P.D, N, nn, s);
+    else if (role == 2) { load_flight_role<2>(P.F, P.I, P.D, N, nn, s); t.status = P.I[(size_t)FI_status * N + nn]; }
+    else {   // the environment wave owns the task bookkeeping; the status word of every missile slot and the tick count come with it
+      load_task(P.F, P.I, N, nn, t);
+      s.ticks = P.I[(size_t)FI_ticks * N + nn];
+#pragma unroll
+      for (int k = 0; k < MSLOTS; ++k) pre_st[k] = P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn];
+      if (TASK == AC_TASK_SHOOT_MISSILE) shoot_raw = act[4];
+    }
+    a4 = load_controls(act, c.act_dim);
+    tc.commit(lds_tab);
+    if (role == 0) { quad_dynamics_wave(P, c, T, LQ, l, n, live, s, t, a4); return; }
+    if (role != 3 && split_helper_wave<true>(s, t, T, LQ.S, l, c.substeps, &a4)) return;
   } else if (PAIR) {
     const bool flight_role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1;
     PairFlightIn fin;
@@ -816,8 +836,14 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
     const int other = __shfl_xor((int)mine, 1);   // (fetched first: a shuffle on the right of || is skipped by the lanes that short-circuit)
     env_has_missiles = mine || (bool)other;
   }
+  int quad_nrun = 0;
+  const int quad_ticks0 = s.ticks;   // (quad form: the environment wave loaded the tick count for the Earth angle of the poses)
   for (int sub = 0; sub < c.substeps; ++sub) {
-    if (PAIR) {
+    bool fly_munitions = HAS_MSL;
+    if (QUAD) {
+      quad_substep_begin(t, LQ, l, sub, env_has_missiles, quad_ticks0, quad_nrun, pr, c);   // (B1 and B2 inside)
+      fly_munitions = env_has_missiles;
+    } else if (PAIR) {
       AC_CLK(2 + 8 * sub);
       pair_substep<true>(t, LP, l, sub, env_has_missiles, pr, c);
       AC_CLK(4 + 8 * sub);
@@ -829,7 +855,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
       f16::tick<false>(s, d, T);
       have_pose = true;
     }
-    if (HAS_MSL) {
+    if (HAS_MSL && fly_munitions) {
       if (!PAIR) {
       f16::locate(s, d);                                       // fp64 geodetic reduction for the NEU pose of this substep
       if (!have_pose) { f16::body_frame(s, d); have_pose = true; }  // frozen pose of a dead aircraft
@@ -849,6 +875,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
       if (__shfl_xor((int)hit_now, 1) && t.status == AC_ALIVE) t.status = AC_SHOTDOWN;
       AC_CLK(5 + 8 * sub);
     }
+    if (QUAD) wg_sync();                                       // B3 of the tick
   }
   const bool split_located = SPLIT && dynamics_wave_finish(s, d, L, l, last_tick, c.substeps);   // (+ the helper waves' fields)
   if (SPLIT) {   // the commands, for the stored state (the dynamics wave itself never reads them: it did not wait for the action row)
@@ -858,6 +885,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : 64), WPE) void
     s.thr = clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
   }
   if (PAIR) {
+    if (QUAD) wg_sync();                           // (quad form: the helper waves hand their fields to the dynamics wave here)
     wg_sync();                                     // the flight wave has posted its final values and stored the flight state
     pair_read_final(LP, l, s, d, pr);
   } else if (!HAS_MSL || c.substeps == 0) {
@@ -1454,6 +1482,7 @@ struct ac_env {
   bool have_hs;
   bool timing;
   bool ctl_fp32;                         // hierarchical tasks: controller_kernel (fp32 MFMA) instead of controller_split_kernel (AIRCOMBAT_CTL=fp32 at ac_create)
+  bool quad_waves;                       // the 1v1 missile tasks up to one workgroup per CU: three FDM waves + the environment wave (step_kernel_1v1<.., 3>)
   bool split_waves;                      // SingleCombat below one wave per SIMD: three waves per 64 aircraft (step_kernel_1v1<.., SPLIT>)
 };
 
@@ -1527,10 +1556,12 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
     else if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 1, 0>), grid, block, 0, h->stream, p, h->dc);
     else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SINGLECOMBAT, 2, 0>), grid, block, 0, h->stream, p, h->dc);
   } else if (h->cfg.task == AC_TASK_DODGE_MISSILE) {
-    if (pair_wpe1) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_DODGE_MISSILE, 1, 2>), grid, dim3(128), 0, h->stream, p, h->dc);
+    if (h->quad_waves) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_DODGE_MISSILE, 1, 3>), grid, dim3(256), 0, h->stream, p, h->dc);
+    else if (pair_wpe1) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_DODGE_MISSILE, 1, 2>), grid, dim3(128), 0, h->stream, p, h->dc);
     else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_DODGE_MISSILE, 2, 2>), grid, dim3(128), 0, h->stream, p, h->dc);
   } else {
-    if (pair_wpe1) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 1, 2>), grid, dim3(128), 0, h->stream, p, h->dc);
+    if (h->quad_waves) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 1, 3>), grid, dim3(256), 0, h->stream, p, h->dc);
+    else if (pair_wpe1) hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 1, 2>), grid, dim3(128), 0, h->stream, p, h->dc);
     else hipLaunchKernelGGL((step_kernel_1v1<AC_TASK_SHOOT_MISSILE, 2, 2>), grid, dim3(128), 0, h->stream, p, h->dc);
   }
   HIP_OK(hipGetLastError());
@@ -1614,6 +1645,9 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     const bool ticks_only = cfg->task == AC_TASK_SINGLECOMBAT || cfg->task == AC_TASK_MULTICOMBAT || cfg->task == AC_TASK_HEADING ||
                             cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER;
     h->split_waves = ticks_only && (e ? (e[0] == '1') : (wgs <= 512));
+    const char* qe = getenv("AIRCOMBAT_QUAD");   // 0 / 1 overrides the choice of the quad form
+    const bool msl_1v1 = cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE;
+    h->quad_waves = msl_1v1 && (qe ? (qe[0] == '1') : (wgs <= 256));
     const char* ce = getenv("AIRCOMBAT_CTL");
     h->ctl_fp32 = ce && ce[0] == 'f';
   }

@@ -39,6 +39,18 @@ __device__ __forceinline__ void ned_velocity(const f16::State& s, f16::Derived& 
   d.vd = d.d_eci[0] * rvx + d.d_eci[1] * rvy + d.d_eci[2] * rvz;
 }
 
+// what the environment wave reads off the aircraft after the last tick (pair_read_final)
+__device__ __forceinline__ void pair_post_final(PairLds& L, int l, const f16::State& s, const f16::Derived& d, const Props& pp) {
+  using namespace pair;
+  L.F64[0][l] = pp.n64; L.F64[1][l] = pp.e64; L.F64[2][l] = pp.u64;
+  L.FIN[FIN_VN][l] = pp.vn; L.FIN[FIN_VE][l] = pp.ve; L.FIN[FIN_VD][l] = pp.vd; L.FIN[FIN_ALT][l] = pp.alt_m;
+  L.FIN[FIN_UB][l] = pp.ub; L.FIN[FIN_VB][l] = pp.vb; L.FIN[FIN_WB][l] = pp.wb; L.FIN[FIN_VC][l] = pp.vc;
+  L.FIN[FIN_SPHI][l] = pp.sphi; L.FIN[FIN_CPHI][l] = pp.cphi; L.FIN[FIN_STHT][l] = pp.stht; L.FIN[FIN_CTHT][l] = pp.ctht;
+  L.FIN[FIN_M11][l] = pp.m11; L.FIN[FIN_M12][l] = pp.m12;
+  L.FIN[FIN_P][l] = d.p; L.FIN[FIN_Q][l] = d.q; L.FIN[FIN_R][l] = d.r; L.FIN[FIN_VECI][l] = d.veci; L.FIN[FIN_HSL][l] = d.h_sl_ft;
+  L.FIN[FIN_NPX][l] = s.npx; L.FIN[FIN_NPY][l] = s.npy; L.FIN[FIN_NPZ][l] = s.npz;
+  L.FIN[FIN_TICKS][l] = __int_as_float(s.ticks);
+}
 // The flight wave. Returns when its part of the step is done (the caller returns).
 // RAW_POSE: post the tick's ECI position / velocity as they are and leave the geodetic reduction to the environment wave -- for the 1v1
 // missile tasks, whose fp32 AIM-9L update leaves that wave the slack (there the flight wave is the longer of the two).
@@ -110,14 +122,7 @@ __device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg&
 #pragma unroll
   for (int i = 0; i < 3; ++i) { d.n_eci[i] = dp.n_eci[i]; d.e_eci[i] = dp.e_eci[i]; d.d_eci[i] = dp.d_eci[i]; }
   make_props(s, d, c, pp);
-  L.F64[0][l] = pp.n64; L.F64[1][l] = pp.e64; L.F64[2][l] = pp.u64;
-  L.FIN[FIN_VN][l] = pp.vn; L.FIN[FIN_VE][l] = pp.ve; L.FIN[FIN_VD][l] = pp.vd; L.FIN[FIN_ALT][l] = pp.alt_m;
-  L.FIN[FIN_UB][l] = pp.ub; L.FIN[FIN_VB][l] = pp.vb; L.FIN[FIN_WB][l] = pp.wb; L.FIN[FIN_VC][l] = pp.vc;
-  L.FIN[FIN_SPHI][l] = pp.sphi; L.FIN[FIN_CPHI][l] = pp.cphi; L.FIN[FIN_STHT][l] = pp.stht; L.FIN[FIN_CTHT][l] = pp.ctht;
-  L.FIN[FIN_M11][l] = pp.m11; L.FIN[FIN_M12][l] = pp.m12;
-  L.FIN[FIN_P][l] = d.p; L.FIN[FIN_Q][l] = d.q; L.FIN[FIN_R][l] = d.r; L.FIN[FIN_VECI][l] = d.veci; L.FIN[FIN_HSL][l] = d.h_sl_ft;
-  L.FIN[FIN_NPX][l] = s.npx; L.FIN[FIN_NPY][l] = s.npy; L.FIN[FIN_NPZ][l] = s.npz;
-  L.FIN[FIN_TICKS][l] = __int_as_float(s.ticks);
+  pair_post_final(L, l, s, d, pp);
   if (live) store_flight(P.F, P.I, P.D, c.N, n, s);
   AC_CLKW(1, 160);
   wg_sync();   // final values posted, flight state stored (the release half of the barrier waits for the stores: an episode reset by
@@ -163,3 +168,57 @@ __device__ __forceinline__ void pair_read_final(const PairLds& L, int l, f16::St
   s.npx = L.FIN[FIN_NPX][l]; s.npy = L.FIN[FIN_NPY][l]; s.npz = L.FIN[FIN_NPZ][l];
   s.ticks = __float_as_int(L.FIN[FIN_TICKS][l]);
 }
+
+// ------------------------------------------------------------------------------------------------ the quad form
+// The 1v1 missile tasks at grids of up to one workgroup per CU: the three waves of the three-wave form (split_kernel.hpp) fly the FDM
+// tick, a fourth -- the environment wave of the pair form -- flies the munitions against each tick's pose and owns the task
+// bookkeeping. It joins the tick's three barriers: who flies (RUNF) is posted before B1, the tick's pose is read after B1 (fp64
+// position from the kinematics wave, ECI velocity from the dynamics wave), the missiles fly between B2 and B3.
+struct QuadLds {
+  SplitLds S;
+  PairLds P;    // (only F64 / FIN: the final values, dynamics wave -> environment wave)
+};
+// Environment wave, first half of a substep (B1 and B2 inside; the caller flies the munitions and then calls wg_sync() for B3).
+// `nrun` counts the ticks this aircraft has flown this step (the Earth angle of the pose).
+__device__ __forceinline__ bool quad_substep_begin(Task& t, QuadLds& Q, int l, int sub, bool need_pose, int ticks0, int& nrun, Props& pr, const DevCfg& c) {
+  using namespace mail;
+  const bool run = t.status == AC_ALIVE;
+  if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;      // simulatior.py:220-222: this tick still integrates
+  Q.S.M[RUNF][l] = run ? 1.0f : 0.0f;
+  wg_sync();                                                // B1
+  nrun += run ? 1 : 0;
+  if (need_pose && (run || sub == 0)) {                     // (a grounded aircraft keeps the pose it had)
+    f16::State sp{}; f16::Derived dp;
+    const int pb = sub & 1;
+    sp.rx = Q.S.MD[GD_R + 3 * pb][l]; sp.ry = Q.S.MD[GD_R + 3 * pb + 1][l]; sp.rz = Q.S.MD[GD_R + 3 * pb + 2][l];
+    sp.vx = Q.S.M[K_V][l]; sp.vy = Q.S.M[K_V + 1][l]; sp.vz = Q.S.M[K_V + 2][l];
+    sp.ticks = ticks0 + nrun;
+    f16::locate(sp, dp);
+    ned_velocity(sp, dp);
+    make_pose(dp, c, pr);
+  }
+  wg_sync();                                                // B2
+  return run;
+}
+// The dynamics wave's whole step in the quad form (the caller returns afterwards).
+__device__ __forceinline__ void quad_dynamics_wave(const DevPtrs& P, const DevCfg& c, const f16::Tab& T, QuadLds& Q, int l, int n, bool live,
+                                                   f16::State& s, Task& t, const float4& a4) {
+  f16::Derived d;
+  bool have_pose = false, d_stale = false;
+  int last_tick = -1;
+  for (int sub = 0; sub < c.substeps; ++sub)
+    if (dynamics_wave_tick<true>(s, t, d, T, Q.S, l, sub, &d_stale)) { have_pose = true; last_tick = sub; }
+  const bool located = dynamics_wave_finish(s, d, Q.S, l, last_tick, c.substeps);   // (+ the helper waves' fields)
+  s.da = f16::clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);   // the commands, for the stored state (normalize_action, singlecombat_task.py:141-153)
+  s.de = f16::clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
+  s.dr = f16::clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);
+  s.thr = f16::clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
+  if (!located) f16::locate(s, d);
+  if (!have_pose || d_stale) f16::body_frame(s, d);        // never flew, or the last piece it ran was undone: the frames of the stored pose
+  Props pp;
+  make_props(s, d, c, pp);
+  pair_post_final(Q.P, l, s, d, pp);
+  if (live) store_flight(P.F, P.I, P.D, c.N, n, s);
+  wg_sync();   // final values posted, flight state stored (an episode reset by the environment wave overwrites it afterwards)
+}
+

@@ -124,11 +124,15 @@ __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::
 // velocity, so the quaternion, the fp64 position, the geodetic reduction, the direction cosine matrix and gravity of tick k+1 are
 // computed here while the other two waves are still in tick k; on an aircraft's last tick of the step it does the fp64 geodetic
 // reduction of the environment layer instead.
+// QUAD: a fourth wave flies the munitions against each tick's pose (step_kernel_1v1, FORM 3). It reads the tick's fp64 position right
+// after B1, so this wave posts every position as soon as it has it -- tick 0's before the first barrier, tick k+1's during tick k.
+template <bool QUAD = false>
 __device__ __forceinline__ void kinematics_wave(f16::State& s, Task& t, const f16::Tab& T, float (*M)[64], double (*MD)[64], int l, int substeps) {
   using namespace mail;
   f16::KinOut o;
   // tick 0 (the dynamics wave integrates its own): from the stored state, if the aircraft is alive at all
   if (t.status == AC_ALIVE && substeps > 0) { f16::kin_position(s, o); f16::kin_attitude(s, o); }
+  if (QUAD) { MD[GD_R][l] = s.rx; MD[GD_R + 1][l] = s.ry; MD[GD_R + 2][l] = s.rz; }
   for (int sub = 0; sub < substeps; ++sub) {
     AC_CLKW(2, 68 + sub * 8);
     wg_sync();                                             // B1: this tick's rates and velocity are known
@@ -136,13 +140,14 @@ __device__ __forceinline__ void kinematics_wave(f16::State& s, Task& t, const f1
     const bool last = sub + 1 == substeps;
     if (run) {                                             // this wave's position / attitude ARE tick `sub`'s: hand them over
       const int pb = sub & 1;
-      MD[GD_R + 3 * pb][l] = s.rx; MD[GD_R + 3 * pb + 1][l] = s.ry; MD[GD_R + 3 * pb + 2][l] = s.rz;
+      if (!QUAD) { MD[GD_R + 3 * pb][l] = s.rx; MD[GD_R + 3 * pb + 1][l] = s.ry; MD[GD_R + 3 * pb + 2][l] = s.rz; }   // (QUAD: posted a tick ago)
       M[G_Q + 4 * pb][l] = s.q0; M[G_Q + 4 * pb + 1][l] = s.q1; M[G_Q + 4 * pb + 2][l] = s.q2; M[G_Q + 4 * pb + 3][l] = s.q3;
     }
     if (run && !last) {                                    // one tick ahead (unused if the aircraft is shot down in between)
       s.wp = M[K_W][l]; s.wq = M[K_W + 1][l]; s.wr = M[K_W + 2][l];
       s.vx = M[K_V][l]; s.vy = M[K_V + 1][l]; s.vz = M[K_V + 2][l];
       f16::kin_position(s, o);
+      if (QUAD) { const int nb = (sub + 1) & 1; MD[GD_R + 3 * nb][l] = s.rx; MD[GD_R + 3 * nb + 1][l] = s.ry; MD[GD_R + 3 * nb + 2][l] = s.rz; }
     } else if (run) {                                      // last substep of the step: the pose the env layer reads
       f16::Derived d;
       s.ticks += substeps;
@@ -181,24 +186,35 @@ struct SplitLds {
 };
 // Helper waves of a three-wave workgroup: run their part of every substep and return true (the caller returns); the dynamics
 // wave (wave 0) gets false. Commands (s.da .. s.thr) must be decoded before the call, or handed over as the raw action row.
+template <bool QUAD = false>
 __device__ __forceinline__ bool split_helper_wave(f16::State& s, Task& t, const f16::Tab& T, SplitLds& L, int l, int substeps, const float4* raw = nullptr) {
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (role == 2) { kinematics_wave(s, t, T, L.M, L.MD, l, substeps); return true; }
+  if (role == 2) { kinematics_wave<QUAD>(s, t, T, L.M, L.MD, l, substeps); return true; }
   if (role == 1) { systems_wave(s, t, T, L.M, l, substeps, raw); return true; }
   return false;
 }
 // One substep of the dynamics wave (three workgroup barriers inside; every lane of the wave must call it). Returns whether this
 // aircraft flew the tick. Afterwards s holds the tick's state except the quaternion (handed over by dynamics_wave_finish); the fp64
 // ECI position IS current, so the caller may run f16::locate(s, d) after any substep (the missile tasks do).
-__device__ __forceinline__ bool dynamics_wave_tick(f16::State& s, Task& t, f16::Derived& d, const f16::Tab& T, SplitLds& L, int l, int sub) {
+// QUAD (step_kernel_1v1, FORM 3): who flies a tick is decided by the environment wave, which posts RUNF before B1 -- too late for this
+// wave's first piece, which runs before that barrier. So the piece runs on the belief "still alive" (`t.status` here is this wave's
+// private copy of that belief: exact for tick 0, cleared when the environment wave says otherwise) and the sixteen values it
+// integrates are put back if the aircraft turns out to have been grounded in the previous substep (the kinematics wave already
+// works one tick ahead like that). *d_stale is set then: d holds the frames of a tick that was not flown.
+template <bool QUAD = false>
+__device__ __forceinline__ bool dynamics_wave_tick(f16::State& s, Task& t, f16::Derived& d, const f16::Tab& T, SplitLds& L, int l, int sub, bool* d_stale = nullptr) {
   using namespace mail;
   float (*M)[64] = L.M;
   double (*MD)[64] = L.MD;
-  const bool run = t.status == AC_ALIVE;
-  if (run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;        // simulatior.py:220-222: this tick still integrates
+  bool run = t.status == AC_ALIVE;
+  if (!QUAD && run && t.bloods <= 0.0f) t.status = AC_SHOTDOWN;        // simulatior.py:220-222: this tick still integrates
   f16::DynVars k;
   AC_CLK(2 + sub * 8);
-  M[RUNF][l] = run ? 1.0f : 0.0f;
+  if (!QUAD) M[RUNF][l] = run ? 1.0f : 0.0f;
+  const float b_wp = s.wp, b_wq = s.wq, b_wr = s.wr, b_vx = s.vx, b_vy = s.vy, b_vz = s.vz, b_ax = s.ha1x, b_ay = s.ha1y, b_az = s.ha1z;
+  const float b_h1x = s.hv1x, b_h1y = s.hv1y, b_h1z = s.hv1z, b_h2x = s.hv2x, b_h2y = s.hv2y, b_h2z = s.hv2z;
+  const int b_ticks = s.ticks;
+  if (QUAD && !run) { M[K_V][l] = s.vx; M[K_V + 1][l] = s.vy; M[K_V + 2][l] = s.vz; }   // a grounded aircraft's (frozen) velocity, for the pose of substep 0
   if (run) {
     if (sub == 0) f16::dyn_p1(s, d, k);                        // (its quaternion goes stale from here on: the kinematics wave
     else {                                                     //  hands the final one over)
@@ -214,6 +230,13 @@ __device__ __forceinline__ bool dynamics_wave_tick(f16::State& s, Task& t, f16::
   AC_CLK(3 + sub * 8);
   wg_sync();                                                   // B1
   AC_CLK(4 + sub * 8);
+  if (QUAD && run && M[RUNF][l] == 0.0f) {                     // grounded in the previous substep after all: undo the first piece
+    s.wp = b_wp; s.wq = b_wq; s.wr = b_wr; s.vx = b_vx; s.vy = b_vy; s.vz = b_vz; s.ha1x = b_ax; s.ha1y = b_ay; s.ha1z = b_az; s.ticks = b_ticks;
+    s.hv1x = b_h1x; s.hv1y = b_h1y; s.hv1z = b_h1z; s.hv2x = b_h2x; s.hv2y = b_h2y; s.hv2z = b_h2z;
+    t.status = AC_SHOTDOWN;                                    // (only "not alive" matters to this wave)
+    run = false;
+    if (d_stale) *d_stale = true;
+  }
   if (run) {
     fetch_mass(M, l, k);
     if (sub == 0) f16::dyn_p2<false>(s, d, k);

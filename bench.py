@@ -49,7 +49,7 @@ def action_pool(np, rng, env, count):
     return pool
 
 
-def pmc_traffic(task, envs):
+def pmc_traffic(task, envs, aircraft):
     """HBM bytes per launch of the step kernel from the rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
     runs of this same command, FETCH_SIZE calibrated on the digest kernel's known byte count; tools/pmc_traffic.py writes the
     summary). Counters cannot be read from inside the process, so this is the committed measurement for the same workload, or
@@ -59,7 +59,7 @@ def pmc_traffic(task, envs):
     except (OSError, ValueError):
         return None
     for r in rec.get("runs", []):
-        if r.get("task") == task and r.get("envs_per_gpu") == envs and r.get("round", 1) >= 2:
+        if r.get("task") == task and r.get("envs_per_gpu") == envs and r.get("aircraft") == aircraft and r.get("round", 1) >= 2:
             return r["traffic_bytes_per_launch"]
     return None
 
@@ -97,11 +97,34 @@ def device_leg(env, dev_ptrs, steps, warmup):
     return wall, ev.value / steps      # seconds of the loop, kernel ms per launch
 
 
+def host_launch_ms(env, pool, steps=200):
+    """Duration of the step kernel when it is launched the way VecEnv.step launches it (actions read from, outputs also written to,
+    mapped host memory): HIP events on the launch stream around every launch of a short leg of its own, outside the timed region
+    (two event records per step would cost the host leg what they measure)."""
+    tot = 0.0
+    ev = C.c_float()
+    dll = env.lib.dll
+    for i in range(steps + 20):
+        cur = env._cur = env._cur ^ 1
+        np_copy(env._sets[cur]["actions"], pool[i % len(pool)])
+        env.lib.check(env.lib.ac_timing_begin(env._h), "ac_timing_begin")
+        env.lib.check(dll.ac_step_host_async(env._h, cur), "ac_step_host_async")
+        env.lib.check(env.lib.ac_timing_end(env._h, C.byref(ev)), "ac_timing_end")
+        if i >= 20:
+            tot += ev.value
+    return tot / steps
+
+
+def np_copy(dst, src):
+    import numpy as np
+    np.copyto(dst, src.reshape(dst.shape))
+
+
 def roofline(env, task, kernel_ms, hierarchical=False):
     algo = algorithmic_bytes(env) * env.num_envs * env.num_agents            # per launch, one GPU
     achieved = algo / (kernel_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": pmc_traffic(task, env.num_envs),
+            "traffic": pmc_traffic(task, env.num_envs, env.num_envs * env.num_agents),
             "kernel": "step kernel of the task" + (" + controller_kernel" if hierarchical else ""), "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": algo, "algorithmic_bytes_per_agent_step": algorithmic_bytes(env)}
 
@@ -226,6 +249,7 @@ def main():
     ap.add_argument("--checksum-calls", type=int, default=0,
                     help="after the timed region launch the read-only state digest kernel this many times (a dispatch with a known "
                          "byte count in the step kernel's access pattern, used to calibrate FETCH_SIZE under rocprofv3 --pmc)")
+    ap.add_argument("--host-only", action="store_true", help="profiling runs: the host-boundary leg alone (no device-resident leg, no further legs)")
     ap.add_argument("--device-only", action="store_true", help="profiling runs: skip the host-boundary leg (value = device-resident rate)")
     args = ap.parse_args()
 
@@ -277,6 +301,14 @@ def main():
     kernel_ms = dev_wall = None
     if not args.device_only:
         elapsed = host_leg(env, pool, args.steps, args.warmup, sync_all)
+    if args.host_only:   # profiling runs: every launch of the process is a host-boundary launch
+        print(json.dumps({"metric": "agent-steps/sec", "value": float(world) * E * A * args.steps / elapsed, "unit": "agent-steps/s",
+                          "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
+                          "config": {"task": args.task, "envs_per_gpu": E, "boundary": "VecEnv.step(numpy) (--host-only: no other leg)"}}))
+        env.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if not args.stub_env:
         dev = [torch.from_numpy(a).cuda(local_rank) for a in pool]
         torch.cuda.synchronize()
@@ -312,6 +344,11 @@ def main():
             result["device_resident"] = {"value": agent_steps / dev_wall, "unit": "agent-steps/s", "ms_per_step": dev_wall / args.steps * 1e3,
                                          "note": "same steps with actions and outputs resident in HBM (step_device, SURVEY N2), launched back to back"}
             result["roofline"] = roofline(env, args.task, kernel_ms, args.hierarchical)
+            if not args.device_only and not args.hierarchical and hasattr(env, "_sets"):
+                result["roofline"]["kernel_ms_host_boundary"] = host_launch_ms(env, pool)
+                result["roofline"]["note"] = ("kernel_ms: launches of the device-resident leg (actions and outputs in HBM), HIP events over that leg; "
+                                              "kernel_ms_host_boundary: the same kernel launched by VecEnv.step (actions read from and a second copy of the "
+                                              "outputs written to mapped host memory, across PCIe), HIP events around each launch of a separate 200-step leg")
             result["episode_check"] = {"max_current_step": int(info_h[:, 0].max()), "envs_reset_last_step": int(info_h[:, 3].sum())}
         else:
             result["stub"] = {"steps_taken": env.steps_taken, "seed": env.seed_value}

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--agents", type=int, default=2)
     ap.add_argument("--kernel", default="step_kernel")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--round", type=int, default=2, help="build round the measurement belongs to (bench.py reports entries of round >= 2)")
     a = ap.parse_args()
     fetch, write = per_kernel(a.fetch_dir, "FETCH_SIZE"), per_kernel(a.write_dir, "WRITE_SIZE")
     lanes = a.envs * a.agents
@@ -48,7 +49,7 @@ def main():
     f = pick(fetch, a.kernel); w = pick(write, a.kernel)
     f = f[len(f) // 4:]; w = w[len(w) // 4:]                       # drop the warm-up quarter
     fetch_kb, write_kb = sum(f) / len(f), sum(w) / len(w)
-    rec = {"task": a.task, "envs_per_gpu": a.envs, "aircraft": lanes, "kernel": a.kernel, "dispatches": len(f),
+    rec = {"task": a.task, "round": a.round, "envs_per_gpu": a.envs, "aircraft": lanes, "kernel": a.kernel, "dispatches": len(f),
            "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
            "fetch_calibration": {"kernel": "state_checksum_kernel", "known_KB": STATE_READ_BYTES * lanes / 1024.0,
                                  "FETCH_SIZE_KB_raw": cal_kb, "factor": factor, "dispatches": len(cal)},
@@ -60,7 +61,7 @@ def main():
             allrec = json.load(open(a.out))
         except (OSError, ValueError):
             allrec = {"runs": []}
-        allrec["runs"] = [r for r in allrec["runs"] if not (r["task"] == a.task and r["envs_per_gpu"] == a.envs)] + [rec]
+        allrec["runs"] = [r for r in allrec["runs"] if not (r["task"] == a.task and r["envs_per_gpu"] == a.envs and r["aircraft"] == lanes)] + [rec]
         json.dump(allrec, open(a.out, "w"), indent=1)
 
 

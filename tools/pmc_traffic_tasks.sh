@@ -1,14 +1,18 @@
 #!/bin/bash
-# HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the step kernels of further tasks -> $out/pmc_traffic.json
+# HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes, device-resident steps only) of the step kernel of every bench configuration
+# -> $out/pmc_traffic.json (copy to profiles/).   usage (inside gpurun): bash tools/pmc_traffic_tasks.sh <tag> <round>
 set -e
 out=gpurun_out/${1:-pmc_tasks}
+round=${2:-2}
 mkdir -p $out
 export TMPDIR=/tmp
 cp profiles/pmc_traffic.json $out/pmc_traffic.json
-for spec in "singlecombat_shoot 2" "scenario1 2" "multiplecombat 4" "scenario_nvn 4"; do
-  set -- $spec; t=$1; A=$2
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${t}_fetch -o pmc -- python3 bench.py --task $t --steps 300 --warmup 100 --no-cpu-baseline --no-saturating --checksum-calls 20 > $out/${t}_fetch.json 2> $out/${t}_fetch.err
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${t}_write -o pmc -- python3 bench.py --task $t --steps 300 --warmup 100 --no-cpu-baseline --no-saturating --checksum-calls 20 > $out/${t}_write.json 2> $out/${t}_write.err
-  python3 tools/pmc_traffic.py $out/${t}_fetch $out/${t}_write --task $t --agents $A --out $out/pmc_traffic.json | grep -E "bytes_per_aircraft_step|traffic_bytes"
+for spec in "singlecombat 1 2" "singlecombat_shoot 1 2" "scenario1 1 2" "scenario_nvn 2 4" "scenario_nvn 4 8" "multiplecombat 2 4"; do
+  set -- $spec; t=$1; ps=$2; A=$3
+  extra=""; if [ $ps != 1 ]; then extra="--per-side $ps"; fi
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/${t}${A}_$c -o pmc -- python3 bench.py --task $t $extra --steps 300 --warmup 100 --device-only --no-configs --no-cpu-baseline --no-saturating --checksum-calls 20 > $out/${t}${A}_$c.json 2> $out/${t}${A}_$c.err
+  done
+  python3 tools/pmc_traffic.py $out/${t}${A}_FETCH_SIZE $out/${t}${A}_WRITE_SIZE --task $t --agents $A --round $round --out $out/pmc_traffic.json | grep -E "bytes_per_aircraft_step|traffic_bytes"
   find $out -name "*.csv" -size +5M -delete
 done

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box pass: plain bench, rocprofv3 kernel stats, and the two PMC passes (own runs, no tracing domains besides kernel-trace).
+# One GPU-box pass: the plain bench line and the rocprofv3 kernel statistics of the same command.
 # usage (inside gpurun): bash tools/profile_round.sh <tag>
 set -e
 tag=${1:-r1}
@@ -9,8 +9,6 @@ python3 bench.py > $out/bench.json 2> $out/bench.err
 cat $out/bench.json
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o stats -- python3 bench.py --no-cpu-baseline --no-saturating > $out/stats_bench.json 2> $out/stats.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o pmc -- python3 bench.py --steps 400 --warmup 100 --no-cpu-baseline --no-saturating --checksum-calls 20 > $out/pmc_fetch.json 2> $out/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o pmc -- python3 bench.py --steps 400 --warmup 100 --no-cpu-baseline --no-saturating --checksum-calls 20 > $out/pmc_write.json 2> $out/pmc_write.err
-python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write --out $out/pmc_traffic.json
+# (the PMC passes -- FETCH_SIZE / WRITE_SIZE, one counter per run, kernel-trace only -- are tools/pmc_traffic_tasks.sh)
 find $out -name "*.csv" -size +20M -delete
 ls -la $out $out/stats
