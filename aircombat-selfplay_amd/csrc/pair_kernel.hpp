@@ -178,8 +178,12 @@ struct QuadLds {
   SplitLds S;
   PairLds P;    // (only F64 / FIN: the final values, dynamics wave -> environment wave)
 };
-// Environment wave, first half of a substep (B1 and B2 inside; the caller flies the munitions and then calls wg_sync() for B3).
-// `nrun` counts the ticks this aircraft has flown this step (the Earth angle of the pose).
+// Environment wave, first part of a substep. `nrun` counts the ticks this aircraft has flown this step (the Earth angle of the pose).
+// RAW_POSE (1v1 missile tasks, fp32 AIM-9L: this wave has the time): B1 and B2 inside, the geodetic reduction of the tick's raw ECI
+// position between them; the caller flies the munitions and then calls wg_sync() for B3.
+// !RAW_POSE (scenario kernels): B1 alone; the kinematics wave has posted the reduced position (kinematics_wave<.., POSE>), this wave adds
+// the NED velocity; the caller spreads the munitions over the tick's three gaps and places B2 and B3 itself.
+template <bool RAW_POSE>
 __device__ __forceinline__ bool quad_substep_begin(Task& t, QuadLds& Q, int l, int sub, bool need_pose, int ticks0, int& nrun, Props& pr, const DevCfg& c) {
   using namespace mail;
   const bool run = t.status == AC_ALIVE;
@@ -192,12 +196,24 @@ __device__ __forceinline__ bool quad_substep_begin(Task& t, QuadLds& Q, int l, i
     const int pb = sub & 1;
     sp.rx = Q.S.MD[GD_R + 3 * pb][l]; sp.ry = Q.S.MD[GD_R + 3 * pb + 1][l]; sp.rz = Q.S.MD[GD_R + 3 * pb + 2][l];
     sp.vx = Q.S.M[K_V][l]; sp.vy = Q.S.M[K_V + 1][l]; sp.vz = Q.S.M[K_V + 2][l];
-    sp.ticks = ticks0 + nrun;
-    f16::locate(sp, dp);
-    ned_velocity(sp, dp);
-    make_pose(dp, c, pr);
+    if (RAW_POSE) {
+      sp.ticks = ticks0 + nrun;
+      f16::locate(sp, dp);
+      ned_velocity(sp, dp);
+      make_pose(dp, c, pr);
+    } else {
+      const int r = QP_F + QP_F_N * pb;
+      pr.n64 = Q.S.MD[GD_QP + 3 * pb][l]; pr.e64 = Q.S.MD[GD_QP + 3 * pb + 1][l]; pr.u64 = Q.S.MD[GD_QP + 3 * pb + 2][l];
+      pr.n = (float)pr.n64; pr.e = (float)pr.e64; pr.u = (float)pr.u64;
+      pr.alt_m = Q.S.M[r][l];
+      dp.n_eci[0] = Q.S.M[r + 1][l]; dp.n_eci[1] = Q.S.M[r + 2][l]; dp.n_eci[2] = Q.S.M[r + 3][l];
+      dp.e_eci[0] = Q.S.M[r + 4][l]; dp.e_eci[1] = Q.S.M[r + 5][l]; dp.e_eci[2] = 0.0f;
+      dp.d_eci[0] = Q.S.M[r + 6][l]; dp.d_eci[1] = Q.S.M[r + 7][l]; dp.d_eci[2] = Q.S.M[r + 8][l];
+      ned_velocity(sp, dp);
+      pr.vn = mps(dp.vn); pr.ve = mps(dp.ve); pr.vd = mps(dp.vd);
+    }
   }
-  wg_sync();                                                // B2
+  if (RAW_POSE) wg_sync();                                  // B2
   return run;
 }
 // The dynamics wave's whole step in the quad form (the caller returns afterwards).

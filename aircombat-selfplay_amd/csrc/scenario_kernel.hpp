@@ -86,11 +86,15 @@ struct EnemyGeo { float AO, TA, R, cAO, cTA; };
 // FORM: FORM_ONE = one wave per 64 aircraft does everything; FORM_SPLIT = the FDM ticks in the three-wave form (split_kernel.hpp; used
 // for the gun-only tasks, which have nothing to fly between ticks); FORM_PAIR = a flight wave and an environment wave
 // (pair_kernel.hpp; every task with munitions, at every batch size).
-enum { FORM_ONE = 0, FORM_SPLIT = 1, FORM_PAIR = 2 };
+// FORM_QUAD = the three waves of FORM_SPLIT flying the ticks under the environment wave of FORM_PAIR (pair_kernel.hpp, "the quad form"),
+// up to one workgroup per CU: the environment wave spreads a substep's munition work over the tick's three barrier gaps.
+enum { FORM_ONE = 0, FORM_SPLIT = 1, FORM_PAIR = 2, FORM_QUAD = 3 };
+// (cycle stamps of the wave that runs the environment layer: wave 3 in the quad form, wave 0 otherwise)
+#define AC_CLKE(i) AC_CLKW(QUAD ? 3 : 0, i)
 template <int A, int WPE, int FORM = FORM_ONE>
-__global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128 : 64), WPE) void step_kernel_scenario(DevPtrs P, DevCfg c, float* XF, int* XI, const float* tXF, const int* tXI) {
+__global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128 : (FORM == FORM_QUAD ? 256 : 64)), WPE) void step_kernel_scenario(DevPtrs P, DevCfg c, float* XF, int* XI, const float* tXF, const int* tXI) {
   using SD = ScenarioDims<A>;
-  constexpr bool SPLIT = FORM == FORM_SPLIT, PAIR = FORM == FORM_PAIR;
+  constexpr bool SPLIT = FORM == FORM_SPLIT, QUAD = FORM == FORM_QUAD, PAIR = FORM == FORM_PAIR || QUAD;   // (the quad form's environment wave runs the pair form's code)
   constexpr bool MULTI = SD::MULTI;
   constexpr int OBS = SD::OBS;
   constexpr int NE = SD::NE;
@@ -99,9 +103,10 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   __shared__ __attribute__((aligned(16))) float lds_out[64 * (OBS + 2)];
   __shared__ float4 cl_pos[64 * 2];   // the chaff clouds of the workgroup's aircraft (position; live flag and multiplicity below)
   __shared__ int2 cl_meta[64 * 2];
-  __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : (PAIR ? sizeof(PairLds) : 16)];
+  __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : (QUAD ? sizeof(QuadLds) : (PAIR ? sizeof(PairLds) : 16))];
   SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
-  PairLds& LP = *reinterpret_cast<PairLds*>(split_lds);
+  QuadLds& LQ = *reinterpret_cast<QuadLds*>(split_lds);
+  PairLds& LP = QUAD ? LQ.P : *reinterpret_cast<PairLds*>(split_lds);
   const Tab T{lds_tab};
   const int N = c.N;
   const int lane = threadIdx.x & 63;
@@ -116,20 +121,30 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   // The environment wave's loads are two dependent round trips to HBM: (1) with the table pack, everything it can ask for up front --
   // the action row, the tick count and the status word of every munition slot; (2) the task bookkeeping and the munition slots that
   // are in use, in one batch.
-  const bool flight_role = PAIR && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool flight_role = FORM == FORM_PAIR && wave == 1;
+  const bool fdm_role = QUAD && wave != 3;      // quad form: waves 0..2 = dynamics, systems, kinematics; wave 3 = the environment wave
   const float* act = P.actions + (size_t)nn * c.act_dim;
   State s; Task t; Derived d; Props pr; Ext x;
   float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
   int mst[MS] = {MSL_INACTIVE, MSL_INACTIVE};
-  if (!flight_role) {
+  if (fdm_role) {   // each FDM wave asks for the state fields its share of the tick reads (load_flight_role), and the action row
+    s = State{}; t = Task{};
+    if (wave == 0) { load_flight_role<0>(P.F, P.I, P.D, N, nn, s); t.status = P.I[(size_t)FI_status * N + nn]; }
+    else if (wave == 1) load_flight_role<1>(P.F, P.I, P.D, N, nn, s);
+    else { load_flight_role<2>(P.F, P.I, P.D, N, nn, s); t.status = P.I[(size_t)FI_status * N + nn]; }
+    a4 = load_controls(act, c.act_dim);
+  } else if (!flight_role) {
     a4 = load_controls(act, c.act_dim);
     if (c.act_dim == 8) b4 = load_controls(act + 4, c.act_dim);
 #pragma unroll
     for (int k = 0; k < MS; ++k) mst[k] = P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn];
     if (PAIR) s = State{};
   }
-  stage_tables<SPLIT ? 192 : (PAIR ? 128 : 64)>(lds_tab, P.tab);
-  AC_CLK(0);
+  stage_tables<SPLIT ? 192 : (QUAD ? 256 : (PAIR ? 128 : 64))>(lds_tab, P.tab);
+  AC_CLKE(0);
+  if (QUAD && wave == 0) { quad_dynamics_wave(P, c, T, LQ, lane, n, live, s, t, a4); return; }
+  if (fdm_role && split_helper_wave<true, true>(s, t, T, LQ.S, lane, c.substeps, &a4, &c)) return;
   if (flight_role) { PairFlightIn in; pair_flight_load(P, c, nn, in); pair_flight_wave<false>(P, c, T, LP, lane, n, live, in); return; }   // (it waits for the environment wave's first flags anyway: its state load hides there)
 
   if (PAIR) load_task(P.F, P.I, N, nn, t);   // the environment wave owns the task bookkeeping; of the flight state it only needs the tick count (Earth angle)
@@ -179,14 +194,21 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   }
   if (SPLIT && split_helper_wave(s, t, T, L, lane, c.substeps)) return;
   int last_tick = -1;   // three-wave form: the last substep this aircraft flew
-  AC_CLK(1);
+  AC_CLKE(1);
+  int quad_nrun = 0;
   for (int sub = 0; sub < c.substeps; ++sub) {
-    AC_CLK(2 + 8 * sub);
-    if (PAIR) {
+    AC_CLKE(2 + 8 * sub);
+    // quad form: the substep's munition work in three parts, one per barrier gap of the tick the other three waves fly meanwhile
+    // (the barriers sit outside every per-env condition: all four waves meet at each of them)
+    bool fly = true;
+    if (QUAD) {
+      quad_substep_begin<false>(t, LQ, lane, sub, env_has_munitions, 0, quad_nrun, pr, c);   // (B1 inside)
+      fly = env_has_munitions;
+    } else if (PAIR) {
       pair_substep<false>(t, LP, lane, sub, env_has_munitions, pr, c);
-      AC_CLK(3 + 8 * sub);
+      AC_CLKE(3 + 8 * sub);
       if (!env_has_munitions) continue;     // nothing to fly: the pose is only needed after the last substep
-      AC_CLK(4 + 8 * sub);
+      AC_CLKE(4 + 8 * sub);
     } else {
     if (SPLIT) {
       if (dynamics_wave_tick(s, t, d, T, L, lane, sub)) { have_pose = true; last_tick = sub; }
@@ -204,10 +226,18 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     }
     const int tick_id = (t.cur_step - 1) * c.substeps + sub + 1;
     // ---- missiles: every dict entry is run(), finished ones included (env_base.py:142-143)
-    int hit_tgt[MS];
+    int hit_tgt[MS] = {-1, -1};
     double tx[MS], ty[MS], tz[MS], tvx[MS], tvy[MS], tvz[MS];
     bool talive[MS];
     int hit_pos[MS];   // dict position of a missile that is inside its fuse radius of a live target this substep (else INT_MAX)
+    auto fly_slot = [&](int k) {
+      hit_tgt[k] = -1;
+      if (ms[k].status != MSL_INACTIVE) {
+        missile_run(ms[k], MP, tx[k], ty[k], tz[k], tvx[k], tvy[k], tvz[k], talive[k], c);
+        if (ms[k].status == MSL_HIT && talive[k]) hit_tgt[k] = ms[k].order & 15;
+      }
+    };
+    if (fly) {
 #pragma unroll
     for (int k = 0; k < MS; ++k) {
       const int tg = ms[k].order & 15;               // target slot lives in the low bits of `order`
@@ -244,15 +274,12 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
         }
       }
     }
-#pragma unroll
-    for (int k = 0; k < MS; ++k) {
-      hit_tgt[k] = -1;
-      if (ms[k].status != MSL_INACTIVE) {
-        missile_run(ms[k], MP, tx[k], ty[k], tz[k], tvx[k], tvy[k], tvz[k], talive[k], c);
-        if (ms[k].status == MSL_HIT && talive[k]) hit_tgt[k] = ms[k].order & 15;
-      }
+    fly_slot(0);
     }
-    AC_CLK(5 + 8 * sub);
+    if (QUAD) wg_sync();                                   // B2 of the tick
+    if (fly) {
+    fly_slot(1);
+    AC_CLKE(5 + 8 * sub);
 #pragma unroll
     for (int j = 0; j < A; ++j)
 #pragma unroll
@@ -260,7 +287,10 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
         int h = __shfl(hit_tgt[k], base + j);
         if (h == slot && t.status == AC_ALIVE) t.status = AC_SHOTDOWN;
       }
-    AC_CLK(6 + 8 * sub);
+    }
+    if (QUAD) wg_sync();                                   // B3 of the tick
+    if (!fly) continue;
+    AC_CLKE(6 + 8 * sub);
     // ---- chaff clouds age (ChaffSimulator.run, simulatior.py:377-381), then the decoy test (env_base.py:146-154). Clouds only come
     // into being in the weapons stage after the substeps: an env without a live cloud at the start of the step has none during it.
 #pragma unroll
@@ -304,11 +334,12 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
       wave_lds_fence();
     }
   }
-  AC_CLK(60);
+  AC_CLKE(60);
   const bool split_located = SPLIT && dynamics_wave_finish(s, d, L, lane, last_tick, c.substeps);   // (+ the helper waves' fields)
   if (PAIR) {
+    if (QUAD) wg_sync();                           // (quad form: the helper waves hand their fields to the dynamics wave here)
     wg_sync();                                     // the flight wave has posted its final values and stored the flight state
-    AC_CLK(61);
+    AC_CLKE(61);
     pair_read_final(LP, lane, s, d, pr);
   } else if (c.substeps == 0) { f16::locate(s, d); f16::body_frame(s, d); make_props(s, d, c, pr); }
   else if (SPLIT && !env_has_munitions) {
@@ -317,7 +348,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     make_props(s, d, c, pr);
   }
 
-  AC_CLK(62);
+  AC_CLKE(62);
   // ---- weapons (scenario1_task.py:61-103). The reference walks the agents one after another in env order; what an agent decides
   // depends on the others only through the chaff rule, which counts the dict's missiles aimed at it (so it sees the launches of the
   // agents before it, and entries those launches replaced are gone). Gun damage lands on bloods, which nobody reads until the next
@@ -426,7 +457,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     }
   }
 
-  AC_CLK(63);
+  AC_CLKE(63);
   // ---- geometry towards my enemies (every reward term iterates agent.enemies in env order)
   EnemyGeo eg[NE];
   float e_u0 = 0.0f;
@@ -467,7 +498,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
 #pragma unroll
   for (int k = 0; k < MS; ++k) if (ms[k].status == MSL_HIT) my_hits += 1;
 
-  AC_CLK(64);
+  AC_CLKE(64);
   // ---- observation
   float ob[OBS];
   if (!MULTI) {
@@ -513,7 +544,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   constexpr bool OBS_IN_LDS = MULTI;   // (the legacy 21-value form of the NvN tasks still goes through ob[] below)
   const bool row_direct = OBS_IN_LDS && !c.legacy_obs;
 
-  AC_CLK(65);
+  AC_CLKE(65);
   // ---- terminations of the 1v1 family come BEFORE the rewards (env_base.py:159-171)
   bool done = false;
   int code = AC_DONE_NONE, last_code = AC_DONE_NONE;
@@ -649,7 +680,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     terminations();
   }
 
-  AC_CLK(66);
+  AC_CLKE(66);
   bool all_done = true;
 #pragma unroll
   for (int j = 0; j < A; ++j) { const int dj = __shfl((int)done, base + j); all_done = all_done && (bool)dj; }
@@ -678,11 +709,11 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     for (int k = 0; k < MS; ++k)
       if (ms[k].status != MSL_INACTIVE || ((msl_was_active >> k) & 1)) store_msl(P.MD, P.MI, N, n, k, ms[k]);
   }
-  AC_CLK(67);
+  AC_CLKE(67);
   // (WVR uses the first 15 of the 21 slots; the *_RWR variants append two reserved zero slots)
   if (row_direct) emit_rows(P, lds_out, c.obs_dim, lane, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);
   else emit_outputs(P, lds_out, c.obs_dim, lane, ob, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);
-  AC_CLK(68);
+  AC_CLKE(68);
 }
 
 // reset template for the scenario tasks: same initial-condition pass, scenario observation layout, potential seeds

@@ -29,10 +29,12 @@ enum { RUNF,                                                       // dynamics -
        K_OUT = K_V + 3, K_OUT_N = 27,                               // kinematics -> dynamics: f16::KinOut of the coming tick
        G_Q = K_OUT + K_OUT_N,                                       // kinematics -> dynamics: quaternion of tick k in rows G_Q + 4 (k & 1) ..
        G_H = G_Q + 8, G_NED = G_H + 1,                              // ... and, from the step's last substep, the env-layer frame
-       ROWS = G_NED + 8 };
+       QP_F = G_NED + 8, QP_F_N = 9,                                // quad form with reduced poses: altitude [m] and the local frame of tick k in rows QP_F + 9 (k & 1) ..
+       ROWS = QP_F + 2 * QP_F_N };
 // fp64 rows: ECI position of tick k in rows GD_R + 3 (k & 1) .. (double-buffered: the kinematics wave is one tick ahead), ECEF
 // position and geodetic cosines of the step's last substep
-enum { GD_R, GD_X = GD_R + 6, GD_LAT = GD_X + 3, DROWS = GD_LAT + 4 };
+// (quad form with reduced poses: the NEU position of tick k in rows GD_QP + 3 (k & 1) ..)
+enum { GD_R, GD_X = GD_R + 6, GD_LAT = GD_X + 3, GD_QP = GD_LAT + 4, DROWS = GD_QP + 6 };
 }
 __device__ __forceinline__ void post_kin(float (*M)[64], int l, const f16::KinOut& o) {
   const float v[mail::K_OUT_N] = {o.T[0], o.T[1], o.T[2], o.T[3], o.T[4], o.T[5], o.T[6], o.T[7], o.T[8], o.h_sl_ft, o.n_eci[0], o.n_eci[1], o.n_eci[2],
@@ -126,13 +128,35 @@ __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::
 // reduction of the environment layer instead.
 // QUAD: a fourth wave flies the munitions against each tick's pose (step_kernel_1v1, FORM 3). It reads the tick's fp64 position right
 // after B1, so this wave posts every position as soon as it has it -- tick 0's before the first barrier, tick k+1's during tick k.
-template <bool QUAD = false>
-__device__ __forceinline__ void kinematics_wave(f16::State& s, Task& t, const f16::Tab& T, float (*M)[64], double (*MD)[64], int l, int substeps) {
+// POSE (the scenario kernels' quad form, whose environment wave has no time for it): the fp64 geodetic reduction and the NEU offset
+// of every tick's position as well, a tick ahead, in the gap this wave has between B3 and the next B1.
+__device__ __forceinline__ void post_quad_pose(float (*M)[64], double (*MD)[64], int l, int pb, const f16::State& s, int ticks, const DevCfg& c) {
+  using namespace mail;
+  f16::State sp{};
+  sp.rx = s.rx; sp.ry = s.ry; sp.rz = s.rz; sp.ticks = ticks;
+  f16::Derived dp;
+  f16::locate(sp, dp);
+  dp.vn = 0.0f; dp.ve = 0.0f; dp.vd = 0.0f;              // (the velocity part of make_pose is the environment wave's: it has the tick's velocity)
+  Props pp;
+  make_pose(dp, c, pp);
+  MD[GD_QP + 3 * pb][l] = pp.n64; MD[GD_QP + 3 * pb + 1][l] = pp.e64; MD[GD_QP + 3 * pb + 2][l] = pp.u64;
+  const int r = QP_F + QP_F_N * pb;
+  M[r][l] = pp.alt_m;
+  M[r + 1][l] = dp.n_eci[0]; M[r + 2][l] = dp.n_eci[1]; M[r + 3][l] = dp.n_eci[2];
+  M[r + 4][l] = dp.e_eci[0]; M[r + 5][l] = dp.e_eci[1];
+  M[r + 6][l] = dp.d_eci[0]; M[r + 7][l] = dp.d_eci[1]; M[r + 8][l] = dp.d_eci[2];
+}
+template <bool QUAD = false, bool POSE = false>
+__device__ __forceinline__ void kinematics_wave(f16::State& s, Task& t, const f16::Tab& T, float (*M)[64], double (*MD)[64], int l, int substeps,
+                                                const DevCfg* cfg = nullptr) {
   using namespace mail;
   f16::KinOut o;
+  const int ticks0 = s.ticks;
   // tick 0 (the dynamics wave integrates its own): from the stored state, if the aircraft is alive at all
-  if (t.status == AC_ALIVE && substeps > 0) { f16::kin_position(s, o); f16::kin_attitude(s, o); }
+  const bool alive0 = t.status == AC_ALIVE && substeps > 0;
+  if (alive0) { f16::kin_position(s, o); f16::kin_attitude(s, o); }
   if (QUAD) { MD[GD_R][l] = s.rx; MD[GD_R + 1][l] = s.ry; MD[GD_R + 2][l] = s.rz; }
+  if (POSE) post_quad_pose(M, MD, l, 0, s, ticks0 + (alive0 ? 1 : 0), *cfg);
   for (int sub = 0; sub < substeps; ++sub) {
     AC_CLKW(2, 68 + sub * 8);
     wg_sync();                                             // B1: this tick's rates and velocity are known
@@ -176,6 +200,7 @@ __device__ __forceinline__ void kinematics_wave(f16::State& s, Task& t, const f1
     }
     AC_CLKW(2, 70 + sub * 8);
     wg_sync();                                             // B3
+    if (POSE && run && !last) post_quad_pose(M, MD, l, (sub + 1) & 1, s, ticks0 + sub + 2, *cfg);   // (position of tick sub + 1: integrated after B1)
   }
   wg_sync();
 }
@@ -186,10 +211,11 @@ struct SplitLds {
 };
 // Helper waves of a three-wave workgroup: run their part of every substep and return true (the caller returns); the dynamics
 // wave (wave 0) gets false. Commands (s.da .. s.thr) must be decoded before the call, or handed over as the raw action row.
-template <bool QUAD = false>
-__device__ __forceinline__ bool split_helper_wave(f16::State& s, Task& t, const f16::Tab& T, SplitLds& L, int l, int substeps, const float4* raw = nullptr) {
+template <bool QUAD = false, bool POSE = false>
+__device__ __forceinline__ bool split_helper_wave(f16::State& s, Task& t, const f16::Tab& T, SplitLds& L, int l, int substeps, const float4* raw = nullptr,
+                                                  const DevCfg* cfg = nullptr) {
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (role == 2) { kinematics_wave<QUAD>(s, t, T, L.M, L.MD, l, substeps); return true; }
+  if (role == 2) { kinematics_wave<QUAD, POSE>(s, t, T, L.M, L.MD, l, substeps, cfg); return true; }
   if (role == 1) { systems_wave(s, t, T, L.M, l, substeps, raw); return true; }
   return false;
 }

@@ -116,16 +116,16 @@ def test_small_batch_both_kernel_forms_match_oracle(pkg, oracle, monkeypatch, ta
     run_sampled(pkg, oracle, task, per_side, 6, list(range(6)), 60)
 
 
-@pytest.mark.parametrize("task", ["singlecombat_shoot", "singlecombat_dodge_missile"])
+@pytest.mark.parametrize("task", ["singlecombat_shoot", "singlecombat_dodge_missile", "scenario1"])
 @pytest.mark.parametrize("quad", ["0", "1"])
 def test_missile_1v1_pair_and_quad_forms_match_oracle(pkg, oracle, monkeypatch, task, quad):
     """AIRCOMBAT_QUAD pins the pair form (0: flight wave + environment wave) or the quad form (1: three FDM waves + environment wave)
-    of the 1v1 missile tasks at a small batch: both against the oracle, every env compared."""
+    of the 1v1 tasks with munitions at a small batch: both against the oracle, every env compared."""
     monkeypatch.setenv("AIRCOMBAT_QUAD", quad)
     run_sampled(pkg, oracle, task, 1, 6, list(range(6)), 100 if task == "singlecombat_dodge_missile" else 60)
 
 
-@pytest.mark.parametrize("task", ["singlecombat_shoot", "singlecombat_dodge_missile"])
+@pytest.mark.parametrize("task", ["singlecombat_shoot", "singlecombat_dodge_missile", "scenario1"])
 def test_missile_1v1_between_256_and_512_workgroups(pkg, oracle, task):
     """9600 envs = 300 workgroups: above the quad form's range (one workgroup per CU), inside the pair form's one-wave-per-SIMD build."""
     E = 9600
