@@ -62,8 +62,13 @@ __device__ __forceinline__ void pair_flight_load(const DevPtrs& P, const DevCfg&
   in.status0 = P.I[(size_t)FI_status * c.N + nn];
   in.a4 = load_controls(P.actions + (size_t)nn * c.act_dim, c.act_dim);
 }
-template <bool RAW_POSE = false>
-__device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg& c, const f16::Tab& T, PairLds& L, int l, int n, bool live, PairFlightIn& in) {
+// `tail(pp)`: work for this wave after its final values are posted and the flight state is stored, while the environment wave runs the
+// weapon rules, rewards and terminations (the NvN scenario kernels build the observation rows here). It receives this aircraft's final
+// Props; whatever it synchronises with the environment wave is its own business.
+struct PairNoTail { __device__ __forceinline__ void operator()(const Props&) const {} };
+template <bool RAW_POSE = false, typename Tail = PairNoTail>
+__device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg& c, const f16::Tab& T, PairLds& L, int l, int n, bool live, PairFlightIn& in,
+                                                 Tail tail = Tail()) {
   using namespace pair;
   f16::State& s = in.s; f16::Derived d;
   const int status0 = in.status0;
@@ -127,6 +132,7 @@ __device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg&
   AC_CLKW(1, 160);
   wg_sync();   // final values posted, flight state stored (the release half of the barrier waits for the stores: an episode reset by
                // the environment wave overwrites them afterwards)
+  tail(pp);
 }
 
 // Environment wave, one substep: post who flies (and whether poses are wanted between the ticks), meet the flight wave, take the

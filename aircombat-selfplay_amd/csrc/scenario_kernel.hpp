@@ -145,7 +145,41 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   AC_CLKE(0);
   if (QUAD && wave == 0) { quad_dynamics_wave(P, c, T, LQ, lane, n, live, s, t, a4); return; }
   if (fdm_role && split_helper_wave<true, true>(s, t, T, LQ.S, lane, c.substeps, &a4, &c)) return;
-  if (flight_role) { PairFlightIn in; pair_flight_load(P, c, nn, in); pair_flight_wave<false>(P, c, T, LP, lane, n, live, in); return; }   // (it waits for the environment wave's first flags anyway: its state load hides there)
+  // The NvN observation row (scenario2_task.py:256-316: ego 9, partners, enemies; the missile block after them is the environment
+  // wave's), not clipped, written straight into this lane's row of the output staging buffer (a block's place in the row is a
+  // run-time index: an LDS address, not a select chain over 63 registers). In the pair form of the NvN tasks the FLIGHT wave builds it
+  // after its last tick, while the environment wave runs the weapon rules, rewards and terminations; one more barrier hands the rows over.
+  constexpr bool ROWS_BY_FLIGHT = MULTI && FORM == FORM_PAIR;
+  auto build_rows = [&](const Props& q) {
+    float* orow = lds_out + lane * c.obs_dim;
+    for (int k = 0; k < c.obs_dim; ++k) orow[k] = 0.0f;
+    orow[0] = q.alt_m / 5000.0f;
+    orow[1] = q.sphi; orow[2] = q.cphi; orow[3] = q.stht; orow[4] = q.ctht;
+    orow[5] = q.ub / 340.0f; orow[6] = q.vb / 340.0f; orow[7] = q.wb / 340.0f; orow[8] = q.vc / 340.0f;
+    const int n_mine = team == 0 ? n_ego : A - n_ego;
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      Enemy E = gather_pose(q, base + j);
+      if (j == slot) continue;
+      Geo g = ao_ta_r<false>(q.n, q.e, q.u, q.vn, q.ve, q.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd);
+      const int team_j = j < n_ego ? 0 : 1;
+      const int idx = (team_j == team) ? (j - (team == 0 ? 0 : n_ego)) - (j > slot ? 1 : 0) : (n_mine - 1) + (j - e_first);
+      float* blk = orow + 9 + idx * 6;
+      blk[0] = (E.ub - q.ub) / 340.0f; blk[1] = (E.alt - q.alt_m) / 1000.0f; blk[2] = g.AO; blk[3] = g.TA; blk[4] = g.R / 10000.0f; blk[5] = g.side;
+    }
+  };
+  if (flight_role) {   // (it waits for the environment wave's first flags anyway: its state load hides there)
+    PairFlightIn in;
+    pair_flight_load(P, c, nn, in);
+    auto rows_tail = [&](const Props& q) {
+      if (ROWS_BY_FLIGHT) {
+        if (!c.legacy_obs) build_rows(q);
+        wg_sync();                                  // the rows are in LDS (the environment wave adds the missile block and sends them)
+      }
+    };
+    pair_flight_wave<false>(P, c, T, LP, lane, n, live, in, rows_tail);
+    return;
+  }
 
   if (PAIR) load_task(P.F, P.I, N, nn, t);   // the environment wave owns the task bookkeeping; of the flight state it only needs the tick count (Earth angle)
   else load_state(P.F, P.I, P.D, N, nn, s, t);
@@ -514,32 +548,8 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     Enemy E = gather_pose(pr, base + e_first + (slot - (team == 0 ? 0 : n_ego)));
     observe_1v1<AC_TASK_SHOOT_MISSILE>(pr, E, inc, ob);
   } else {
-    // scenario2_task.py:256-316: ego 9, partners, enemies, then the missile block directly after them; not clipped. Written straight
-    // into this lane's row of the output staging buffer (a block's place in the row is a run-time index: an LDS address, not a
-    // select chain over 63 registers)
-    float* orow = lds_out + lane * c.obs_dim;
-    for (int k = 0; k < c.obs_dim; ++k) orow[k] = 0.0f;
-    orow[0] = pr.alt_m / 5000.0f;
-    orow[1] = pr.sphi; orow[2] = pr.cphi; orow[3] = pr.stht; orow[4] = pr.ctht;
-    orow[5] = pr.ub / 340.0f; orow[6] = pr.vb / 340.0f; orow[7] = pr.wb / 340.0f; orow[8] = pr.vc / 340.0f;
-    const int n_mine = team == 0 ? n_ego : A - n_ego;
-#pragma unroll
-    for (int j = 0; j < A; ++j) {
-      Enemy E = gather_pose(pr, base + j);
-      if (j == slot) continue;
-      Geo g = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd);
-      const int team_j = j < n_ego ? 0 : 1;
-      const int idx = (team_j == team) ? (j - (team == 0 ? 0 : n_ego)) - (j > slot ? 1 : 0) : (n_mine - 1) + (j - e_first);
-      float* blk = orow + 9 + idx * 6;
-      blk[0] = (E.ub - pr.ub) / 340.0f; blk[1] = (E.alt - pr.alt_m) / 1000.0f; blk[2] = g.AO; blk[3] = g.TA; blk[4] = g.R / 10000.0f; blk[5] = g.side;
-    }
-    if (inc.any) {
-      Geo gm = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, inc.px, inc.py, inc.pz, inc.vx, inc.vy, inc.vz);
-      float* blk = orow + 9 + 6 * (A - 1);
-      blk[0] = (sqrtf(inc.vx * inc.vx + inc.vy * inc.vy + inc.vz * inc.vz) - pr.ub) / 340.0f;
-      blk[1] = (inc.pz - pr.alt_m) / 1000.0f;
-      blk[2] = gm.AO; blk[3] = gm.TA; blk[4] = gm.R / 10000.0f; blk[5] = gm.side;
-    }
+    // (the row itself: build_rows above -- by this wave, or by the flight wave in the pair form)
+    if (!ROWS_BY_FLIGHT) build_rows(pr);
   }
   constexpr bool OBS_IN_LDS = MULTI;   // (the legacy 21-value form of the NvN tasks still goes through ob[] below)
   const bool row_direct = OBS_IN_LDS && !c.legacy_obs;
@@ -681,6 +691,15 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   }
 
   AC_CLKE(66);
+  if (ROWS_BY_FLIGHT) wg_sync();                    // the flight wave has built the observation rows
+  if (row_direct && inc.any) {                       // the missile block directly after the enemies
+    float* orow = lds_out + lane * c.obs_dim;
+    Geo gm = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, inc.px, inc.py, inc.pz, inc.vx, inc.vy, inc.vz);
+    float* blk = orow + 9 + 6 * (A - 1);
+    blk[0] = (sqrtf(inc.vx * inc.vx + inc.vy * inc.vy + inc.vz * inc.vz) - pr.ub) / 340.0f;
+    blk[1] = (inc.pz - pr.alt_m) / 1000.0f;
+    blk[2] = gm.AO; blk[3] = gm.TA; blk[4] = gm.R / 10000.0f; blk[5] = gm.side;
+  }
   bool all_done = true;
 #pragma unroll
   for (int j = 0; j < A; ++j) { const int dj = __shfl((int)done, base + j); all_done = all_done && (bool)dj; }

@@ -359,7 +359,7 @@ def main():
                                       "frac": VALU_PER_AGENT_STEP * rate / 1e12 / VALU_PEAK_TINST,
                                       "note": "lane-instructions of the one-wave kernel form (the algorithm's count) over the measured kernel time"}
         plain = args.task == "singlecombat" and not args.hierarchical
-        if plain:
+        if plain and not args.device_only:
             # SURVEY 8(d)'s second, "benign" run: the reference's straight-fly action [20, 18.6 -> 19, 20, 0] (baseline.py:168) held in
             # every env, so no aircraft crashes early and the timed mix is all level flight
             env.reset()
