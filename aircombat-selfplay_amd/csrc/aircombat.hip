@@ -2124,6 +2124,16 @@ int ac_load_controller(ac_env_t* h, const float* weights, int64_t n) {
   }
   return 0;
 }
+int ac_split_bf16x3(const float* x, int64_t n, float* hi, float* mid, float* lo) {
+  if (!x || !hi || !mid || !lo || n < 0) return fail("ac_split_bf16x3: bad argument");
+  for (int64_t i = 0; i < n; ++i) {
+    unsigned p[3];
+    ctls::split3(x[i], p[0], p[1], p[2]);
+    float* out[3] = {hi, mid, lo};
+    for (int k = 0; k < 3; ++k) { const unsigned b = p[k] << 16; memcpy(&out[k][i], &b, 4); }
+  }
+  return 0;
+}
 int ac_get_controller_state(ac_env_t* h, int32_t env, int32_t agent, float* hidden, float* low_action) {
   if (check_idx(h, env, agent)) return fail("ac_get_controller_state: bad argument");
   if (!h->cfg.hierarchical) return fail("ac_get_controller_state: not a hierarchical handle");

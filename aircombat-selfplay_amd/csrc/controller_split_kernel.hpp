@@ -2,10 +2,10 @@
 // bf16 pieces, so that the GEMMs run on the bf16 matrix path of gfx950 (v_mfma_f32_32x32x16_bf16: 16 k per 32 cycles) instead of the
 // fp32 one (v_mfma_f32_32x32x2_f32: 2 k per 64 cycles).
 //
-// An fp32 value x is exactly hi + mid + lo, three bf16 numbers: hi = x with its low 16 bits cleared, mid = (x - hi) with its low 16
-// bits cleared, lo = x - hi - mid (8 significand bits each, 24 together; both subtractions are exact). A product of two such sums has
-// nine terms; the six that reach 2^-16 of the product are kept -- hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid -- and the three left
-// out (mid*lo, lo*mid, lo*lo) are below 2^-24 of it, the rounding of an fp32 multiply. Every kept term is an exact bf16 x bf16
+// An fp32 value x is exactly hi + mid + lo, three bf16 numbers: hi = x rounded to bf16, mid = (x - hi) rounded to bf16, lo = x - hi - mid
+// (8 significand bits each, 24 together; both subtractions are exact and the last remainder fits). A product of two such sums has
+// nine terms; the six that can reach 2^-16 of the product are kept -- hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid -- and the three
+// left out (mid*lo, lo*mid, lo*lo) are at most 2^-23 of it (one fp32 ulp, at the worst case of both roundings; typically 2^-27). Every kept term is an exact bf16 x bf16
 // product accumulated in fp32 by the matrix core, like the fp32 instruction accumulates its own. Six bf16 instructions per 16 k are
 // 12 cycles per k against 32: the matrix time of the controller drops from ~13 us to ~5 us at 8192 aircraft. What bounds the GEMM phases
 // then is the L2: every workgroup (32 aircraft, one per CU at 8192) streams all 0.7 MB of weight pieces once per call, 180 MB per
@@ -37,22 +37,27 @@ enum : int {
   B_BA = B_BE3 + 128,                        // [160]
   B_END = B_BA + NHP
 };
-// x = hi + mid + lo (bit patterns of the three bf16, i.e. the high halves of three floats)
+// x = hi + mid + lo (bit patterns of the three bf16, i.e. the high halves of three floats). Each piece is the round-to-nearest-even
+// bf16 of what is left: |x - hi| <= 2^-8 |x|, |x - hi - mid| <= 2^-16 |x|, and the last remainder has at most 8 significant bits, so
+// lo takes it exactly.
+__host__ __device__ __forceinline__ unsigned bf16_rne_bits(unsigned b) {   // float bit pattern -> the same with the low half rounded away
+  const unsigned r = b + 0x7FFFu + ((b >> 16) & 1u);
+  return (((r & 0x7F800000u) == 0x7F800000u) ? b : r) & 0xFFFF0000u;      // (never round a finite value up to infinity)
+}
 __host__ __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
 #ifdef __HIP_DEVICE_COMPILE__
-  const unsigned xb = __float_as_uint(x);
-  const float h = __uint_as_float(xb & 0xFFFF0000u);
-  const float r1 = x - h;
-  const float m = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
-  const float r2 = r1 - m;
-  hi = xb >> 16; mid = __float_as_uint(r1) >> 16; lo = __float_as_uint(r2) >> 16;
+  const unsigned hb = bf16_rne_bits(__float_as_uint(x));
+  const float r1 = x - __uint_as_float(hb);
+  const unsigned mb = bf16_rne_bits(__float_as_uint(r1));
+  const float r2 = r1 - __uint_as_float(mb);
+  hi = hb >> 16; mid = mb >> 16; lo = __float_as_uint(r2) >> 16;
 #else
   unsigned xb; memcpy(&xb, &x, 4);
-  unsigned hb = xb & 0xFFFF0000u; float h; memcpy(&h, &hb, 4);
+  const unsigned hb = bf16_rne_bits(xb); float h; memcpy(&h, &hb, 4);
   const float r1 = x - h; unsigned r1b; memcpy(&r1b, &r1, 4);
-  unsigned mb = r1b & 0xFFFF0000u; float m; memcpy(&m, &mb, 4);
+  const unsigned mb = bf16_rne_bits(r1b); float m; memcpy(&m, &mb, 4);
   const float r2 = r1 - m; unsigned r2b; memcpy(&r2b, &r2, 4);
-  hi = xb >> 16; mid = r1b >> 16; lo = r2b >> 16;
+  hi = hb >> 16; mid = mb >> 16; lo = r2b >> 16;
 #endif
 }
 // 16 consecutive features of one aircraft -> the three planes (two 16-byte LDS stores per plane)

@@ -168,6 +168,10 @@ int ac_load_controller(ac_env_t* h, const float* weights, int64_t n);
 /* test access to _inner_rnn_states[agent] (float[128]) and the controller's last output (float[act_low]: 4 control indices (+ bits)) */
 int ac_get_controller_state(ac_env_t* h, int32_t env, int32_t agent, float* hidden, float* low_action);
 int ac_set_controller_state(ac_env_t* h, int32_t env, int32_t agent, const float* hidden);
+/* Host-side check of the arithmetic behind the controller's GEMMs (no GPU, no handle): every fp32 weight and activation is taken apart
+ * into three bf16 pieces, hi + mid + lo == x exactly, and the products run on the bf16 matrix path (controller_split_kernel.hpp). Writes
+ * the three pieces of x[0..n) as float32 values (each with at most 8 significant bits). */
+int ac_split_bf16x3(const float* x, int64_t n, float* hi, float* mid, float* lo);
 
 /* timing helper for the bench: average device milliseconds per step kernel over the last n ac_step* calls, measured
  * with HIP events on the handle's stream */

@@ -238,3 +238,32 @@ def test_acmi_records_match_the_reference_log_text(pkg):
         seen_explosion |= "Type=Misc+Explosion" in got_text
         seen_removed_chaff |= "-B010012" in got_text
     assert seen_explosion and seen_removed_chaff and exploded
+
+
+def test_controller_products_split_into_exact_bf16_pieces(pkg):
+    """The arithmetic claim behind controller_split_kernel (host side of it, no GPU): x = hi + mid + lo EXACTLY with three bf16 pieces
+    (round-to-nearest each, 8 significant bits, low 16 bits of the float pattern clear), for normal floats of every sign and magnitude
+    the network sees; and the six kept product terms reproduce the exact product to within one fp32 ulp (worst case)."""
+    import ctypes as C
+    import numpy as np
+    lib = pkg.load_library()
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.standard_normal(20000) * 10.0 ** rng.integers(-6, 4, 20000), [0.0, -0.0, 1.0, -1.0, 3.4e38, -3.4e38, 1e-30, 0.1, 1.0 / 3.0]]).astype(np.float32)
+    hi, mid, lo = (np.empty_like(x) for _ in range(3))
+    assert lib.dll.ac_split_bf16x3(x.ctypes.data_as(C.c_void_p), x.size, hi.ctypes.data_as(C.c_void_p), mid.ctypes.data_as(C.c_void_p),
+                                   lo.ctypes.data_as(C.c_void_p)) == 0
+    for p in (hi, mid, lo):
+        assert (p.view(np.uint32) & 0xFFFF == 0).all()                      # a bf16 value each
+    assert ((hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64)) == x.astype(np.float64)).all()   # exact
+    assert ((hi + mid) + lo == x).all()                                      # and exact in float32 arithmetic too
+    # six of the nine product terms (those that reach 2^-16 of the product) against the exact product
+    y = rng.permutation(x)
+    yh, ym, yl = (np.empty_like(y) for _ in range(3))
+    lib.dll.ac_split_bf16x3(y.ctypes.data_as(C.c_void_p), y.size, yh.ctypes.data_as(C.c_void_p), ym.ctypes.data_as(C.c_void_p), yl.ctypes.data_as(C.c_void_p))
+    f = lambda a: a.astype(np.float64)
+    kept = f(hi) * f(yh) + f(hi) * f(ym) + f(mid) * f(yh) + f(hi) * f(yl) + f(lo) * f(yh) + f(mid) * f(ym)
+    exact = f(x) * f(y)
+    ok = np.isfinite(exact) & (np.abs(exact) > 1e-30) & (np.abs(exact) < 1e30)
+    rel = np.abs(kept - exact)[ok] / np.abs(exact)[ok]
+    assert rel.max() <= 2.0 ** -23 * 1.01, rel.max()   # dropped terms mid*lo, lo*mid, lo*lo: at most 2 * 2^-8 * 2^-16 of the product (one fp32 ulp) ...
+    assert np.median(rel) <= 2.0 ** -26                 # ... and typically a tenth of that
