@@ -1508,7 +1508,7 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
     ctl::Args a{h->d_ctlW, h->d_ctlWs, p.actions, p.obs, p.H, h->d_low, h->N, h->obs_dim, h->act_dim, h->act_low,
                 h->cfg.use_baseline, h->A, h->cfg.n_ego, h->cfg.use_artillery,
                 (float)h->cfg.agent_interaction_steps / (float)h->cfg.sim_freq, p.man_step, p.man_h0, p, h->dc, h->d_scripted};
-    if (h->cfg.use_baseline) {
+    if (h->cfg.use_baseline && h->ctl_fp32) {   // (controller_split_kernel computes the scripted opponents' inputs itself)
       hipLaunchKernelGGL(scripted_inputs_kernel, grid, block, 0, h->stream, a);
       HIP_OK(hipGetLastError());
     }

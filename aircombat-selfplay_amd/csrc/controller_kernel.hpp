@@ -144,45 +144,49 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __ex
 __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f); }
 }  // namespace ctl
 
-// Inputs of the scripted opponents (`use_baseline`): one lane per aircraft, enemy-team lanes only. Kept out of controller_kernel
-// so that the state -> pose code (fp64 geodesy) does not inflate the MFMA kernel's register allocation.
-__global__ __launch_bounds__(64) void scripted_inputs_kernel(ctl::Args a) {
+// Inputs of a scripted opponent (`use_baseline`; aircraft n of the enemy team): BaselineAgent.get_observation (baseline.py:45-63) on the
+// geometry of PursueAgent / ManeuverAgent. controller_split_kernel computes them while it stages its inputs; the fp32 form of the
+// controller keeps them in a kernel of their own (scripted_inputs_kernel) so that the state -> pose code (fp64 geodesy) does not
+// inflate its register allocation.
+namespace ctl {
+__device__ __forceinline__ void scripted_inputs(const Args& a, int n, float (&x)[12]) {
+  // (singlecombat_task.py:224-228, scenario1_task.py:41-49, scenario2_task.py:49-58)
+  Props pr; float psi;
+  aircraft_props(a.P, a.c, n, pr, psi);
+  float dv0, dv1, dv2;
+  if (a.use_baseline == 2) {   // ManeuverAgent('triangle').set_delta_value (baseline.py:137-155)
+    int st = a.man_step[n];
+    float h0 = (st == 0) ? psi : a.man_h0[n];
+    int i = 0;
+    for (i = 0; i < 300; ++i) if ((float)st <= (float)(i + 1) * 30.0f / a.time_interval) break;
+    i = min(i, 299) % 3;
+    dv1 = h0 + (i == 0 ? 1.0471975511965976f : (i == 1 ? 3.14159265358979f : -1.0471975511965976f)) - psi;
+    dv0 = 6000.0f - pr.alt_m; dv2 = 243.0f - pr.ub;
+    a.man_step[n] = st + 1; a.man_h0[n] = h0;
+  } else {                      // PursueAgent.set_delta_value(env, task, k) (baseline.py:85-104): chase aircraft k of the list
+    Props pt; float psit;
+    aircraft_props(a.P, a.c, n - a.n_ego, pt, psit);
+    dv0 = pt.u - pr.u;
+    const float ev = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve), dx = pt.n - pr.n, dy = pt.e - pr.e;
+    const float R = sqrtf(dx * dx + dy * dy);
+    const float ao = acosf(clampf(-1.0f, (dx * pr.vn + dy * pr.ve) / (R * ev + 1e-8f), 1.0f));
+    const float cr = pr.vn * dy - pr.ve * dx;
+    dv1 = ao * (float)((cr > 0.0f) - (cr < 0.0f));
+    dv2 = pt.ub - pr.ub;
+  }
+  // BaselineAgent.get_observation (baseline.py:45-63)
+  x[0] = dv0 / 1000.0f; x[1] = in_range_rad_f(dv1); x[2] = dv2 / 340.0f; x[3] = pr.alt_m / 5000.0f;
+  x[4] = pr.sphi; x[5] = pr.cphi; x[6] = pr.stht; x[7] = pr.ctht;
+  x[8] = pr.ub / 340.0f; x[9] = pr.vb / 340.0f; x[10] = pr.wb / 340.0f; x[11] = pr.vc / 340.0f;
+}
+}  // namespace ctl
+__global__ __launch_bounds__(64) void scripted_inputs_kernel(ctl::Args a) {   // one lane per aircraft, enemy-team lanes only
   using namespace ctl;
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= a.N) return;
-  const int slot = n % a.A;
-  if (slot < a.n_ego) return;
+  if (n % a.A < a.n_ego) return;
   float x[12];
-  {
-    // (singlecombat_task.py:224-228, scenario1_task.py:41-49, scenario2_task.py:49-58)
-    Props pr; float psi;
-    aircraft_props(a.P, a.c, n, pr, psi);
-    float dv0, dv1, dv2;
-    if (a.use_baseline == 2) {   // ManeuverAgent('triangle').set_delta_value (baseline.py:137-155)
-      int st = a.man_step[n];
-      float h0 = (st == 0) ? psi : a.man_h0[n];
-      int i = 0;
-      for (i = 0; i < 300; ++i) if ((float)st <= (float)(i + 1) * 30.0f / a.time_interval) break;
-      i = min(i, 299) % 3;
-      dv1 = h0 + (i == 0 ? 1.0471975511965976f : (i == 1 ? 3.14159265358979f : -1.0471975511965976f)) - psi;
-      dv0 = 6000.0f - pr.alt_m; dv2 = 243.0f - pr.ub;
-      a.man_step[n] = st + 1; a.man_h0[n] = h0;
-    } else {                      // PursueAgent.set_delta_value(env, task, k) (baseline.py:85-104): chase aircraft k of the list
-      Props pt; float psit;
-      aircraft_props(a.P, a.c, n - a.n_ego, pt, psit);
-      dv0 = pt.u - pr.u;
-      const float ev = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve), dx = pt.n - pr.n, dy = pt.e - pr.e;
-      const float R = sqrtf(dx * dx + dy * dy);
-      const float ao = acosf(clampf(-1.0f, (dx * pr.vn + dy * pr.ve) / (R * ev + 1e-8f), 1.0f));
-      const float cr = pr.vn * dy - pr.ve * dx;
-      dv1 = ao * (float)((cr > 0.0f) - (cr < 0.0f));
-      dv2 = pt.ub - pr.ub;
-    }
-    // BaselineAgent.get_observation (baseline.py:45-63)
-    x[0] = dv0 / 1000.0f; x[1] = in_range_rad_f(dv1); x[2] = dv2 / 340.0f; x[3] = pr.alt_m / 5000.0f;
-    x[4] = pr.sphi; x[5] = pr.cphi; x[6] = pr.stht; x[7] = pr.ctht;
-    x[8] = pr.ub / 340.0f; x[9] = pr.vb / 340.0f; x[10] = pr.wb / 340.0f; x[11] = pr.vc / 340.0f;
-  }
+  scripted_inputs(a, n, x);
   for (int k = 0; k < 12; ++k) a.scripted[(size_t)n * 12 + k] = x[k];
 }
 

@@ -221,9 +221,11 @@ __global__ __launch_bounds__(256) void controller_split_kernel(ctl::Args a) {
     const float* ob = a.obs + (size_t)sn * a.obs_dim;
     const int slot = sn % a.A;
     if (a.use_baseline && slot >= a.n_ego) {
-      // the enemy team is flown by BaselineAgent k: its 12 inputs were prepared by scripted_inputs_kernel
+      // the enemy team is flown by BaselineAgent k: its 12 inputs come from the geometry (no action row is read for it)
+      float xs[12];
+      ctl::scripted_inputs(a, sn, xs);
 #pragma unroll
-      for (int k = 0; k < 12; ++k) x[k] = a.scripted[(size_t)sn * 12 + k];
+      for (int k = 0; k < 12; ++k) x[k] = xs[k];
     } else {
       const int c0 = (int)hi[0], c1 = (int)hi[1], c2 = (int)hi[2];
       // singlecombat_task.py:217-219, 235-241: below 3500 m the altitude choice is overridden by "climb"
