@@ -796,8 +796,37 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
     tc.commit(lds_tab);
   }
   AC_CLK(1);
-  if (SPLIT) {   // helper waves: run their part of every substep, done (the systems wave decodes the commands it integrates)
-    if (split_helper_wave(s, t, T, L, l, c.substeps, &a4)) return;
+  // Three-wave form: after the last tick the kinematics wave stays and builds the observation rows from the pose the dynamics wave
+  // posts (two more barriers between those two waves), while the dynamics wave runs terminations, rewards and the state stores.
+  constexpr bool OBS_BY_KIN = SPLIT && TASK == AC_TASK_SINGLECOMBAT;
+  if (SPLIT) {   // helper waves: run their part of every substep (the systems wave decodes the commands it integrates)
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (split_helper_wave(s, t, T, L, l, c.substeps, &a4)) {
+      if (OBS_BY_KIN && role == 2) {
+        using namespace mail;
+        wg_sync();                                   // the dynamics wave has posted the final pose
+        Props q;
+        q.alt_m = L.M[T_PR][l]; q.sphi = L.M[T_PR + 1][l]; q.cphi = L.M[T_PR + 2][l]; q.stht = L.M[T_PR + 3][l]; q.ctht = L.M[T_PR + 4][l];
+        q.ub = L.M[T_PR + 5][l]; q.vb = L.M[T_PR + 6][l]; q.wb = L.M[T_PR + 7][l]; q.vc = L.M[T_PR + 8][l];
+        q.n = L.M[T_PR + 9][l]; q.e = L.M[T_PR + 10][l]; q.u = L.M[T_PR + 11][l];
+        q.vn = L.M[T_PR + 12][l]; q.ve = L.M[T_PR + 13][l]; q.vd = L.M[T_PR + 14][l];
+        const Enemy Eq = exchange_1v1(q);
+        const Incoming none{false, 0, 0, 0, 0, 0, 0};
+        float obq[OBS];
+        observe_1v1<TASK>(q, Eq, none, obq);
+        wg_sync();                                   // ... and whether the env ends its episode: then the template's observation goes out
+        if (L.M[T_DONE][l] != 0.0f) {
+          const float* tobs = (const float*)(P.tF + (size_t)NF * 2) + slot * OBS;
+#pragma unroll
+          for (int k = 0; k < OBS; ++k) obq[k] = tobs[k];
+        }
+        float* row = lds_out + l * OBS;
+#pragma unroll
+        for (int k = 0; k < OBS; ++k) row[k] = obq[k];
+        emit_obs_rows(P, lds_out, OBS, l);
+      }
+      return;
+    }
   }
   Msl ms[MSLOTS];
   int nslots = 0, msl_was_active = 0;
@@ -894,6 +923,14 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
     make_props(s, d, c, pr);
   }
   AC_CLK(52);
+  if (OBS_BY_KIN) {
+    using namespace mail;
+    L.M[T_PR][l] = pr.alt_m; L.M[T_PR + 1][l] = pr.sphi; L.M[T_PR + 2][l] = pr.cphi; L.M[T_PR + 3][l] = pr.stht; L.M[T_PR + 4][l] = pr.ctht;
+    L.M[T_PR + 5][l] = pr.ub; L.M[T_PR + 6][l] = pr.vb; L.M[T_PR + 7][l] = pr.wb; L.M[T_PR + 8][l] = pr.vc;
+    L.M[T_PR + 9][l] = pr.n; L.M[T_PR + 10][l] = pr.e; L.M[T_PR + 11][l] = pr.u;
+    L.M[T_PR + 12][l] = pr.vn; L.M[T_PR + 13][l] = pr.ve; L.M[T_PR + 14][l] = pr.vd;
+    wg_sync();                                       // the kinematics wave builds the observation from here
+  }
   Enemy E = exchange_1v1(pr);
 
   // ---- task.step
@@ -970,7 +1007,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
     inc.vx = __shfl_xor(a3, 1); inc.vy = __shfl_xor(a4, 1); inc.vz = __shfl_xor(a5, 1);
   }
   float ob[OBS];
-  observe_1v1<TASK>(pr, E, inc, ob);
+  if (!OBS_BY_KIN) observe_1v1<TASK>(pr, E, inc, ob);
   AC_CLK(58);
 
   // ---- terminations (singlecombat_task.py:34-40; first condition that fires wins, task_base.py:88-112).
@@ -1004,7 +1041,10 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
   const int other_done = __shfl_xor((int)done, 1);   // fetched outside the && (a short-circuited shuffle would read a masked-off lane)
   const bool all_done = done && (bool)other_done;
   const int other_code = __shfl_xor(code, 1);
-  if (all_done) {
+  if (OBS_BY_KIN) {
+    L.M[mail::T_DONE][l] = all_done ? 1.0f : 0.0f;
+    wg_sync();                                       // the kinematics wave sends the rows (the template's if the episode ends)
+  } else if (all_done) {
     const float* tobs = (const float*)(P.tF + (size_t)NF * 2) + slot * OBS;  // template observation follows the template fields
 #pragma unroll
     for (int k = 0; k < OBS; ++k) ob[k] = tobs[k];
@@ -1089,7 +1129,8 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
   // info['done_condition'] keeps the last agent's message
   // (sending the observation rows ahead of the rewards and the state stores was tried for the host-boundary path, where their trip
   // across PCIe is what the step waits for in the end: 0.5 us slower, not faster)
-  emit_outputs(P, lds_out, OBS, l, ob, reward, done, 2, step_out, other_code ? other_code : code, 0, all_done ? 1 : 0);
+  if (OBS_BY_KIN) emit_scalars(P, l, reward, done, 2, step_out, other_code ? other_code : code, 0, all_done ? 1 : 0);
+  else emit_outputs(P, lds_out, OBS, l, ob, reward, done, 2, step_out, other_code ? other_code : code, 0, all_done ? 1 : 0);
   AC_CLK(54);
 }
 

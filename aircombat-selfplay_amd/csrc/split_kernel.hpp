@@ -30,7 +30,9 @@ enum { RUNF,                                                       // dynamics -
        G_Q = K_OUT + K_OUT_N,                                       // kinematics -> dynamics: quaternion of tick k in rows G_Q + 4 (k & 1) ..
        G_H = G_Q + 8, G_NED = G_H + 1,                              // ... and, from the step's last substep, the env-layer frame
        QP_F = G_NED + 8, QP_F_N = 9,                                // quad form with reduced poses: altitude [m] and the local frame of tick k in rows QP_F + 9 (k & 1) ..
-       ROWS = QP_F + 2 * QP_F_N };
+       T_PR = QP_F + 2 * QP_F_N, T_PR_N = 15,                       // three-wave SingleCombat: dynamics -> kinematics after the last tick, the pose
+       T_DONE = T_PR + T_PR_N,                                      //   the observation is built from, and whether the env ends its episode
+       ROWS = T_DONE + 1 };
 // fp64 rows: ECI position of tick k in rows GD_R + 3 (k & 1) .. (double-buffered: the kinematics wave is one tick ahead), ECEF
 // position and geodetic cosines of the step's last substep
 // (quad form with reduced poses: the NEU position of tick k in rows GD_QP + 3 (k & 1) ..)
@@ -215,7 +217,7 @@ template <bool QUAD = false, bool POSE = false>
 __device__ __forceinline__ bool split_helper_wave(f16::State& s, Task& t, const f16::Tab& T, SplitLds& L, int l, int substeps, const float4* raw = nullptr,
                                                   const DevCfg* cfg = nullptr) {
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (role == 2) { kinematics_wave<QUAD, POSE>(s, t, T, L.M, L.MD, l, substeps, cfg); return true; }
+  if (role == 2) { kinematics_wave<QUAD, POSE>(s, t, T, L.M, L.MD, l, substeps, cfg); return true; }   // (a caller with work left for this wave tests the role itself)
   if (role == 1) { systems_wave(s, t, T, L.M, l, substeps, raw); return true; }
   return false;
 }
