@@ -39,6 +39,24 @@ __global__ void k_coalesced(const float4* act, float* obs, float* rew, unsigned 
       ((b >> (4 * threadIdx.x)) & 1) | (((b >> (4 * threadIdx.x + 1)) & 1) << 8) | (((b >> (4 * threadIdx.x + 2)) & 1) << 16) | (((b >> (4 * threadIdx.x + 3)) & 1) << 24);
 }
 
+// the same with non-temporal stores (do they leave the GPU as larger PCIe writes?)
+__global__ void k_coalesced_nt(const float4* act, float* obs, float* rew, unsigned char* done, int iters) {
+  __shared__ float L[64 * OBS];
+  int n = blockIdx.x * 64 + threadIdx.x;
+  float4 a = act[n];
+  float x = a.x + a.y + a.z + a.w;
+  x = spin(x, iters);
+  for (int k = 0; k < OBS; ++k) L[threadIdx.x * OBS + k] = x + k;
+  __syncthreads();
+  typedef float fx4 __attribute__((ext_vector_type(4)));
+  fx4* o4 = reinterpret_cast<fx4*>(obs + (size_t)blockIdx.x * 64 * OBS);
+  const fx4* l4 = reinterpret_cast<const fx4*>(L);
+  for (int i = threadIdx.x; i < 64 * OBS / 4; i += 64) __builtin_nontemporal_store(l4[i], &o4[i]);
+  __builtin_nontemporal_store(x, &rew[n]);
+  unsigned long long b = __ballot(x > 1e30f);
+  if (threadIdx.x < 16) reinterpret_cast<unsigned*>(done + blockIdx.x * 64)[threadIdx.x] = (unsigned)((b >> (4 * threadIdx.x)) & 1);
+}
+
 // completion flag in mapped host memory: every workgroup fences its output stores at system scope and bumps a device counter; the last one
 // to arrive writes the launch's sequence number where the host is polling
 __global__ void k_flag(const float4* act, float* obs, float* rew, unsigned char* done, int iters, unsigned* counter, volatile unsigned* flag, unsigned seq) {
@@ -115,6 +133,9 @@ int main(int argc, char** argv) {
       t0 = now();
       for (int r = 0; r < R; ++r) { hipLaunchKernelGGL(k_coalesced, dim3(N / 64), dim3(64), 0, s, (const float4*)d_act, m_obs, m_rew, m_done, iters); wait(); }
       printf("%-24s actions from device, outputs to host    %7.1f us/step\n", wn, (now() - t0) / R * 1e6);
+      t0 = now();
+      for (int r = 0; r < R; ++r) { hipLaunchKernelGGL(k_coalesced_nt, dim3(N / 64), dim3(64), 0, s, (const float4*)d_act, m_obs, m_rew, m_done, iters); wait(); }
+      printf("%-24s the same, non-temporal stores           %7.1f us/step\n", wn, (now() - t0) / R * 1e6);
       // (d) one packed D2H after the kernel
       t0 = now();
       for (int r = 0; r < R; ++r) {
