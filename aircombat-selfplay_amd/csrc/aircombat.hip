@@ -1555,7 +1555,8 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
     }
     // the bf16-piece form (controller_split_kernel.hpp) unless the handle was created under AIRCOMBAT_CTL=fp32 (the fp32 matrix instructions)
     if (h->ctl_fp32) hipLaunchKernelGGL(controller_kernel, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
-    else hipLaunchKernelGGL(controller_split_kernel, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
+    else if (h->cfg.use_baseline) hipLaunchKernelGGL(controller_split_kernel<true>, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL(controller_split_kernel<false>, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
     HIP_OK(hipGetLastError());
     p.actions = h->d_low;
   }

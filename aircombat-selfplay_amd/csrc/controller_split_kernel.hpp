@@ -60,15 +60,26 @@ __host__ __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned&
   hi = hb >> 16; mid = mb >> 16; lo = r2b >> 16;
 #endif
 }
+// Two values at once on the device: v_cvt_pk_bf16_f32 rounds a pair to nearest-even and packs it (the same rounding as bf16_rne_bits
+// for every value the network produces).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  const floatx2 f = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = pack_bf16x2(a, b);
+  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xFFFF0000u);
+  mid = pack_bf16x2(ra, rb);
+  const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xFFFF0000u);
+  lo = pack_bf16x2(sa, sb);   // (exact: at most 8 significant bits are left)
+}
 // 16 consecutive features of one aircraft -> the three planes (two 16-byte LDS stores per plane)
 __device__ __forceinline__ void write_planes(unsigned short* planes, int row, int k0, const float (&v)[16]) {
   unsigned h[8], m[8], l[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    unsigned h0, m0, l0, h1, m1, l1;
-    split3(v[2 * q], h0, m0, l0); split3(v[2 * q + 1], h1, m1, l1);
-    h[q] = h0 | (h1 << 16); m[q] = m0 | (m1 << 16); l[q] = l0 | (l1 << 16);
-  }
+  for (int q = 0; q < 8; ++q) split3_pair(v[2 * q], v[2 * q + 1], h[q], m[q], l[q]);
   uint4* ph = reinterpret_cast<uint4*>(planes + 0 * PLANE + row * KS + k0);
   uint4* pm = reinterpret_cast<uint4*>(planes + 1 * PLANE + row * KS + k0);
   uint4* pl = reinterpret_cast<uint4*>(planes + 2 * PLANE + row * KS + k0);
@@ -78,11 +89,11 @@ __device__ __forceinline__ void write_planes(unsigned short* planes, int row, in
 }
 // four consecutive features of one aircraft -> the three planes (one 8-byte LDS store per plane)
 __device__ __forceinline__ void write_planes4(unsigned short* planes, int row, int k0, const float4& v) {
-  unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
-  split3(v.x, h0, m0, l0); split3(v.y, h1, m1, l1); split3(v.z, h2, m2, l2); split3(v.w, h3, m3, l3);
-  *reinterpret_cast<uint2*>(planes + 0 * PLANE + row * KS + k0) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-  *reinterpret_cast<uint2*>(planes + 1 * PLANE + row * KS + k0) = make_uint2(m0 | (m1 << 16), m2 | (m3 << 16));
-  *reinterpret_cast<uint2*>(planes + 2 * PLANE + row * KS + k0) = make_uint2(l0 | (l1 << 16), l2 | (l3 << 16));
+  unsigned h0, m0, l0, h1, m1, l1;
+  split3_pair(v.x, v.y, h0, m0, l0); split3_pair(v.z, v.w, h1, m1, l1);
+  *reinterpret_cast<uint2*>(planes + 0 * PLANE + row * KS + k0) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(planes + 1 * PLANE + row * KS + k0) = make_uint2(m0, m1);
+  *reinterpret_cast<uint2*>(planes + 2 * PLANE + row * KS + k0) = make_uint2(l0, l1);
 }
 // A operands of one layer for this lane: piece p, chunk g = planes[p][row = lane % 32][k = 16 g + 8 (lane / 32) .. + 7]
 template <int K>
@@ -192,6 +203,8 @@ __device__ __forceinline__ void layer_norm_planes(const float* buf, unsigned sho
 }
 }  // namespace ctls
 
+// SCRIPTED: the handle has scripted opponents (`use_baseline`); their state -> pose code is compiled into that instantiation only.
+template <bool SCRIPTED>
 __global__ __launch_bounds__(256) void controller_split_kernel(ctl::Args a) {
   using namespace ctls;
   using ctl::sigmoid_f; using ctl::tanh_f;
@@ -220,7 +233,7 @@ __global__ __launch_bounds__(256) void controller_split_kernel(ctl::Args a) {
     const float* hi = a.hi + (size_t)sn * a.act_hi;
     const float* ob = a.obs + (size_t)sn * a.obs_dim;
     const int slot = sn % a.A;
-    if (a.use_baseline && slot >= a.n_ego) {
+    if (SCRIPTED && a.use_baseline && slot >= a.n_ego) {
       // the enemy team is flown by BaselineAgent k: its 12 inputs come from the geometry (no action row is read for it)
       float xs[12];
       ctl::scripted_inputs(a, sn, xs);

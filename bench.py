@@ -300,9 +300,17 @@ def main():
     # ---- setup, not part of W or K: bring the device to its running clocks (a run as short as the driver's --steps 20 --warmup 5 is
     # over in a millisecond, before the power state has followed), then put every env back to its initial state
     SETUP_STEPS = 0 if args.stub_env else 300
+    dev = None
+    if not args.stub_env:
+        dev = [torch.from_numpy(a).cuda(local_rank) for a in pool]
+        torch.cuda.synchronize()
     for i in range(SETUP_STEPS):
-        env.step(pool[i % len(pool)])
+        if args.device_only:   # (profiling runs: every launch of the process is a device-resident one)
+            env.step_device(dev[i % len(dev)].data_ptr())
+        else:
+            env.step(pool[i % len(pool)])
     if SETUP_STEPS:
+        env.sync()
         env.reset()
 
     # ---- headline: VecEnv.step(numpy) at the Python boundary; W untimed, then exactly K timed steps between barriers
@@ -318,8 +326,6 @@ def main():
             dist.destroy_process_group()
         return
     if not args.stub_env:
-        dev = [torch.from_numpy(a).cuda(local_rank) for a in pool]
-        torch.cuda.synchronize()
         sync_all()
         dev_wall, kernel_ms = device_leg(env, [t.data_ptr() for t in dev], args.steps, args.warmup)
         sync_all()
