@@ -1273,22 +1273,23 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
   bool done = false;
   int code = AC_DONE_NONE;
   int last_code = AC_DONE_NONE;
-  int st[A];
-#pragma unroll
-  for (int j = 0; j < A; ++j) st[j] = __shfl(t.status, base_lane + j);
   float np_max = fmaxf(fabsf(s.npx), fmaxf(fabsf(s.npy), fabsf(s.npz)));
   float pqr = sqrtf(d.p * d.p + d.q * d.q + d.r * d.r);
   const bool extreme = (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);
   const bool overload = (s.ticks >= kTickOverload) &&
                         (fabsf(s.npx) > c.acc_x || fabsf(s.npy) > c.acc_y || fabsf(s.npz + 1.0f) > c.acc_z);
   const bool low = pr.alt_m <= c.altitude_limit;
+  // (the statuses travel as one ballot per round -- to the others a status only matters as "alive or not" -- instead of two
+  // cross-lane fetches per round whose latency the walk serialises)
+  const unsigned long long env_mask = ((A == 64) ? ~0ull : ((1ull << A) - 1ull)) << base_lane;
+  unsigned long long enemy_lanes = 0;
+#pragma unroll
+  for (int j = 0; j < A; ++j) if ((j < c.n_ego ? 0 : 1) != team) enemy_lanes |= 1ull << (base_lane + j);
+  unsigned long long alive = __ballot(t.status == AC_ALIVE);
 #pragma unroll
   for (int i = 0; i < A; ++i) {
     if (slot == i) {
-      bool enemies_dead = true;
-#pragma unroll
-      for (int j = 0; j < A; ++j)
-        if ((j < c.n_ego ? 0 : 1) != team && st[j] == AC_ALIVE) enemies_dead = false;
+      const bool enemies_dead = (alive & enemy_lanes) == 0;
       if (t.status == AC_SHOTDOWN) { code = AC_DONE_SHOTDOWN; done = true; }
       else if (t.status == AC_CRASH) { code = AC_DONE_CRASHED; done = true; }
       else if (enemies_dead) { code = AC_DONE_MISSION_COMPLETE; done = true; }   // no missiles in this task
@@ -1297,11 +1298,12 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
       else if (low) { t.status = AC_CRASH; code = AC_DONE_LOW_ALTITUDE; done = true; }
       else if (t.cur_step >= c.max_steps) { code = AC_DONE_TIMEOUT; done = true; }
     }
-    int si = __shfl(t.status, base_lane + i);
-    int ci = __shfl(code, base_lane + i);
-#pragma unroll
-    for (int j = 0; j < A; ++j) if (j == i) st[j] = si;
-    if (ci) last_code = ci;
+    alive = __ballot(t.status == AC_ALIVE);
+  }
+  {   // info['done_condition'] keeps the message of the last agent (in env order) that has one
+    const unsigned long long coded = __ballot(code != AC_DONE_NONE) & env_mask;
+    const int last = coded ? 63 - __clzll((long long)coded) : l;
+    last_code = __shfl(code, last);
   }
   bool all_done = true;
 #pragma unroll
