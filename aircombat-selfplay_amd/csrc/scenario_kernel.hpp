@@ -634,36 +634,52 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   }
   AC_CLKE(71);
   float own = 0.0f;
-  // MissilePostureReward's single shared `previous_missile_v` (missile_posture_reward.py:18-46) is walked agent by agent
+  // MissilePostureReward's single shared `previous_missile_v` (missile_posture_reward.py:18-46) is walked agent by agent: an evaluating
+  // agent WITHOUT an incoming missile clears the remembered missile, one WITH a missile sets it if it is clear and then scores against
+  // it. In closed form: the remembered missile at agent i's turn is the incoming missile of the first missile-holding evaluator after
+  // the last clearing evaluator before i (or the one carried over from the previous step if nobody cleared it yet) -- two ballots and
+  // one fetch instead of A rounds of dependent cross-lane fetches.
   float r_mp = 0.0f;
   {
     float sp[MS];
 #pragma unroll
     for (int k = 0; k < MS; ++k) sp[k] = (float)sqrt(ms[k].vx * ms[k].vx + ms[k].vy * ms[k].vy + ms[k].vz * ms[k].vz);
-    int prev = x.mp_prev;   // identical in every lane of the env
+    const bool holds = evaluates && inc_id != 0;
+    const unsigned long long EV = __ballot(evaluates) & env_mask;
+    const unsigned long long HM = __ballot(holds) & env_mask;          // evaluators with an incoming missile
+    const unsigned long long NM = EV & ~HM;                            // evaluators without: they clear
+    auto after = [](int p) { return p < 0 ? ~0ull : (p >= 63 ? 0ull : ~((2ull << p) - 1ull)); };   // lanes above p (p = -1 .. 63)
+    auto remembered_at = [&](int upto) {   // lane whose incoming missile is remembered when the walk reaches lane `upto` (exclusive of later lanes); -1: carried over
+      const unsigned long long clr = NM & ~after(upto - 1);            // clearing evaluators before `upto`
+      const int last_clr = clr ? 63 - __clzll((long long)clr) : base - 1;
+      const unsigned long long run = HM & after(last_clr) & ~after(upto);   // holders after the last clearing one, up to and including `upto`
+      if (!clr && x.mp_prev != 0) return -1;
+      return run ? (int)__ffsll((long long)run) - 1 : -2;               // -2: nothing remembered
+    };
+    const int src = remembered_at(lane);                                // (a holder finds at least itself)
+    const int src_id = __shfl(inc_id, src >= 0 ? src : lane);
+    const int prev_mine = (src == -1) ? x.mp_prev : (src >= 0 ? src_id : 0);
+    // speeds of the remembered missile and of my incoming missile (the owner lane holds both of its slots' speeds)
+    const int pid = holds ? prev_mine : 1, cid = holds ? inc_id : 1;
+    float v_prev = 0.0f, v_cur = 0.0f;
 #pragma unroll
-    for (int i = 0; i < A; ++i) {
-      int ev_i = __shfl((int)evaluates, base + i), id_i = __shfl(inc_id, base + i);
-      if (!ev_i) continue;
-      if (id_i) {
-        if (!prev) prev = id_i;
-        // speeds of the remembered missile and of agent i's incoming missile
-        float v_prev = 0.0f, v_cur = 0.0f;
-#pragma unroll
-        for (int k = 0; k < MS; ++k) {
-          float a = __shfl(sp[k], base + ((prev - 1) / MS)), b = __shfl(sp[k], base + ((id_i - 1) / MS));
-          if (k == (prev - 1) % MS) v_prev = a;
-          if (k == (id_i - 1) % MS) v_cur = b;
-        }
-        if (slot == i) {
-          float v_dec = (v_prev - v_cur) / 340.0f * c.missile_posture_scale;
-          float va = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve + pr.vd * pr.vd);
-          float ang = (inc.vx * pr.vn + inc.vy * pr.ve + inc.vz * pr.vd) / (v_cur * va);
-          r_mp = (ang < 0.0f) ? ang / (fmaxf(v_dec, 0.0f) + 1.0f) : ang * fmaxf(v_dec, 0.0f);
-        }
-      } else prev = 0;
+    for (int k = 0; k < MS; ++k) {
+      const float a = __shfl(sp[k], base + ((pid - 1) / MS)), b = __shfl(sp[k], base + ((cid - 1) / MS));
+      if (k == (pid - 1) % MS) v_prev = a;
+      if (k == (cid - 1) % MS) v_cur = b;
     }
-    x.mp_prev = prev;
+    if (holds) {
+      float v_dec = (v_prev - v_cur) / 340.0f * c.missile_posture_scale;
+      float va = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve + pr.vd * pr.vd);
+      float ang = (inc.vx * pr.vn + inc.vy * pr.ve + inc.vz * pr.vd) / (v_cur * va);
+      r_mp = (ang < 0.0f) ? ang / (fmaxf(v_dec, 0.0f) + 1.0f) : ang * fmaxf(v_dec, 0.0f);
+    }
+    // what the env remembers after its last evaluator (identical in every lane of the env)
+    if (EV) {
+      const int last_ev = 63 - __clzll((long long)EV);
+      const int carried = __shfl(prev_mine, last_ev);                   // (meaningful when that lane holds a missile)
+      x.mp_prev = ((HM >> last_ev) & 1ull) ? carried : 0;
+    }
   }
   AC_CLKE(72);
   if (evaluates) {
