@@ -2178,6 +2178,23 @@ int ac_split_bf16x3(const float* x, int64_t n, float* hi, float* mid, float* lo)
   }
   return 0;
 }
+int ac_selftest_missile_walk(int32_t device_id, int32_t* mismatches) {
+  if (!mismatches) return fail("ac_selftest_missile_walk: null argument");
+  HIP_OK(hipSetDevice(device_id));
+  int* d = nullptr;
+  HIP_OK(hipMalloc(&d, 2 * sizeof(int)));
+  HIP_OK(hipMemset(d, 0, 2 * sizeof(int)));
+  const unsigned long long c4 = 2ull << (2 * 4), c8 = 2ull << (2 * 8);   // 4^A agent-state combinations x (carried-in missile or not)
+  hipLaunchKernelGGL(mp_walk_selftest_kernel<4>, dim3((unsigned)((c4 + 15) / 16)), dim3(64), 0, 0, d, c4);
+  hipLaunchKernelGGL(mp_walk_selftest_kernel<8>, dim3((unsigned)((c8 + 7) / 8)), dim3(64), 0, 0, d, c8);
+  HIP_OK(hipGetLastError());
+  int out[2] = {-1, 0};
+  HIP_OK(hipMemcpy(out, d, sizeof out, hipMemcpyDeviceToHost));
+  HIP_OK(hipFree(d));
+  if (out[1] < 100000) return fail("ac_selftest_missile_walk: the sweep did not reach the cases it is there for");   // (an agent scoring against another agent's missile)
+  *mismatches = out[0];
+  return 0;
+}
 int ac_get_controller_state(ac_env_t* h, int32_t env, int32_t agent, float* hidden, float* low_action) {
   if (check_idx(h, env, agent)) return fail("ac_get_controller_state: bad argument");
   if (!h->cfg.hierarchical) return fail("ac_get_controller_state: not a hierarchical handle");

@@ -89,6 +89,69 @@ struct EnemyGeo { float AO, TA, R, cAO, cTA; };
 // FORM_QUAD = the three waves of FORM_SPLIT flying the ticks under the environment wave of FORM_PAIR (pair_kernel.hpp, "the quad form"),
 // up to one workgroup per CU: the environment wave spreads a substep's munition work over the tick's three barrier gaps.
 enum { FORM_ONE = 0, FORM_SPLIT = 1, FORM_PAIR = 2, FORM_QUAD = 3 };
+// MissilePostureReward's single shared `previous_missile_v` (missile_posture_reward.py:18-46) is walked agent by agent in env order: an
+// evaluating agent WITHOUT an incoming missile clears the remembered missile id, one WITH a missile sets it if it is clear and then
+// scores against it; agents that do not evaluate are skipped. `prev_mine` = the remembered id at this lane's turn (meaningful for an
+// evaluating lane with a missile), `prev_out` = what the env remembers after its last agent (identical in every lane of the env).
+struct MpWalk { int prev_mine, prev_out; };
+// the walk as the reference makes it, round by round (the self-test's yardstick: ac_selftest)
+template <int A>
+__device__ __forceinline__ MpWalk mp_walk_sequential(bool evaluates, int inc_id, int mp_prev, int slot, int base) {
+  int prev = mp_prev, mine = 0;
+#pragma unroll
+  for (int i = 0; i < A; ++i) {
+    const int ev_i = __shfl((int)evaluates, base + i), id_i = __shfl(inc_id, base + i);
+    if (!ev_i) continue;
+    if (id_i) {
+      if (!prev) prev = id_i;
+      if (slot == i) mine = prev;
+    } else prev = 0;
+  }
+  return MpWalk{mine, prev};
+}
+// the same in closed form: the remembered missile at agent i's turn is the incoming missile of the first missile-holding evaluator after
+// the last clearing evaluator before i (or the one carried over from the previous step if nobody has cleared it yet) -- two ballots
+// and two fetches instead of A rounds of dependent cross-lane fetches
+__device__ __forceinline__ MpWalk mp_walk_closed(bool evaluates, int inc_id, int mp_prev, int lane, int base, unsigned long long env_mask) {
+  const bool holds = evaluates && inc_id != 0;
+  const unsigned long long EV = __ballot(evaluates) & env_mask;
+  const unsigned long long HM = __ballot(holds) & env_mask;          // evaluators with an incoming missile
+  const unsigned long long NM = EV & ~HM;                            // evaluators without: they clear
+  auto after = [](int p) { return p < 0 ? ~0ull : (p >= 63 ? 0ull : ~((2ull << p) - 1ull)); };   // lanes above p (p = -1 .. 63)
+  const unsigned long long clr = NM & ~after(lane - 1);              // clearing evaluators before me
+  const int last_clr = clr ? 63 - __clzll((long long)clr) : base - 1;
+  const unsigned long long run = HM & after(last_clr) & ~after(lane);   // holders after the last clearing one, up to and including me
+  const int src = (!clr && mp_prev != 0) ? -1 : (run ? (int)__ffsll((long long)run) - 1 : -2);   // -1: carried over, -2: nothing remembered
+  const int src_id = __shfl(inc_id, src >= 0 ? src : lane);
+  MpWalk w;
+  w.prev_mine = (src == -1) ? mp_prev : (src >= 0 ? src_id : 0);
+  w.prev_out = mp_prev;
+  if (EV) {   // (env-uniform)
+    const int last_ev = 63 - __clzll((long long)EV);
+    const int carried = __shfl(w.prev_mine, last_ev);                // (meaningful when that lane holds a missile)
+    w.prev_out = ((HM >> last_ev) & 1ull) ? carried : 0;
+  }
+  return w;
+}
+// Every combination of (does not evaluate | evaluates without a missile | evaluates with missile id a | ... id b) over the A agents of an
+// env, with and without a remembered missile carried in: the closed form against the round-by-round walk. One env per A lanes.
+template <int A>
+__global__ void mp_walk_selftest_kernel(int* mismatches, unsigned long long combos) {
+  const int lane = threadIdx.x & 63, slot = lane % A, base = lane - slot;
+  const unsigned long long env = (unsigned long long)blockIdx.x * (64 / A) + lane / A;
+  const unsigned long long combo = env < combos ? env : 0;
+  const int st = (int)((combo >> (2 * slot)) & 3ull);
+  const int carry = (int)((combo >> (2 * A)) & 1ull) ? 3 : 0;
+  const bool evaluates = st != 0;
+  const int inc_id = st == 0 ? slot + 1 : (st == 1 ? 0 : (st == 2 ? slot + 1 : ((slot + 3) % (2 * A)) + 1));   // (a non-evaluating agent may well have a missile coming)
+  const unsigned long long env_mask = ((A == 64) ? ~0ull : ((1ull << A) - 1ull)) << base;
+  const MpWalk a = mp_walk_sequential<A>(evaluates, inc_id, carry, slot, base);
+  const MpWalk b = mp_walk_closed(evaluates, inc_id, carry, lane, base, env_mask);
+  const bool holds = evaluates && inc_id != 0;
+  if (env < combos && ((holds && a.prev_mine != b.prev_mine) || a.prev_out != b.prev_out)) atomicAdd(mismatches, 1);
+  if (env < combos && holds && a.prev_mine != 0 && a.prev_mine != inc_id) atomicAdd(mismatches + 1, 1);   // cases where the remembered missile is another agent's
+}
+
 // (cycle stamps of the wave that runs the environment layer: wave 3 in the quad form, wave 0 otherwise)
 #define AC_CLKE(i) AC_CLKW(QUAD ? 3 : 0, i)
 template <int A, int WPE, int FORM = FORM_ONE>
@@ -634,31 +697,15 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   }
   AC_CLKE(71);
   float own = 0.0f;
-  // MissilePostureReward's single shared `previous_missile_v` (missile_posture_reward.py:18-46) is walked agent by agent: an evaluating
-  // agent WITHOUT an incoming missile clears the remembered missile, one WITH a missile sets it if it is clear and then scores against
-  // it. In closed form: the remembered missile at agent i's turn is the incoming missile of the first missile-holding evaluator after
-  // the last clearing evaluator before i (or the one carried over from the previous step if nobody cleared it yet) -- two ballots and
-  // one fetch instead of A rounds of dependent cross-lane fetches.
+  // MissilePostureReward's shared remembered missile, in closed form (mp_walk_closed above)
   float r_mp = 0.0f;
   {
     float sp[MS];
 #pragma unroll
     for (int k = 0; k < MS; ++k) sp[k] = (float)sqrt(ms[k].vx * ms[k].vx + ms[k].vy * ms[k].vy + ms[k].vz * ms[k].vz);
     const bool holds = evaluates && inc_id != 0;
-    const unsigned long long EV = __ballot(evaluates) & env_mask;
-    const unsigned long long HM = __ballot(holds) & env_mask;          // evaluators with an incoming missile
-    const unsigned long long NM = EV & ~HM;                            // evaluators without: they clear
-    auto after = [](int p) { return p < 0 ? ~0ull : (p >= 63 ? 0ull : ~((2ull << p) - 1ull)); };   // lanes above p (p = -1 .. 63)
-    auto remembered_at = [&](int upto) {   // lane whose incoming missile is remembered when the walk reaches lane `upto` (exclusive of later lanes); -1: carried over
-      const unsigned long long clr = NM & ~after(upto - 1);            // clearing evaluators before `upto`
-      const int last_clr = clr ? 63 - __clzll((long long)clr) : base - 1;
-      const unsigned long long run = HM & after(last_clr) & ~after(upto);   // holders after the last clearing one, up to and including `upto`
-      if (!clr && x.mp_prev != 0) return -1;
-      return run ? (int)__ffsll((long long)run) - 1 : -2;               // -2: nothing remembered
-    };
-    const int src = remembered_at(lane);                                // (a holder finds at least itself)
-    const int src_id = __shfl(inc_id, src >= 0 ? src : lane);
-    const int prev_mine = (src == -1) ? x.mp_prev : (src >= 0 ? src_id : 0);
+    const MpWalk walk = mp_walk_closed(evaluates, inc_id, x.mp_prev, lane, base, env_mask);
+    const int prev_mine = walk.prev_mine;
     // speeds of the remembered missile and of my incoming missile (the owner lane holds both of its slots' speeds)
     const int pid = holds ? prev_mine : 1, cid = holds ? inc_id : 1;
     float v_prev = 0.0f, v_cur = 0.0f;
@@ -674,12 +721,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
       float ang = (inc.vx * pr.vn + inc.vy * pr.ve + inc.vz * pr.vd) / (v_cur * va);
       r_mp = (ang < 0.0f) ? ang / (fmaxf(v_dec, 0.0f) + 1.0f) : ang * fmaxf(v_dec, 0.0f);
     }
-    // what the env remembers after its last evaluator (identical in every lane of the env)
-    if (EV) {
-      const int last_ev = 63 - __clzll((long long)EV);
-      const int carried = __shfl(prev_mine, last_ev);                   // (meaningful when that lane holds a missile)
-      x.mp_prev = ((HM >> last_ev) & 1ull) ? carried : 0;
-    }
+    x.mp_prev = walk.prev_out;
   }
   AC_CLKE(72);
   if (evaluates) {

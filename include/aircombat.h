@@ -172,6 +172,10 @@ int ac_set_controller_state(ac_env_t* h, int32_t env, int32_t agent, const float
  * into three bf16 pieces, hi + mid + lo == x exactly, and the products run on the bf16 matrix path (controller_split_kernel.hpp). Writes
  * the three pieces of x[0..n) as float32 values (each with at most 8 significant bits). */
 int ac_split_bf16x3(const float* x, int64_t n, float* hi, float* mid, float* lo);
+/* Device self-test (needs the GPU, no handle): the closed form the NvN kernels use for MissilePostureReward's agent-by-agent walk over its
+ * shared remembered missile (missile_posture_reward.py:18-46) against the round-by-round walk, for every combination of agent states
+ * of a 2v2 and a 4v4 env. *mismatches receives the number of combinations that differ (0 = the two agree everywhere). */
+int ac_selftest_missile_walk(int32_t device_id, int32_t* mismatches);
 
 /* timing helper for the bench: average device milliseconds per step kernel over the last n ac_step* calls, measured
  * with HIP events on the handle's stream */

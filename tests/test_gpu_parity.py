@@ -973,3 +973,15 @@ def test_large_grid_kernel_variants_match_small_grid(pkg, task):
             assert (rb[-2][idx] == rs[-2][0]).all(), (step, idx)
             assert (np.abs(rb[-3][idx] - rs[-3][0]) <= 5e-2 + 1e-2 * np.abs(rs[-3][0])).all(), (step, idx)
     big.close(); small.close()
+
+
+def test_missile_posture_walk_closed_form_equals_the_round_by_round_walk(pkg):
+    """MissilePostureReward keeps ONE remembered missile for the whole env and the reference walks the agents one by one over it
+    (missile_posture_reward.py:18-46). The NvN kernels use a closed form over two ballots; the library checks it on the device against
+    the round-by-round walk for every combination of agent states (not evaluating / evaluating without / with one of two missile ids)
+    of a 2v2 and a 4v4 env, with and without a missile carried in from the step before: 512 + 131 072 combinations."""
+    import ctypes as C
+    lib = pkg.load_library()
+    bad = C.c_int32(-1)
+    lib.check(lib.dll.ac_selftest_missile_walk(0, C.byref(bad)), "ac_selftest_missile_walk")
+    assert bad.value == 0
