@@ -82,6 +82,14 @@ struct ScenarioDims {
 
 // Relative-geometry quantities of every reward term towards the enemies of this lane, in enemy order.
 struct EnemyGeo { float AO, TA, R, cAO, cTA; };
+// the distances of the two gun-track reward terms to one enemy (scenario1_task.py rewards; sin / cos of the two angles: the angles are
+// acos of these very cosines, utils.py:74-77)
+__device__ __forceinline__ void gun_track_distances(float R, float cA, float cT, float& dwez, float& dtail) {
+  const float r3 = 3000.0f * kFt2M, r5 = 5000.0f * kFt2M;
+  const float sA = sqrtf((1.0f - cA) * (1.0f + cA)), sT = sqrtf((1.0f - cT) * (1.0f + cT));
+  dwez = (R >= 500.0f * kFt2M && R <= r3) ? R * sA : sqrtf(R * R + r3 * r3 - 2.0f * R * r3 * cA);
+  dtail = (R >= r3 && R <= r5) ? R * sT : ((R <= r3) ? sqrtf(R * R + r3 * r3 - 2.0f * R * r3 * cT) : sqrtf(R * R + r5 * r5 - 2.0f * R * r5 * cT));
+}
 
 // FORM: FORM_ONE = one wave per 64 aircraft does everything; FORM_SPLIT = the FDM ticks in the three-wave form (split_kernel.hpp; used
 // for the gun-only tasks, which have nothing to fly between ticks); FORM_PAIR = a flight wave and an environment wave
@@ -164,6 +172,9 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   constexpr int MS = 2;  // munition slots (uids) per aircraft
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
   __shared__ __attribute__((aligned(16))) float lds_out[64 * (OBS + 2)];
+  // NvN pair form: what the rewards need of the geometry towards each enemy (AO, TA, R, the two gun-track distances, the posture term) and
+  // the first enemy's altitude, computed by the flight wave after its last tick
+  __shared__ float geo_lds[(SD::MULTI && FORM == FORM_PAIR) ? (SD::NE * 6 + 1) * 64 : 1];
   __shared__ float4 cl_pos[64 * 2];   // the chaff clouds of the workgroup's aircraft (position; live flag and multiplicity below)
   __shared__ int2 cl_meta[64 * 2];
   __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : (QUAD ? sizeof(QuadLds) : (PAIR ? sizeof(PairLds) : 16))];
@@ -236,6 +247,18 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     pair_flight_load(P, c, nn, in);
     auto rows_tail = [&](const Props& q) {
       if (ROWS_BY_FLIGHT) {
+        // geometry towards my enemies, for the environment wave's reward terms (every term iterates agent.enemies in env order)
+#pragma unroll
+        for (int qe = 0; qe < NE; ++qe) {
+          const Enemy E = gather_pose(q, base + e_first + qe);
+          const Geo g = ao_ta_r<false>(q.n, q.e, q.u, q.vn, q.ve, q.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd);
+          float dw, dt;
+          gun_track_distances(g.R, g.cAO, g.cTA, dw, dt);
+          float* gq = geo_lds + (qe * 6) * 64 + lane;
+          gq[0] = g.AO; gq[64] = g.TA; gq[128] = g.R; gq[192] = dw; gq[256] = dt; gq[320] = posture_fn(g.AO, g.TA, g.R * 0.001f);
+          if (qe == 0) geo_lds[(NE * 6) * 64 + lane] = E.u;
+        }
+        wg_sync();                                  // the geometry is in LDS
         if (!c.legacy_obs) build_rows(q);
         wg_sync();                                  // the rows are in LDS (the environment wave adds the missile block and sends them)
       }
@@ -557,13 +580,27 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   AC_CLKE(63);
   // ---- geometry towards my enemies (every reward term iterates agent.enemies in env order)
   EnemyGeo eg[NE];
+  float dwez[NE], dtail[NE], posture_e[NE];   // per enemy: the distances of the two gun-track terms, the posture term
   float e_u0 = 0.0f;
+  if (ROWS_BY_FLIGHT) {
+    wg_sync();                                     // the flight wave has posted them
 #pragma unroll
-  for (int q = 0; q < NE; ++q) {
-    Enemy E = gather_pose(pr, base + e_first + q);
-    Geo g = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd);
-    eg[q].AO = g.AO; eg[q].TA = g.TA; eg[q].R = g.R; eg[q].cAO = g.cAO; eg[q].cTA = g.cTA;
-    if (q == 0) e_u0 = E.u;
+    for (int q = 0; q < NE; ++q) {
+      const float* gq = geo_lds + (q * 6) * 64 + lane;
+      eg[q].AO = gq[0]; eg[q].TA = gq[64]; eg[q].R = gq[128]; eg[q].cAO = 0.0f; eg[q].cTA = 0.0f;
+      dwez[q] = gq[192]; dtail[q] = gq[256]; posture_e[q] = gq[320];
+    }
+    e_u0 = geo_lds[(NE * 6) * 64 + lane];
+  } else {
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      Enemy E = gather_pose(pr, base + e_first + q);
+      Geo g = ao_ta_r<false>(pr.n, pr.e, pr.u, pr.vn, pr.ve, pr.vd, E.n, E.e, E.u, E.vn, E.ve, E.vd);
+      eg[q].AO = g.AO; eg[q].TA = g.TA; eg[q].R = g.R; eg[q].cAO = g.cAO; eg[q].cTA = g.cTA;
+      gun_track_distances(g.R, g.cAO, g.cTA, dwez[q], dtail[q]);
+      posture_e[q] = posture_fn(g.AO, g.TA, g.R * 0.001f);
+      if (q == 0) e_u0 = E.u;
+    }
   }
   // ---- my first alive incoming missile in launch order (check_missile_warning), and whether any is alive
   Incoming inc{false, 0, 0, 0, 0, 0, 0};
@@ -674,16 +711,6 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   // the shared reference lists are written by the first agent that evaluates after a reset
   const unsigned long long ev_mask = __ballot(evaluates) & (((A == 64) ? ~0ull : ((1ull << A) - 1ull)) << base);
   const int first_lane = ev_mask ? (__ffsll((long long)ev_mask) - 1) : base;
-  // per-enemy distances of the two gun-track terms
-  float dwez[NE], dtail[NE];
-#pragma unroll
-  for (int q = 0; q < NE; ++q) {
-    const float R = eg[q].R, r3 = 3000.0f * kFt2M, r5 = 5000.0f * kFt2M;
-    // sin / cos of the two angles: the angles are acos of these very cosines (utils.py:74-77)
-    const float cA = eg[q].cAO, cT = eg[q].cTA, sA = sqrtf((1.0f - cA) * (1.0f + cA)), sT = sqrtf((1.0f - cT) * (1.0f + cT));
-    dwez[q] = (R >= 500.0f * kFt2M && R <= r3) ? R * sA : sqrtf(R * R + r3 * r3 - 2.0f * R * r3 * cA);
-    dtail[q] = (R >= r3 && R <= r5) ? R * sT : ((R <= r3) ? sqrtf(R * R + r3 * r3 - 2.0f * R * r3 * cT) : sqrtf(R * R + r5 * r5 - 2.0f * R * r5 * cT));
-  }
   if (ev_mask && !(x.ref_set & 1)) {   // first evaluation since reset: everybody copies the first evaluator's values
     x.cg_AO = __shfl(eg[0].AO, first_lane); x.cg_TA = __shfl(eg[0].TA, first_lane);
 #pragma unroll
@@ -737,7 +764,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
       float isr = rsqrtf(R);
       tailr += -(1.0f / 60.0f) * tanh_fast((dtail[q] - x.tail[q]) * isr);
       wezdot += -(1.0f / 60.0f) * tanh_fast((dwez[q] - x.wez[q]) * isr);
-      posture += posture_fn(eg[q].AO, eg[q].TA, R * 0.001f);
+      posture += posture_e[q];
     }
     float ev = ((t.status != AC_ALIVE) ? -200.0f : 0.0f) + 200.0f * (float)my_hits;
     float r_ev = potential(ev, c.event_scale, c.event_pot, t.pre_event);
