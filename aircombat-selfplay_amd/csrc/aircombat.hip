@@ -1285,21 +1285,28 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
   unsigned long long enemy_lanes = 0;
 #pragma unroll
   for (int j = 0; j < A; ++j) if ((j < c.n_ego ? 0 : 1) != team) enemy_lanes |= 1ull << (base_lane + j);
+  // (the rounds only carry who is still alive -- note the enemies' state at my turn, crash if my checks say so, re-take the ballot --
+  // and the messages are assigned afterwards: SafeReturn comes first, so only an aircraft that is still flying and has no
+  // mission-complete reaches the crash checks)
+  const int st0 = t.status;
+  const bool crash_cond = extreme || overload || low;
+  bool enemies_dead = false;
   unsigned long long alive = __ballot(t.status == AC_ALIVE);
 #pragma unroll
   for (int i = 0; i < A; ++i) {
     if (slot == i) {
-      const bool enemies_dead = (alive & enemy_lanes) == 0;
-      if (t.status == AC_SHOTDOWN) { code = AC_DONE_SHOTDOWN; done = true; }
-      else if (t.status == AC_CRASH) { code = AC_DONE_CRASHED; done = true; }
-      else if (enemies_dead) { code = AC_DONE_MISSION_COMPLETE; done = true; }   // no missiles in this task
-      else if (extreme) { t.status = AC_CRASH; code = AC_DONE_EXTREME_STATE; done = true; }
-      else if (overload) { t.status = AC_CRASH; code = AC_DONE_OVERLOAD; done = true; }
-      else if (low) { t.status = AC_CRASH; code = AC_DONE_LOW_ALTITUDE; done = true; }
-      else if (t.cur_step >= c.max_steps) { code = AC_DONE_TIMEOUT; done = true; }
+      enemies_dead = (alive & enemy_lanes) == 0;
+      if (st0 == AC_ALIVE && !enemies_dead && crash_cond) t.status = AC_CRASH;
     }
     alive = __ballot(t.status == AC_ALIVE);
   }
+  if (st0 == AC_SHOTDOWN) { code = AC_DONE_SHOTDOWN; done = true; }
+  else if (st0 == AC_CRASH) { code = AC_DONE_CRASHED; done = true; }
+  else if (enemies_dead) { code = AC_DONE_MISSION_COMPLETE; done = true; }   // no missiles in this task
+  else if (extreme) { code = AC_DONE_EXTREME_STATE; done = true; }
+  else if (overload) { code = AC_DONE_OVERLOAD; done = true; }
+  else if (low) { code = AC_DONE_LOW_ALTITUDE; done = true; }
+  else if (t.cur_step >= c.max_steps) { code = AC_DONE_TIMEOUT; done = true; }
   {   // info['done_condition'] keeps the message of the last agent (in env order) that has one
     const unsigned long long coded = __ballot(code != AC_DONE_NONE) & env_mask;
     const int last = coded ? 63 - __clzll((long long)coded) : l;

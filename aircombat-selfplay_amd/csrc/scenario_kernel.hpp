@@ -671,31 +671,41 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     unsigned long long enemy_lanes = 0;
 #pragma unroll
     for (int j = 0; j < A; ++j) if ((j < n_ego ? 0 : 1) != team) enemy_lanes |= 1ull << (base + j);
+    // The walk itself only has to carry who is still alive: an agent's own checks change its status in one way (a crash condition
+    // makes it CRASH), and what it sees of the others is whether any enemy is alive at its turn. So the rounds do just that -- note
+    // the enemies' state at my turn, crash if my checks say so, re-take the ballot -- and the messages are assigned afterwards.
+    const int st0 = t.status;
+    const bool crash_cond = low || extreme || overload;
+    bool enemies_dead = false;
     unsigned long long alive = __ballot(t.status == AC_ALIVE);
 #pragma unroll
     for (int i = 0; i < A; ++i) {
       if (slot == i) {
-        const bool enemies_dead = (alive & enemy_lanes) == 0;
-        if (MULTI) {   // SafeReturn, ExtremeState, Overload, LowAltitude, Timeout (multiplecombat_task.py:33-39)
-          if (t.status == AC_SHOTDOWN) { code = AC_DONE_SHOTDOWN; done = true; }
-          else if (t.status == AC_CRASH) { code = AC_DONE_CRASHED; done = true; }
-          else if (enemies_dead && !inc.any) { code = AC_DONE_MISSION_COMPLETE; done = true; }
-          else if (extreme) { t.status = AC_CRASH; code = AC_DONE_EXTREME_STATE; done = true; }
-          else if (overload) { t.status = AC_CRASH; code = AC_DONE_OVERLOAD; done = true; }
-          else if (low) { t.status = AC_CRASH; code = AC_DONE_LOW_ALTITUDE; done = true; }
-          else if (t.cur_step >= c.max_steps) { code = AC_DONE_TIMEOUT; done = true; }
-        } else {       // LowAltitude, ExtremeState, Overload, SafeReturn, Timeout (singlecombat_task.py:34-40)
-          if (low) { t.status = AC_CRASH; code = AC_DONE_LOW_ALTITUDE; done = true; }
-          else if (extreme) { t.status = AC_CRASH; code = AC_DONE_EXTREME_STATE; done = true; }
-          else if (overload) { t.status = AC_CRASH; code = AC_DONE_OVERLOAD; done = true; }
-          else if (wvr) { if (t.cur_step >= c.max_steps) { code = AC_DONE_TIMEOUT; done = true; } }   // WVR_task.py:31-36: no SafeReturn
-          else if (t.status == AC_SHOTDOWN) { code = AC_DONE_SHOTDOWN; done = true; }
-          else if (t.status == AC_CRASH) { code = AC_DONE_CRASHED; done = true; }
-          else if (enemies_dead && !inc.any) { code = AC_DONE_MISSION_COMPLETE; done = true; }
-          else if (t.cur_step >= c.max_steps) { code = AC_DONE_TIMEOUT; done = true; }
-        }
+        enemies_dead = (alive & enemy_lanes) == 0;
+        // NvN: SafeReturn comes first, so only an aircraft that is still flying and has no mission-complete reaches the crash checks;
+        // 1v1 family: the crash checks come first and apply whatever the status was
+        const bool crash_now = MULTI ? (st0 == AC_ALIVE && !(enemies_dead && !inc.any) && crash_cond) : crash_cond;
+        if (crash_now) t.status = AC_CRASH;
       }
       alive = __ballot(t.status == AC_ALIVE);
+    }
+    if (MULTI) {   // SafeReturn, ExtremeState, Overload, LowAltitude, Timeout (multiplecombat_task.py:33-39)
+      if (st0 == AC_SHOTDOWN) { code = AC_DONE_SHOTDOWN; done = true; }
+      else if (st0 == AC_CRASH) { code = AC_DONE_CRASHED; done = true; }
+      else if (enemies_dead && !inc.any) { code = AC_DONE_MISSION_COMPLETE; done = true; }
+      else if (extreme) { code = AC_DONE_EXTREME_STATE; done = true; }
+      else if (overload) { code = AC_DONE_OVERLOAD; done = true; }
+      else if (low) { code = AC_DONE_LOW_ALTITUDE; done = true; }
+      else if (t.cur_step >= c.max_steps) { code = AC_DONE_TIMEOUT; done = true; }
+    } else {       // LowAltitude, ExtremeState, Overload, SafeReturn, Timeout (singlecombat_task.py:34-40)
+      if (low) { code = AC_DONE_LOW_ALTITUDE; done = true; }
+      else if (extreme) { code = AC_DONE_EXTREME_STATE; done = true; }
+      else if (overload) { code = AC_DONE_OVERLOAD; done = true; }
+      else if (wvr) { if (t.cur_step >= c.max_steps) { code = AC_DONE_TIMEOUT; done = true; } }   // WVR_task.py:31-36: no SafeReturn
+      else if (st0 == AC_SHOTDOWN) { code = AC_DONE_SHOTDOWN; done = true; }
+      else if (st0 == AC_CRASH) { code = AC_DONE_CRASHED; done = true; }
+      else if (enemies_dead && !inc.any) { code = AC_DONE_MISSION_COMPLETE; done = true; }
+      else if (t.cur_step >= c.max_steps) { code = AC_DONE_TIMEOUT; done = true; }
     }
     // info['done_condition'] keeps the message of the last agent (in env order) that has one
     const unsigned long long coded = __ballot(code != AC_DONE_NONE) & env_mask;
