@@ -547,21 +547,28 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
       const bool can = t.status == AC_ALIVE && (x.bits & 8) && x.rem_chaff > 0 && (x.last_chaff < 0 || lc_status == 1);
       int n_rel = 0;
       if (__ballot(can) & env_mask) {
+        // one packed word per dict entry says whether it exists and whom it is aimed at; where it is gets fetched only for the entries
+        // that are aimed at somebody in this env who can release chaff (rare) -- it was five fetches per entry
+        const int my_new = (launched_k + 1) | (tg << 4);                   // this step's launch: slot + 1 (0: none) and its target
+        int my_old[MS];
+#pragma unroll
+        for (int k = 0; k < MS; ++k) my_old[k] = (old_st[k] + 1) | (old_tg[k] << 4);   // (status + 1: MSL_INACTIVE is -1)
 #pragma unroll
         for (int j = 0; j < A; ++j) {
           const int src = base + j;
-          const int lk = __shfl(launched_k, src), ntg = __shfl(tg, src);
-          const float lx = __shfl(pr.n, src), ly = __shfl(pr.e, src), lz = __shfl(pr.u, src);
+          const int nw = __shfl(my_new, src);
 #pragma unroll
           for (int k = 0; k < MS; ++k) {
-            const int ost = __shfl(old_st[k], src), otg = __shfl(old_tg[k], src);
-            const float ox = __shfl(old_x[k], src), oy = __shfl(old_y[k], src), oz = __shfl(old_z[k], src);
-            const bool fresh = lk == k && j <= slot;           // launched this step by an agent that acted before me (or by me)
-            const int st = fresh ? MSL_LAUNCHED : ost, mtg = fresh ? ntg : otg;
-            const float mx = fresh ? lx : ox, my = fresh ? ly : oy, mz = fresh ? lz : oz;
-            if (can && st != MSL_INACTIVE && mtg == slot) {
+            const int ow = __shfl(my_old[k], src);
+            const bool fresh = (nw & 15) == k + 1 && j <= slot;            // launched this step by an agent that acted before me (or by me)
+            const int st = fresh ? MSL_LAUNCHED : (ow & 15) - 1, mtg = fresh ? (nw >> 4) : (ow >> 4);
+            const bool aimed = can && st != MSL_INACTIVE && mtg == slot;
+            if (__ballot(aimed) & env_mask) {
+              const float lx = __shfl(pr.n, src), ly = __shfl(pr.e, src), lz = __shfl(pr.u, src);
+              const float ox = __shfl(old_x[k], src), oy = __shfl(old_y[k], src), oz = __shfl(old_z[k], src);
+              const float mx = fresh ? lx : ox, my = fresh ? ly : oy, mz = fresh ? lz : oz;
               const float dx = pr.n - mx, dy = pr.e - my, dz = pr.u - mz;
-              if (sqrtf(dx * dx + dy * dy + dz * dz) < 1000.0f) n_rel += 1;
+              if (aimed && sqrtf(dx * dx + dy * dy + dz * dz) < 1000.0f) n_rel += 1;
             }
           }
         }
