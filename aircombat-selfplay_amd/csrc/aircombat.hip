@@ -632,7 +632,12 @@ __device__ __forceinline__ void emit_scalars(const DevPtrs& P, int lane, float r
     if (!rew) continue;
     rew[n] = reward;
     if (lane < 16) reinterpret_cast<unsigned*>(dn + blk * 64)[lane] = dword;
-    if (lane % A == 0) *reinterpret_cast<int4*>(info + (n / A) * 4) = inf;
+    // the device copy keeps the four-word row; the host copy of ac_step_host is one packed word per env (AC_INFO_* in aircombat.h):
+    // a quarter of the bytes across PCIe, and the lanes' words are adjacent
+    if (lane % A == 0) {
+      if (set) info[n / A] = (i0 & 0xFFFF) | ((i1 & 0xFF) << 16) | ((i2 & 0x7F) << 24) | ((i3 & 1) << 31);
+      else *reinterpret_cast<int4*>(info + (n / A) * 4) = inf;
+    }
   }
 }
 __device__ __forceinline__ void emit_rows(const DevPtrs& P, float* lds, int ow, int lane, float reward, bool done, int A, int i0, int i1, int i2, int i3) {
@@ -1678,6 +1683,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     return fail("ac_create: the paired-enemy observation of AC_TASK_MULTICOMBAT belongs to hierarchical_multiplecombat_shoot (set hierarchical)");
   if (cfg->rwr && !scenario) return fail("ac_create: rwr is a variant of the scenario tasks (Scenario1_RWR, Scenario2_RWR, Scenario3_RWR)");
   if (n_envs <= 0) return fail("ac_create: n_envs must be positive");
+  if (cfg->max_steps > 65535) return fail("ac_create: max_steps above 65535 (the host-boundary info word carries current_step in 16 bits)");
   if ((long long)n_envs * cfg->n_agents > (1 << 23))   // 32-bit byte offsets into the per-field arrays (AC_AT): 63 fields x 4 B x N < 4 GB
     return fail("ac_create: more than 2^23 aircraft in one handle; shard the envs over handles / GPUs");
   if (cfg->sim_freq != 60) return fail("ac_create: sim_freq must be 60 (the FDM tick is compiled for 1/60 s)");
@@ -1896,9 +1902,9 @@ int ac_host_buffers(ac_env_t* h, int32_t set, float** actions, float** obs, floa
       HIP_OK(hipHostMalloc((void**)&hs.obs, sizeof(float) * Npad * h->obs_dim, hipHostMallocDefault));
       HIP_OK(hipHostMalloc((void**)&hs.rew, sizeof(float) * Npad, hipHostMallocDefault));
       HIP_OK(hipHostMalloc((void**)&hs.done, Npad, hipHostMallocDefault));
-      HIP_OK(hipHostMalloc((void**)&hs.info, sizeof(int) * 4 * (Npad / h->A), hipHostMallocDefault));
+      HIP_OK(hipHostMalloc((void**)&hs.info, sizeof(int) * (Npad / h->A), hipHostMallocDefault));
       memset(hs.act, 0, sizeof(float) * Npad * h->act_dim); memset(hs.obs, 0, sizeof(float) * Npad * h->obs_dim);
-      memset(hs.rew, 0, sizeof(float) * Npad); memset(hs.done, 0, Npad); memset(hs.info, 0, sizeof(int) * 4 * (Npad / h->A));
+      memset(hs.rew, 0, sizeof(float) * Npad); memset(hs.done, 0, Npad); memset(hs.info, 0, sizeof(int) * (Npad / h->A));
     }
     h->have_hs = true;
   }

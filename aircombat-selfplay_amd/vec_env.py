@@ -65,7 +65,9 @@ class LazyInfos:
     __slots__ = ("_codes",)
 
     def __init__(self, codes):
-        self._codes = codes          # [E, 4] int32: current_step, done code, heading_turn_counts, env-reset flag
+        # [E, 4] int32 rows (current_step, done code, heading_turn_counts, env-reset flag), or the packed words [E] of ac_host_buffers
+        # (AC_INFO_* in include/aircombat.h: bits 0-15, 16-23, 24-30, 31)
+        self._codes = codes
 
     def __len__(self):
         return len(self._codes)
@@ -74,7 +76,11 @@ class LazyInfos:
     ndim, dtype = 1, np.dtype(object)
 
     def _one(self, i):
-        step, code, turns = (int(v) for v in self._codes[i, :3])
+        if self._codes.ndim == 1:
+            w = int(self._codes[i]) & 0xFFFFFFFF
+            step, code, turns = w & 0xFFFF, (w >> 16) & 0xFF, (w >> 24) & 0x7F
+        else:
+            step, code, turns = (int(v) for v in self._codes[i, :3])
         d = {"current_step": step}
         if code:
             d["done_condition"] = DONE_MESSAGES.get(code, "")
@@ -175,7 +181,7 @@ class HipVecEnv:
                 "obs": arr(ptrs[1], (E, A, self.obs_dim), C.c_float),
                 "rew": arr(ptrs[2], (E, A, 1), C.c_float),
                 "done": arr(ptrs[3], (E, A, 1), C.c_uint8).view(np.bool_),     # the kernel writes 0 / 1
-                "info": arr(ptrs[4], (E, 4), C.c_int32),
+                "info": arr(ptrs[4], (E,), C.c_int32),
             })
         self._cur = 0
         self._actions = self._sets[0]["actions"]

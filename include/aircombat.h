@@ -116,6 +116,12 @@ int ac_step(ac_env_t* h, const float* actions, float* obs, float* rewards, uint8
  * calls ac_step_host_async (= SubprocVecEnv.step_async, R/envs/env_wrappers.py:269-273) and ac_step_host_wait (= step_wait,
  * :275-282); alternating the two sets keeps the arrays of one step valid while the next one runs. The device buffers of
  * ac_device_buffers are written as well. ac_reset(h, obs) may be pointed at a set's obs buffer. */
+/* `info` of a set is ONE packed word per env (the four-word rows of ac_step / ac_device_buffers are 11 % of a step's bytes across PCIe
+ * otherwise): current_step in bits 0-15, done_code in bits 16-23, heading_turn_counts in bits 24-30, episode_was_reset in bit 31. */
+#define AC_INFO_STEP(w) ((int32_t)((uint32_t)(w) & 0xFFFFu))
+#define AC_INFO_DONE_CODE(w) ((int32_t)(((uint32_t)(w) >> 16) & 0xFFu))
+#define AC_INFO_TURN_COUNTS(w) ((int32_t)(((uint32_t)(w) >> 24) & 0x7Fu))
+#define AC_INFO_WAS_RESET(w) ((int32_t)((uint32_t)(w) >> 31))
 int ac_host_buffers(ac_env_t* h, int32_t set, float** actions, float** obs, float** rewards, uint8_t** dones, int32_t** info);
 int ac_step_host_async(ac_env_t* h, int32_t set);
 int ac_step_host_wait(ac_env_t* h);
