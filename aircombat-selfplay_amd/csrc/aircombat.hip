@@ -625,6 +625,7 @@ __device__ __forceinline__ void emit_scalars(const DevPtrs& P, int lane, float r
 #pragma unroll
   for (int b = 0; b < 4; ++b) dword |= (unsigned)((dmask >> (4 * (lane & 15) + b)) & 1ull) << (8 * b);
   const int4 inf = make_int4(i0, i1, i2, i3);
+  const int packed = (i0 & 0xFFFF) | ((i1 & 0xFF) << 16) | ((i2 & 0x7F) << 24) | ((i3 & 1) << 31);
   const size_t n = blk * 64 + lane;
 #pragma unroll
   for (int set = 1; set >= 0; --set) {
@@ -634,10 +635,10 @@ __device__ __forceinline__ void emit_scalars(const DevPtrs& P, int lane, float r
     if (lane < 16) reinterpret_cast<unsigned*>(dn + blk * 64)[lane] = dword;
     // the device copy keeps the four-word row; the host copy of ac_step_host is one packed word per env (AC_INFO_* in aircombat.h):
     // a quarter of the bytes across PCIe, and the lanes' words are adjacent
-    if (lane % A == 0) {
-      if (set) info[n / A] = (i0 & 0xFFFF) | ((i1 & 0xFF) << 16) | ((i2 & 0x7F) << 24) | ((i3 & 1) << 31);
-      else *reinterpret_cast<int4*>(info + (n / A) * 4) = inf;
-    }
+    if (set) {   // (env e of the block sits in lane e * A: fetched into lane e, so that the words leave as one run of adjacent lanes)
+      const int w = __shfl(packed, (lane * A) & 63);
+      if (lane < 64 / A) info[blk * (64 / A) + lane] = w;
+    } else if (lane % A == 0) *reinterpret_cast<int4*>(info + (n / A) * 4) = inf;
   }
 }
 __device__ __forceinline__ void emit_rows(const DevPtrs& P, float* lds, int ow, int lane, float reward, bool done, int A, int i0, int i1, int i2, int i3) {
