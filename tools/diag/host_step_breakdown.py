@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a VecEnv.step(numpy) of the headline config spends its time on the host: the action copy into the mapped buffer, the launch
+"""Where a VecEnv.step(numpy) of the headline config (or: <envs> <task> <per_side>) spends its time on the host: the action copy into the mapped buffer, the launch
 call, the wait. (time.perf_counter_ns around the three pieces; ~0.1 us of timer overhead each.)"""
 import os
 import sys
@@ -12,10 +12,15 @@ sys.path.insert(0, ROOT)
 import aircombat_selfplay_amd as pkg
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-env = pkg.HipVecEnv(pkg.default_config("singlecombat"), E, seed=1)
+task = sys.argv[2] if len(sys.argv) > 2 else "singlecombat"
+per_side = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+cfg = pkg.default_nvn_config(per_side, task=task) if per_side > 1 else pkg.default_config(task)
+env = (pkg.HipShareVecEnv if cfg.n_agents > 2 else pkg.HipVecEnv)(cfg, E, seed=1)
 env.reset()
 rng = np.random.default_rng(0)
-acts = [np.stack([rng.integers(0, n, size=(E, 2)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32) for _ in range(16)]
+A = env.num_agents
+acts = [np.concatenate([np.stack([rng.integers(0, n, size=(E, A)) for n in (41, 41, 41, 30)], axis=-1),
+                        rng.random((E, A, env.act_dim - 4)) < 0.05], axis=-1).astype(np.float32) for _ in range(16)]
 dll = env.lib.dll
 h = env._h
 now = time.perf_counter_ns
