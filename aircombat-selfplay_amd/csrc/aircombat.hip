@@ -1153,13 +1153,17 @@ __device__ __forceinline__ Enemy gather_pose(const Props& pr, int lane) {
   E.ub = __shfl(pr.ub, lane); E.alt = __shfl(pr.alt_m, lane);
   return E;
 }
-// observation (9 + 6*(A-1), clipped) and the raw posture reward (sum over enemies) in one pass over the other aircraft
+// observation (9 + 6*(A-1), clipped) and the raw posture reward (sum over enemies) in one pass over the other aircraft. The row is
+// this lane's row of the output staging buffer in LDS (null: the posture alone): a block's place in it is a run-time index -- an LDS
+// address; on a register array the compiler turns the select chain into a dynamically indexed store and the array goes to scratch.
 template <int A>
 __device__ __forceinline__ float observe_nvn(const Props& pr, int slot, int base_lane, int n_ego, float* ob) {
-  constexpr int OBS = 9 + 6 * (A - 1);
-  ob[0] = pr.alt_m / 5000.0f;
-  ob[1] = pr.sphi; ob[2] = pr.cphi; ob[3] = pr.stht; ob[4] = pr.ctht;
-  ob[5] = pr.ub / 340.0f; ob[6] = pr.vb / 340.0f; ob[7] = pr.wb / 340.0f; ob[8] = pr.vc / 340.0f;
+  auto c10 = [](float v) { return clampf(-10.0f, v, 10.0f); };
+  if (ob) {
+    ob[0] = c10(pr.alt_m / 5000.0f);
+    ob[1] = c10(pr.sphi); ob[2] = c10(pr.cphi); ob[3] = c10(pr.stht); ob[4] = c10(pr.ctht);
+    ob[5] = c10(pr.ub / 340.0f); ob[6] = c10(pr.vb / 340.0f); ob[7] = c10(pr.wb / 340.0f); ob[8] = c10(pr.vc / 340.0f);
+  }
   const int my_team = slot < n_ego ? 0 : 1;
   // position of aircraft j in my observation: partners (same team, in env order, skipping me) first, then enemies
   const int n_mine = my_team == 0 ? n_ego : A - n_ego;
@@ -1179,16 +1183,12 @@ __device__ __forceinline__ float observe_nvn(const Props& pr, int slot, int base
       idx = (n_mine - 1) + (j - first);
       posture += posture_fn(g.AO, g.TA, g.R * 0.001f);
     }
-    const float v[6] = {(E.ub - pr.ub) / 340.0f, (E.alt - pr.alt_m) / 1000.0f, g.AO, g.TA, g.R / 10000.0f, g.side};
-#pragma unroll
-    for (int q = 0; q < A - 1; ++q)
-      if (q == idx) {
-#pragma unroll
-        for (int m = 0; m < 6; ++m) ob[9 + q * 6 + m] = v[m];
-      }
+    if (ob) {
+      float* blk = ob + 9 + idx * 6;
+      blk[0] = c10((E.ub - pr.ub) / 340.0f); blk[1] = c10((E.alt - pr.alt_m) / 1000.0f);
+      blk[2] = c10(g.AO); blk[3] = c10(g.TA); blk[4] = c10(g.R / 10000.0f); blk[5] = c10(g.side);
+    }
   }
-#pragma unroll
-  for (int k = 0; k < OBS; ++k) ob[k] = clampf(-10.0f, ob[k], 10.0f);
   return posture;
 }
 
@@ -1196,7 +1196,7 @@ __device__ __forceinline__ float observe_nvn(const Props& pr, int slot, int base
 // like MultipleCombatDodgeMissileTask.get_obs (:33-117): 21 values, 3-D AO / TA, unclipped, against the enemy with the agent's own
 // index in its team, and a missile block that stays zero (this task's step() never launches anything, :202-203).
 template <int A>
-__device__ __forceinline__ void legacy_obs_nvn(const Props& pr, int slot, int base_lane, int n_ego, float* ob) {
+__device__ __forceinline__ void legacy_obs_nvn(const Props& pr, int slot, int base_lane, int n_ego, float* row) {
   const int team = slot < n_ego ? 0 : 1;
   const int paired = (team == 0 ? n_ego : 0) + (slot - (team == 0 ? 0 : n_ego));
   const Enemy E = gather_pose(pr, base_lane + paired);
@@ -1204,7 +1204,7 @@ __device__ __forceinline__ void legacy_obs_nvn(const Props& pr, int slot, int ba
   float o21[21];
   observe_1v1<AC_TASK_SHOOT_MISSILE>(pr, E, none, o21);
 #pragma unroll
-  for (int k = 0; k < 9 + 6 * (A - 1); ++k) ob[k] = (k < 21) ? o21[k] : 0.0f;
+  for (int k = 0; k < 21; ++k) row[k] = o21[k];
 }
 
 template <int A, int WPE, bool SPLIT = false>
@@ -1252,11 +1252,11 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
   }
   make_props(s, d, c, pr);
 
-  float ob[OBS];
-#pragma unroll
-  for (int k = 0; k < OBS; ++k) ob[k] = 0.0f;
-  float posture = observe_nvn<A>(pr, slot, base_lane, c.n_ego, ob);
-  if (c.legacy_obs) legacy_obs_nvn<A>(pr, slot, base_lane, c.n_ego, ob);
+  // (the template keeps the kernel's own OBS stride; hierarchical_multiplecombat_shoot puts out the first 21 values)
+  const int ow = c.legacy_obs ? 21 : OBS;
+  float* orow = lds_out + l * ow;                      // this lane's row of the output staging buffer
+  float posture = observe_nvn<A>(pr, slot, base_lane, c.n_ego, c.legacy_obs ? nullptr : orow);
+  if (c.legacy_obs) legacy_obs_nvn<A>(pr, slot, base_lane, c.n_ego, orow);
 
   // ---- rewards first (multiplecombat_env.py:166-175), only while alive (multiplecombat_task.py:147-151)
   float own = 0.0f;
@@ -1326,14 +1326,12 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
     load_state(P.tF, P.tI, P.tD, A, slot, s, t);
     zero_controller_state(P, N, n, live);
     const float* tobs = P.tF + (size_t)NF * A + slot * OBS;
-#pragma unroll
-    for (int k = 0; k < OBS; ++k) ob[k] = tobs[k];
+    for (int k = 0; k < ow; ++k) orow[k] = tobs[k];
   }
   if (live) {
     store_state(P.F, P.I, P.D, N, n, s, t);
   }
-  // (the template keeps the kernel's own OBS stride; hierarchical_multiplecombat_shoot puts out the first 21 values)
-  emit_outputs(P, lds_out, c.legacy_obs ? 21 : OBS, l, ob, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);
+  emit_rows(P, lds_out, ow, l, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------ initial conditions
