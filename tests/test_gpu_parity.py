@@ -985,3 +985,37 @@ def test_missile_posture_walk_closed_form_equals_the_round_by_round_walk(pkg):
     bad = C.c_int32(-1)
     lib.check(lib.dll.ac_selftest_missile_walk(0, C.byref(bad)), "ac_selftest_missile_walk")
     assert bad.value == 0
+
+
+@pytest.mark.parametrize("task", ["singlecombat", "heading", "scenario_nvn"])
+def test_host_info_words_equal_the_device_info_rows(pkg, task):
+    """ac_step_host's output set carries one packed word per env (AC_INFO_* in include/aircombat.h: current_step, done code, heading turn
+    counts, reset flag); the device buffers keep the four-word rows. Both are written by the same kernel launch: unpacked, they must be
+    equal for every env after every step (episode ends, resets and UnreachHeading counts included)."""
+    if task == "scenario_nvn":
+        cfg, cls = pkg.default_nvn_config(2, task=task), pkg.HipShareVecEnv
+    else:
+        cfg, cls = pkg.default_config(task), pkg.HipVecEnv
+    E = 96
+    env = cls(cfg, E, seed=3)
+    env.reset()
+    rng = np.random.default_rng(1)
+    A = env.num_agents
+    ends = 0
+    for step in range(400):
+        cols = [rng.integers(0, n, size=(E, A)) for n in (41, 41, 41, 30)]
+        act = np.stack(cols, axis=-1).astype(np.float32)
+        if env.act_dim > 4:
+            act = np.concatenate([act, (rng.random((E, A, env.act_dim - 4)) < 0.05).astype(np.float32)], axis=-1)
+        res = env.step(act)
+        infos = res[-1]
+        w = infos._codes.astype(np.int64) & 0xFFFFFFFF
+        assert w.shape == (E,)
+        rows = env.device_tensors()[4].cpu().numpy()
+        assert (rows[:, 0] == (w & 0xFFFF)).all() and (rows[:, 1] == ((w >> 16) & 0xFF)).all()
+        assert (rows[:, 2] == ((w >> 24) & 0x7F)).all() and (rows[:, 3] == (w >> 31)).all()
+        ends += int(rows[:, 3].sum()) + int((rows[:, 1] != 0).sum())
+        e = int(rng.integers(0, E))
+        assert infos[e]["current_step"] == rows[e, 0]
+    assert ends > 0, "no termination message or episode end during the comparison"
+    env.close()
