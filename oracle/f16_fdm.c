@@ -414,6 +414,29 @@ static void fcs_run(F16State* s) {
   s->speedbrake_pos_rad = s->speedbrake_pos_deg * DEGTORAD;
 }
 
+/* test hook: ONE pass of the whole <flight_control> section. st[18] = the section's memory (three PIDs {in_prev, in_prev2, i_total, out},
+ * tef-control, left-aileron-pos-norm, elevator-pos-norm, rudder-pos-norm, speedbrake-pos-deg, gear-pos-norm), updated in place;
+ * in[17] in the order of tests/golden/make_f16_fcs_check.py IN_PROPS (calibrated airspeed in knots); out[16] in the order of its OUT_PROPS. */
+void f16_test_fcs(double* st, const double* in, double* out) {
+  F16State s;
+  memset(&s, 0, sizeof s);
+  OrPid* pid[3] = {&s.pid_roll, &s.pid_pitch, &s.pid_yaw};
+  for (int i = 0; i < 3; i++) { pid[i]->in_prev = st[4 * i]; pid[i]->in_prev2 = st[4 * i + 1]; pid[i]->i_total = st[4 * i + 2]; pid[i]->out = st[4 * i + 3]; }
+  s.tef_control = st[12]; s.left_aileron_pos_norm = st[13]; s.elevator_pos_norm = st[14]; s.rudder_pos_norm = st[15];
+  s.speedbrake_pos_deg = st[16]; s.gear_pos_norm = st[17];
+  s.da_cmd = in[0]; s.de_cmd = in[1]; s.dr_cmd = in[2]; s.throttle_cmd = in[3]; s.gear_cmd_norm = in[4];
+  s.vc_fps = in[5] * KTSTOFPS; s.mach = in[6]; s.aero_pqr[0] = in[7]; s.aero_pqr[1] = in[8]; s.aero_pqr[2] = in[9];
+  s.vg = in[10]; s.uvw[1] = in[11]; s.tht = in[12]; s.phi = in[13]; s.npilot[2] = in[14]; s.npilot[1] = in[15]; s.alpha = in[16];
+  fcs_run(&s);
+  for (int i = 0; i < 3; i++) { st[4 * i] = pid[i]->in_prev; st[4 * i + 1] = pid[i]->in_prev2; st[4 * i + 2] = pid[i]->i_total; st[4 * i + 3] = pid[i]->out; }
+  st[12] = s.tef_control; st[13] = s.left_aileron_pos_norm; st[14] = s.elevator_pos_norm; st[15] = s.rudder_pos_norm;
+  st[16] = s.speedbrake_pos_deg; st[17] = s.gear_pos_norm;
+  out[0] = s.aileron_pos_rad; out[1] = s.elevator_pos_rad; out[2] = s.rudder_pos_rad; out[3] = s.lef_pos_rad; out[4] = s.flaperon_mix_rad;
+  out[5] = s.speedbrake_pos_rad; out[6] = s.throttle_pos; out[7] = s.gear_pos_norm; out[8] = s.tef_control; out[9] = s.left_aileron_pos_norm;
+  out[10] = s.elevator_pos_norm; out[11] = s.rudder_pos_norm; out[12] = s.pid_roll.out; out[13] = s.pid_pitch.out; out[14] = s.pid_yaw.out;
+  out[15] = s.speedbrake_pos_deg;
+}
+
 /* ------------------------------------------------------------------ FGPropagate */
 static void propagate_derived(F16State* s) { /* tail of FGPropagate::Run, S/models/FGPropagate.cpp:237-283 */
   double ce = cos(s->epa), se = sin(s->epa);
@@ -499,7 +522,7 @@ static void pointmass_inertia(const double cg[3], double mass_sl, const double r
 }
 static const double TANK_XYZ[4][3] = {{F16_TANK0_X, F16_TANK0_Y, F16_TANK0_Z}, {F16_TANK1_X, F16_TANK1_Y, F16_TANK1_Z},
                                       {F16_TANK2_X, F16_TANK2_Y, F16_TANK2_Z}, {F16_TANK3_X, F16_TANK3_Y, F16_TANK3_Z}};
-static void massbalance_run(F16State* s) {
+static void massbalance_core(F16State* s, double pm0_w, double pm1_w) {
   const double base_cg[3] = {F16_CG_X, F16_CG_Y, F16_CG_Z};
   const double pm0[3] = {F16_PM0_X, F16_PM0_Y, F16_PM0_Z}, pm1[3] = {F16_PM1_X, F16_PM1_Y, F16_PM1_Z};
   /* in.TankInertia is loaded BEFORE Run (FGFDMExec.cpp:572) with the cg of the previous tick */
@@ -510,15 +533,15 @@ static void massbalance_run(F16State* s) {
     tanks_w += s->tank[i];
     for (int k = 0; k < 3; k++) tanks_m[k] += TANK_XYZ[i][k] * s->tank[i];
   }
-  s->weight = F16_EMPTYWT + tanks_w + F16_PM0_WEIGHT + F16_PM1_WEIGHT;
+  s->weight = F16_EMPTYWT + tanks_w + pm0_w + pm1_w;
   s->mass = LBTOSLUG * s->weight;
   for (int k = 0; k < 3; k++)
-    s->cg[k] = (F16_EMPTYWT * base_cg[k] + F16_PM0_WEIGHT * pm0[k] + F16_PM1_WEIGHT * pm1[k] + tanks_m[k]) / s->weight;
+    s->cg[k] = (F16_EMPTYWT * base_cg[k] + pm0_w * pm0[k] + pm1_w * pm1[k] + tanks_m[k]) / s->weight;
   /* baseJ with negated_crossproduct_inertia="true" (FGMassBalance.cpp:91-112) */
   double J[9] = {F16_IXX, -F16_IXY, F16_IXZ, -F16_IXY, F16_IYY, -F16_IYZ, F16_IXZ, -F16_IYZ, F16_IZZ};
   pointmass_inertia(s->cg, LBTOSLUG * F16_EMPTYWT, base_cg, J);
-  pointmass_inertia(s->cg, LBTOSLUG * F16_PM0_WEIGHT, pm0, J);
-  pointmass_inertia(s->cg, LBTOSLUG * F16_PM1_WEIGHT, pm1, J);
+  pointmass_inertia(s->cg, LBTOSLUG * pm0_w, pm0, J);
+  pointmass_inertia(s->cg, LBTOSLUG * pm1_w, pm1, J);
   for (int k = 0; k < 9; k++) J[k] += tankJ[k];
   memcpy(s->J, J, sizeof J);
   double Ixx = J[0], Iyy = J[4], Izz = J[8], Ixy = -J[1], Ixz = -J[2], Iyz = -J[5];
@@ -528,9 +551,36 @@ static void massbalance_run(F16State* s) {
   double k4 = (Izz * Ixx - Ixz * Ixz) * denom, k5 = (Ixy * Ixz + Iyz * Ixx) * denom, k6 = (Ixx * Iyy - Ixy * Ixy) * denom;
   double Ji[9] = {k1, k2, k3, k2, k4, k5, k3, k5, k6};
   memcpy(s->Jinv, Ji, sizeof Ji);
+  memcpy(s->tankJ, tankJ, sizeof tankJ);
+}
+static void massbalance_run(F16State* s) { massbalance_core(s, F16_PM0_WEIGHT, F16_PM1_WEIGHT); }
+/* test hook: FGMassBalance::Run for given tank contents [lbs] and point-mass weights [lbs]; the tank inertia is taken about cg_tanks
+ * (the executive hands MassBalance the tank inertia computed with the previous pass's CG, FGFDMExec.cpp:572).
+ * out = weight, cg[3], J[9], Jinv[9], tank inertia[9] */
+void f16_test_massbalance(const double* tanks4, const double* pm2, const double* cg_tanks, double* out31) {
+  F16State s;
+  memset(&s, 0, sizeof s);
+  for (int i = 0; i < 4; i++) s.tank[i] = tanks4[i];
+  for (int i = 0; i < 3; i++) s.cg[i] = cg_tanks[i];
+  massbalance_core(&s, pm2[0], pm2[1]);
+  out31[0] = s.weight;
+  for (int i = 0; i < 3; i++) out31[1 + i] = s.cg[i];
+  for (int i = 0; i < 9; i++) { out31[4 + i] = s.J[i]; out31[13 + i] = s.Jinv[i]; out31[22 + i] = s.tankJ[i]; }
 }
 
 /* ------------------------------------------------------------------ FGAuxiliary::Run (S/models/FGAuxiliary.cpp:134-232) */
+/* vPilotAccel = vBodyAccel + vPQRidot x r + vPQRi x (vPQRi x r), r = StructuralToBody(eye point) (:205-213); [in], [ft/s2], [rad/s] */
+static void pilot_accel(const double cg[3], const double eye[3], const double body_accel[3], const double pqridot[3], const double pqri[3], double out[3]) {
+  double r[3], t1[3], t2[3];
+  struct_to_body(cg, eye, r);
+  cross3(pqridot, r, t1);
+  cross3(pqri, r, t2);
+  cross3(pqri, t2, t2);
+  for (int i = 0; i < 3; i++) out[i] = body_accel[i] + t1[i] + t2[i];
+}
+void f16_test_pilot_accel(const double* cg, const double* eye, const double* body_accel, const double* pqridot, const double* pqri, double* out3) {
+  pilot_accel(cg, eye, body_accel, pqridot, pqri, out3);
+}
 static void auxiliary_run(F16State* s) {
   for (int i = 0; i < 3; i++) s->aero_pqr[i] = s->pqr[i];
   double u = s->uvw[0], v = s->uvw[1], w = s->uvw[2];
@@ -550,12 +600,9 @@ static void auxiliary_run(F16State* s) {
   s->vc_fps = (fabs(s->mach) > 0.0) ? f16_vcas_from_mach(s->mach, s->P) : 0.0;
   /* pilot station acceleration uses last tick's Accelerations and the inertial rates (:205-217) */
   const double eye[3] = {F16_EYEPOINT_X, F16_EYEPOINT_Y, F16_EYEPOINT_Z};
-  double r[3], t1[3], t2[3];
-  struct_to_body(s->cg, eye, r);
-  cross3(s->pqridot, r, t1);
-  cross3(s->pqr_i, r, t2);
-  cross3(s->pqr_i, t2, t2);
-  for (int i = 0; i < 3; i++) s->npilot[i] = (s->body_accel[i] + t1[i] + t2[i]) / G0_FT;
+  double apilot[3];
+  pilot_accel(s->cg, eye, s->body_accel, s->pqridot, s->pqr_i, apilot);
+  for (int i = 0; i < 3; i++) s->npilot[i] = apilot[i] / G0_FT;
   /* hoverbmac: (AGL - (Tb2l*RPBody).z)/b, terrain elevation 0 => AGL = geodetic altitude */
   const double rp[3] = {F16_AERORP_X, F16_AERORP_Y, F16_AERORP_Z};
   double rpb[3], mac[3];

@@ -60,7 +60,7 @@ typedef struct {
   double Tw2b[9];
   double h_b_mac;
   /* ---------------- FGMassBalance */
-  double mass, weight, cg[3], last_cg[3], J[9], Jinv[9];
+  double mass, weight, cg[3], last_cg[3], J[9], Jinv[9], tankJ[9];
   int have_last_cg;
   /* ---------------- FGPropulsion / FGTurbine / FGTank */
   double tank[4];
@@ -102,6 +102,11 @@ void f16_test_aero_sums(const double* in17, double* out6);
 /* one FGPID::Run at a given dt (tests only); st = {in_prev, in_prev2, i_total, out} */
 double f16_test_pid(double* st, double in, double trigger, double kp, double ki, double kd, double dt);
 double f16_kinemat(double out, double in, const double* detents, const double* times, int n, double dt);
+/* one pass of the <flight_control> section / FGMassBalance::Run / the pilot-station acceleration with everything they read passed in
+ * (tests only: tests/test_oracle_f16_wiring.py holds them to an independent generic reading of f16.xml) */
+void f16_test_fcs(double* st18, const double* in17, double* out16);
+void f16_test_massbalance(const double* tanks4, const double* pm2, const double* cg_tanks, double* out31);
+void f16_test_pilot_accel(const double* cg, const double* eye, const double* body_accel, const double* pqridot, const double* pqri, double* out3);
 
 #ifdef __cplusplus
 }

@@ -109,6 +109,12 @@ def lib():
         L.f16_vcas_from_mach.restype = C.c_double
         L.f16_kinemat.argtypes = [C.c_double, C.c_double, dp, dp, C.c_int, C.c_double]
         L.f16_kinemat.restype = C.c_double
+        L.f16_test_fcs.argtypes = [dp, dp, dp]
+        L.f16_test_fcs.restype = None
+        L.f16_test_massbalance.argtypes = [dp, dp, dp, dp]
+        L.f16_test_massbalance.restype = None
+        L.f16_test_pilot_accel.argtypes = [dp] * 6
+        L.f16_test_pilot_accel.restype = None
         L.or_posture_orientation.argtypes = [C.c_double] * 2
         L.or_posture_orientation.restype = C.c_double
         L.or_posture_range.argtypes = [C.c_double]

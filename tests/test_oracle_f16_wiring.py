@@ -1,0 +1,187 @@
+"""The F-16's own wiring in the FDM oracle — fcs_run() (f16.xml:317-992 read by hand), massbalance_run() (f16.xml:62-92,272-316) and the
+pilot-station acceleration — against an independent GENERIC reading of the same XML (tests/golden/f16_fcs_check.npz, written by
+tests/golden/make_f16_fcs_check.py: the <flight_control> section interpreted component by component in document order with the
+semantics of the reference's FGSwitch / FGGain / FGSummer / FGPID / FGKinemat / FGFCSFunction sources; <metrics>, <mass_balance> and the
+tanks evaluated per FGMassBalance.cpp:181-262), plus the expectations the reference's JSBSim unit tests make about these blocks
+(tests/golden/jsbsim_relations.npz, make_jsbsim_relations.py)."""
+import ctypes as C
+import importlib.util
+import os
+import re
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dbl(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+@pytest.fixture(scope="module")
+def fcs():
+    return np.load(os.path.join(GOLD, "f16_fcs_check.npz"))
+
+
+@pytest.fixture(scope="module")
+def gen():
+    """The generator module, for expand_inputs() only (knots -> per-tick inputs); importing it does not touch the reference tree."""
+    spec = importlib.util.spec_from_file_location("make_f16_fcs_check", os.path.join(GOLD, "make_f16_fcs_check.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_flight_control_component_inventory(fcs):
+    """What the generic reading found in <flight_control>: the section the oracle restates has exactly these components."""
+    counts = {k: int(v) for k, v in fcs["component_counts"]}
+    assert counts == {"summer": 13, "switch": 11, "pure_gain": 9, "kinematic": 9, "aerosurface_scale": 7, "scheduled_gain": 5, "pid": 3, "fcs_function": 1}
+
+
+def test_fcs_run_against_the_generic_reading_of_flight_control(oracle, fcs, gen):
+    """512 input sequences x 200 ticks (every switch branch, every clip, PID triggers 0 and 1, every kinematic in motion; 64 of them
+    checked at every tick, the rest every 10th tick — the section's memory carries any earlier difference forward): every named surface,
+    the throttle position, the three PID outputs and the actuator positions, 1e-9."""
+    L = oracle.lib()
+    knots, linear, gear0 = fcs["knots"], fcs["linear"], fcs["gear_pos0"]
+    full, sampled = fcs["out_full"], fcs["out_sampled"]
+    assert [str(p) for p in fcs["in_props"]] == gen.IN_PROPS and [str(p) for p in fcs["out_props"]] == gen.OUT_PROPS
+    assert float(fcs["fcs_dt"]) == 1.0 / 120.0
+    nfull, every = full.shape[0], gen.KNOT_EVERY
+    worst = 0.0
+    out, outp = dbl(np.zeros(16))
+    for s in range(knots.shape[0]):
+        X = gen.expand_inputs(knots[s], linear[s])
+        st, stp = dbl(np.zeros(18))
+        st[17] = gear0[s]                        # gear/gear-pos-norm starts DOWN (FGFCS.cpp:81) unless the sequence set it
+        for t in range(X.shape[0]):
+            x, xp = dbl(X[t])
+            L.f16_test_fcs(stp, xp, outp)
+            if s < nfull:
+                want = full[s, t]
+            elif t % every == every - 1:
+                want = sampled[s - nfull, t // every]
+            else:
+                continue
+            err = np.abs(out - want) / np.maximum(1.0, np.abs(want))
+            worst = max(worst, float(err.max()))
+            assert err.max() <= 1e-9, (s, t, [str(p) for p in fcs["out_props"][err > 1e-9]], out[err > 1e-9], want[err > 1e-9])
+    assert worst <= 1e-9
+
+
+def header_defines(path):
+    txt = open(path).read()
+    return {m.group(1): float(m.group(2)) for m in re.finditer(r"#define\s+(F16_\w+)\s+\(([-+0-9.eE]+)\)", txt)}
+
+
+@pytest.mark.parametrize("header", ["oracle/f16_tables.h", "aircombat-selfplay_amd/csrc/f16_tables.h"])
+def test_metrics_mass_and_tank_constants_of_both_headers(fcs, header):
+    """<metrics>, <mass_balance>, the point masses and the four tanks as the second tokenizer reads them, against the constants BOTH
+    generated headers carry (the oracle's and the device's)."""
+    d = header_defines(os.path.join(ROOT, header))
+    m = {k[5:]: fcs[k] for k in fcs.files if k.startswith("mass|")}
+    for key, name in (("wingarea", "WINGAREA"), ("wingspan", "WINGSPAN"), ("chord", "CHORD"), ("ixx", "IXX"), ("iyy", "IYY"), ("izz", "IZZ"),
+                      ("ixy", "IXY"), ("ixz", "IXZ"), ("iyz", "IYZ"), ("emptywt", "EMPTYWT")):
+        assert d["F16_" + name] == float(m[key]), key
+    for key, name in (("loc_AERORP", "AERORP"), ("loc_EYEPOINT", "EYEPOINT"), ("loc_VRP", "VRP"), ("cg", "CG")):
+        assert [d[f"F16_{name}_{a}"] for a in "XYZ"] == list(m[key]), key
+    assert float(m["negated"]) == 1.0            # negated_crossproduct_inertia="true" (f16.xml:62), the branch massbalance_run hard-codes
+    assert len(m["pm_weight"]) == 2 and len(m["tank_contents"]) == 4 and float(m["n_engines"]) == 1.0
+    for i in range(2):
+        assert d[f"F16_PM{i}_WEIGHT"] == m["pm_weight"][i] and [d[f"F16_PM{i}_{a}"] for a in "XYZ"] == list(m["pm_xyz"][i])
+    for i in range(4):
+        assert d[f"F16_TANK{i}_CONTENTS"] == m["tank_contents"][i] and d[f"F16_TANK{i}_CAPACITY"] == m["tank_capacity"][i]
+        assert [d[f"F16_TANK{i}_{a}"] for a in "XYZ"] == list(m["tank_xyz"][i])
+    for tag in ("milthrust", "maxthrust", "bypassratio", "tsfc", "atsfc", "idlen1", "idlen2", "maxn1", "maxn2", "augmented", "augmethod", "injected"):
+        assert d["F16_ENG_" + tag.upper()] == float(m["eng_" + tag]), tag      # F100-PW-229.xml scalars
+    assert list(m["thruster_xyz"]) == [0.0, 0.0, 0.0]     # thrust acts at the structural origin: propulsion_run's moment arm is the CG itself
+
+
+def massbalance(L, tanks, pm, cg_tanks):
+    o, op = dbl(np.zeros(31))
+    L.f16_test_massbalance(dbl(tanks)[1], dbl(pm)[1], dbl(cg_tanks)[1], op)
+    return o
+
+
+def test_massbalance_run_against_the_generic_reading(oracle, fcs):
+    """200 tank loadings (incl. the as-shipped one and the empty, pilot-less aircraft): weight, CG, J, J^-1 and the tanks' share of J."""
+    L = oracle.lib()
+    for tanks, pm, want in zip(fcs["mb_tanks"], fcs["mb_pm_weight"], fcs["mb_result"]):
+        cg = massbalance(L, tanks, pm, np.zeros(3))[1:4]       # first pass: the CG does not depend on the tank inertia's reference point
+        got = massbalance(L, tanks, pm, cg)                    # second pass: tank inertia about the CG of the previous pass = this CG
+        assert np.all(np.abs(got[:13] - want[:13]) <= 1e-9 * np.maximum(1.0, np.abs(want[:13]))), (tanks, got[:13], want[:13])
+        assert np.all(np.abs(got[13:22] - want[13:22]) <= 1e-9 * np.abs(want[13:22]).max())
+        assert np.all(np.abs(got[22:] - want[22:]) <= 1e-9 * np.maximum(1.0, np.abs(want[22:])))
+
+
+@pytest.fixture(scope="module")
+def rel():
+    return np.load(os.path.join(GOLD, "jsbsim_relations.npz"))
+
+
+def test_inertia_matrix_expectations_of_TestPointMassInertia(oracle, fcs, rel):
+    """TestPointMassInertia.testInertiaMatrix runs on the F-16 itself (script f16_test -> aircraft f16): J * Jinv is the identity to 7
+    places; with the point-mass weight and both internal tanks at 0 the weight is the empty weight and inertia/ixz-slugs_ft2 is the number
+    in the file's <ixz> element (the test reads it from the XML: the recorded value), i.e. no parallel-axis term is left and the
+    negated_crossproduct_inertia branch puts the file's value, sign included, at J(1,3)."""
+    L = oracle.lib()
+    m = {k[5:]: fcs[k] for k in fcs.files if k.startswith("mass|")}
+    places = int(rel["inertia_identity_places"])
+    for tanks in (m["tank_contents"], [0, 0, 0, 0], [1234.5, 2900.0, 0, 0]):
+        cg = massbalance(L, tanks, m["pm_weight"], np.zeros(3))[1:4]
+        got = massbalance(L, tanks, m["pm_weight"], cg)
+        ident = got[4:13].reshape(3, 3) @ got[13:22].reshape(3, 3)
+        assert np.all(np.abs(ident - rel["inertia_identity"]) < 0.5 * 10.0 ** -places)
+    got = massbalance(L, [0, 0, 0, 0], [0, 0], m["cg"])
+    assert round(got[0] - float(m["emptywt"]), places) == 0                 # inertia/weight-lbs == inertia/empty-weight-lbs
+    assert round(got[4 + 2] - float(rel["f16_ixz_expected"]), places) == 0   # J(1,3) holds the file's ixz
+    assert float(rel["f16_ixz_expected"]) == float(m["ixz"])
+
+
+def test_tank_inertia_scales_with_contents_as_in_TestFuelTanksInertia(oracle, fcs, rel):
+    """TestFuelTanksInertia.test_fuel_tanks_inertia: a tank's inertia varies as its contents (ratio 0.5 -> 0.5, delta 1e-7). The F-16's
+    tanks carry no <radius> (generic reading asserts it), so their local inertia is 0 and what scales is the parallel-axis share of J."""
+    L = oracle.lib()
+    m = {k[5:]: fcs[k] for k in fcs.files if k.startswith("mass|")}
+    ratio, delta = float(rel["tank_ratio"]), float(rel["tank_delta"])
+    cg = np.array([-190.0, 1.5, -3.0])
+    full = massbalance(L, m["tank_contents"], m["pm_weight"], cg)[22:]
+    part = massbalance(L, ratio * m["tank_contents"], m["pm_weight"], cg)[22:]
+    assert np.all(np.abs(part - ratio * full) <= delta)
+    assert np.abs(full).max() > 100.0
+
+
+def test_pilot_station_acceleration_relations_of_TestAccelerometer(oracle, rel):
+    """TestAccelerometer.testOrbit: a body in free fall (no body-frame force, no rotation relative to the inertial frame) reads 0 at the
+    pilot station (1e-8); testSpinningBodyOnOrbit: spinning at r_inertial = 1 rad/s about body z with the CG offset along structural
+    y by d, the station at the structural origin reads (0, d r^2, 0) (a-pilot-y / cg-y = 1 to 1e-8): the w x (w x r) term on the
+    INERTIAL rates with r = StructuralToBody(station)."""
+    L = oracle.lib()
+    o, op = dbl(np.zeros(3))
+    z = np.zeros(3)
+    L.f16_test_pilot_accel(dbl([-193.0, 0.0, -5.1])[1], dbl([-336.2, 0.0, 29.5])[1], dbl(z)[1], dbl(z)[1], dbl(z)[1], op)
+    assert np.all(np.abs(o - rel["orbit_a_pilot"]) <= float(rel["orbit_delta"]))
+    cgy_in = 17.0
+    L.f16_test_pilot_accel(dbl([0.0, cgy_in, 0.0])[1], dbl(z)[1], dbl(z)[1], dbl(z)[1], dbl([0.0, 0.0, float(rel["spin_r_inertial"])])[1], op)
+    assert abs(o[0] - rel["spin_a_pilot_x"]) <= float(rel["spin_delta"]) and abs(o[2] - rel["spin_a_pilot_z"]) <= float(rel["spin_delta"])
+    assert abs(o[1] / (cgy_in / 12.0) - float(rel["spin_ay_over_cgy_ft"])) <= float(rel["spin_delta"])
+
+
+def test_initial_geodetic_latitude_of_TestInitialConditions(oracle, rel):
+    """TestInitialConditions.test_set_initial_geodetic_latitude: after run_ic, position/lat-geod-deg is the ic/lat-geod-deg that was set and
+    the altitude above sea level is unchanged (assertAlmostEqual, 7 places) — f16_reset places the aircraft by geodetic latitude."""
+    O = oracle
+    places = int(rel["ic_places"])
+    for dlat in rel["ic_lat_shift_deg"]:
+        for lat0, h in ((60.0, 20000.0), (35.2, 9000.0), (-12.0, 31000.0)):
+            cfg = O.default_config(O.TASK_SINGLECOMBAT)
+            cfg.init[0].lat_geod_deg = lat0 + float(dlat)
+            cfg.init[0].h_sl_ft = h
+            env = O.OracleEnv(cfg)
+            env.reset()
+            lon, lat, alt_m = env.pose(0)[:3]        # position/lat-geod-deg and position/h-sl-ft * 0.3048, as AircraftSimulator caches them
+            assert round(lat - (lat0 + float(dlat)), places) == 0
+            assert abs(alt_m / 0.3048 - h) < 1e-5    # h_sl goes through radius - sea-level radius at 2e7 ft: 1e-5 ft is fp64's floor there
