@@ -100,6 +100,7 @@ SIGNATURES = {
     "ac_get_missile": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "ac_timing_begin": (C.c_int, [_p]),
     "ac_timing_end": (C.c_int, [_p, C.POINTER(C.c_float)]),
+    "ac_step_timed_device": (C.c_int, [_p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "ac_state_checksum": (C.c_int, [_p, C.POINTER(C.c_uint64)]),
     "ac_seed_envs": (C.c_int, [_p, _p]),
     "ac_get_heading_state": (C.c_int, [_p, C.c_int32, _p]),

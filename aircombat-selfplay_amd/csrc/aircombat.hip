@@ -126,7 +126,19 @@ struct DevPtrs {
   float* obs; float* rew; uint8_t* done; int* info;        // outputs, rows padded to whole workgroups (64 aircraft)
   float* obs2; float* rew2; uint8_t* done2; int* info2;    // second copy of the outputs (pinned host memory mapped into the device:
                                                            // ac_step_host), or null
+  int* err;                              // one word of page-locked host memory: 1 + index of an aircraft whose state or reward went non-finite
 };
+
+// ------------------------------------------------------------------------------------------------ non-finite guard
+// The reference traps NaN in BaseEnv._pack (env_base.py:277-281, a pdb prompt) and raises RuntimeError("JSBSim failed.") when the FDM gives up
+// (simulatior.py:223-225); ExtremeState is meant to end an episode before that (catalog.py:386-416) but its tests are all `>=`, which a NaN
+// fails. Here: a NaN / Inf anywhere in the quantities ExtremeState looks at (inertial speed, body rates, altitude, pilot-station load
+// factors: every integrator state reaches one of them within a tick) counts as an extreme state, so the aircraft terminates, and poisons
+// the step's reward, which emit_scalars reports through P.err; the host then fails the step with the aircraft's index.
+__device__ __forceinline__ bool nonfinite_probe(float veci, float pqr, float h_sl_ft, float np_max) {
+  return !(fabsf(veci + pqr + h_sl_ft + np_max) < INFINITY);
+}
+__device__ __forceinline__ float poison_if(bool bad, float reward) { return bad ? __int_as_float(0x7fc00000) : reward; }
 
 // ------------------------------------------------------------------------------------------------ device helpers
 // Field f of lane n at byte offset (f*N + n)*sizeof from ONE wave-uniform base pointer: the offset is a 32-bit lane value (one VALU
@@ -627,6 +639,7 @@ __device__ __forceinline__ void emit_scalars(const DevPtrs& P, int lane, float r
   const int4 inf = make_int4(i0, i1, i2, i3);
   const int packed = (i0 & 0xFFFF) | ((i1 & 0xFF) << 16) | ((i2 & 0x7F) << 24) | ((i3 & 1) << 31);
   const size_t n = blk * 64 + lane;
+  if (!(fabsf(reward) < INFINITY)) *(volatile int*)P.err = (int)n + 1;   // (any of the offending lanes wins; the host keeps it sticky)
 #pragma unroll
   for (int set = 1; set >= 0; --set) {
     float* rew = set ? P.rew2 : P.rew; uint8_t* dn = set ? P.done2 : P.done; int* info = set ? P.info2 : P.info;
@@ -1022,10 +1035,12 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
   const int status_pre = t.status;
   int code = AC_DONE_NONE;
   bool done = false;
+  bool nonfinite = false;
   {
     float np_max = fmaxf(fabsf(s.npx), fmaxf(fabsf(s.npy), fabsf(s.npz)));
     float pqr = sqrtf(d.p * d.p + d.q * d.q + d.r * d.r);
-    bool extreme = (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);  // catalog.py:386-416
+    nonfinite = nonfinite_probe(d.veci, pqr, d.h_sl_ft, np_max);
+    bool extreme = nonfinite || (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);  // catalog.py:386-416
     bool overload = (s.ticks >= kTickOverload) &&
                     (fabsf(s.npx) > c.acc_x || fabsf(s.npy) > c.acc_y || fabsf(s.npz + 1.0f) > c.acc_z);  // overload.py:38-46
     if (pr.alt_m <= c.altitude_limit) { t.status = AC_CRASH; code = AC_DONE_LOW_ALTITUDE; done = true; }
@@ -1135,6 +1150,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
   // info['done_condition'] keeps the last agent's message
   // (sending the observation rows ahead of the rewards and the state stores was tried for the host-boundary path, where their trip
   // across PCIe is what the step waits for in the end: 0.5 us slower, not faster)
+  reward = poison_if(nonfinite, reward);
   if (OBS_BY_KIN) emit_scalars(P, l, reward, done, 2, step_out, other_code ? other_code : code, 0, all_done ? 1 : 0);
   else emit_outputs(P, lds_out, OBS, l, ob, reward, done, 2, step_out, other_code ? other_code : code, 0, all_done ? 1 : 0);
   AC_CLK(54);
@@ -1281,7 +1297,8 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
   int last_code = AC_DONE_NONE;
   float np_max = fmaxf(fabsf(s.npx), fmaxf(fabsf(s.npy), fabsf(s.npz)));
   float pqr = sqrtf(d.p * d.p + d.q * d.q + d.r * d.r);
-  const bool extreme = (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);
+  const bool nonfinite = nonfinite_probe(d.veci, pqr, d.h_sl_ft, np_max);
+  const bool extreme = nonfinite || (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);
   const bool overload = (s.ticks >= kTickOverload) &&
                         (fabsf(s.npx) > c.acc_x || fabsf(s.npy) > c.acc_y || fabsf(s.npz + 1.0f) > c.acc_z);
   const bool low = pr.alt_m <= c.altitude_limit;
@@ -1331,7 +1348,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
   if (live) {
     store_state(P.F, P.I, P.D, N, n, s, t);
   }
-  emit_rows(P, lds_out, ow, l, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);
+  emit_rows(P, lds_out, ow, l, poison_if(nonfinite, reward), done, A, step_out, last_code, 0, all_done ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------ initial conditions
@@ -1530,11 +1547,16 @@ struct ac_env {
   HeadingPtrs hp; HeadingCfg hc;         // HeadingTask: targets, check clock, numpy-PCG64 state per env
   int act_low;                           // width of the low-level action the step kernels decode
   hipEvent_t ev0, ev1;
+  hipEvent_t ev_mid;                     // ac_step_timed_device: between the controller kernel and the step kernel
+  bool mark_mid;
   hipEvent_t ev_order;                   // stream-ordering hand-shake with the caller's streams (ac_order_after / ac_order_before)
   // ac_step_host: two library-owned sets of pinned host buffers mapped into the device (actions in; obs, rewards, dones, info out)
   struct HostSet { float* act; float* obs; float* rew; uint8_t* done; int* info; } hs[2];
   bool have_hs;
+  int* err_host;                         // P.err: one word of page-locked host memory the step kernels write on a non-finite state (sticky until ac_reset)
+  int err_sticky;
   bool timing;
+  int ctl_tiles;                         // AIRCOMBAT_CTL_TILES at ac_create: 1 / 2 aircraft tiles per controller workgroup (0: chosen from the batch size)
   bool ctl_fp32;                         // hierarchical tasks: controller_kernel (fp32 MFMA) instead of controller_split_kernel (AIRCOMBAT_CTL=fp32 at ac_create)
   bool quad_waves;                       // the 1v1 tasks with munitions up to one workgroup per CU: three FDM waves + the environment wave (FORM 3 / FORM_QUAD)
   bool split_waves;                      // SingleCombat below one wave per SIMD: three waves per 64 aircraft (step_kernel_1v1<.., SPLIT>)
@@ -1549,6 +1571,16 @@ static void geodetic2ecef_m(double lat_deg, double lon_deg, double alt, double* 
   *z = (Nn * (b / a) * (b / a) + alt) * sin(lat);
 }
 
+// The non-finite guard's host half: after a completed step, a set error word fails the call with the reference's message
+// (RuntimeError("JSBSim failed."), simulatior.py:223-225) and the aircraft it was seen on; it stays set until ac_reset.
+static int check_nonfinite(ac_env* h, const char* who) {
+  if (h->err_host && *(volatile int*)h->err_host) h->err_sticky = *(volatile int*)h->err_host;
+  if (!h->err_sticky) return 0;
+  const int n = std::min(h->err_sticky - 1, h->N - 1);
+  char msg[192];
+  snprintf(msg, sizeof msg, "%s: JSBSim failed. Non-finite state or reward in env %d, agent %d (ac_reset clears the condition)", who, n / h->A, n % h->A);
+  return fail(msg);
+}
 static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
   DevPtrs p = h->dp;
   p.actions = d_actions ? d_actions : h->d_actions;
@@ -1567,10 +1599,20 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
       HIP_OK(hipGetLastError());
     }
     // the bf16-piece form (controller_split_kernel.hpp) unless the handle was created under AIRCOMBAT_CTL=fp32 (the fp32 matrix instructions)
+    // Two 32-aircraft tiles per workgroup sharing one weight stream once the one-tile form would queue two workgroups per CU anyway
+    // (16 384 aircraft = 512 tiles on 256 CUs: BASELINE C4 / C5 as shipped); AIRCOMBAT_CTL_TILES=1/2 pins the form (tests, profiling).
+    const int tiles = h->ctl_tiles ? h->ctl_tiles : (h->N >= 16384 ? 2 : 1);
+    const dim3 cgrid((h->N + ctl::MT * tiles - 1) / (ctl::MT * tiles));
     if (h->ctl_fp32) hipLaunchKernelGGL(controller_kernel, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
-    else if (h->cfg.use_baseline) hipLaunchKernelGGL(controller_split_kernel<true>, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
-    else hipLaunchKernelGGL(controller_split_kernel<false>, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
+    else if (h->cfg.use_baseline) {
+      if (tiles == 2) hipLaunchKernelGGL((controller_split_kernel<true, 2>), cgrid, dim3(256), 0, h->stream, a);
+      else hipLaunchKernelGGL((controller_split_kernel<true, 1>), cgrid, dim3(256), 0, h->stream, a);
+    } else {
+      if (tiles == 2) hipLaunchKernelGGL((controller_split_kernel<false, 2>), cgrid, dim3(256), 0, h->stream, a);
+      else hipLaunchKernelGGL((controller_split_kernel<false, 1>), cgrid, dim3(256), 0, h->stream, a);
+    }
     HIP_OK(hipGetLastError());
+    if (h->mark_mid) HIP_OK(hipEventRecord(h->ev_mid, h->stream));
     p.actions = h->d_low;
   }
   const bool one_wave_per_simd = grid.x <= 1024;  // 256 CUs x 4 SIMDs
@@ -1709,6 +1751,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     h->quad_waves = munitions_1v1 && (qe ? (qe[0] == '1') : (wgs <= 256));
     const char* ce = getenv("AIRCOMBAT_CTL");
     h->ctl_fp32 = ce && ce[0] == 'f';
+    const char* te = getenv("AIRCOMBAT_CTL_TILES");
+    h->ctl_tiles = (te && (te[0] == '1' || te[0] == '2')) ? te[0] - '0' : 0;
   }
   h->obs_dim = heading ? 12 : (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
@@ -1755,6 +1799,10 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   HIP_OK(hipEventCreate(&h->ev0));
   HIP_OK(hipEventCreate(&h->ev1));
   HIP_OK(hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming));
+  HIP_OK(hipEventCreate(&h->ev_mid));
+  HIP_OK(hipHostMalloc((void**)&h->err_host, sizeof(int), hipHostMallocDefault));
+  *h->err_host = 0; h->err_sticky = 0;
+  h->dp.err = h->err_host;
   const size_t N = (size_t)h->N;
   DevPtrs& p = h->dp;
   HIP_OK(hipMalloc(&p.F, sizeof(float) * NF * N));
@@ -1853,7 +1901,8 @@ int ac_destroy(ac_env_t* h) {
   for (void* b : bufs) (void)hipFree(b);
   if (h->have_hs)
     for (auto& hs : h->hs) { (void)hipHostFree(hs.act); (void)hipHostFree(hs.obs); (void)hipHostFree(hs.rew); (void)hipHostFree(hs.done); (void)hipHostFree(hs.info); }
-  (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); (void)hipEventDestroy(h->ev_order);
+  if (h->err_host) (void)hipHostFree(h->err_host);
+  (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); (void)hipEventDestroy(h->ev_order); (void)hipEventDestroy(h->ev_mid);
   (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -1866,6 +1915,8 @@ int ac_num_agents(const ac_env_t* h) { return h ? h->A : -1; }
 int ac_reset(ac_env_t* h, float* obs) {
   if (!h) return fail("ac_reset: null handle");
   HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));    // (a step still in flight may yet write the error word)
+  *h->err_host = 0; h->err_sticky = 0;
   if (launch_reset(h)) return -1;
   if (obs) HIP_OK(hipMemcpyAsync(obs, h->dp.obs, sizeof(float) * (size_t)h->N * h->obs_dim, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
@@ -1883,7 +1934,7 @@ int ac_step(ac_env_t* h, const float* actions, float* obs, float* rewards, uint8
   if (dones) HIP_OK(hipMemcpyAsync(dones, h->dp.done, N, hipMemcpyDeviceToHost, h->stream));
   if (info) HIP_OK(hipMemcpyAsync(info, h->dp.info, sizeof(int) * 4 * h->E, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
-  return 0;
+  return check_nonfinite(h, "ac_step");
 }
 
 // ---- zero-copy host boundary. The step kernel reads the actions straight from pinned host memory mapped into the device and
@@ -1926,7 +1977,7 @@ int ac_step_host_wait(ac_env_t* h) {
   // (hipStreamSynchronize spins on the completion signal itself; polling hipStreamQuery measured 5 us slower per step,
   //  tools/micro/host_io.hip)
   HIP_OK(hipStreamSynchronize(h->stream));
-  return 0;
+  return check_nonfinite(h, "ac_step_host_wait");
 }
 int ac_step_host(ac_env_t* h, int32_t set) {   // step_async + step_wait in one call (VecEnv.step, env_wrappers.py:30-42)
   if (ac_step_host_async(h, set)) return -1;
@@ -1969,7 +2020,7 @@ int ac_sync(ac_env_t* h) {
   if (!h) return fail("ac_sync: null handle");
   HIP_OK(hipSetDevice(h->device));
   HIP_OK(hipStreamSynchronize(h->stream));
-  return 0;
+  return check_nonfinite(h, "ac_sync");
 }
 int ac_timing_begin(ac_env_t* h) {
   if (!h) return fail("ac_timing_begin: null handle");
@@ -1982,6 +2033,24 @@ int ac_timing_end(ac_env_t* h, float* total_ms) {
   HIP_OK(hipEventSynchronize(h->ev1));
   HIP_OK(hipEventElapsedTime(total_ms, h->ev0, h->ev1));
   return 0;
+}
+
+int ac_step_timed_device(ac_env_t* h, const float* d_actions, float* controller_ms, float* step_ms) {
+  if (!h || !controller_ms || !step_ms) return fail("ac_step_timed_device: null argument");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipEventRecord(h->ev0, h->stream));
+  h->mark_mid = h->cfg.hierarchical != 0;
+  const int rc = launch_step(h, d_actions);
+  h->mark_mid = false;
+  if (rc) return rc;
+  HIP_OK(hipEventRecord(h->ev1, h->stream));
+  HIP_OK(hipEventSynchronize(h->ev1));
+  *controller_ms = 0.0f;
+  if (h->cfg.hierarchical) {
+    HIP_OK(hipEventElapsedTime(controller_ms, h->ev0, h->ev_mid));
+    HIP_OK(hipEventElapsedTime(step_ms, h->ev_mid, h->ev1));
+  } else HIP_OK(hipEventElapsedTime(step_ms, h->ev0, h->ev1));
+  return check_nonfinite(h, "ac_step_timed_device");
 }
 
 // state vector layout: rx ry rz | float fields | task floats | eng ticks | task ints   (names: ac_state_field_name)

@@ -167,11 +167,12 @@ __device__ __forceinline__ void scripted_inputs(const Args& a, int n, float (&x)
     Props pt; float psit;
     aircraft_props(a.P, a.c, n - a.n_ego, pt, psit);
     dv0 = pt.u - pr.u;
-    const float ev = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve), dx = pt.n - pr.n, dy = pt.e - pr.e;
-    const float R = sqrtf(dx * dx + dy * dy);
-    const float ao = acosf(clampf(-1.0f, (dx * pr.vn + dy * pr.ve) / (R * ev + 1e-8f), 1.0f));
+    // get2d_AO_TA_R's angle-off (utils.py:86-103) is acos(dot / (R |v| + 1e-8)) with the sign of the 2-D cross product. A pursuer
+    // drives exactly that angle to zero, where acos turns an fp32 rounding of its argument into sqrt(2 eps) = 3.5e-4 rad; the same angle
+    // as atan2(cross, dot) is good to an ulp everywhere and differs from the float64 acos form by the 1e-8 in its denominator only
+    const float dx = pt.n - pr.n, dy = pt.e - pr.e;
     const float cr = pr.vn * dy - pr.ve * dx;
-    dv1 = ao * (float)((cr > 0.0f) - (cr < 0.0f));
+    dv1 = (cr == 0.0f) ? 0.0f : atan2f(cr, dx * pr.vn + dy * pr.ve);
     dv2 = pt.ub - pr.ub;
   }
   // BaselineAgent.get_observation (baseline.py:45-63)

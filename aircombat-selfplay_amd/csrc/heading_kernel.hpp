@@ -178,6 +178,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, SPLIT ? 1 : 2) void step_kernel_h
 
   // ---- terminations, first that fires wins (heading_task.py:20-26)
   bool done = false;
+  bool nonfinite = false;
   int code = AC_DONE_NONE;
   {
     // UnreachHeading (unreach_heading.py:22-65): at each check time either give up or draw the next targets
@@ -201,10 +202,11 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, SPLIT ? 1 : 2) void step_kernel_h
         x.turn_counts += 1;
       }
     }
+    const float np_max = fmaxf(fabsf(s.npx), fmaxf(fabsf(s.npy), fabsf(s.npz)));
+    const float pqr = sqrtf(d.p * d.p + d.q * d.q + d.r * d.r);
+    nonfinite = nonfinite_probe(d.veci, pqr, d.h_sl_ft, np_max);
     if (!done) {
-      const float np_max = fmaxf(fabsf(s.npx), fmaxf(fabsf(s.npy), fabsf(s.npz)));
-      const float pqr = sqrtf(d.p * d.p + d.q * d.q + d.r * d.r);
-      const bool extreme = (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);
+      const bool extreme = nonfinite || (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);
       const bool overload = (s.ticks >= kTickOverload) && (fabsf(s.npx) > c.acc_x || fabsf(s.npy) > c.acc_y || fabsf(s.npz + 1.0f) > c.acc_z);
       const bool low = pr.alt_m <= c.altitude_limit;
       if (hc.approach && low) { t.status = AC_CRASH; code = AC_DONE_LOW_ALTITUDE; done = true; }   // approach_task.py:23-28: LowAltitude first
@@ -232,5 +234,5 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, SPLIT ? 1 : 2) void step_kernel_h
     store_state(P.F, P.I, P.D, N, n, s, t);
     store_heading(H, N, n, x);
   }
-  emit_outputs(P, lds_out, OBS, l, ob, reward, done, 1, step_out, code, turns_out, done ? 1 : 0);
+  emit_outputs(P, lds_out, OBS, l, ob, poison_if(nonfinite, reward), done, 1, step_out, code, turns_out, done ? 1 : 0);
 }

@@ -667,7 +667,8 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   int code = AC_DONE_NONE, last_code = AC_DONE_NONE;
   float np_max = fmaxf(fabsf(s.npx), fmaxf(fabsf(s.npy), fabsf(s.npz)));
   float pqr = sqrtf(d.p * d.p + d.q * d.q + d.r * d.r);
-  const bool extreme = (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);
+  const bool nonfinite = nonfinite_probe(d.veci, pqr, d.h_sl_ft, np_max);
+  const bool extreme = nonfinite || (d.veci >= 1e10f) || (pqr >= 1000.0f) || (d.h_sl_ft >= 1e10f) || (np_max > 10.0f);
   const bool overload = (s.ticks >= kTickOverload) &&
                         (fabsf(s.npx) > c.acc_x || fabsf(s.npy) > c.acc_y || fabsf(s.npz + 1.0f) > c.acc_z);
   const bool low = pr.alt_m <= c.altitude_limit;
@@ -840,6 +841,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   }
   AC_CLKE(67);
   // (WVR uses the first 15 of the 21 slots; the *_RWR variants append two reserved zero slots)
+  reward = poison_if(nonfinite, reward);
   if (row_direct) emit_rows(P, lds_out, c.obs_dim, lane, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);
   else emit_outputs(P, lds_out, c.obs_dim, lane, ob, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);
   AC_CLKE(68);

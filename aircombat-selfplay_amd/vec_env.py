@@ -5,6 +5,13 @@ Mirrors ``SubprocVecEnv`` / ``DummyVecEnv`` of the reference (envs/env_wrappers.
 ``step_wait``, ``close()``; the same return shapes ``obs[E,A,obs_dim]``, ``rewards[E,A,1]``, ``dones[E,A,1]`` (bool),
 ``infos`` (ndarray of dict), and the same auto-reset rule (env_wrappers.py:191-204). Outputs are float32
 (the buffers cast to float32 on insert, algorithms/utils/buffer.py:52-58).
+
+Ownership of what ``step`` returns. The reference hands back fresh arrays every step (``np.stack``, env_wrappers.py:276-282), so a
+caller may keep ``obs`` / ``dones`` / ``infos`` of step t for as long as it likes. That is the default here too: ``step`` returns
+copies. ``copy=False`` (constructor argument; bench.py uses it, INTEGRATION.md section 3 describes it) returns live views of the
+library's two alternating page-locked buffer sets instead: valid until the step after next overwrites them, and never after
+``close()``. A non-finite aircraft state surfaces as ``RuntimeError`` (the reference's ``RuntimeError("JSBSim failed.")``,
+core/simulatior.py:223-225; its ``pdb`` NaN trap in ``_pack``, env_base.py:277-281, is not reproduced).
 """
 import ctypes as C
 import os
@@ -64,10 +71,11 @@ class LazyInfos:
 
     __slots__ = ("_codes",)
 
-    def __init__(self, codes):
+    def __init__(self, codes, snapshot=False):
         # [E, 4] int32 rows (current_step, done code, heading_turn_counts, env-reset flag), or the packed words [E] of ac_host_buffers
-        # (AC_INFO_* in include/aircombat.h: bits 0-15, 16-23, 24-30, 31)
-        self._codes = codes
+        # (AC_INFO_* in include/aircombat.h: bits 0-15, 16-23, 24-30, 31). snapshot: keep a private copy of the words (16 KB at 4096
+        # envs), so that the dicts read later are still this step's
+        self._codes = np.array(codes, copy=True) if snapshot else codes
 
     def __len__(self):
         return len(self._codes)
@@ -123,11 +131,12 @@ CONTROLLER_WEIGHTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "d
 class HipVecEnv:
     """E parallel 1v1 air-combat envs advanced by one HIP kernel launch per ``step``."""
 
-    def __init__(self, config, num_envs, device_id=0, seed=0, lib=None):
+    def __init__(self, config, num_envs, device_id=0, seed=0, lib=None, copy=True):
         if not isinstance(config, AcConfig):
             raise TypeError("config must be an AcConfig (see config_from_yaml / default_config)")
         self.lib = lib or load_library()
         self.config = config
+        self.copy = bool(copy)
         self.num_envs = int(num_envs)
         self.num_agents = int(config.n_agents)
         handle = C.c_void_p()
@@ -223,15 +232,19 @@ class HipVecEnv:
         self.waiting = True
 
     def step_wait(self):
-        """SubprocVecEnv.step_wait (env_wrappers.py:275-282). The returned arrays are views of the step's buffer set: valid until
-        the step after next overwrites it (float32; the buffers cast on insert, algorithms/utils/buffer.py:52-58)."""
+        """SubprocVecEnv.step_wait (env_wrappers.py:275-282): fresh float32 arrays (the buffers cast on insert,
+        algorithms/utils/buffer.py:52-58), or with copy=False views of the step's buffer set, valid until the step after next."""
         self._assert_not_closed()
         self.lib.check(self.lib.ac_step_host_wait(self._h), "ac_step_host_wait")
         self.waiting = False
-        return self._results[self._cur]
+        return self._fresh(self._cur) if self.copy else self._results[self._cur]
 
     def _result(self, st):
         return st["obs"], st["rew"], st["done"], LazyInfos(st["info"])
+
+    def _fresh(self, cur):
+        st = self._sets[cur]
+        return st["obs"].copy(), st["rew"].copy(), st["done"].copy(), LazyInfos(st["info"], snapshot=True)
 
     def step(self, actions):
         """VecEnv.step = step_async + step_wait (env_wrappers.py:30-42), through one library call."""
@@ -243,8 +256,8 @@ class HipVecEnv:
             a = a.reshape(dst.shape)
         np.copyto(dst, a)
         if self._step_host(self._h, cur) != 0:
-            self.lib.check(-1, "ac_step_host")
-        return self._results[cur]
+            self.lib.check(-1, "ac_step_host")      # RuntimeError: a HIP failure, or a non-finite aircraft state ("JSBSim failed.")
+        return self._fresh(cur) if self.copy else self._results[cur]
 
     def render(self, mode="txt", filepath="./JSBSimRecording.txt.acmi", env=0):
         """BaseEnv.render (env_base.py:207-250) for one env (the reference renders through DummyVecEnv, i.e. env 0): appends one
@@ -323,6 +336,8 @@ class HipVecEnv:
         return self._names.index(name)
 
     def close(self):
+        """Frees the handle and its page-locked buffers. With copy=False the views handed out earlier point into those buffers: they
+        must not be read after close() (with the default copy=True nothing the caller holds refers to library memory)."""
         if self.closed:
             return
         self._sets, self._results = [], []           # views of library-owned memory: dropped before the handle frees it
@@ -432,8 +447,8 @@ class HipShareVecEnv(HipVecEnv):
     observations of env ``e`` (BaseEnv.get_state, env_base.py:183-189), i.e. ``obs`` flattened per env; it is returned as a
     read-only broadcast view (the buffers copy on insert)."""
 
-    def __init__(self, config, num_envs, device_id=0, seed=0, lib=None):
-        super().__init__(config, num_envs, device_id=device_id, seed=seed, lib=lib)
+    def __init__(self, config, num_envs, device_id=0, seed=0, lib=None, copy=True):
+        super().__init__(config, num_envs, device_id=device_id, seed=seed, lib=lib, copy=copy)
         Box = _spaces()[0]
         self.share_observation_space = Box(low=-10, high=10.0, shape=(self.num_agents * self.obs_dim,))
 
@@ -448,6 +463,11 @@ class HipShareVecEnv(HipVecEnv):
     def _result(self, st):
         obs = st["obs"]
         return obs, self._share(obs), st["rew"], st["done"], LazyInfos(st["info"])
+
+    def _fresh(self, cur):
+        st = self._sets[cur]
+        obs = st["obs"].copy()
+        return obs, self._share(obs), st["rew"].copy(), st["done"].copy(), LazyInfos(st["info"], snapshot=True)
 
 
 class MultiDeviceVecEnv:
@@ -467,7 +487,8 @@ class MultiDeviceVecEnv:
         self.blocks = [env_block(r, len(device_ids), num_envs) for r in range(len(device_ids))]
         if min(c for _, c in self.blocks) < 1:
             raise ValueError("fewer envs than devices")
-        self.parts = [cls(config, count, device_id=dev, seed=seed + 1000 * start) for dev, (start, count) in zip(device_ids, self.blocks)]
+        # (the parts hand out views; _cat concatenates them into fresh arrays, so the caller of this class always owns what it gets)
+        self.parts = [cls(config, count, device_id=dev, seed=seed + 1000 * start, copy=False) for dev, (start, count) in zip(device_ids, self.blocks)]
         self.share = share
         self.num_envs, self.num_agents = int(num_envs), self.parts[0].num_agents
         self.obs_dim, self.act_dim = self.parts[0].obs_dim, self.parts[0].act_dim
@@ -511,8 +532,8 @@ class MultiDeviceVecEnv:
         self._pool.shutdown(wait=True)
 
 
-def make_env(scenario=None, num_envs=1, task=None, device_id=0, seed=0):
+def make_env(scenario=None, num_envs=1, task=None, device_id=0, seed=0, copy=True):
     """``scenario``: path of a scenario YAML (reference format) or None for the 1v1 block of WVR_selfplay.yaml."""
     cfg = config_from_yaml(scenario, task=task) if scenario else default_config(task or "singlecombat")
     cls = HipShareVecEnv if cfg.task in (AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO_NVN) else HipVecEnv
-    return cls(cfg, num_envs, device_id=device_id, seed=seed)
+    return cls(cfg, num_envs, device_id=device_id, seed=seed, copy=copy)

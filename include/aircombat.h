@@ -5,6 +5,12 @@
  * All functions return 0 on success or a negative error code; ac_last_error() gives the message.
  * Blocking unless the name says _async. One handle drives one GPU; handles are not thread-safe.
  *
+ * Non-finite state. A NaN / Inf in an aircraft's integrator state (or its reward) terminates that aircraft like the reference's
+ * ExtremeState condition (R/envs/JSBSim/core/catalog.py:386-416, whose `>=` tests a NaN would pass unnoticed) and makes every call that
+ * completes a step -- ac_step, ac_step_host_wait / ac_step_host, ac_sync, ac_step_timed_device -- return -1 with
+ * "JSBSim failed. Non-finite state or reward in env E, agent A" in ac_last_error(), until ac_reset clears it: the reference's
+ * RuntimeError("JSBSim failed.") (R/envs/JSBSim/core/simulatior.py:223-225) in place of its pdb NaN trap (R/envs/JSBSim/envs/env_base.py:277-281).
+ *
  * Array conventions (E = n_envs, A = n_agents, row-major, agents ordered ego team first then enemy team,
  * exactly like BaseEnv._pack, R/envs/JSBSim/envs/env_base.py:269-283):
  *   actions  float32 [E][A][act_dim]   integer-valued indices, as the runners hand them over (act_dim = ac_act_dim(): control
@@ -187,6 +193,9 @@ int ac_selftest_missile_walk(int32_t device_id, int32_t* mismatches);
  * with HIP events on the handle's stream */
 int ac_timing_begin(ac_env_t* h);
 int ac_timing_end(ac_env_t* h, float* total_ms);
+/* one device-resident step (as ac_step_async_device + ac_sync) with HIP events around its two kernels: the low-level controller of the
+ * hierarchical tasks (0 for the control-index form) and the step kernel, each in milliseconds. For the bench's per-kernel rooflines. */
+int ac_step_timed_device(ac_env_t* h, const float* d_actions, float* controller_ms, float* step_ms);
 
 const char* ac_last_error(void);
 const char* ac_version(void);

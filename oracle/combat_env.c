@@ -980,7 +980,16 @@ void or_env_step(OrEnv* e, const double* actions, double* obs, double* rew, uint
         for (int k = 0; k < 9; k++) x[3 + k] = pre_obs[i * e->obs_dim + k];
       }
       for (int k = 0; k < 12; k++) e->ac[i].ctl_in[k] = x[k];
-      or_actor_forward(x, e->ac[i].rnn, e->ac[i].low_action, NULL);
+      {
+        double lg[153];
+        static const int off[5] = {0, 41, 82, 123, 153};
+        or_actor_forward(x, e->ac[i].rnn, e->ac[i].low_action, lg);
+        for (int hd = 0; hd < 4; hd++) {   /* best minus second best of the head */
+          double best = lg[off[hd] + e->ac[i].low_action[hd]], second = -1e300;
+          for (int j = off[hd]; j < off[hd + 1]; j++) if (j != off[hd] + e->ac[i].low_action[hd] && lg[j] > second) second = lg[j];
+          e->ac[i].ctl_gap[hd] = best - second;
+        }
+      }
       for (int k = 0; k < 4; k++) low[k] = e->ac[i].low_action[k];
       if (scripted) { for (int k = 0; k < 4; k++) e->ac[i].shoot4[k] = c->use_artillery ? 1 : 0; }
       else if (c->task == OR_TASK_SCENARIO_NVN || (c->task == OR_TASK_SCENARIO1 && e->ac[i].team == 0))

@@ -97,6 +97,8 @@ typedef struct {
   int low_action[4];    /* last output of the low-level controller */
   int man_step, man_init_set; double man_init_heading;   /* ManeuverAgent.step / init_heading (baseline.py:133-136) */
   double ctl_in[12];    /* last controller input vector (test hook) */
+  double ctl_gap[4];    /* top-two logit gap of each of the four heads at the last controller call (test hook: an argmax that differs on
+                           the fp32 device must sit on a near-tie here) */
 } OrAircraft;
 
 typedef struct {

@@ -141,6 +141,7 @@ def lib():
         L.or_actor_forward.restype = None
         L.or_env_get_rnn.argtypes = [C.c_void_p, C.c_int, dp, C.POINTER(C.c_int)]
         L.or_env_set_rnn.argtypes = [C.c_void_p, C.c_int, dp]
+        L.or_env_get_ctl_gaps.argtypes = [C.c_void_p, C.c_int, dp]
         assert L.or_env_config_sizeof() == C.sizeof(OrEnvConfig), "OrEnvConfig layout mismatch"
         _lib = L
     return _lib
@@ -272,6 +273,12 @@ class OracleEnv:
         low = (C.c_int * 4)()
         self.L.or_env_get_rnn(self.p, i, h.ctypes.data_as(C.POINTER(C.c_double)), low)
         return h, np.array(low[:])
+
+    def ctl_gaps(self, i):
+        """Top-two logit gap of each of the controller's four heads at its last call for aircraft i."""
+        g = np.zeros(4)
+        self.L.or_env_get_ctl_gaps(self.p, i, g.ctypes.data_as(C.POINTER(C.c_double)))
+        return g
 
     def set_rnn(self, i, h):
         h = np.ascontiguousarray(h, dtype=np.float64)

@@ -191,6 +191,7 @@ void or_env_get_rnn(const OrEnv* e, int i, double* h, int* low_action) {
   if (low_action) for (int k = 0; k < 4; k++) low_action[k] = e->ac[i].low_action[k];
 }
 void or_env_set_rnn(OrEnv* e, int i, const double* h) { for (int k = 0; k < 128; k++) e->ac[i].rnn[k] = h[k]; }
+void or_env_get_ctl_gaps(const OrEnv* e, int i, double* gaps4) { for (int k = 0; k < 4; k++) gaps4[k] = e->ac[i].ctl_gap[k]; }
 
 /* scripted-opponent golden hooks: delta values and the 12 controller inputs of aircraft i chasing aircraft j / flying the schedule */
 void or_pursue_delta(const OrAircraft* ego, const OrAircraft* tgt, double dv[3]);

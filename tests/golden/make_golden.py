@@ -347,6 +347,50 @@ def gen_singlecombat_sequences(rng):
     np.savez_compressed(os.path.join(OUT, "singlecombat_sequences.npz"), **flat)
 
 
+def gen_artillery(rng):
+    """SingleCombatTask.step with use_artillery (singlecombat_task.py:162-188): every aircraft drains the blood of each ALIVE enemy by
+    orientation_fn(AO) * distance_fn(R / 1000) per env step. Scripted close-in geometries (inside and outside the 30 deg cone and the
+    1 km / 3 km range bands, dead targets, dead shooters -- the rule does not ask whether the SHOOTER is alive), bloods after every step."""
+    from envs.JSBSim.tasks.singlecombat_task import SingleCombatTask
+    cfg = make_config(use_artillery=True)
+    task = SingleCombatTask(cfg)
+    assert task.use_artillery
+    poses, bloods = [], []
+    for ep in range(40):
+        a, b = FakeAircraft("A0100", "Blue"), FakeAircraft("B0100", "Red")
+        link([a, b])
+        env = FakeEnv([a, b])
+        task.reset(env)
+        for t in range(12):
+            # shooter a somewhere, target b placed at a chosen range / off-boresight angle from a's velocity vector, and vice versa at random
+            random_pose(rng, a, spread_km=5.0)
+            dist = rng.choice([300.0, 900.0, 1000.0, 1500.0, 2500.0, 3000.0, 3400.0]) * rng.uniform(0.97, 1.03)
+            off = np.deg2rad(rng.choice([0.0, 5.0, 15.0, 29.0, 30.0, 31.0, 60.0, 170.0]) + rng.uniform(-0.4, 0.4))
+            v = np.array(a._velocity); vhat = v / np.linalg.norm(v)
+            perp = np.cross(vhat, rng.normal(size=3)); perp /= np.linalg.norm(perp)
+            # get_AO_TA_R is fed get_position() (N, E, U) + get_velocity() (vN, vE, vDOWN): the cone is about that mixed vector
+            d = np.cos(off) * vhat + np.sin(off) * perp
+            pa = np.array(a._position)
+            pb = pa + dist * d
+            random_pose(rng, b, spread_km=5.0)
+            lon, lat, alt = utils_neu2lla(pb)
+            b.set_pose(lon, lat, alt, tuple(b._posture), tuple(b._velocity))
+            if ep % 5 == 1 and t >= 6:
+                b.shotdown()
+            if ep % 5 == 2 and t >= 4:
+                a.crash()
+            before = np.stack([pose_vector(a), pose_vector(b)])
+            task.step(env)
+            poses.append(before)
+            bloods.append([a.bloods, b.bloods])
+    np.savez_compressed(os.path.join(OUT, "artillery.npz"), pose=np.array(poses), bloods_after=np.array(bloods))
+
+
+def utils_neu2lla(neu):
+    from envs.JSBSim.utils.utils import NEU2LLA
+    return NEU2LLA(*neu, 120.0, 60.0, 0.0)
+
+
 def gen_missile(rng):
     """MissileSimulator fly-outs (AIM-9L defaults and the AIM_9M/AIM_120B parameter set) against scripted targets."""
     from envs.JSBSim.core.simulatior import MissileSimulator, AIM_120B
@@ -1120,6 +1164,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "acmi":         # this fixture alone
         gen_acmi_records()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "artillery":
+        gen_artillery(np.random.default_rng(86))
+        return
     rng = np.random.default_rng(20250321)
     gen_geometry(rng)
     gen_reward_functions(rng)
@@ -1138,6 +1185,7 @@ def main():
     gen_rollout_buffer(np.random.default_rng(84))
     gen_approach(np.random.default_rng(85))
     gen_acmi_records()
+    gen_artillery(np.random.default_rng(86))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,0 +1,83 @@
+"""A non-finite aircraft state must surface as an error, never fly on silently. The reference traps NaN in
+BaseEnv._pack with a pdb prompt (env_base.py:277-281) and raises RuntimeError("JSBSim failed.") when the FDM gives up
+(simulatior.py:223-225); its ExtremeState condition (catalog.py:386-416) is all `>=` comparisons, which a NaN fails. Here a NaN / Inf in
+any integrator state makes the aircraft an ExtremeState termination AND fails the step with RuntimeError naming the env and agent;
+reset() clears the condition."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def actions(env, rng):
+    E, A = env.num_envs, env.num_agents
+    a = np.stack([rng.integers(0, n, size=(E, A)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
+    if env.act_dim > 4:
+        a = np.concatenate([a, np.zeros((E, A, env.act_dim - 4), dtype=np.float32)], axis=-1)
+    return a
+
+
+@pytest.mark.parametrize("task,field,value", [("singlecombat", "wq", np.nan), ("singlecombat", "vx", np.inf), ("singlecombat", "rx", np.nan),
+                                              ("singlecombat", "tank0", np.nan), ("singlecombat", "q2", np.nan), ("heading", "wp", np.nan),
+                                              ("multiplecombat", "vz", np.nan), ("singlecombat_shoot", "wr", np.nan), ("scenario1", "vy", np.nan),
+                                              ("scenario_nvn", "wq", np.nan), ("wvr_lowlevel", "q0", np.nan)])
+def test_non_finite_state_fails_the_step_and_terminates_the_aircraft(pkg, task, field, value):
+    cfg = pkg.default_config(task)
+    A = cfg.n_agents
+    E = 70                       # ragged last workgroup
+    cls = pkg.HipShareVecEnv if A > 2 else pkg.HipVecEnv
+    env = cls(cfg, E, seed=3, copy=False)
+    env.reset()
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        env.step(actions(env, rng))                     # a healthy batch steps without complaint
+    bad_env, bad_agent = 37, A - 1
+    ix = env.lib.state_field_names().index(field)
+    st = env.get_state(bad_env, bad_agent)
+    st[ix] = value
+    env.set_state(bad_env, bad_agent, st)
+    with pytest.raises(RuntimeError) as err:
+        for _ in range(3):                              # (a poisoned tank reaches the load factors one tick later than a poisoned rate)
+            env.step(actions(env, rng))
+    assert "JSBSim failed" in str(err.value) and f"env {bad_env}, agent {bad_agent}" in str(err.value), str(err.value)
+    # the step itself completed: the aircraft was terminated like an ExtremeState, every other env's outputs are sound
+    res = env._results[env._cur]
+    obs, rew, done = res[0], res[-3], res[-2]
+    assert done[bad_env, bad_agent, 0]
+    others = np.ones(E, dtype=bool); others[bad_env] = False
+    assert np.isfinite(obs[others]).all() and np.isfinite(rew[others]).all()
+    # sticky until reset() ...
+    with pytest.raises(RuntimeError):
+        env.step(actions(env, rng))
+    # ... which clears it
+    assert np.isfinite(env.reset() if A <= 2 else env.reset()[0]).all()
+    for _ in range(3):
+        out = env.step(actions(env, rng))
+        assert np.isfinite(out[0]).all()
+    env.close()
+
+
+def test_default_step_returns_arrays_the_caller_owns(pkg):
+    """The reference's VecEnv returns fresh arrays every step (np.stack, env_wrappers.py:276-282): with the default copy=True what a
+    caller keeps from step t is untouched by later steps, reset() and close(); copy=False hands out the live buffer views."""
+    cfg = pkg.default_config("heading")
+    env = pkg.HipVecEnv(cfg, 8, seed=5)
+    env.reset()
+    rng = np.random.default_rng(2)
+    kept = []
+    for k in range(6):
+        obs, rew, done, infos = env.step(actions(env, rng))
+        kept.append((obs, obs.copy(), rew, rew.copy(), done, done.copy(), infos, [dict(d) for d in infos]))
+    for obs, obs0, rew, rew0, done, done0, infos, infos0 in kept:
+        assert (obs == obs0).all() and (rew == rew0).all() and (done == done0).all() and list(infos) == infos0
+    assert [i[0]["current_step"] for i in [k[6] for k in kept]] == [1, 2, 3, 4, 5, 6]
+    env.reset()
+    env.close()
+    assert (kept[-1][0] == kept[-1][1]).all()           # still readable after close(): the caller's own memory
+    view = pkg.HipVecEnv(cfg, 8, seed=5, copy=False)
+    view.reset()
+    a = view.step(actions(view, rng))[0]
+    view.step(actions(view, rng))
+    c = view.step(actions(view, rng))[0]
+    assert a is c                                        # two alternating buffer sets
+    view.close()

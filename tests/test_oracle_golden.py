@@ -382,3 +382,30 @@ def test_wvr_task_sequences(oracle, which):
                 assert close(r, rew[t], rtol=1e-7, atol=1e-6).all(), (ep, t, r, rew[t])
             shot += int((state[t][:, 1] == 2).any()); crashed += int((state[t][:, 1] == 1).any())
     assert shot and crashed
+
+
+def test_artillery_blood_drain_of_singlecombat_task_step(oracle):
+    """SingleCombatTask.step with use_artillery (singlecombat_task.py:162-188): 480 scripted frames from the reference itself -- targets
+    inside / on / outside the 30 deg cone and the 1 km / 3 km bands, dead targets (no drain), dead shooters (still drain)."""
+    g = load("artillery.npz")
+    cfg = oracle.default_config(oracle.TASK_SINGLECOMBAT)
+    cfg.use_artillery = 1
+    env = oracle.OracleEnv(cfg)
+    L = oracle.lib()
+    hits = 0
+    for pose, want in zip(g["pose"], g["bloods_after"]):
+        for i in range(2):
+            env.set_pose(i, pose[i])
+        L.or_env_task_step(env.p)
+        got = np.array([L.or_env_bloods(env.p, i) for i in range(2)])
+        assert close(got, want, rtol=1e-9, atol=1e-9).all(), (pose[:, 17:19], got, want)
+        hits += int((pose[:, 18] - want > 0).sum())
+    assert hits > 150
+    # without the flag the same frames leave the blood alone
+    cfg.use_artillery = 0
+    env = oracle.OracleEnv(cfg)
+    for pose in g["pose"][:40]:
+        for i in range(2):
+            env.set_pose(i, pose[i])
+        L.or_env_task_step(env.p)
+        assert [L.or_env_bloods(env.p, i) for i in range(2)] == list(pose[:, 18])

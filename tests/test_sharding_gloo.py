@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 
@@ -88,6 +89,34 @@ def test_bench_control_flow_two_ranks_under_torchrun(tmp_path):
     assert abs(r["value"] - 2 * 64 * 2 * 30 / (r["ms_per_step"] * 1e-3 * 30)) < 1e-6 * r["value"]   # whole-job agent-steps / max-over-ranks time
     assert r["ms_per_step"] >= 0.2                                                        # the stand-in sleeps 0.2 ms per step
     assert "stub" in r["data"]
+
+
+@pytest.mark.parametrize("per_side,world", [(2, 2), (4, 2)])
+def test_bench_multi_gpu_configs_c4_c5_under_torchrun(tmp_path, per_side, world):
+    """BASELINE's multi-GPU configs through the same contract: `bench.py --gpus N --task scenario_nvn --per-side 2|4 --hierarchical` (C4 =
+    Scenario2_NvN 2v2 over 2 GPUs, C5 = Scenario3_NvN 4v4 over 8; as shipped: [3,5,3] + four weapon bits, act_dim 7), rehearsed with two
+    gloo ranks and the stand-in handle: the action batches have the config's shape, the value counts A = 2 per_side aircraft per env,
+    the workload string names the config."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "20", "--warmup", "5", "--envs", "32", "--stub-env",
+           "--task", "scenario_nvn", "--per-side", str(per_side), "--hierarchical"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    A = 2 * per_side
+    assert r["n_gpus"] == world and r["config"]["aircraft_per_env"] == A and r["config"]["hierarchical"] is True
+    assert r["stub"]["agents"] == A and r["stub"]["act_dim"] == 7 and r["stub"]["steps_taken"] == 25
+    assert ("C4" if per_side == 2 else "C5") in r["config"]["workload"] and "as shipped" in r["config"]["workload"]
+    assert abs(r["value"] - world * 32 * A * 20 / (r["ms_per_step"] * 1e-3 * 20)) < 1e-6 * r["value"]
 
 
 def test_bench_rank_seed_blocks_do_not_overlap(pkg):
