@@ -1496,7 +1496,7 @@ __global__ void init_kernel_nvn(InitArgs ia, DevCfg c, const float* tab, float* 
 }
 
 #include "scenario_kernel.hpp"
-#include "controller_kernel.hpp"
+#include "controller_common.hpp"
 #include "controller_split_kernel.hpp"
 #include "heading_kernel.hpp"
 
@@ -1541,9 +1541,8 @@ struct ac_env {
   float* d_tab;
   float* d_tF; int* d_tI; double* d_tD;
   float* d_XF; int* d_XI;                // scenario-task extension state
-  float* d_scripted;                     // [N][12] controller inputs of scripted opponents
-  float* d_ctlW; float* d_low;           // hierarchical tasks: controller weights (device layout), low-level action buffer
-  float* d_ctlWs;                        // the same weights as bf16 pieces (controller_split_kernel)
+  float* d_low;                          // hierarchical tasks: low-level action buffer (the controller's output, the step kernel's input)
+  float* d_ctlWs;                        // controller weights as bf16 pieces (controller_split_kernel.hpp)
   HeadingPtrs hp; HeadingCfg hc;         // HeadingTask: targets, check clock, numpy-PCG64 state per env
   int act_low;                           // width of the low-level action the step kernels decode
   hipEvent_t ev0, ev1;
@@ -1556,8 +1555,6 @@ struct ac_env {
   int* err_host;                         // P.err: one word of page-locked host memory the step kernels write on a non-finite state (sticky until ac_reset)
   int err_sticky;
   bool timing;
-  int ctl_tiles;                         // AIRCOMBAT_CTL_TILES at ac_create: 1 / 2 aircraft tiles per controller workgroup (0: chosen from the batch size)
-  bool ctl_fp32;                         // hierarchical tasks: controller_kernel (fp32 MFMA) instead of controller_split_kernel (AIRCOMBAT_CTL=fp32 at ac_create)
   bool quad_waves;                       // the 1v1 tasks with munitions up to one workgroup per CU: three FDM waves + the environment wave (FORM 3 / FORM_QUAD)
   bool split_waves;                      // SingleCombat below one wave per SIMD: three waves per 64 aircraft (step_kernel_1v1<.., SPLIT>)
 };
@@ -1590,27 +1587,13 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
   }
   dim3 block(64), grid((h->N + 63) / 64);
   if (h->cfg.hierarchical) {   // [3,5,3] (+ weapon bits) -> control indices, then the ordinary step on those
-    if (!h->d_ctlW) return fail("hierarchical task: ac_load_controller has not been called");
-    ctl::Args a{h->d_ctlW, h->d_ctlWs, p.actions, p.obs, p.H, h->d_low, h->N, h->obs_dim, h->act_dim, h->act_low,
+    if (!h->d_ctlWs) return fail("hierarchical task: ac_load_controller has not been called");
+    ctl::Args a{h->d_ctlWs, p.actions, p.obs, p.H, h->d_low, h->N, h->obs_dim, h->act_dim, h->act_low,
                 h->cfg.use_baseline, h->A, h->cfg.n_ego, h->cfg.use_artillery,
-                (float)h->cfg.agent_interaction_steps / (float)h->cfg.sim_freq, p.man_step, p.man_h0, p, h->dc, h->d_scripted};
-    if (h->cfg.use_baseline && h->ctl_fp32) {   // (controller_split_kernel computes the scripted opponents' inputs itself)
-      hipLaunchKernelGGL(scripted_inputs_kernel, grid, block, 0, h->stream, a);
-      HIP_OK(hipGetLastError());
-    }
-    // the bf16-piece form (controller_split_kernel.hpp) unless the handle was created under AIRCOMBAT_CTL=fp32 (the fp32 matrix instructions)
-    // Two 32-aircraft tiles per workgroup sharing one weight stream once the one-tile form would queue two workgroups per CU anyway
-    // (16 384 aircraft = 512 tiles on 256 CUs: BASELINE C4 / C5 as shipped); AIRCOMBAT_CTL_TILES=1/2 pins the form (tests, profiling).
-    const int tiles = h->ctl_tiles ? h->ctl_tiles : (h->N >= 16384 ? 2 : 1);
-    const dim3 cgrid((h->N + ctl::MT * tiles - 1) / (ctl::MT * tiles));
-    if (h->ctl_fp32) hipLaunchKernelGGL(controller_kernel, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
-    else if (h->cfg.use_baseline) {
-      if (tiles == 2) hipLaunchKernelGGL((controller_split_kernel<true, 2>), cgrid, dim3(256), 0, h->stream, a);
-      else hipLaunchKernelGGL((controller_split_kernel<true, 1>), cgrid, dim3(256), 0, h->stream, a);
-    } else {
-      if (tiles == 2) hipLaunchKernelGGL((controller_split_kernel<false, 2>), cgrid, dim3(256), 0, h->stream, a);
-      else hipLaunchKernelGGL((controller_split_kernel<false, 1>), cgrid, dim3(256), 0, h->stream, a);
-    }
+                (float)h->cfg.agent_interaction_steps / (float)h->cfg.sim_freq, p.man_step, p.man_h0, p, h->dc};
+    // (the scripted opponents' inputs -- use_baseline -- are computed inside that instantiation of the kernel)
+    if (h->cfg.use_baseline) hipLaunchKernelGGL(controller_split_kernel<true>, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL(controller_split_kernel<false>, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
     HIP_OK(hipGetLastError());
     if (h->mark_mid) HIP_OK(hipEventRecord(h->ev_mid, h->stream));
     p.actions = h->d_low;
@@ -1749,10 +1732,6 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     const char* qe = getenv("AIRCOMBAT_QUAD");   // 0 / 1 overrides the choice of the quad form
     const bool munitions_1v1 = cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE || cfg->task == AC_TASK_SCENARIO1;
     h->quad_waves = munitions_1v1 && (qe ? (qe[0] == '1') : (wgs <= 256));
-    const char* ce = getenv("AIRCOMBAT_CTL");
-    h->ctl_fp32 = ce && ce[0] == 'f';
-    const char* te = getenv("AIRCOMBAT_CTL_TILES");
-    h->ctl_tiles = (te && (te[0] == '1' || te[0] == '2')) ? te[0] - '0' : 0;
   }
   h->obs_dim = heading ? 12 : (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
   if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
@@ -1859,8 +1838,6 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     HIP_OK(hipMemset(p.H, 0, sizeof(float) * 128 * N));
     HIP_OK(hipMalloc(&h->d_low, sizeof(float) * N * h->act_low));
     HIP_OK(hipMemset(h->d_low, 0, sizeof(float) * N * h->act_low));
-    HIP_OK(hipMalloc(&h->d_scripted, sizeof(float) * 12 * N));
-    HIP_OK(hipMemset(h->d_scripted, 0, sizeof(float) * 12 * N));
     HIP_OK(hipMalloc(&p.man_step, sizeof(int) * N));
     HIP_OK(hipMemset(p.man_step, 0, sizeof(int) * N));
     HIP_OK(hipMalloc(&p.man_h0, sizeof(float) * N));
@@ -1897,7 +1874,7 @@ int ac_destroy(ac_env_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->dp.F, h->dp.I, h->dp.D, h->dp.MF, h->dp.MD, h->dp.MI, h->dp.obs, h->dp.rew, h->dp.done, h->dp.info,
-                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_scripted, h->d_ctlW, h->d_ctlWs, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
+                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_ctlWs, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
   for (void* b : bufs) (void)hipFree(b);
   if (h->have_hs)
     for (auto& hs : h->hs) { (void)hipHostFree(hs.act); (void)hipHostFree(hs.obs); (void)hipHostFree(hs.rew); (void)hipHostFree(hs.done); (void)hipHostFree(hs.info); }
@@ -2202,26 +2179,7 @@ int ac_load_controller(ac_env_t* h, const float* weights, int64_t n) {
   if (!h->cfg.hierarchical) return fail("ac_load_controller: the handle was not created with cfg.hierarchical");
   if (n != S_END) return fail("ac_load_controller: expected 137753 floats (layout of tools/export_baseline_actor.py)");
   HIP_OK(hipSetDevice(h->device));
-  std::vector<float> d(D_END, 0.0f);
-  // B-operand tiles of v_mfma_f32_32x32x2_f32: element (group g, lane, q) of column tile c is W[j = 32 c + lane % 32][k = 2 (4 g + q) + lane / 32]
-  auto tiles = [&](int src, int dst, int J, int K, int Kpad, int ntiles) {
-    for (int c = 0; c < ntiles; ++c)
-      for (int g = 0; g < Kpad / 8; ++g)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int q = 0; q < 4; ++q) {
-            const int k = 2 * (4 * g + q) + lane / 32, j = 32 * c + lane % 32;
-            d[dst + ((size_t)(c * (Kpad / 8) + g) * 64 + lane) * 4 + q] = (j < J && k < K) ? weights[src + j * K + k] : 0.0f;
-          }
-  };
-  auto copy = [&](int src, int dst, int cnt) { for (int i = 0; i < cnt; ++i) d[dst + i] = weights[src + i]; };
-  tiles(S_W1, D_W1, 128, 12, 16, 4); copy(S_B1, D_B1, 128); copy(S_G1, D_G1, 128); copy(S_BE1, D_BE1, 128);
-  tiles(S_W2, D_W2, 128, 128, 128, 4); copy(S_B2, D_B2, 128); copy(S_G2, D_G2, 128); copy(S_BE2, D_BE2, 128);
-  tiles(S_WIH, D_WIH, 384, 128, 128, 12); tiles(S_WHH, D_WHH, 384, 128, 128, 12); copy(S_BIH, D_BIH, 384); copy(S_BHH, D_BHH, 384);
-  copy(S_G3, D_G3, 128); copy(S_BE3, D_BE3, 128);
-  tiles(S_WA, D_WA, NH, 128, 128, 5); copy(S_BA, D_BA, NH);
-  if (!h->d_ctlW) HIP_OK(hipMalloc(&h->d_ctlW, sizeof(float) * D_END));
-  HIP_OK(hipMemcpy(h->d_ctlW, d.data(), sizeof(float) * D_END, hipMemcpyHostToDevice));
-  {   // the same weights as bf16 pieces: tile(c) = K/16 chunks x 3 pieces x 64 lanes x 8 values, element (g, p, lane, i) = piece p of
+  {   // the weights as bf16 pieces: tile(c) = K/16 chunks x 3 pieces x 64 lanes x 8 values, element (g, p, lane, i) = piece p of
       // W[j = 32 c + lane % 32][k = 16 g + 8 (lane / 32) + i]
     using namespace ctls;
     std::vector<float> e(B_END, 0.0f);

@@ -1,4 +1,4 @@
-// The low-level controller (controller_kernel.hpp: same network, same arguments, same outputs) with every fp32 product taken apart into
+// The low-level controller kernel (network, arguments and weight blob: controller_common.hpp) with every fp32 product taken apart into
 // bf16 pieces, so that the GEMMs run on the bf16 matrix path of gfx950 (v_mfma_f32_32x32x16_bf16: 16 k per 32 cycles) instead of the
 // fp32 one (v_mfma_f32_32x32x2_f32: 2 k per 64 cycles).
 //
@@ -171,8 +171,7 @@ __device__ __forceinline__ float group8_sum(float v) {
   v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
   return v;
 }
-template <bool UNUSED = true>
-__device__ __forceinline__ void layer_norm_planes(const float* buf, unsigned short* planes, const float* __restrict__ g, const float* __restrict__ b, int tid, bool barrier = true) {
+__device__ __forceinline__ void layer_norm_planes(const float* buf, unsigned short* planes, const float* __restrict__ g, const float* __restrict__ b, int tid) {
   const int row = tid >> 3, part = tid & 7;
   float4 x[4], gg[4], bb[4];
 #pragma unroll
@@ -200,53 +199,25 @@ __device__ __forceinline__ void layer_norm_planes(const float* buf, unsigned sho
                                  fmaf(x[q].z * is, gg[q].z, bb[q].z), fmaf(x[q].w * is, gg[q].w, bb[q].w));
     write_planes4(planes, row, 4 * part + 32 * q, y);
   }
-  if (barrier) __syncthreads();   // (a workgroup's tiles are normalised one after the other: one barrier behind the last)
-}
-}  // namespace ctls
-
-// One 16-k chunk of one aircraft tile's A operands (the RT = 2 form re-reads them per chunk: the whole K range of two tiles does not fit
-// next to twelve accumulators)
-namespace ctls {
-struct AChunk { uint4 a[3]; };
-__device__ __forceinline__ void load_a_chunk(const unsigned short* planes, int lane, int g, AChunk& A) {
-  const unsigned short* base = planes + (lane & 31) * KS + 8 * (lane >> 5) + 16 * g;
-#pragma unroll
-  for (int p = 0; p < 3; ++p) A.a[p] = *reinterpret_cast<const uint4*>(base + p * PLANE);
-}
-#define CTLS_CHUNK3C(a0, a1, a2, A, B)                                                          \
-  do {                                                                                          \
-    a0 = mf(A.a[2], B[0].b[0], a0); a1 = mf(A.a[2], B[1].b[0], a1); a2 = mf(A.a[2], B[2].b[0], a2); \
-    a0 = mf(A.a[0], B[0].b[2], a0); a1 = mf(A.a[0], B[1].b[2], a1); a2 = mf(A.a[0], B[2].b[2], a2); \
-    a0 = mf(A.a[1], B[0].b[1], a0); a1 = mf(A.a[1], B[1].b[1], a1); a2 = mf(A.a[1], B[2].b[1], a2); \
-    a0 = mf(A.a[1], B[0].b[0], a0); a1 = mf(A.a[1], B[1].b[0], a1); a2 = mf(A.a[1], B[2].b[0], a2); \
-    a0 = mf(A.a[0], B[0].b[1], a0); a1 = mf(A.a[0], B[1].b[1], a1); a2 = mf(A.a[0], B[2].b[1], a2); \
-    a0 = mf(A.a[0], B[0].b[0], a0); a1 = mf(A.a[0], B[1].b[0], a1); a2 = mf(A.a[0], B[2].b[0], a2); \
-  } while (0)
-// the GRU state back from its three bf16 planes: hi + mid + lo is the fp32 value exactly (split3), so no fp32 copy is kept in LDS
-__device__ __forceinline__ float from_planes(const unsigned short* planes, int row, int k) {
-  const unsigned short* p = planes + row * KS + k;
-  return (__uint_as_float((unsigned)p[0] << 16) + __uint_as_float((unsigned)p[PLANE] << 16)) + __uint_as_float((unsigned)p[2 * PLANE] << 16);
+  __syncthreads();
 }
 }  // namespace ctls
 
 // SCRIPTED: the handle has scripted opponents (`use_baseline`); their state -> pose code is compiled into that instantiation only.
-// RT: aircraft tiles (of MT = 32) per workgroup. One weight stream -- every tile prefetch and every stage of the GRU ring -- feeds the
-// matrix instructions of all RT tiles, so the L2 traffic per matrix instruction is 1 / RT of the one-tile form's, which is what bounds its
-// GEMM phases (above); the first HBM round trip (inputs, GRU state) is paid once per workgroup as well. Each tile's arithmetic is the
-// one-tile form's, instruction for instruction in the same order per accumulator: an aircraft's result does not depend on RT.
-// launch_step uses RT = 2 from 16 384 aircraft on (BASELINE C4 / C5 as shipped: the one-tile form would queue 2 / 4 workgroups per CU).
-template <bool SCRIPTED, int RT = 1>
+template <bool SCRIPTED>
 __global__ __launch_bounds__(256) void controller_split_kernel(ctl::Args a) {
   using namespace ctls;
   using ctl::sigmoid_f; using ctl::tanh_f;
-  __shared__ __attribute__((aligned(16))) unsigned short PA[RT][3 * PLANE];   // activations as bf16 planes [piece][aircraft][k]
-  __shared__ __attribute__((aligned(16))) unsigned short PH[RT][3 * PLANE];   // the GRU state likewise; the head logits (fp32 [160][LS]) later
-  __shared__ __attribute__((aligned(16))) float stg[RT][HID * LS];   // a layer's fp32 outputs [aircraft][k] (row stride RS) on their way to LayerNorm
+  __shared__ __attribute__((aligned(16))) unsigned short PA[3 * PLANE];   // activations as bf16 planes [piece][aircraft][k]
+  __shared__ __attribute__((aligned(16))) unsigned short PH[3 * PLANE];   // the GRU state likewise; the head logits (fp32 [160][LS]) later
+  __shared__ __attribute__((aligned(16))) float stg[HID * LS];   // a layer's fp32 outputs [aircraft][k] (row stride RS) on their way to LayerNorm
+  __shared__ float hbuf[HID * LS];   // GRU state of the 32 aircraft, fp32 (gate algebra)
   static_assert(MT * RS <= HID * LS, "staging rows fit");
   static_assert(sizeof(unsigned short) * 3 * PLANE >= sizeof(float) * NHP * LS, "the logits reuse the GRU-state planes");
+  float* lg = reinterpret_cast<float*>(PH);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i0 = blockIdx.x * (MT * RT);
+  const int i0 = blockIdx.x * MT;
   const float* __restrict__ W = a.Ws;
   const int col = lane & 31;
 
@@ -256,74 +227,64 @@ __global__ __launch_bounds__(256) void controller_split_kernel(ctl::Args a) {
   BTile<16> b1;
   BTile<HID> b2;
   const int srow = tid & 31, spart = tid >> 5;   // staging: thread = (aircraft, 16-feature part)
-  int sn[RT];
-  float x[RT][16];
+  const int sn = min(i0 + srow, a.N - 1);
+  float x[16];
+  if (spart == 0) {
+    const float* hi = a.hi + (size_t)sn * a.act_hi;
+    const float* ob = a.obs + (size_t)sn * a.obs_dim;
+    const int slot = sn % a.A;
+    if (SCRIPTED && a.use_baseline && slot >= a.n_ego) {
+      // the enemy team is flown by BaselineAgent k: its 12 inputs come from the geometry (no action row is read for it)
+      float xs[12];
+      ctl::scripted_inputs(a, sn, xs);
 #pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    sn[t] = min(i0 + t * MT + srow, a.N - 1);
-    if (spart == 0) {
-      const float* hi = a.hi + (size_t)sn[t] * a.act_hi;
-      const float* ob = a.obs + (size_t)sn[t] * a.obs_dim;
-      const int slot = sn[t] % a.A;
-      if (SCRIPTED && a.use_baseline && slot >= a.n_ego) {
-        // the enemy team is flown by BaselineAgent k: its 12 inputs come from the geometry (no action row is read for it)
-        float xs[12];
-        ctl::scripted_inputs(a, sn[t], xs);
+      for (int k = 0; k < 12; ++k) x[k] = xs[k];
+    } else {
+      const int c0 = (int)hi[0], c1 = (int)hi[1], c2 = (int)hi[2];
+      // singlecombat_task.py:217-219, 235-241: below 3500 m the altitude choice is overridden by "climb"
+      x[0] = (ob[0] * 5000.0f < 3500.0f) ? 0.1f : (c0 == 0 ? 0.1f : (c0 == 1 ? 0.0f : -0.1f));
+      x[1] = (float)(c1 - 2) * 0.26179938779914943f;   // {-pi/6, -pi/12, 0, pi/12, pi/6}
+      x[2] = c2 == 0 ? 0.05f : (c2 == 1 ? 0.0f : -0.05f);
 #pragma unroll
-        for (int k = 0; k < 12; ++k) x[t][k] = xs[k];
-      } else {
-        const int c0 = (int)hi[0], c1 = (int)hi[1], c2 = (int)hi[2];
-        // singlecombat_task.py:217-219, 235-241: below 3500 m the altitude choice is overridden by "climb"
-        x[t][0] = (ob[0] * 5000.0f < 3500.0f) ? 0.1f : (c0 == 0 ? 0.1f : (c0 == 1 ? 0.0f : -0.1f));
-        x[t][1] = (float)(c1 - 2) * 0.26179938779914943f;   // {-pi/6, -pi/12, 0, pi/12, pi/6}
-        x[t][2] = c2 == 0 ? 0.05f : (c2 == 1 ? 0.0f : -0.05f);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) x[t][3 + k] = ob[k];
-      }
-      x[t][12] = 0.0f; x[t][13] = 0.0f; x[t][14] = 0.0f; x[t][15] = 0.0f;   // (k 12..15 of the one 16-k chunk)
+      for (int k = 0; k < 9; ++k) x[3 + k] = ob[k];
     }
+    x[12] = 0.0f; x[13] = 0.0f; x[14] = 0.0f; x[15] = 0.0f;   // (k 12..15 of the one 16-k chunk)
   }
   __builtin_amdgcn_sched_barrier(0);
   prefetch_b<16>(W + B_W1 + w * tile_floats(16), lane, b1);
-  float hv[RT][16];
+  float hv[16];
 #pragma unroll
-  for (int t = 0; t < RT; ++t)
-#pragma unroll
-    for (int f = 0; f < 16; ++f) hv[t][f] = a.H[(size_t)(spart * 16 + f) * a.N + sn[t]];
+  for (int f = 0; f < 16; ++f) hv[f] = a.H[(size_t)(spart * 16 + f) * a.N + sn];
   prefetch_b<HID>(W + B_W2 + w * tile_floats(HID), lane, b2);
   __builtin_amdgcn_sched_barrier(0);
-  if (spart == 0) {
-#pragma unroll
-    for (int t = 0; t < RT; ++t) write_planes(PA[t], srow, 0, x[t]);
-  }
+  if (spart == 0) write_planes(PA, srow, 0, x);
   __syncthreads();
 
   AC_CLK(201);
   // ---- MLP layer 1: Linear(12, 128) + ReLU + LayerNorm; wave w owns output columns 32 w .. 32 w + 31
-#pragma unroll
-  for (int t = 0; t < RT; ++t) {
+  {
     AOps<16> A;
-    load_a<16>(PA[t], lane, A);
+    load_a<16>(PA, lane, A);
     const floatx16 acc = mma1<16>(b1, A, splat(W[B_B1 + w * 32 + col]));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) stg[t][c_row(r, lane) * RS + w * 32 + col] = fmaxf(acc[r], 0.0f);
+    for (int r = 0; r < 16; ++r) stg[c_row(r, lane) * RS + w * 32 + col] = fmaxf(acc[r], 0.0f);
   }
-  // the GRU state has arrived behind layer 1: as bf16 planes (hi + mid + lo is the fp32 value exactly: the gate algebra reads them back)
+  {   // the GRU state has arrived behind layer 1: fp32 for the gate algebra, bf16 planes for the products
 #pragma unroll
-  for (int t = 0; t < RT; ++t) write_planes(PH[t], srow, spart * 16, hv[t]);
+    for (int f = 0; f < 16; ++f) hbuf[(spart * 16 + f) * LS + srow] = hv[f];
+    write_planes(PH, srow, spart * 16, hv);
+  }
   __syncthreads();
   AC_CLK(202);
-#pragma unroll
-  for (int t = 0; t < RT; ++t) layer_norm_planes<true>(stg[t], PA[t], W + B_G1, W + B_BE1, tid, t == RT - 1);
+  layer_norm_planes(stg, PA, W + B_G1, W + B_BE1, tid);
   AC_CLK(203);
   // ---- MLP layer 2
-#pragma unroll
-  for (int t = 0; t < RT; ++t) {
+  {
     AOps<HID> A;
-    load_a<HID>(PA[t], lane, A);
+    load_a<HID>(PA, lane, A);
     const floatx16 acc = mma1<HID>(b2, A, splat(W[B_B2 + w * 32 + col]));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) stg[t][c_row(r, lane) * RS + w * 32 + col] = fmaxf(acc[r], 0.0f);
+    for (int r = 0; r < 16; ++r) stg[c_row(r, lane) * RS + w * 32 + col] = fmaxf(acc[r], 0.0f);
   }
   BRing ring;   // the GRU's first two chunks, behind LayerNorm 2
   ring_load(W, w, lane, 0, ring.s[0]);
@@ -331,51 +292,26 @@ __global__ __launch_bounds__(256) void controller_split_kernel(ctl::Args a) {
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   AC_CLK(204);
-#pragma unroll
-  for (int t = 0; t < RT; ++t) layer_norm_planes<true>(stg[t], PA[t], W + B_G2, W + B_BE2, tid, t == RT - 1);
+  layer_norm_planes(stg, PA, W + B_G2, W + B_BE2, tid);
   AC_CLK(205);
   // ---- GRU cell (torch gate order r, z, n): wave w owns hidden units 32 w .. 32 w + 31, i.e. gate tiles w, 4 + w, 8 + w
   BTile<HID> bh;
   BChunk b5a, b5b;
   {
-    floatx16 ir[RT], iz[RT], in_[RT], hr[RT], hz[RT], hn[RT];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-      ir[t] = splat(W[B_BIH + 0 * 128 + w * 32 + col]); iz[t] = splat(W[B_BIH + 1 * 128 + w * 32 + col]); in_[t] = splat(W[B_BIH + 2 * 128 + w * 32 + col]);
-      hr[t] = splat(W[B_BHH + 0 * 128 + w * 32 + col]); hz[t] = splat(W[B_BHH + 1 * 128 + w * 32 + col]); hn[t] = splat(W[B_BHH + 2 * 128 + w * 32 + col]);
-    }
-    if constexpr (RT == 1) {
+    floatx16 ir = splat(W[B_BIH + 0 * 128 + w * 32 + col]), iz = splat(W[B_BIH + 1 * 128 + w * 32 + col]), in_ = splat(W[B_BIH + 2 * 128 + w * 32 + col]);
+    floatx16 hr = splat(W[B_BHH + 0 * 128 + w * 32 + col]), hz = splat(W[B_BHH + 1 * 128 + w * 32 + col]), hn = splat(W[B_BHH + 2 * 128 + w * 32 + col]);
+    {
       AOps<HID> A;
 #pragma unroll
       for (int st = 0; st < 16; ++st) {
         // (the scheduling fences keep the loads where they are written: left alone, the machine scheduler sinks every weight load
         // to just in front of its first use to save registers, which serialises an L2 round trip with every chunk)
         if (st + 2 < 16) ring_load(W, w, lane, st + 2, ring.s[(st + 2) % 3]);
-        if (st == 0) load_a<HID>(PA[0], lane, A);
-        if (st == 8) load_a<HID>(PH[0], lane, A);
+        if (st == 0) load_a<HID>(PA, lane, A);
+        if (st == 8) load_a<HID>(PH, lane, A);
         __builtin_amdgcn_sched_barrier(0);
-        if (st < 8) CTLS_CHUNK3(ir[0], iz[0], in_[0], A, st & 7, ring.s[st % 3]);
-        else CTLS_CHUNK3(hr[0], hz[0], hn[0], A, st & 7, ring.s[st % 3]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      // every ring stage feeds the 18 matrix instructions of each tile; a tile's A operands of the chunk come from LDS one chunk ahead
-      AChunk ac[2][RT];
-#pragma unroll
-      for (int t = 0; t < RT; ++t) load_a_chunk(PA[t], lane, 0, ac[0][t]);
-#pragma unroll
-      for (int st = 0; st < 16; ++st) {
-        if (st + 2 < 16) ring_load(W, w, lane, st + 2, ring.s[(st + 2) % 3]);
-        if (st + 1 < 16) {
-#pragma unroll
-          for (int t = 0; t < RT; ++t) load_a_chunk(st + 1 < 8 ? PA[t] : PH[t], lane, (st + 1) & 7, ac[(st + 1) & 1][t]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-          if (st < 8) CTLS_CHUNK3C(ir[t], iz[t], in_[t], ac[st & 1][t], ring.s[st % 3]);
-          else CTLS_CHUNK3C(hr[t], hz[t], hn[t], ac[st & 1][t], ring.s[st % 3]);
-        }
+        if (st < 8) CTLS_CHUNK3(ir, iz, in_, A, st & 7, ring.s[st % 3]);
+        else CTLS_CHUNK3(hr, hz, hn, A, st & 7, ring.s[st % 3]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -388,41 +324,34 @@ __global__ __launch_bounds__(256) void controller_split_kernel(ctl::Args a) {
     __builtin_amdgcn_sched_barrier(0);
     AC_CLK(206);
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = c_row(r, lane), unit = w * 32 + col;
-        const float rg = sigmoid_f(ir[t][r] + hr[t][r]);
-        const float zg = sigmoid_f(iz[t][r] + hz[t][r]);
-        const float ng = tanh_f(in_[t][r] + rg * hn[t][r]);
-        const float hnew = (1.0f - zg) * ng + zg * from_planes(PH[t], row, unit);
-        stg[t][row * RS + unit] = hnew;
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int row = c_row(r, lane), unit = w * 32 + col;
+      const float rg = sigmoid_f(ir[r] + hr[r]);
+      const float zg = sigmoid_f(iz[r] + hz[r]);
+      // (explicit fused multiply-adds: which products the compiler fuses on its own depends on the code around them, and two builds of
+      // this kernel would differ by an ulp)
+      const float ng = tanh_f(fmaf(rg, hn[r], in_[r]));
+      const float hnew = fmaf(zg, hbuf[unit * LS + row], (1.0f - zg) * ng);
+      stg[row * RS + unit] = hnew;
+    }
   }
   __syncthreads();
   AC_CLK(207);
   {   // the new hidden state goes out row-contiguous (128-byte runs per feature) from LDS; thread = (row, 16-feature part): the very
       // elements this thread normalises next
-    const int row = tid & 31, part = tid >> 5;
+    const int row = tid & 31, part = tid >> 5, n = i0 + row;
+    if (n < a.N) {
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
-      const int n = i0 + t * MT + row;
-      if (n < a.N) {
-#pragma unroll
-        for (int f = 0; f < 16; ++f) a.H[(size_t)(part * 16 + f) * a.N + n] = stg[t][row * RS + part * 16 + f];
-      }
+      for (int f = 0; f < 16; ++f) a.H[(size_t)(part * 16 + f) * a.N + n] = stg[row * RS + part * 16 + f];
     }
   }
   AC_CLK(208);
-#pragma unroll
-  for (int t = 0; t < RT; ++t) layer_norm_planes<true>(stg[t], PA[t], W + B_G3, W + B_BE3, tid, t == RT - 1);
+  layer_norm_planes(stg, PA, W + B_G3, W + B_BE3, tid);
   AC_CLK(209);
   // ---- heads: 153 logits = five column tiles; wave w takes tile w and a quarter of the fifth tile's K range
-#pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    float* lg = reinterpret_cast<float*>(PH[t]);
+  {
     AOps<HID> A;
-    load_a<HID>(PA[t], lane, A);
+    load_a<HID>(PA, lane, A);
     const floatx16 acc = mma1<HID>(bh, A, splat(W[B_BA + w * 32 + col]));
 #pragma unroll
     for (int r = 0; r < 16; ++r) lg[(w * 32 + col) * LS + c_row(r, lane)] = acc[r];   // (the GRU-state planes under lg were last read before two barriers)
@@ -432,7 +361,7 @@ __global__ __launch_bounds__(256) void controller_split_kernel(ctl::Args a) {
       floatx16 part = splat(0.0f);
       // this wave's K slice read again from LDS: indexing A by w would put it in scratch
       AOps<32> Aw;
-      const unsigned short* base = PA[t] + (lane & 31) * KS + 8 * (lane >> 5) + 32 * w;
+      const unsigned short* base = PA + (lane & 31) * KS + 8 * (lane >> 5) + 32 * w;
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -440,44 +369,35 @@ __global__ __launch_bounds__(256) void controller_split_kernel(ctl::Args a) {
       CTLS_CHUNK(part, Aw, 0, b5a);
       CTLS_CHUNK(part, Aw, 1, b5b);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) stg[t][(w * 32 + col) * LS + c_row(r, lane)] = part[r];
+      for (int r = 0; r < 16; ++r) stg[(w * 32 + col) * LS + c_row(r, lane)] = part[r];
     }
   }
   __syncthreads();
   AC_CLK(210);
   // logits 128 .. 152 = bias + the four K-partials, summed in a fixed order (25 columns x 32 aircraft over 256 threads)
-#pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    float* lg = reinterpret_cast<float*>(PH[t]);
-    for (int e = tid; e < 25 * 32; e += 256) {
-      const int q = e >> 5, row = e & 31;
-      lg[(128 + q) * LS + row] = (((W[B_BA + 128 + q] + stg[t][q * LS + row]) + stg[t][(32 + q) * LS + row]) + stg[t][(64 + q) * LS + row]) + stg[t][(96 + q) * LS + row];
-    }
+  for (int e = tid; e < 25 * 32; e += 256) {
+    const int q = e >> 5, row = e & 31;
+    lg[(128 + q) * LS + row] = (((W[B_BA + 128 + q] + stg[q * LS + row]) + stg[(32 + q) * LS + row]) + stg[(64 + q) * LS + row]) + stg[(96 + q) * LS + row];
   }
   __syncthreads();
   AC_CLK(211);
-#pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    const float* lg = reinterpret_cast<const float*>(PH[t]);
-    const int t0 = i0 + t * MT;
-    if (tid < 128) {   // thread = (head, aircraft): first maximum, like torch argmax
-      const int head = tid >> 5, row = tid & 31;
-      const int off = head * 41, cnt = (head == 3) ? 30 : 41;
-      float best = lg[off * LS + row];
-      int bi = 0;
-      for (int j = 1; j < cnt; ++j) {
-        const float v = lg[(off + j) * LS + row];
-        if (v > best) { best = v; bi = j; }
-      }
-      if (t0 + row < a.N) a.low[(size_t)(t0 + row) * a.act_low + head] = (float)bi;
-    } else if (tid < 160) {   // weapon bits ride along unchanged
-      const int row = tid & 31;
-      if (t0 + row < a.N) {
-        const int nn = t0 + row;
-        const bool scripted = a.use_baseline && (nn % a.A) >= a.n_ego;   // scenario1_task.py:42-48: bits [0,0,0,0], or all ones with artillery
-        for (int k = 4; k < a.act_low; ++k)
-          a.low[(size_t)nn * a.act_low + k] = scripted ? (a.use_artillery ? 1.0f : 0.0f) : a.hi[(size_t)nn * a.act_hi + (k - 1)];
-      }
+  if (tid < 128) {   // thread = (head, aircraft): first maximum, like torch argmax
+    const int head = tid >> 5, row = tid & 31;
+    const int off = head * 41, cnt = (head == 3) ? 30 : 41;
+    float best = lg[off * LS + row];
+    int bi = 0;
+    for (int j = 1; j < cnt; ++j) {
+      const float v = lg[(off + j) * LS + row];
+      if (v > best) { best = v; bi = j; }
+    }
+    if (i0 + row < a.N) a.low[(size_t)(i0 + row) * a.act_low + head] = (float)bi;
+  } else if (tid < 160) {   // weapon bits ride along unchanged
+    const int row = tid & 31;
+    if (i0 + row < a.N) {
+      const int nn = i0 + row;
+      const bool scripted = a.use_baseline && (nn % a.A) >= a.n_ego;   // scenario1_task.py:42-48: bits [0,0,0,0], or all ones with artillery
+      for (int k = 4; k < a.act_low; ++k)
+        a.low[(size_t)nn * a.act_low + k] = scripted ? (a.use_artillery ? 1.0f : 0.0f) : a.hi[(size_t)nn * a.act_hi + (k - 1)];
     }
   }
   AC_CLK(212);

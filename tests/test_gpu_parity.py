@@ -503,13 +503,6 @@ def test_hierarchical_tasks_lowlevel_controller(pkg, oracle, task, baseline):
     _lowlevel_controller_parity(pkg, oracle, task, baseline)
 
 
-def test_lowlevel_controller_fp32_matrix_form(pkg, oracle, monkeypatch):
-    """The same check with the controller on the fp32 matrix instructions (controller_kernel, AIRCOMBAT_CTL=fp32 when the handle is
-    created) instead of the default bf16-piece form (controller_split_kernel): both forms are held to the same bounds."""
-    monkeypatch.setenv("AIRCOMBAT_CTL", "fp32")
-    _lowlevel_controller_parity(pkg, oracle, "hierarchical_singlecombat", 0)
-
-
 FLIP_GAP = 1e-4     # an argmax index that differs from the oracle's must sit on a top-two logit gap below this in the oracle's own fp64 logits
 
 
@@ -610,44 +603,6 @@ def _lowlevel_controller_parity(pkg, oracle, task, baseline, E=6, sample=None, p
           f"; worst |d hidden| learned {worst_hid[False]:.2e} scripted {worst_hid[True]:.2e}")
     assert flips <= max(2, calls // 200), (flips, calls)      # (and near-ties themselves are rare)
     env.close()
-
-
-def test_controller_tile_forms_are_bit_identical(pkg, monkeypatch):
-    """The controller runs one 32-aircraft tile per workgroup below 16 384 aircraft and two tiles sharing one weight stream from there on
-    (AIRCOMBAT_CTL_TILES pins the form). Each tile's arithmetic is the same instruction sequence in both forms, so an aircraft's control
-    indices, GRU state and everything downstream must not depend on the form: two handles, ragged batch (37 envs = 74 aircraft: a full
-    tile pair and a partial one), same [3,5,3] + weapon-bit actions, 80 steps, bit for bit."""
-    cfg = pkg.default_config("scenario1", hierarchical=True)
-    cfg.init[1].lon_deg, cfg.init[1].lat_geod_deg, cfg.init[1].psi_deg = 120.02, 60.06, 171.0
-    cfg.init[0].psi_deg = 9.0
-    E = 37
-    envs = []
-    for tiles in ("1", "2"):
-        monkeypatch.setenv("AIRCOMBAT_CTL_TILES", tiles)
-        envs.append(pkg.HipVecEnv(cfg, E, seed=9))
-    assert (envs[0].reset() == envs[1].reset()).all()
-    rng = np.random.default_rng(77)
-    for step in range(80):
-        act = np.concatenate([np.stack([rng.integers(0, n, size=(E, 2)) for n in (3, 5, 3)], axis=-1), rng.random((E, 2, 4)) < 0.3], axis=-1).astype(np.float32)
-        a, b = envs[0].step(act), envs[1].step(act)
-        for x, y in zip(a[:3], b[:3]):
-            assert (x == y).all(), step
-        if step % 10 == 0:
-            for e in (0, 15, 16, 31, 32, 36):
-                for ag in range(2):
-                    ha, la = envs[0].get_controller_state(e, ag)
-                    hb, lb = envs[1].get_controller_state(e, ag)
-                    assert (ha == hb).all() and (la == lb).all(), (step, e, ag)
-    for env in envs:
-        env.close()
-
-
-@pytest.mark.parametrize("tiles", ["1", "2"])
-def test_controller_tile_forms_match_oracle_on_a_ragged_batch(pkg, oracle, monkeypatch, tiles):
-    """Both controller forms against the oracle at 74 and 36 aircraft (neither a multiple of a 32-aircraft tile, nor of a tile pair)."""
-    monkeypatch.setenv("AIRCOMBAT_CTL_TILES", tiles)
-    _lowlevel_controller_parity(pkg, oracle, "scenario1", 0, E=37, steps=50)
-    _lowlevel_controller_parity(pkg, oracle, "scenario_nvn", 1, E=9, per_side=2, steps=50)
 
 
 @pytest.mark.parametrize("per_side", [2, 4])
@@ -1048,7 +1003,7 @@ def test_long_random_rollouts_stay_finite(pkg, task):
 
 @pytest.mark.parametrize("task", ["hierarchical_singlecombat", "scenario1", "scenario_nvn"])
 def test_long_hierarchical_rollouts_stay_finite(pkg, task):
-    """The same soak through the as-shipped action space ([3,5,3] (+ weapon bits) -> controller_kernel -> step): 600 steps."""
+    """The same soak through the as-shipped action space ([3,5,3] (+ weapon bits) -> controller kernel -> step): 600 steps."""
     cfg = pkg.default_config(task, hierarchical=True)
     A, E = cfg.n_agents, 128
     env = (pkg.HipShareVecEnv if A > 2 else pkg.HipVecEnv)(cfg, E, seed=4)
