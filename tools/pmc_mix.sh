@@ -5,7 +5,7 @@ tag=${1:-mix}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out/pmc -o pmc -- python3 bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-saturating ${@:2} > $out/bench.json 2> $out/err.txt
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out/pmc -o pmc -- python3 bench.py --steps 300 --warmup 50 --device-only --no-configs --no-cpu-baseline --no-saturating --no-steady-state ${@:2} > $out/bench.json 2> $out/err.txt
 python3 - <<PY
 import csv,glob,collections
 acc=collections.defaultdict(lambda: collections.defaultdict(list))

@@ -3,7 +3,7 @@
 # -> $out/pmc_traffic.json (copy to profiles/).   usage (inside gpurun): bash tools/pmc_traffic_tasks.sh <tag> <round>
 set -e
 out=gpurun_out/${1:-pmc_tasks}
-round=${2:-2}
+round=${2:-3}
 mkdir -p $out
 export TMPDIR=/tmp
 cp profiles/pmc_traffic.json $out/pmc_traffic.json
@@ -11,7 +11,7 @@ for spec in "singlecombat 1 2" "singlecombat_shoot 1 2" "scenario1 1 2" "scenari
   set -- $spec; t=$1; ps=$2; A=$3
   extra=""; if [ $ps != 1 ]; then extra="--per-side $ps"; fi
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/${t}${A}_$c -o pmc -- python3 bench.py --task $t $extra --steps 300 --warmup 100 --device-only --no-configs --no-cpu-baseline --no-saturating --checksum-calls 20 > $out/${t}${A}_$c.json 2> $out/${t}${A}_$c.err
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/${t}${A}_$c -o pmc -- python3 bench.py --task $t $extra --steps 300 --warmup 100 --device-only --no-configs --no-cpu-baseline --no-saturating --no-steady-state --checksum-calls 20 > $out/${t}${A}_$c.json 2> $out/${t}${A}_$c.err
   done
   python3 tools/pmc_traffic.py $out/${t}${A}_FETCH_SIZE $out/${t}${A}_WRITE_SIZE --task $t --agents $A --round $round --out $out/pmc_traffic.json | grep -E "bytes_per_aircraft_step|traffic_bytes"
   find $out -name "*.csv" -size +5M -delete
