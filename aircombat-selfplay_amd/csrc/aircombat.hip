@@ -1601,7 +1601,8 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
   const bool one_wave_per_simd = grid.x <= 1024;  // 256 CUs x 4 SIMDs
   if (h->cfg.task == AC_TASK_HEADING) {
     if (h->split_waves) hipLaunchKernelGGL(step_kernel_heading<true>, grid, dim3(192), 0, h->stream, p, h->dc, h->hp, h->hc, 0);
-    else hipLaunchKernelGGL(step_kernel_heading<false>, grid, block, 0, h->stream, p, h->dc, h->hp, h->hc, 0);
+    else if (one_wave_per_simd) hipLaunchKernelGGL((step_kernel_heading<false, 1>), grid, block, 0, h->stream, p, h->dc, h->hp, h->hc, 0);
+    else hipLaunchKernelGGL((step_kernel_heading<false, 2>), grid, block, 0, h->stream, p, h->dc, h->hp, h->hc, 0);
     HIP_OK(hipGetLastError());
     return 0;
   }
@@ -1653,7 +1654,7 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
 static int launch_reset(ac_env* h) {
   dim3 block(64), grid((h->N + 63) / 64);
   if (h->cfg.task == AC_TASK_HEADING) {   // every env draws a new episode from its own generator
-    hipLaunchKernelGGL(step_kernel_heading<false>, grid, block, 0, h->stream, h->dp, h->dc, h->hp, h->hc, 1);
+    hipLaunchKernelGGL((step_kernel_heading<false, 1>), grid, block, 0, h->stream, h->dp, h->dc, h->hp, h->hc, 1);
     HIP_OK(hipGetLastError());
     return 0;
   }

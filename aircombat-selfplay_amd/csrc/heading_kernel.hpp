@@ -117,8 +117,10 @@ __device__ void heading_reset(const HeadingCfg& hc, const DevCfg& c, const Tab& 
   heading_obs(pr, d, x, ob);
 }
 
-template <bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? 192 : 64, SPLIT ? 1 : 2) void step_kernel_heading(DevPtrs P, DevCfg c, HeadingPtrs H, HeadingCfg hc, int reset_only) {
+// WPE: waves per SIMD the build is sized for (1: 512 registers, nothing in scratch -- every grid up to 1024 workgroups and every reset launch;
+// 2: 256 registers for the saturating grids beyond, where the in-kernel initial-condition procedure of an episode end keeps values in scratch)
+template <bool SPLIT, int WPE = 1>
+__global__ __launch_bounds__(SPLIT ? 192 : 64, SPLIT ? 1 : WPE) void step_kernel_heading(DevPtrs P, DevCfg c, HeadingPtrs H, HeadingCfg hc, int reset_only) {
   constexpr int OBS = 12;
   __shared__ __attribute__((aligned(16))) float lds_out[64 * OBS];
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];

@@ -15,7 +15,6 @@ core/simulatior.py:223-225; its ``pdb`` NaN trap in ``_pack``, env_base.py:277-2
 """
 import ctypes as C
 import os
-import sys
 
 import numpy as np
 
@@ -194,7 +193,6 @@ class HipVecEnv:
                 "info": arr(ptrs[4], (E,), C.c_int32),
             })
         self._cur = 0
-        self._pool = {}
         self._actions = self._sets[0]["actions"]
         # what step() hands back for each set, built once: the arrays are views of fixed buffers, and LazyInfos reads its codes when asked
         self._results = [self._result(st) for st in self._sets]
@@ -244,24 +242,9 @@ class HipVecEnv:
     def _result(self, st):
         return st["obs"], st["rew"], st["done"], LazyInfos(st["info"])
 
-    def _own(self, key, src):
-        """A copy of `src` in an array nobody else holds: like a fresh np.array for the caller (the reference's np.stack,
-        env_wrappers.py:276-282), but taken from a small pool of earlier result arrays whose every outside reference -- the caller's
-        names, slices, views -- is gone (refcount back to the pool's own): a new 0.5 MB array per step is an mmap plus a page fault
-        per 4 KB, which cost more than the copy itself. An array the caller still holds, in any way, is never reused."""
-        pool = self._pool.setdefault(key, [])
-        for arr in pool:
-            if sys.getrefcount(arr) == 3:      # the pool's list, the loop variable, getrefcount's argument: nobody else
-                np.copyto(arr, src)
-                return arr
-        arr = src.copy()
-        if len(pool) < 8:
-            pool.append(arr)
-        return arr
-
     def _fresh(self, cur):
         st = self._sets[cur]
-        return self._own("obs", st["obs"]), self._own("rew", st["rew"]), self._own("done", st["done"]), LazyInfos(st["info"], snapshot=True)
+        return st["obs"].copy(), st["rew"].copy(), st["done"].copy(), LazyInfos(st["info"], snapshot=True)
 
     def step(self, actions):
         """VecEnv.step = step_async + step_wait (env_wrappers.py:30-42), through one library call."""
@@ -357,7 +340,7 @@ class HipVecEnv:
         must not be read after close() (with the default copy=True nothing the caller holds refers to library memory)."""
         if self.closed:
             return
-        self._sets, self._results, self._pool = [], [], {}    # views of library-owned memory: dropped before the handle frees it
+        self._sets, self._results = [], []           # views of library-owned memory: dropped before the handle frees it
         self._actions = None
         self.lib.ac_destroy(self._h)
         self._h = None
@@ -483,8 +466,8 @@ class HipShareVecEnv(HipVecEnv):
 
     def _fresh(self, cur):
         st = self._sets[cur]
-        obs = self._own("obs", st["obs"])
-        return obs, self._share(obs), self._own("rew", st["rew"]), self._own("done", st["done"]), LazyInfos(st["info"], snapshot=True)
+        obs = st["obs"].copy()
+        return obs, self._share(obs), st["rew"].copy(), st["done"].copy(), LazyInfos(st["info"], snapshot=True)
 
 
 class MultiDeviceVecEnv:

@@ -35,7 +35,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TINST = 256 * 4 * 32 * 2.4e9 / 1e12   # lane-instructions/s: 256 CUs x 4 SIMD-32 x 2.4 GHz (157.3 TFLOP/s fp32 = 2 flop FMA)
 # SQ_INSTS_VALU per aircraft-step of the SingleCombat kernel (profiles/round3_pmc_mix.txt, tools/pmc_mix.sh): the one-wave form executes
 # the algorithm once per lane; the three-wave form of the BASELINE batch executes the same tick cut in three plus the mailbox traffic
-VALU_PER_AGENT_STEP = {"one_wave": 8796.0, "three_wave": 9412.0}
+VALU_PER_AGENT_STEP = {"one_wave": 8379.0, "three_wave": 9386.0}
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
