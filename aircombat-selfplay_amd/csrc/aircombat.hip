@@ -2047,7 +2047,15 @@ int ac_get_state(ac_env_t* h, int32_t env, int32_t agent, double* out) {
   for (int f = 0; f < NF; ++f) { float v; HIP_OK(hipMemcpy(&v, h->dp.F + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
   for (int f = 0; f < NI; ++f) { int v; HIP_OK(hipMemcpy(&v, h->dp.I + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
   if (h->d_XF) {  // read-only tail: scenario-task extension (weapon counters, chaff clouds, shared reward references)
-    for (int f = 0; f < NXI; ++f) { int v; HIP_OK(hipMemcpy(&v, h->d_XI + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
+    {   // the fourteen counters / flags live in two packed words (scenario_kernel.hpp: ext_pack0 / ext_pack1); reported one by one
+      int w[NXI];
+      for (int f = 0; f < NXI; ++f) HIP_OK(hipMemcpy(&w[f], h->d_XI + f * N + n, sizeof(int), hipMemcpyDeviceToHost));
+      Ext x{};
+      ext_unpack(w[XI_w0], w[XI_w1], x);
+      const int v[NXI_UNPACKED] = {x.rem_gun, x.rem_9m, x.rem_120b, x.rem_chaff, x.bits, x.last_chaff, x.orphan_hits, x.mp_prev, x.ref_set,
+                                   x.ch_status[0], x.ch_mult[0], x.ch_status[1], x.ch_mult[1], x.n_ch};
+      for (int f = 0; f < NXI_UNPACKED; ++f) out[k++] = v[f];
+    }
     for (int f = 0; f < NXF; ++f) { float v; HIP_OK(hipMemcpy(&v, h->d_XF + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
   }
   for (; k < AC_STATE_LEN; ++k) out[k] = 0.0;

@@ -11,11 +11,19 @@
 // needs (target pose, missile pose, chaff clouds, statuses) is fetched from the owning lane with __shfl.
 #pragma once
 
-// extension state of the scenario tasks, SoA [field][N]
-enum { XI_rem_gun, XI_rem_9m, XI_rem_120b, XI_rem_chaff, XI_bits, XI_last_chaff, XI_orphan_hits, XI_mp_prev, XI_ref_set,
-       XI_ch_status0, XI_ch_mult0, XI_ch_status1, XI_ch_mult1, XI_n_ch, NXI };
+// extension state of the scenario tasks, SoA [field][N]. The counters and flags the reference keeps in Python attributes (remaining rounds per
+// weapon, the four weapon bits, the chaff bookkeeping, MissilePostureReward's remembered missile, ...) are 14 small integers: they live bit-packed in
+// TWO words per aircraft, and every part of the record is written back only when it has changed -- the words when their value differs from what was
+// loaded, the ten shared reward references when they are (re)set, a chaff cloud while it exists -- instead of 32 words in and 32 words out on
+// every env step (round 2: 256 of the scenario kernels' ~1400 B per aircraft-step).
+enum { XI_w0, XI_w1, NXI };
+//  w0: rem_gun 0-3 | rem_9m 4-7 | rem_120b 8-11 | bits 12-15 | mp_prev 16-20 | ref_set 21-23 | orphan_hits 24-27
+//  w1: last_chaff + 1 0-1 | n_ch 2-3 | ch_status0 4 | ch_status1 5 | ch_mult0 6-10 | ch_mult1 11-15 | rem_chaff 16-23 (signed: a release event takes
+//      one round per qualifying incoming missile and can take the count below zero, scenario1_task.py:97-103)
+// (a cloud's age keeps counting after it has dissolved, like ChaffSimulator.run's; nothing reads it then, and it is no longer written back)
 enum { XF_cg_AO, XF_cg_TA, XF_wez0, XF_wez1, XF_wez2, XF_wez3, XF_tail0, XF_tail1, XF_tail2, XF_tail3,
        XF_c0x, XF_c0y, XF_c0z, XF_c0t, XF_c1x, XF_c1y, XF_c1z, XF_c1t, NXF };
+enum { NXI_UNPACKED = 14 };   // ac_get_state still reports the integers one by one (x_rem_gun ... x_n_ch)
 
 struct Ext {
   int rem_gun, rem_9m, rem_120b, rem_chaff, bits, last_chaff, orphan_hits, mp_prev, ref_set;
@@ -23,31 +31,49 @@ struct Ext {
   float cg_AO, cg_TA, wez[4], tail[4];
   float cx[2], cy[2], cz[2], ct[2];
 };
-__device__ __forceinline__ void load_ext(const float* XF, const int* XI, int N, int n, Ext& x) {
+struct ExtLoaded { int w0, w1, ref_set; bool cloud[2]; };   // what the record held when it was loaded (store_ext writes the differences)
+__host__ __device__ __forceinline__ int ext_pack0(const Ext& x) {
+  return (x.rem_gun & 15) | ((x.rem_9m & 15) << 4) | ((x.rem_120b & 15) << 8) | ((x.bits & 15) << 12) | ((x.mp_prev & 31) << 16) | ((x.ref_set & 7) << 21) |
+         ((x.orphan_hits & 15) << 24);
+}
+__host__ __device__ __forceinline__ int ext_pack1(const Ext& x) {
+  return ((x.last_chaff + 1) & 3) | ((x.n_ch & 3) << 2) | ((x.ch_status[0] & 1) << 4) | ((x.ch_status[1] & 1) << 5) | ((x.ch_mult[0] & 31) << 6) | ((x.ch_mult[1] & 31) << 11) |
+         ((x.rem_chaff & 255) << 16);
+}
+__host__ __device__ __forceinline__ void ext_unpack(int w0, int w1, Ext& x) {
+  x.rem_gun = w0 & 15; x.rem_9m = (w0 >> 4) & 15; x.rem_120b = (w0 >> 8) & 15;
+  x.bits = (w0 >> 12) & 15; x.mp_prev = (w0 >> 16) & 31; x.ref_set = (w0 >> 21) & 7; x.orphan_hits = (w0 >> 24) & 15;
+  x.last_chaff = (w1 & 3) - 1; x.n_ch = (w1 >> 2) & 3; x.ch_status[0] = (w1 >> 4) & 1; x.ch_status[1] = (w1 >> 5) & 1;
+  x.ch_mult[0] = (w1 >> 6) & 31; x.ch_mult[1] = (w1 >> 11) & 31;
+  x.rem_chaff = (int)((unsigned)w1 << 8) >> 24;           // sign-extended 8 bits
+}
+__device__ __forceinline__ void load_ext(const float* XF, const int* XI, int N, int n, Ext& x, ExtLoaded& was) {
   AC_LANE_INDEX(n);
-  x.rem_gun = AC_AT(XI, XI_rem_gun); x.rem_9m = AC_AT(XI, XI_rem_9m); x.rem_120b = AC_AT(XI, XI_rem_120b);
-  x.rem_chaff = AC_AT(XI, XI_rem_chaff); x.bits = AC_AT(XI, XI_bits); x.last_chaff = AC_AT(XI, XI_last_chaff);
-  x.orphan_hits = AC_AT(XI, XI_orphan_hits); x.mp_prev = AC_AT(XI, XI_mp_prev); x.ref_set = AC_AT(XI, XI_ref_set);
-  x.ch_status[0] = AC_AT(XI, XI_ch_status0); x.ch_mult[0] = AC_AT(XI, XI_ch_mult0);
-  x.ch_status[1] = AC_AT(XI, XI_ch_status1); x.ch_mult[1] = AC_AT(XI, XI_ch_mult1); x.n_ch = AC_AT(XI, XI_n_ch);
+  was.w0 = AC_AT(XI, XI_w0); was.w1 = AC_AT(XI, XI_w1);
   x.cg_AO = AC_AT(XF, XF_cg_AO); x.cg_TA = AC_AT(XF, XF_cg_TA);
 #pragma unroll
   for (int k = 0; k < 4; ++k) { x.wez[k] = AC_AT(XF, XF_wez0 + k); x.tail[k] = AC_AT(XF, XF_tail0 + k); }
   x.cx[0] = AC_AT(XF, XF_c0x); x.cy[0] = AC_AT(XF, XF_c0y); x.cz[0] = AC_AT(XF, XF_c0z); x.ct[0] = AC_AT(XF, XF_c0t);
   x.cx[1] = AC_AT(XF, XF_c1x); x.cy[1] = AC_AT(XF, XF_c1y); x.cz[1] = AC_AT(XF, XF_c1z); x.ct[1] = AC_AT(XF, XF_c1t);
-}
-__device__ __forceinline__ void store_ext(float* XF, int* XI, int N, int n, const Ext& x) {
-  AC_LANE_INDEX(n);
-  AC_AT(XI, XI_rem_gun) = x.rem_gun; AC_AT(XI, XI_rem_9m) = x.rem_9m; AC_AT(XI, XI_rem_120b) = x.rem_120b;
-  AC_AT(XI, XI_rem_chaff) = x.rem_chaff; AC_AT(XI, XI_bits) = x.bits; AC_AT(XI, XI_last_chaff) = x.last_chaff;
-  AC_AT(XI, XI_orphan_hits) = x.orphan_hits; AC_AT(XI, XI_mp_prev) = x.mp_prev; AC_AT(XI, XI_ref_set) = x.ref_set;
-  AC_AT(XI, XI_ch_status0) = x.ch_status[0]; AC_AT(XI, XI_ch_mult0) = x.ch_mult[0];
-  AC_AT(XI, XI_ch_status1) = x.ch_status[1]; AC_AT(XI, XI_ch_mult1) = x.ch_mult[1]; AC_AT(XI, XI_n_ch) = x.n_ch;
-  AC_AT(XF, XF_cg_AO) = x.cg_AO; AC_AT(XF, XF_cg_TA) = x.cg_TA;
+  ext_unpack(was.w0, was.w1, x);
+  was.ref_set = x.ref_set;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { AC_AT(XF, XF_wez0 + k) = x.wez[k]; AC_AT(XF, XF_tail0 + k) = x.tail[k]; }
-  AC_AT(XF, XF_c0x) = x.cx[0]; AC_AT(XF, XF_c0y) = x.cy[0]; AC_AT(XF, XF_c0z) = x.cz[0]; AC_AT(XF, XF_c0t) = x.ct[0];
-  AC_AT(XF, XF_c1x) = x.cx[1]; AC_AT(XF, XF_c1y) = x.cy[1]; AC_AT(XF, XF_c1z) = x.cz[1]; AC_AT(XF, XF_c1t) = x.ct[1];
+  for (int q = 0; q < 2; ++q) was.cloud[q] = q < x.n_ch && x.ch_status[q] == 0;
+}
+// `all` : the whole record (reset of an episode / of the handle)
+__device__ __forceinline__ void store_ext(float* XF, int* XI, int N, int n, const Ext& x, const ExtLoaded& was, bool all) {
+  AC_LANE_INDEX(n);
+  const int w0 = ext_pack0(x), w1 = ext_pack1(x);
+  if (all || w0 != was.w0) AC_AT(XI, XI_w0) = w0;
+  if (all || w1 != was.w1) AC_AT(XI, XI_w1) = w1;
+  if (all || x.ref_set != was.ref_set) {   // the shared reward references: written by the first evaluation after a reset, never again
+    AC_AT(XF, XF_cg_AO) = x.cg_AO; AC_AT(XF, XF_cg_TA) = x.cg_TA;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { AC_AT(XF, XF_wez0 + k) = x.wez[k]; AC_AT(XF, XF_tail0 + k) = x.tail[k]; }
+  }
+  // a chaff cloud: its release point and its age, while it exists (released this step, or ageing since an earlier one)
+  if (all || was.cloud[0] || (x.n_ch > 0 && x.ch_status[0] == 0)) { AC_AT(XF, XF_c0x) = x.cx[0]; AC_AT(XF, XF_c0y) = x.cy[0]; AC_AT(XF, XF_c0z) = x.cz[0]; AC_AT(XF, XF_c0t) = x.ct[0]; }
+  if (all || was.cloud[1] || (x.n_ch > 1 && x.ch_status[1] == 0)) { AC_AT(XF, XF_c1x) = x.cx[1]; AC_AT(XF, XF_c1y) = x.cy[1]; AC_AT(XF, XF_c1z) = x.cz[1]; AC_AT(XF, XF_c1t) = x.ct[1]; }
 }
 __device__ __forceinline__ Ext fresh_ext(int num) {
   Ext x{};
@@ -269,7 +295,8 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
 
   if (PAIR) load_task(P.F, P.I, N, nn, t);   // the environment wave owns the task bookkeeping; of the flight state it only needs the tick count (Earth angle)
   else load_state(P.F, P.I, P.D, N, nn, s, t);
-  load_ext(XF, XI, N, nn, x);
+  ExtLoaded x_was;
+  load_ext(XF, XI, N, nn, x, x_was);
   MslD ms[MS];
 #pragma unroll
   for (int k = 0; k < MS; ++k) {
@@ -834,7 +861,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
       if (all_done) store_flight(P.F, P.I, P.D, N, n, s);
       store_task(P.F, P.I, N, n, t);
     }
-    store_ext(XF, XI, N, n, x);
+    store_ext(XF, XI, N, n, x, x_was, all_done);
 #pragma unroll
     for (int k = 0; k < MS; ++k)
       if (ms[k].status != MSL_INACTIVE || ((msl_was_active >> k) & 1)) store_msl(P.MD, P.MI, N, n, k, ms[k]);
@@ -914,5 +941,5 @@ __global__ void reset_ext_kernel(DevCfg c, float* XF, int* XI) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= c.N) return;
   Ext x = fresh_ext(c.num_missiles[n % c.A]);
-  store_ext(XF, XI, c.N, n, x);
+  store_ext(XF, XI, c.N, n, x, ExtLoaded{}, true);
 }
