@@ -102,6 +102,7 @@ SIGNATURES = {
     "ac_timing_end": (C.c_int, [_p, C.POINTER(C.c_float)]),
     "ac_step_timed_device": (C.c_int, [_p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "ac_state_checksum": (C.c_int, [_p, C.POINTER(C.c_uint64)]),
+    "ac_munitions_in_flight": (C.c_int, [_p, C.POINTER(C.c_int32)]),
     "ac_seed_envs": (C.c_int, [_p, _p]),
     "ac_get_heading_state": (C.c_int, [_p, C.c_int32, _p]),
     "ac_pin_host_buffer": (C.c_int, [_p, _p, C.c_int64]),

@@ -637,7 +637,8 @@ __device__ __forceinline__ void emit_scalars(const DevPtrs& P, int lane, float r
 #pragma unroll
   for (int b = 0; b < 4; ++b) dword |= (unsigned)((dmask >> (4 * (lane & 15) + b)) & 1ull) << (8 * b);
   const int4 inf = make_int4(i0, i1, i2, i3);
-  const int packed = (i0 & 0xFFFF) | ((i1 & 0xFF) << 16) | ((i2 & 0x7F) << 24) | ((i3 & 1) << 31);
+  // (current_step < 65536 is checked by ac_create; the turn count saturates at its field's 127 -- the reference's increment_size list has 15 stages)
+  const int packed = (i0 & 0xFFFF) | ((i1 & 0xFF) << 16) | (min(i2, 127) << 24) | ((i3 & 1) << 31);
   const size_t n = blk * 64 + lane;
   if (!(fabsf(reward) < INFINITY)) *(volatile int*)P.err = (int)n + 1;   // (any of the offending lanes wins; the host keeps it sticky)
 #pragma unroll
@@ -730,6 +731,8 @@ struct TaskTraits {
 // 2 = the pair form (pair_kernel.hpp: flight wave + environment wave) for the tasks with missiles.
 template <int TASK, int WPE, int FORM = 0>
 __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 256 : 64)), WPE) void step_kernel_1v1(DevPtrs P, DevCfg c) {
+  // forms launch_step reaches: SingleCombat in the one-wave (0) and three-wave (1) forms; the two tasks with munitions in the pair (2) and quad (3) forms only
+  static_assert(TASK == AC_TASK_SINGLECOMBAT ? FORM <= 1 : FORM >= 2, "no launch path for this (task, form)");
   using TT = TaskTraits<TASK>;
   constexpr bool SPLIT = FORM == 1, QUAD = FORM == 3, PAIR = FORM == 2 || QUAD;   // (the quad form's environment wave runs the pair form's code)
   constexpr bool HAS_MSL = TT::HAS_MSL;
@@ -2141,6 +2144,33 @@ int ac_state_checksum(ac_env_t* h, uint64_t* out) {
   HIP_OK(hipMemcpy(&v, d_out, sizeof v, hipMemcpyDeviceToHost));
   HIP_OK(hipFree(d_out));
   *out = (uint64_t)v;
+  return 0;
+}
+// Munitions in flight (status LAUNCHED) over the whole handle: SURVEY 8(d) counts 192 algorithmic bytes per live missile-step, so the bench needs
+// the number; one status word per slot, summed per wave.
+__global__ void munitions_in_flight_kernel(DevPtrs P, DevCfg c, int* out) {
+  const int N = c.N;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  int cnt = 0;
+  if (n < N)
+    for (int k = 0; k < c.msl_slots; ++k) cnt += P.MI[((size_t)k * NMI + MI_status) * (size_t)N + n] == MSL_LAUNCHED;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(out, cnt);
+}
+int ac_munitions_in_flight(ac_env_t* h, int32_t* count) {
+  if (!h || !count) return fail("ac_munitions_in_flight: null argument");
+  *count = 0;
+  if (!h->dc.msl_slots || !h->dp.MI) return 0;
+  HIP_OK(hipSetDevice(h->device));
+  int* d_out;
+  HIP_OK(hipMalloc(&d_out, sizeof(int)));
+  HIP_OK(hipMemsetAsync(d_out, 0, sizeof(int), h->stream));
+  hipLaunchKernelGGL(munitions_in_flight_kernel, dim3((h->N + 63) / 64), dim3(64), 0, h->stream, h->dp, h->dc, d_out);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipMemcpy(count, d_out, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_OK(hipFree(d_out));
   return 0;
 }
 int ac_seed_envs(ac_env_t* h, const uint64_t* states) {

@@ -191,6 +191,8 @@ __global__ void mp_walk_selftest_kernel(int* mismatches, unsigned long long comb
 template <int A, int WPE, int FORM = FORM_ONE>
 __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128 : (FORM == FORM_QUAD ? 256 : 64)), WPE) void step_kernel_scenario(DevPtrs P, DevCfg c, float* XF, int* XI, const float* tXF, const int* tXI) {
   using SD = ScenarioDims<A>;
+  // forms launch_step reaches: the gun-only 1v1 tasks in the three-wave form, everything else in the pair form, the 1v1 scenario also in the quad form
+  static_assert(FORM != FORM_ONE && (FORM == FORM_PAIR || A == 2), "no launch path for this (A, form)");
   constexpr bool SPLIT = FORM == FORM_SPLIT, QUAD = FORM == FORM_QUAD, PAIR = FORM == FORM_PAIR || QUAD;   // (the quad form's environment wave runs the pair form's code)
   constexpr bool MULTI = SD::MULTI;
   constexpr int OBS = SD::OBS;

@@ -435,6 +435,12 @@ class HipVecEnv:
         self.lib.check(self.lib.ac_state_checksum(self._h, C.byref(out)), "ac_state_checksum")
         return int(out.value)
 
+    def munitions_in_flight(self):
+        """Munitions with status LAUNCHED over all envs (ac_munitions_in_flight)."""
+        out = C.c_int32()
+        self.lib.check(self.lib.ac_munitions_in_flight(self._h, C.byref(out)), "ac_munitions_in_flight")
+        return int(out.value)
+
     def get_missile(self, env, agent, k):
         out = (C.c_double * 12)()
         self.lib.check(self.lib.ac_get_missile(self._h, env, agent, k, out), "ac_get_missile")

@@ -144,18 +144,36 @@ def host_launch_ms(env, pool, steps=200):
     return tot / steps
 
 
-def roofline(env, task, kernel_ms, hierarchical=False, controller_ms=None, step_ms=None):
-    """HBM roofline of the launch: algorithmic bytes (SURVEY 8d accounting) over the measured kernel time. For a hierarchical handle the
-    launch is controller kernel + step kernel; `step_kernel` prices the step kernel alone and `controller` reports the controller's
-    matrix rate (its bound is the matrix pipe / L2 weight stream, not HBM: DESIGN.md section 5)."""
-    algo = algorithmic_bytes(env) * env.num_envs * env.num_agents            # per launch, one GPU
+def munitions_per_aircraft(env, dev_ptrs, steps=100, every=10):
+    """Average number of munitions in flight per aircraft over a short device-resident leg (ac_munitions_in_flight, sampled every
+    `every` steps): SURVEY 8(d) prices each live missile-step at 192 algorithmic bytes."""
+    if not hasattr(env, "munitions_in_flight") or env.config.task in (0, 1, 4, 7, 8):     # heading, singlecombat, multiplecombat, wvr, maneuver: no munitions
+        return 0.0
+    tot = cnt = 0
+    for i in range(steps):
+        env.step_device(dev_ptrs[i % len(dev_ptrs)])
+        if i % every == every - 1:
+            tot += env.munitions_in_flight()
+            cnt += 1
+    return tot / max(cnt, 1) / (env.num_envs * env.num_agents)
+
+
+def roofline(env, task, kernel_ms, hierarchical=False, controller_ms=None, step_ms=None, missiles=0.0):
+    """HBM roofline of the launch: algorithmic bytes (SURVEY 8d accounting, incl. 192 B per live missile-step when `missiles` = munitions in
+    flight per aircraft is given) over the measured kernel time. For a hierarchical handle the launch is controller kernel + step kernel;
+    `step_kernel` prices the step kernel alone and `controller` reports the controller's matrix rate (its bound is the matrix pipe, not
+    HBM: DESIGN.md section 5)."""
+    algo = algorithmic_bytes(env, missiles) * env.num_envs * env.num_agents  # per launch, one GPU
     achieved = algo / (kernel_ms * 1e-3) / 1e9
     traffic = pmc_traffic(task, env.num_envs, env.num_envs * env.num_agents, hierarchical)
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
            "traffic": traffic, "traffic_committed_pmc": traffic,
            "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes of this workload (profiles/pmc_traffic.json); NOT measured in this run",
            "kernel": "step kernel of the task" + (" + controller_split_kernel" if hierarchical else ""), "kernel_ms": kernel_ms,
-           "algorithmic_bytes_per_launch": algo, "algorithmic_bytes_per_agent_step": algorithmic_bytes(env)}
+           "algorithmic_bytes_per_launch": algo, "algorithmic_bytes_per_agent_step": algorithmic_bytes(env, missiles),
+           "munitions_in_flight_per_aircraft": missiles}
+    if traffic:
+        out["traffic_over_algorithmic"] = traffic / algo
     if step_ms is not None:
         a = algo / (step_ms * 1e-3) / 1e9
         out["step_kernel"] = {"kernel_ms": step_ms, "achieved": a, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS}
@@ -180,6 +198,7 @@ def config_leg(pkg, np, torch, name, task, per_side, envs, device_id, hierarchic
     torch.cuda.synchronize()
     hb = host_leg(env, pool, steps, warmup)
     wall, kernel_ms = device_leg(env, ptrs, steps, warmup)
+    missiles = munitions_per_aircraft(env, ptrs)       # (right after the device-resident leg: the mix that leg ran with)
     ctl_ms, stp_ms = per_kernel_ms(env, ptrs, 100)
     hb_kernel_ms = host_launch_ms(env, pool, 100)
     n = env.num_envs * env.num_agents
@@ -194,7 +213,7 @@ def config_leg(pkg, np, torch, name, task, per_side, envs, device_id, hierarchic
            "pcie_bound_frac": max(0.0, hb_kernel_ms - kernel_ms) / (hb / steps * 1e3),
            "pcie_note": "share of the host-boundary step spent with the step's action and output bytes crossing PCIe = (kernel time with mapped host buffers - "
                         "kernel time with everything in HBM) / ms_per_step; the host-boundary `value` of this config is a PCIe number to that extent, not a kernel number",
-           "roofline": roofline(env, task, kernel_ms, hierarchical, ctl_ms, stp_ms)}
+           "roofline": roofline(env, task, kernel_ms, hierarchical, ctl_ms, stp_ms, missiles)}
     env.close()
     return out
 
@@ -452,8 +471,9 @@ def main():
         if not args.stub_env:
             result["device_resident"] = {"value": agent_steps / dev_wall, "unit": "agent-steps/s", "ms_per_step": dev_wall / args.steps * 1e3,
                                          "note": "same steps with actions and outputs resident in HBM (step_device, SURVEY N2), launched back to back"}
+            missiles = munitions_per_aircraft(env, ptrs) if world == 1 else 0.0
             ctl_ms, stp_ms = per_kernel_ms(env, ptrs) if world == 1 else (None, None)
-            result["roofline"] = roofline(env, args.task, kernel_ms, args.hierarchical, ctl_ms, stp_ms)
+            result["roofline"] = roofline(env, args.task, kernel_ms, args.hierarchical, ctl_ms, stp_ms, missiles)
             if not args.device_only and hasattr(env, "_sets") and world == 1:
                 hb_ms = host_launch_ms(env, pool)
                 bb = boundary_bytes(env)

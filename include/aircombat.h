@@ -159,6 +159,10 @@ int ac_get_missile(ac_env_t* h, int32_t env, int32_t agent, int32_t k, double ou
  * the step kernel's access pattern, (4*63 + 4*12 + 8*3) bytes per aircraft; no reference counterpart. */
 int ac_state_checksum(ac_env_t* h, uint64_t* out);
 
+/* Number of munitions with status LAUNCHED over the whole handle (len of the live entries of env._tempsims, R/envs/JSBSim/envs/env_base.py:142-143,
+ * summed over envs): the bench prices SURVEY 8(d)'s 192 algorithmic bytes per live missile-step with it. 0 for the tasks without munitions. */
+int ac_munitions_in_flight(ac_env_t* h, int32_t* count);
+
 /* AC_TASK_HEADING: replaces env.seed(seed) -> gymnasium seeding.np_random(seed) (R/envs/JSBSim/envs/env_base.py:252-258): the four
  * 64-bit words (state_hi, state_lo, inc_hi, inc_lo) of numpy's PCG64 bit generator for every env, [E][4]. The reference seeds env i
  * with seed + 1000 i (scripts/train/train_jsbsim.py:33); resets and UnreachHeading then draw exactly numpy's stream on the device. */
