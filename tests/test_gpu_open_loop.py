@@ -45,16 +45,16 @@ def test_straight_flight_600_steps_open_loop(pkg, oracle):
 
 
 def test_random_actions_open_loop_until_a_switch_differs(pkg, oracle):
-    """64 envs, uniform random control indices redrawn every 5 steps (violent manoeuvring: episodes end in crashes and restart),
-    400 steps. Every env is compared as long as its discrete decisions agree; the envelope is the straight-flight one widened 8x
+    """32 envs, uniform random control indices redrawn every 5 steps (violent manoeuvring: episodes end in crashes and restart),
+    300 steps (tools/diag/open_loop.py runs the same at 64 envs x 600 steps: DESIGN.md section 8). Every env is compared as long as its discrete decisions agree; the envelope is the straight-flight one widened 8x
     (a manoeuvring aircraft turns a position difference into an attitude difference and back), in episode age."""
-    E = 64
+    E, STEPS = 32, 300
     pair = OpenLoopPair(pkg, oracle, E, spread=True)
     rng = np.random.default_rng(20250321)
     age = np.zeros(E, dtype=np.int64)
     worst = {}
     act = None
-    for k in range(400):
+    for k in range(STEPS):
         if k % 5 == 0:
             act = np.stack([rng.integers(0, n, size=(E, 2)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
         m = pair.step(act)
@@ -67,8 +67,8 @@ def test_random_actions_open_loop_until_a_switch_differs(pkg, oracle):
             assert ok.all(), (key, k, np.argwhere(~ok)[:4].tolist(), m[key][~ok][:4], b[np.argwhere(~ok)[:4, 0], 0], age[np.argwhere(~ok)[:4, 0]])
             worst[key] = max(worst.get(key, 0.0), float((m[key] / b)[live].max()) if live.any() else 0.0)
         age[pair.last_reset] = 0
-    h = np.minimum(pair.horizon, 400)
-    print(f"random actions: envs still comparable after 400 steps {int((pair.horizon > 400).sum())}/{E}; horizon min {int(h.min())}, "
+    h = np.minimum(pair.horizon, STEPS)
+    print(f"random actions: envs still comparable after {STEPS} steps {int((pair.horizon > STEPS).sum())}/{E}; horizon min {int(h.min())}, "
           f"p10 {np.percentile(h, 10):.0f}, median {np.median(h):.0f}; first differing decision: {pair.reason_counts()}; "
           f"worst fraction of the 8x envelope used: { {k: round(v, 3) for k, v in worst.items()} }")
     assert not pair.done_mismatch.any() or all(r == "done" or r for r in pair.reason)
