@@ -24,10 +24,16 @@ def obs_bounds(want, scale=1.0):
     return tol, free
 
 
-def assert_obs(got, want, scale, ctx):
+USED = {}   # worst fraction of the bound used, per context label (printed by the tests that pass one: how much room the scale leaves)
+
+
+def assert_obs(got, want, scale, ctx, label=None):
     tol, free = obs_bounds(want, scale)
     bad = (np.abs(got - want) > tol) & ~free
     assert not bad.any(), (ctx, np.argwhere(bad)[:6].tolist(), got[bad][:6], want[bad][:6], tol[bad][:6])
+    if label is not None and got.size:
+        frac = np.where(free, 0.0, np.abs(got - want) / tol)
+        USED[label] = max(USED.get(label, 0.0), float(frac.max()))
 
 
 class RewardBound:

@@ -5,7 +5,8 @@ of a task. These tests run the BASELINE shapes themselves -- C3 (1v1 with muniti
 and a > 1024-workgroup batch, replay a sample of envs on the oracle, and hold them to per-element tolerances (no aggregate pass
 criteria). The flight state of the sampled envs is re-synchronised from the oracle before every step (fp32 vs fp64 open-loop
 divergence through the discontinuous FCS is not a kernel error); munitions, chaff, decoy draws and all weapon bookkeeping run
-open-loop on both sides."""
+open-loop on both sides; their observations are held to 2x and their rewards to 4x the stated one-step bounds (round 2: 10x both; the worst
+case measured is 0.6x / 2.2x, printed by every test as the fraction of the bound used)."""
 import numpy as np
 import pytest
 
@@ -61,7 +62,7 @@ def run_sampled(pkg, oracle, task, per_side, E, sample, steps, seed=77, expect_k
     en_from = 9 + 6 * (A // 2 - 1) if (A > 2 and not cfg.legacy_obs) else 9
     rng = np.random.default_rng(seed)
     launched = 0
-    bound = RewardBound(cfg.posture_scale, en_from, n_en, 10.0 if weapons else 1.0)
+    bound = RewardBound(cfg.posture_scale, en_from, n_en, 4.0 if weapons else 1.0)    # (measured: 2.2x the base bound at worst, round 3)
     for step in range(steps):
         for k, e in enumerate(sample):
             for a in range(A):
@@ -73,17 +74,22 @@ def run_sampled(pkg, oracle, task, per_side, E, sample, steps, seed=77, expect_k
         obs, rew, done = (res[0], res[2], res[3]) if A > 2 else (res[0], res[1], res[2])
         robs, rrew, rdone, rinfo = ref.step(act[sample])
         assert (done[sample] == rdone).all(), (task, step, done[sample][..., 0], rdone[..., 0])
-        sc = 10.0 if weapons else 1.0      # munition poses integrate open-loop in fp64 against fp32 target poses
-        assert_obs(obs[sample], robs, sc, (task, step))
+        sc = 2.0 if weapons else 1.0       # munition poses integrate open-loop in fp64 against fp32 target poses (measured: 0.6x the base bound at worst)
+        assert_obs(obs[sample], robs, sc, (task, step), label=f"{task} x{per_side} E={E} scale {sc}")
         rt = bound(rrew, robs)
         if nvn_order:
             rt = team_max(rt, A)
         bad = np.abs(rew[sample] - rrew) > rt
         assert not bad.any(), (task, step, np.argwhere(bad)[:4].tolist(), rew[sample][bad][:4], rrew[bad][:4], rt[bad][:4])
+        import parity_util
+        lab = f"{task} x{per_side} E={E} reward scale {bound.scale}"
+        parity_util.USED[lab] = max(parity_util.USED.get(lab, 0.0), float((np.abs(rew[sample] - rrew) / rt).max()))
         if weapons:
             launched = max(launched, max(len(r.missiles()) for r in ref.envs))
     if weapons:
         assert launched >= 1, "no munition flew during the comparison"
+    import parity_util
+    print("fraction of the observation bound used:", {k: round(v, 3) for k, v in parity_util.USED.items() if k.startswith(f"{task} x{per_side} E={E} ")})
     env.close()
 
 

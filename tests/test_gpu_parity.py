@@ -314,7 +314,7 @@ def test_scenario_weapon_tasks_match_oracle(pkg, oracle, task, per_side, geometr
     rng = np.random.default_rng(11)
     launched = 0
     seen = {"gun": False, "chaff": False, "shotdown": False}
-    bound = RewardBound(cfg.posture_scale, 9 + 6 * (A // 2 - 1) if (A > 2 and not cfg.legacy_obs) else 9, max(1, A // 2), 10.0)
+    bound = RewardBound(cfg.posture_scale, 9 + 6 * (A // 2 - 1) if (A > 2 and not cfg.legacy_obs) else 9, max(1, A // 2), 4.0)
     for step in range(150 if rwr else 330):
         for e in range(E):
             for a in range(A):
@@ -330,13 +330,16 @@ def test_scenario_weapon_tasks_match_oracle(pkg, oracle, task, per_side, geometr
         robs, rrew, rdone, rinfo = ref.step(act)
         same = (done == rdone).all(axis=(1, 2))
         assert same.all(), (step, done[..., 0], rdone[..., 0])
-        # every element to its own bound (x10: munition poses integrate open-loop in fp64 against fp32 target poses)
-        assert_obs(obs, robs, 10.0, (task, geometry, step))
+        # every element to its own bound (x3 for 330 open-loop steps of the munitions, in fp64 against fp32 target poses: 1.6x measured at worst; rewards x4: 0.1x)
+        assert_obs(obs, robs, 3.0, (task, geometry, step), label=f"weapons {task} x{per_side} {geometry} rwr{rwr}")
         rt = bound(rrew, robs)
         if A > 2:
             rt = team_max(rt, A)
         bad = np.abs(rew - rrew) > rt
         assert not bad.any(), (step, np.argwhere(bad)[:4].tolist(), rew[bad][:4], rrew[bad][:4], rt[bad][:4])
+        import parity_util
+        lab = f"weapons {task} x{per_side} {geometry} rwr{rwr}"
+        parity_util.USED[lab + " reward"] = max(parity_util.USED.get(lab + " reward", 0.0), float((np.abs(rew - rrew) / rt).max()))
         for e in range(E):
             for a in range(A):
                 g = env.get_state(e, a)
@@ -353,6 +356,8 @@ def test_scenario_weapon_tasks_match_oracle(pkg, oracle, task, per_side, geometr
     want = {"closing": ("shotdown",), "tail": ("gun",)}[geometry] + (("chaff",) if A > 2 else ())
     assert rwr or all(seen[k] for k in want), seen
     assert obs.shape[-1] == (21 if rwr == 2 else (21 if A == 2 else 9 + 6 * A + 6) + (2 if rwr else 0))
+    import parity_util
+    print("fraction of the bounds used:", {k: round(v, 3) for k, v in parity_util.USED.items() if k.startswith(f"weapons {task} x{per_side} {geometry} rwr{rwr}")})
     env.close()
 
 
@@ -597,7 +602,9 @@ def _lowlevel_controller_parity(pkg, oracle, task, baseline, E=6, sample=None, p
         ok = (done == rdone).all(axis=(1, 2)) | ~same_env
         assert ok.all(), (step, done[..., 0], rdone[..., 0])
         good = same_env & (done == rdone).all(axis=(1, 2))
-        assert_obs(obs[good], robs[good], 10.0, (task, step))
+        assert_obs(obs[good], robs[good], 2.0, (task, step), label=f"hier {task} E={E}")   # (measured: 0.7x the base bound at worst)
+    import parity_util
+    print("fraction of the 2x observation bound used:", round(parity_util.USED.get(f"hier {task} E={E}", 0.0), 3))
     print(f"{task} E={E} A={A}: {calls} controller outputs compared, {flips} differ from the oracle's argmax, oracle logit gaps there: "
           f"{[float(f'{g:.2e}') for g in sorted(flip_gaps)]}"
           f"; worst |d hidden| learned {worst_hid[False]:.2e} scripted {worst_hid[True]:.2e}")
