@@ -6,7 +6,9 @@ must agree to
   * observation entries: |d| <= 2e-4 + 2e-4*|x|   (angles in rad, speeds in Mach-ish units, ranges in 10 km)
   * rewards:             |d| <= 5e-3 + 1e-3*|x|   (PostureReward is scaled by 15 and differenced; atanh amplifies near TA=0)
   * state vector:        relative 2e-5 on velocities / rates / quaternion, 0.05 ft on ECI position
-Open-loop rollouts accumulate error through the discontinuous FCS; they are checked over short horizons with 10x looser bounds.
+Open-loop pieces inside these tests (ten free steps between re-synchronisations, twelve free steps at the BASELINE size, munitions flying
+open-loop for hundreds of steps) are held to 2-4x those bounds; free flight proper -- no re-synchronisation at all, 600 steps -- has its own
+stated envelopes in tests/test_gpu_open_loop.py.
 """
 import numpy as np
 import pytest
@@ -94,7 +96,7 @@ def test_teacher_forced_steps(pkg, oracle, task):
         # hold each action for a while in half of the envs so the aircraft also fly smooth segments
         obs, rew, done, info = env.step(act)
         robs, rrew, rdone, rinfo = ref.step(act)
-        scale = 1.0 if task == "singlecombat" else 10.0
+        scale = 1.0 if task == "singlecombat" else 3.0     # (the shoot task's missiles fly open-loop for the 60 steps)
         ok = obs_close(obs, robs, scale)
         assert ok.all(), (step, np.argwhere(~ok)[:5], obs[~ok][:5], robs[~ok][:5])
         assert (np.abs(rew - rrew) <= scale * (5e-3 + 1e-3 * np.abs(rrew))).all(), (step, np.abs(rew - rrew).max())
@@ -206,7 +208,7 @@ def test_open_loop_rollout_with_terminations(pkg, oracle):
         robs, rrew, rdone, rinfo = ref.step(act)
         mismatched_done += int((done != rdone).sum())
         same = (done == rdone).all(axis=(1, 2))
-        assert obs_close(obs[same], robs[same], 20.0).all(), step
+        assert obs_close(obs[same], robs[same], 2.0).all(), step      # (ten free steps between re-synchronisations: section 8's envelope at k = 10)
     assert mismatched_done == 0
 
 
@@ -378,8 +380,8 @@ def test_full_size_batch_sampled_envs_match_oracle(pkg, oracle):
         obs, rew, done, info = env.step(act)
         robs, rrew, rdone, rinfo = ref.step(act[sample])
         assert (done[sample] == rdone).all(), step
-        assert obs_close(obs[sample], robs, 20.0).all(), (step, np.abs(obs[sample] - robs).max())
-        assert (np.abs(rew[sample] - rrew) <= 20 * (5e-3 + 1e-3 * np.abs(rrew))).all(), step
+        assert obs_close(obs[sample], robs, 2.0).all(), (step, np.abs(obs[sample] - robs).max())     # (12 steps of free flight: tests/test_gpu_open_loop.py has the envelope)
+        assert (np.abs(rew[sample] - rrew) <= 2 * (5e-3 + 1e-3 * np.abs(rrew))).all(), step
     env.close()
 
 
@@ -442,9 +444,9 @@ def test_dodge_missile_rule_based_launch(pkg, oracle, rule):
         obs, rew, done, info = env.step(act)
         robs, rrew, rdone, rinfo = ref.step(act)
         assert (done == rdone).all(), (step, done[..., 0], rdone[..., 0])
-        ok = obs_close(obs, robs, 10.0)
+        ok = obs_close(obs, robs, 3.0)
         assert ok.all(), (step, np.argwhere(~ok)[:5], obs[~ok][:5], robs[~ok][:5])
-        assert (np.abs(rew - rrew) <= 10 * (5e-3 + 1e-3 * np.abs(rrew))).all(), (step, rew.ravel(), rrew.ravel())
+        assert (np.abs(rew - rrew) <= 4 * (5e-3 + 1e-3 * np.abs(rrew))).all(), (step, rew.ravel(), rrew.ravel())
         for e in range(E):
             shotdowns += int(rinfo[e][1]) == 4 and int(rinfo[e][3]) == 1
             if not rinfo[e][3]:
