@@ -205,6 +205,16 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   __shared__ float geo_lds[(SD::MULTI && FORM == FORM_PAIR) ? (SD::NE * 6 + 1) * 64 : 1];
   __shared__ float4 cl_pos[64 * 2];   // the chaff clouds of the workgroup's aircraft (position; live flag and multiplicity below)
   __shared__ int2 cl_meta[64 * 2];
+  // What the aircraft of an env need of each other after the last substep (weapon rules, chaff rule, missile warning) goes through rows of
+  // LDS owned by the environment wave: a lane posts its pose / status / munition entries once and reads the rows of the lanes it needs,
+  // and the two rules that COUNT over the env's munitions (gun damage, chaff releases) and the one that takes a minimum over them (the
+  // first incoming missile in launch order) are turned around -- the owner of an entry adds into / takes the minimum with its target's
+  // cell -- instead of every lane walking all A x 2 entries with dependent cross-lane fetches (round 3: 9.4 k of the 4v4 kernel's 82 k cycles).
+  __shared__ float xp_pose[3][64];     // final NEU position, fp32
+  __shared__ int xp_status[64];        // status when the weapons are evaluated
+  __shared__ int xp_cnt[2][64];        // [0] gun hits taken this step, [1] dict munitions within chaff range as this aircraft sees the dict at its turn
+  __shared__ unsigned xp_inc[64];      // launch-order key of the first live munition aimed at this aircraft
+  __shared__ float xp_mun[2 * 7][64];  // munition slot k: position, velocity (fp32) and speed, rows 7 k .. 7 k + 6
   __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : (QUAD ? sizeof(QuadLds) : (PAIR ? sizeof(PairLds) : 16))];
   SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
   QuadLds& LQ = *reinterpret_cast<QuadLds*>(split_lds);
@@ -339,7 +349,8 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   const bool env_has_clouds = (__ballot(x.n_ch > 0 && (x.ch_status[0] == 0 || x.ch_status[1] == 0)) & env_mask) != 0;
   if (env_has_clouds) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) cl_pos[lane * 2 + q] = make_float4(x.cx[q], x.cy[q], x.cz[q], 0.0f);
+    for (int q = 0; q < 2; ++q) { cl_pos[lane * 2 + q] = make_float4(x.cx[q], x.cy[q], x.cz[q], 0.0f); cl_meta[lane * 2 + q] = make_int2(0, x.ch_mult[q]); }
+    wave_lds_fence();
   }
   if (SPLIT && split_helper_wave(s, t, T, L, lane, c.substeps)) return;
   int last_tick = -1;   // three-wave form: the last substep this aircraft flew
@@ -446,41 +457,39 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     for (int q = 0; q < 2; ++q)
       if (q < x.n_ch) { x.ct[q] += 1.0f / 60.0f; if (x.ct[q] > 20.0f) x.ch_status[q] = 1; }
     if (env_has_clouds) {
-      // the env's clouds sit in LDS (position once per step, the live flag refreshed as they expire): a missile's test against a cloud
-      // is two LDS reads instead of seven cross-lane shuffles
-#pragma unroll
-      for (int q = 0; q < 2; ++q) cl_meta[lane * 2 + q] = make_int2((q < x.n_ch && x.ch_status[q] == 0) ? 1 : 0, x.ch_mult[q]);
-      wave_lds_fence();
-      int2 me[A * 2];                                        // every cloud record of the env in one batch of LDS reads
-#pragma unroll
-      for (int i = 0; i < A * 2; ++i) me[i] = cl_meta[base * 2 + i];
-      bool any_live = false;
-#pragma unroll
-      for (int i = 0; i < A * 2; ++i) any_live = any_live || me[i].x != 0;
+      // the env's clouds sit in LDS (position and multiplicity, once per step); which of them are live is two ballots, and a missile
+      // in flight walks the LIVE clouds of its env only (most steps: none or one of the A x 2 records)
+      constexpr unsigned amask_cl = (A >= 32) ? ~0u : ((1u << A) - 1u);
+      const unsigned live0 = (unsigned)(__ballot(0 < x.n_ch && x.ch_status[0] == 0) >> base) & amask_cl;
+      const unsigned live1 = (unsigned)(__ballot(1 < x.n_ch && x.ch_status[1] == 0) >> base) & amask_cl;
       bool mine_flying = false;
 #pragma unroll
       for (int k = 0; k < MS; ++k) mine_flying = mine_flying || ms[k].status == MSL_LAUNCHED;
-      if (any_live && mine_flying) {
+      if (mine_flying) {
+        float mpx[MS], mpy[MS], mpz[MS];
 #pragma unroll
-        for (int j = 0; j < A; ++j)
+        for (int k = 0; k < MS; ++k) { mpx[k] = (float)ms[k].px; mpy[k] = (float)ms[k].py; mpz[k] = (float)ms[k].pz; }
 #pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            if (!me[j * 2 + q].x) continue;
+        for (int q = 0; q < 2; ++q) {
+          unsigned todo = q == 0 ? live0 : live1;          // (the draws are keyed by what is tested: the order of the walk does not matter)
+          while (todo) {
+            const int j = __ffs(todo) - 1;
+            todo &= todo - 1u;
             const float4 cp = cl_pos[(base + j) * 2 + q];
-            const int cm = me[j * 2 + q].y;
-            const int cbase = (q == 0) ? 0 : me[j * 2].y;   // release index of the first chaff of this event
+            const int cm = cl_meta[(base + j) * 2 + q].y;
+            const int cbase = (q == 0) ? 0 : cl_meta[(base + j) * 2].y;   // release index of the first chaff of this event
 #pragma unroll
             for (int k = 0; k < MS; ++k) {
               if (ms[k].status != MSL_LAUNCHED) continue;
-              float dx = cp.x - (float)ms[k].px, dy = cp.y - (float)ms[k].py, dz = cp.z - (float)ms[k].pz;
+              float dx = cp.x - mpx[k], dy = cp.y - mpy[k], dz = cp.z - mpz[k];
               if (dx * dx + dy * dy + dz * dz <= 300.0f * 300.0f) {
                 for (int m = 0; m < cm; ++m)   // one draw per chaff of the event; the missile stays "not done" only until one succeeds
                   if (ms[k].status == MSL_LAUNCHED && decoy_uniform(c.chaff_seed + (unsigned long long)(nn / A), tick_id, slot, MS - k, j, cbase + m) < 0.85f) ms[k].status = MSL_MISS;
               }
             }
           }
+        }
       }
-      wave_lds_fence();
     }
   }
   AC_CLKE(60);
@@ -506,15 +515,19 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     const float hv = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve + pr.vd * pr.vd);
     // farthest enemy (get_target, :139-145): poses and statuses do not change while the weapons are evaluated
     int tg = e_first; float bd = -1.0f, tdx = 0, tdy = 0, tdz = 0; int tg_status = AC_ALIVE;
+    xp_pose[0][lane] = pr.n; xp_pose[1][lane] = pr.e; xp_pose[2][lane] = pr.u; xp_status[lane] = t.status;
+    xp_cnt[0][lane] = 0; xp_cnt[1][lane] = 0; xp_inc[lane] = 0xffffffffu;
+    wave_lds_fence();
 #pragma unroll
     for (int q = 0; q < NE; ++q) {
       const int src = base + e_first + q;
-      float ex = __shfl(pr.n, src) - pr.n, ey = __shfl(pr.e, src) - pr.e, ez = __shfl(pr.u, src) - pr.u;
-      int est = __shfl(t.status, src);
+      float ex = xp_pose[0][src] - pr.n, ey = xp_pose[1][src] - pr.e, ez = xp_pose[2][src] - pr.u;
+      int est = xp_status[src];
       float dd = sqrtf(ex * ex + ey * ey + ez * ez);
       if (dd > bd) { bd = dd; tg = e_first + q; tdx = ex; tdy = ey; tdz = ez; tg_status = est; }
     }
     const float ang = 57.29577951f * acos_fast(clampf(-1.0f, (tdx * pr.vn + tdy * pr.ve + tdz * pr.vd) / (bd * hv + 1e-8f), 1.0f));
+    AC_CLKE(80);
     // my dict entries before this step's launches (what an agent that acts before me still sees of them)
     int old_st[MS], old_tg[MS]; float old_x[MS], old_y[MS], old_z[MS];
 #pragma unroll
@@ -562,46 +575,45 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
         launched_k = want_k;
       }
     }
-    // gun damage lands on the target's blood right away (:70-73)
-#pragma unroll
-    for (int j = 0; j < A; ++j) {
-      const int gt = __shfl(gun_tgt, base + j);
-      const float gd = __shfl(gun_dmg, base + j);
-      if (gt == slot) t.bloods -= gd;
-    }
+    AC_CLKE(81);
+    // gun damage lands on the target's blood right away (:70-73): 5 per shooter, counted into the target's cell (bloods are multiples of 5
+    // below 100: n subtractions of 5 and one of 5 n are the same number)
+    if (gun_tgt >= 0) atomicAdd(&xp_cnt[0][base + gun_tgt], 1);
+    AC_CLKE(82);
     // chaff (:97-103): one release per dict missile (done ones included) aimed at this agent within 1000 m, as the dict stands when
-    // the agent acts: entries of agents up to and including itself already hold this step's launches
+    // the agent acts: entries of agents up to and including itself already hold this step's launches, those of the agents after it are
+    // still what they were. The OWNER of an entry tells its target: an entry that was not launched this step counts for its target;
+    // one launched this step counts for its (new) target if that one acts at or after the launcher, and the entry it replaced counts
+    // for ITS target if that one acts before the launcher.
+    if (!gun_only) {
+      auto in_range = [&](int r, float mx, float my, float mz) {
+        const float dx = xp_pose[0][base + r] - mx, dy = xp_pose[1][base + r] - my, dz = xp_pose[2][base + r] - mz;
+        return sqrtf(dx * dx + dy * dy + dz * dz) < 1000.0f;
+      };
+#pragma unroll
+      for (int k = 0; k < MS; ++k) {
+        if (launched_k == k) {
+          if (tg >= slot && in_range(tg, pr.n, pr.e, pr.u)) atomicAdd(&xp_cnt[1][base + tg], 1);
+          if (old_st[k] != MSL_INACTIVE && old_tg[k] < slot && in_range(old_tg[k], old_x[k], old_y[k], old_z[k])) atomicAdd(&xp_cnt[1][base + old_tg[k]], 1);
+        } else if (old_st[k] != MSL_INACTIVE && in_range(old_tg[k], old_x[k], old_y[k], old_z[k])) atomicAdd(&xp_cnt[1][base + old_tg[k]], 1);
+      }
+    }
+    // the munition entries as they stand after the launches: the missile warning and MissilePostureReward read them below
+#pragma unroll
+    for (int k = 0; k < MS; ++k) {
+      if (ms[k].status == MSL_LAUNCHED) {
+        atomicMin(&xp_inc[base + (ms[k].order & 15)], ((unsigned)(ms[k].order >> 4) << 1) | (unsigned)k);   // launch order (step, launcher), then the slot
+        xp_mun[7 * k + 0][lane] = (float)ms[k].px; xp_mun[7 * k + 1][lane] = (float)ms[k].py; xp_mun[7 * k + 2][lane] = (float)ms[k].pz;
+        xp_mun[7 * k + 3][lane] = (float)ms[k].vx; xp_mun[7 * k + 4][lane] = (float)ms[k].vy; xp_mun[7 * k + 5][lane] = (float)ms[k].vz;
+      }
+      xp_mun[7 * k + 6][lane] = (float)sqrt(ms[k].vx * ms[k].vx + ms[k].vy * ms[k].vy + ms[k].vz * ms[k].vz);
+    }
+    wave_lds_fence();
+    t.bloods -= 5.0f * (float)xp_cnt[0][lane];
     if (!gun_only) {
       const int lc_status = (x.last_chaff & 1) ? x.ch_status[1] : x.ch_status[0];
       const bool can = t.status == AC_ALIVE && (x.bits & 8) && x.rem_chaff > 0 && (x.last_chaff < 0 || lc_status == 1);
-      int n_rel = 0;
-      if (__ballot(can) & env_mask) {
-        // one packed word per dict entry says whether it exists and whom it is aimed at; where it is gets fetched only for the entries
-        // that are aimed at somebody in this env who can release chaff (rare) -- it was five fetches per entry
-        const int my_new = (launched_k + 1) | (tg << 4);                   // this step's launch: slot + 1 (0: none) and its target
-        int my_old[MS];
-#pragma unroll
-        for (int k = 0; k < MS; ++k) my_old[k] = (old_st[k] + 1) | (old_tg[k] << 4);   // (status + 1: MSL_INACTIVE is -1)
-#pragma unroll
-        for (int j = 0; j < A; ++j) {
-          const int src = base + j;
-          const int nw = __shfl(my_new, src);
-#pragma unroll
-          for (int k = 0; k < MS; ++k) {
-            const int ow = __shfl(my_old[k], src);
-            const bool fresh = (nw & 15) == k + 1 && j <= slot;            // launched this step by an agent that acted before me (or by me)
-            const int st = fresh ? MSL_LAUNCHED : (ow & 15) - 1, mtg = fresh ? (nw >> 4) : (ow >> 4);
-            const bool aimed = can && st != MSL_INACTIVE && mtg == slot;
-            if (__ballot(aimed) & env_mask) {
-              const float lx = __shfl(pr.n, src), ly = __shfl(pr.e, src), lz = __shfl(pr.u, src);
-              const float ox = __shfl(old_x[k], src), oy = __shfl(old_y[k], src), oz = __shfl(old_z[k], src);
-              const float mx = fresh ? lx : ox, my = fresh ? ly : oy, mz = fresh ? lz : oz;
-              const float dx = pr.n - mx, dy = pr.e - my, dz = pr.u - mz;
-              if (aimed && sqrtf(dx * dx + dy * dy + dz * dz) < 1000.0f) n_rel += 1;
-            }
-          }
-        }
-      }
+      const int n_rel = can ? xp_cnt[1][lane] : 0;
       if (n_rel > 0 && x.n_ch < 2) {
         const bool second = x.n_ch == 1;
         x.cx[0] = second ? x.cx[0] : pr.n; x.cy[0] = second ? x.cy[0] : pr.e; x.cz[0] = second ? x.cz[0] : pr.u;
@@ -638,28 +650,17 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
       if (q == 0) e_u0 = E.u;
     }
   }
+  AC_CLKE(83);
   // ---- my first alive incoming missile in launch order (check_missile_warning), and whether any is alive
   Incoming inc{false, 0, 0, 0, 0, 0, 0};
   int inc_id = 0;    // 1 + launcher*MS + slot of that missile
   {
-    // one word per entry finds it (launch order and target sit in `order`), then its six floats come from that one lane
-    int key[MS];
-#pragma unroll
-    for (int k = 0; k < MS; ++k) key[k] = ms[k].status == MSL_LAUNCHED ? ms[k].order : 0x7fffffff;
-    int best = 0x7fffffff, bj = 0, bk = -1;
-#pragma unroll
-    for (int j = 0; j < A; ++j)
-#pragma unroll
-      for (int k = 0; k < MS; ++k) {
-        const int kk = __shfl(key[k], base + j);
-        if (kk != 0x7fffffff && (kk & 15) == slot && (kk >> 4) < best) { best = kk >> 4; bj = j; bk = k; }
-      }
-#pragma unroll
-    for (int k = 0; k < MS; ++k) {
-      const int src = base + bj;
-      const float a0 = __shfl((float)ms[k].px, src), a1 = __shfl((float)ms[k].py, src), a2 = __shfl((float)ms[k].pz, src);
-      const float a3 = __shfl((float)ms[k].vx, src), a4 = __shfl((float)ms[k].vy, src), a5 = __shfl((float)ms[k].vz, src);
-      if (k == bk) { inc.px = a0; inc.py = a1; inc.pz = a2; inc.vx = a3; inc.vy = a4; inc.vz = a5; }
+    // the minimum taken above finds it (launch order, launcher and slot sit in the key), then its six floats come from its owner's rows
+    const unsigned key = xp_inc[lane];
+    const int bj = (int)(key >> 1) & 15, bk = key == 0xffffffffu ? -1 : (int)(key & 1u);
+    if (bk >= 0) {
+      const float* mrow = &xp_mun[7 * bk][base + bj];
+      inc.px = mrow[0]; inc.py = mrow[64]; inc.pz = mrow[128]; inc.vx = mrow[192]; inc.vy = mrow[256]; inc.vz = mrow[320];
     }
     inc.any = bk >= 0;
     inc_id = bk >= 0 ? 1 + bj * MS + bk : 0;
@@ -705,27 +706,31 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   // after it. The statuses travel as one ballot per round -- a status only matters as "alive or not" to the others -- instead of two
   // cross-lane fetches per round, whose latency was serialised by the walk: 5.6 k of the 4v4 kernel's 91 k cycles.)
   auto terminations = [&]() {
-    unsigned long long enemy_lanes = 0;
-#pragma unroll
-    for (int j = 0; j < A; ++j) if ((j < n_ego ? 0 : 1) != team) enemy_lanes |= 1ull << (base + j);
     // The walk itself only has to carry who is still alive: an agent's own checks change its status in one way (a crash condition
-    // makes it CRASH), and what it sees of the others is whether any enemy is alive at its turn. So the rounds do just that -- note
-    // the enemies' state at my turn, crash if my checks say so, re-take the ballot -- and the messages are assigned afterwards.
+    // makes it CRASH), and what it sees of the others is whether any enemy is alive at its turn. Three ballots give every lane the
+    // env's inputs as A-bit masks (alive, crash condition, no missile coming); every lane then runs the A rounds on those bits in its
+    // own registers and keeps what happened at its own turn -- the rounds used to be A dependent ballots. The messages are assigned afterwards.
     const int st0 = t.status;
     const bool crash_cond = low || extreme || overload;
-    bool enemies_dead = false;
-    unsigned long long alive = __ballot(t.status == AC_ALIVE);
+    constexpr unsigned amask = (A >= 32) ? ~0u : ((1u << A) - 1u);
+    const unsigned al0 = (unsigned)(__ballot(st0 == AC_ALIVE) >> base) & amask;
+    const unsigned ccb = (unsigned)(__ballot(crash_cond) >> base) & amask;
+    const unsigned nob = (unsigned)(__ballot(!inc.any) >> base) & amask;
+    const unsigned team0 = (1u << n_ego) - 1u, team1 = amask & ~team0;
+    unsigned alive = al0;
+    bool enemies_dead = false, crash_mine = false;
 #pragma unroll
     for (int i = 0; i < A; ++i) {
-      if (slot == i) {
-        enemies_dead = (alive & enemy_lanes) == 0;
-        // NvN: SafeReturn comes first, so only an aircraft that is still flying and has no mission-complete reaches the crash checks;
-        // 1v1 family: the crash checks come first and apply whatever the status was
-        const bool crash_now = MULTI ? (st0 == AC_ALIVE && !(enemies_dead && !inc.any) && crash_cond) : crash_cond;
-        if (crash_now) t.status = AC_CRASH;
-      }
-      alive = __ballot(t.status == AC_ALIVE);
+      const bool ed = (alive & (i < n_ego ? team1 : team0)) == 0;
+      // NvN: SafeReturn comes first, so only an aircraft that is still flying and has no mission-complete reaches the crash checks;
+      // 1v1 family: the crash checks come first and apply whatever the status was
+      const bool ci = (ccb >> i) & 1u;
+      const bool crash_now = MULTI ? (((al0 >> i) & 1u) && !(ed && ((nob >> i) & 1u)) && ci) : ci;
+      if (crash_now) alive &= ~(1u << i);
+      if (i == slot) { enemies_dead = ed; crash_mine = crash_now; }
     }
+    if (crash_mine) t.status = AC_CRASH;
+    AC_CLKE(84);
     if (MULTI) {   // SafeReturn, ExtremeState, Overload, LowAltitude, Timeout (multiplecombat_task.py:33-39)
       if (st0 == AC_SHOTDOWN) { code = AC_DONE_SHOTDOWN; done = true; }
       else if (st0 == AC_CRASH) { code = AC_DONE_CRASHED; done = true; }
@@ -744,6 +749,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
       else if (enemies_dead && !inc.any) { code = AC_DONE_MISSION_COMPLETE; done = true; }
       else if (t.cur_step >= c.max_steps) { code = AC_DONE_TIMEOUT; done = true; }
     }
+    AC_CLKE(85);
     // info['done_condition'] keeps the message of the last agent (in env order) that has one
     const unsigned long long coded = __ballot(code != AC_DONE_NONE) & env_mask;
     const int last = coded ? 63 - __clzll((long long)coded) : lane;
@@ -774,21 +780,12 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   // MissilePostureReward's shared remembered missile, in closed form (mp_walk_closed above)
   float r_mp = 0.0f;
   {
-    float sp[MS];
-#pragma unroll
-    for (int k = 0; k < MS; ++k) sp[k] = (float)sqrt(ms[k].vx * ms[k].vx + ms[k].vy * ms[k].vy + ms[k].vz * ms[k].vz);
     const bool holds = evaluates && inc_id != 0;
     const MpWalk walk = mp_walk_closed(evaluates, inc_id, x.mp_prev, lane, base, env_mask);
     const int prev_mine = walk.prev_mine;
-    // speeds of the remembered missile and of my incoming missile (the owner lane holds both of its slots' speeds)
+    // speeds of the remembered missile and of my incoming missile (the speed row of the owner's slot)
     const int pid = holds ? prev_mine : 1, cid = holds ? inc_id : 1;
-    float v_prev = 0.0f, v_cur = 0.0f;
-#pragma unroll
-    for (int k = 0; k < MS; ++k) {
-      const float a = __shfl(sp[k], base + ((pid - 1) / MS)), b = __shfl(sp[k], base + ((cid - 1) / MS));
-      if (k == (pid - 1) % MS) v_prev = a;
-      if (k == (cid - 1) % MS) v_cur = b;
-    }
+    const float v_prev = xp_mun[7 * ((pid - 1) % MS) + 6][base + ((pid - 1) / MS)], v_cur = xp_mun[7 * ((cid - 1) % MS) + 6][base + ((cid - 1) / MS)];
     if (holds) {
       float v_dec = (v_prev - v_cur) / 340.0f * c.missile_posture_scale;
       float va = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve + pr.vd * pr.vd);
@@ -840,9 +837,8 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     blk[1] = (inc.pz - pr.alt_m) / 1000.0f;
     blk[2] = gm.AO; blk[3] = gm.TA; blk[4] = gm.R / 10000.0f; blk[5] = gm.side;
   }
-  bool all_done = true;
-#pragma unroll
-  for (int j = 0; j < A; ++j) { const int dj = __shfl((int)done, base + j); all_done = all_done && (bool)dj; }
+  constexpr unsigned amask_env = (A >= 32) ? ~0u : ((1u << A) - 1u);
+  const bool all_done = ((unsigned)(__ballot(done) >> base) & amask_env) == amask_env;
   int step_out = t.cur_step;
   if (all_done) {
     load_state(P.tF, P.tI, P.tD, A, slot, s, t);
