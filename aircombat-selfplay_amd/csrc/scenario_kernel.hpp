@@ -195,6 +195,10 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   static_assert(FORM != FORM_ONE && (FORM == FORM_PAIR || A == 2), "no launch path for this (A, form)");
   constexpr bool SPLIT = FORM == FORM_SPLIT, QUAD = FORM == FORM_QUAD, PAIR = FORM == FORM_PAIR || QUAD;   // (the quad form's environment wave runs the pair form's code)
   constexpr bool MULTI = SD::MULTI;
+  // pair form, who makes the fp64 geodetic reduction of each tick's pose (1.4 k cycles): the flight wave (8.8 k cycles per substep with it).
+  // Handing it to this wave pays while at most one dict entry per aircraft flies (4.8 k -> 6.2 k here, 8.8 k -> 7.4 k there) and costs
+  // with two (7.5 k -> 8.9 k here):
+  constexpr bool RAWP = false;   // (measured round 3 with true: 2v2 34.2 -> 36.9 us, 4v4 39.7 -> 42.4 us on the bench workload, where most aircraft keep two dict entries flying)
   constexpr int OBS = SD::OBS;
   constexpr int NE = SD::NE;
   constexpr int MS = 2;  // munition slots (uids) per aircraft
@@ -215,6 +219,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   __shared__ int xp_cnt[2][64];        // [0] gun hits taken this step, [1] dict munitions within chaff range as this aircraft sees the dict at its turn
   __shared__ unsigned xp_inc[64];      // launch-order key of the first live munition aimed at this aircraft
   __shared__ float xp_mun[2 * 7][64];  // munition slot k: position, velocity (fp32) and speed, rows 7 k .. 7 k + 6
+  __shared__ int xp_hit[64];           // during the substeps: hit by a munition this substep (set by the munition's owner, cleared by the aircraft)
   __shared__ __attribute__((aligned(16))) char split_lds[SPLIT ? sizeof(SplitLds) : (QUAD ? sizeof(QuadLds) : (PAIR ? sizeof(PairLds) : 16))];
   SplitLds& L = *reinterpret_cast<SplitLds*>(split_lds);
   QuadLds& LQ = *reinterpret_cast<QuadLds*>(split_lds);
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
         wg_sync();                                  // the rows are in LDS (the environment wave adds the missile block and sends them)
       }
     };
-    pair_flight_wave<false>(P, c, T, LP, lane, n, live, in, rows_tail);
+    pair_flight_wave<RAWP, decltype(rows_tail), ROWS_BY_FLIGHT>(P, c, T, LP, lane, n, live, in, rows_tail);   // (rows_tail ends in two barriers)
     return;
   }
 
@@ -353,6 +358,8 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     wave_lds_fence();
   }
   if (SPLIT && split_helper_wave(s, t, T, L, lane, c.substeps)) return;
+  xp_hit[lane] = 0;
+  wave_lds_fence();
   int last_tick = -1;   // three-wave form: the last substep this aircraft flew
   AC_CLKE(1);
   int quad_nrun = 0;
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
       quad_substep_begin<false>(t, LQ, lane, sub, env_has_munitions, 0, quad_nrun, pr, c);   // (B1 inside)
       fly = env_has_munitions;
     } else if (PAIR) {
-      pair_substep<false>(t, LP, lane, sub, env_has_munitions, pr, c);
+      pair_substep<RAWP>(t, LP, lane, sub, env_has_munitions, pr, c);
       AC_CLKE(3 + 8 * sub);
       if (!env_has_munitions) continue;     // nothing to fly: the pose is only needed after the last substep
       AC_CLKE(4 + 8 * sub);
@@ -440,13 +447,11 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     if (fly) {
     fly_slot(1);
     AC_CLKE(5 + 8 * sub);
+    // a hit grounds its target (simulatior.py:525-527): the munition's owner flags the target's cell
 #pragma unroll
-    for (int j = 0; j < A; ++j)
-#pragma unroll
-      for (int k = 0; k < MS; ++k) {
-        int h = __shfl(hit_tgt[k], base + j);
-        if (h == slot && t.status == AC_ALIVE) t.status = AC_SHOTDOWN;
-      }
+    for (int k = 0; k < MS; ++k) if (hit_tgt[k] >= 0) xp_hit[base + hit_tgt[k]] = 1;
+    wave_lds_fence();
+    if (xp_hit[lane]) { xp_hit[lane] = 0; if (t.status == AC_ALIVE) t.status = AC_SHOTDOWN; }
     }
     if (QUAD) wg_sync();                                   // B3 of the tick
     if (!fly) continue;
