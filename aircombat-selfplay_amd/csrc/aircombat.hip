@@ -1305,27 +1305,27 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
   const bool overload = (s.ticks >= kTickOverload) &&
                         (fabsf(s.npx) > c.acc_x || fabsf(s.npy) > c.acc_y || fabsf(s.npz + 1.0f) > c.acc_z);
   const bool low = pr.alt_m <= c.altitude_limit;
-  // (the statuses travel as one ballot per round -- to the others a status only matters as "alive or not" -- instead of two
-  // cross-lane fetches per round whose latency the walk serialises)
+  // (To the others a status only matters as "alive or not", and an agent's own checks change it in one way -- a crash condition makes
+  // it CRASH. Two ballots give every lane the env's inputs as A-bit masks; every lane runs the A rounds on those bits in its own
+  // registers and keeps what happened at its own turn; the messages are assigned afterwards: SafeReturn comes first, so only an
+  // aircraft that is still flying and has no mission-complete reaches the crash checks. Same form as the scenario kernels' walk.)
   const unsigned long long env_mask = ((A == 64) ? ~0ull : ((1ull << A) - 1ull)) << base_lane;
-  unsigned long long enemy_lanes = 0;
-#pragma unroll
-  for (int j = 0; j < A; ++j) if ((j < c.n_ego ? 0 : 1) != team) enemy_lanes |= 1ull << (base_lane + j);
-  // (the rounds only carry who is still alive -- note the enemies' state at my turn, crash if my checks say so, re-take the ballot --
-  // and the messages are assigned afterwards: SafeReturn comes first, so only an aircraft that is still flying and has no
-  // mission-complete reaches the crash checks)
   const int st0 = t.status;
   const bool crash_cond = extreme || overload || low;
-  bool enemies_dead = false;
-  unsigned long long alive = __ballot(t.status == AC_ALIVE);
+  constexpr unsigned amask = (A >= 32) ? ~0u : ((1u << A) - 1u);
+  const unsigned al0 = (unsigned)(__ballot(st0 == AC_ALIVE) >> base_lane) & amask;
+  const unsigned ccb = (unsigned)(__ballot(crash_cond) >> base_lane) & amask;
+  const unsigned team0 = (1u << c.n_ego) - 1u, team1 = amask & ~team0;
+  unsigned alive = al0;
+  bool enemies_dead = false, crash_mine = false;
 #pragma unroll
   for (int i = 0; i < A; ++i) {
-    if (slot == i) {
-      enemies_dead = (alive & enemy_lanes) == 0;
-      if (st0 == AC_ALIVE && !enemies_dead && crash_cond) t.status = AC_CRASH;
-    }
-    alive = __ballot(t.status == AC_ALIVE);
+    const bool ed = (alive & (i < c.n_ego ? team1 : team0)) == 0;
+    const bool crash_now = ((al0 >> i) & 1u) && !ed && ((ccb >> i) & 1u);
+    if (crash_now) alive &= ~(1u << i);
+    if (i == slot) { enemies_dead = ed; crash_mine = crash_now; }
   }
+  if (crash_mine) t.status = AC_CRASH;
   if (st0 == AC_SHOTDOWN) { code = AC_DONE_SHOTDOWN; done = true; }
   else if (st0 == AC_CRASH) { code = AC_DONE_CRASHED; done = true; }
   else if (enemies_dead) { code = AC_DONE_MISSION_COMPLETE; done = true; }   // no missiles in this task
@@ -1338,9 +1338,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
     const int last = coded ? 63 - __clzll((long long)coded) : l;
     last_code = __shfl(code, last);
   }
-  bool all_done = true;
-#pragma unroll
-  for (int j = 0; j < A; ++j) { const int dj = __shfl((int)done, base_lane + j); all_done = all_done && (bool)dj; }
+  const bool all_done = ((unsigned)(__ballot(done) >> base_lane) & amask) == amask;
   int step_out = t.cur_step;
   if (all_done) {
     load_state(P.tF, P.tI, P.tD, A, slot, s, t);
