@@ -66,9 +66,9 @@ __device__ __forceinline__ void pair_flight_load(const DevPtrs& P, const DevCfg&
 // weapon rules, rewards and terminations (the NvN scenario kernels build the observation rows here). It receives this aircraft's final
 // Props; whatever it synchronises with the environment wave is its own business.
 struct PairNoTail { __device__ __forceinline__ void operator()(const Props&) const {} };
-// LATE_STORE: the flight state is stored AFTER the barrier that hands the final values over, so that the environment wave starts on the
-// weapon rules while the stores drain -- for tails that meet the environment wave at a later barrier of their own (whose release half
-// then orders the stores before that wave's episode reset).
+// LATE_STORE: the TAIL stores the flight state (store_flight of in.s), after the barrier that hands the final values over, so that
+// the environment wave starts on the weapon rules while the stores drain -- for tails that meet the environment wave at a later
+// barrier of their own (whose release half then orders the stores before that wave's episode reset).
 template <bool RAW_POSE = false, typename Tail = PairNoTail, bool LATE_STORE = false>
 __device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg& c, const f16::Tab& T, PairLds& L, int l, int n, bool live, PairFlightIn& in,
                                                  Tail tail = Tail()) {
@@ -135,7 +135,6 @@ __device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg&
   AC_CLKW(1, 160);
   wg_sync();   // final values posted, flight state stored (the release half of the barrier waits for the stores: an episode reset by
                // the environment wave overwrites them afterwards)
-  if (LATE_STORE && live) store_flight(P.F, P.I, P.D, c.N, n, s);
   tail(pp);
 }
 

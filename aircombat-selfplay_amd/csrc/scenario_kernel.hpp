@@ -302,6 +302,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
           if (qe == 0) geo_lds[(NE * 6) * 64 + lane] = E.u;
         }
         wg_sync();                                  // the geometry is in LDS
+        if (live) store_flight(P.F, P.I, P.D, c.N, n, in.s);   // (LATE_STORE: ordered before the environment wave's episode reset by the barrier below)
         if (!c.legacy_obs) build_rows(q);
         wg_sync();                                  // the rows are in LDS (the environment wave adds the missile block and sends them)
       }
