@@ -188,14 +188,15 @@ class Component:
             d = child(node, "default")
             if d is not None:
                 self.tests.append((None, None, d[1]["value"]))
-            for t in children(node, "test"):
-                conds = []
+            def group(t):   # FGCondition.cpp:55-100: the element's data lines, then its nested <test> groups, under one AND / OR
+                leaves = []
                 for ln in t[3].strip().splitlines():
                     if ln.strip():
                         a, op, b = ln.split()
-                        conds.append((a, OPS[op] if op in OPS else OPS[op.upper()], b))
-                assert not children(t, "test")
-                self.tests.append((t[1].get("logic", "AND"), conds, t[1]["value"]))
+                        leaves.append((a, OPS[op] if op in OPS else OPS[op.upper()], b))
+                return (t[1].get("logic", "AND"), leaves, [group(c) for c in children(t, "test")])
+            for t in children(node, "test"):
+                self.tests.append((group(t), None, t[1]["value"]))
         elif self.kind in ("pure_gain", "scheduled_gain", "aerosurface_scale"):
             g = child(node, "gain")
             self.gain = g[3] if g is not None else "1.0"
@@ -223,12 +224,15 @@ class Component:
         k = self.kind
         if k == "switch":
             passed, default_out = False, 0.0
-            for logic, conds, value in self.tests:
-                if conds is None:
+            def evaluate(g):   # FGCondition::Evaluate, FGCondition.cpp:150-205
+                logic, leaves, subs = g
+                r = [self.compare(st, *c) for c in leaves] + [evaluate(x) for x in subs]
+                return all(r) if logic == "AND" else any(r)
+            for cond, _, value in self.tests:
+                if cond is None:
                     default_out = st.value_of(value)
                 else:
-                    r = [self.compare(st, *c) for c in conds]
-                    passed = all(r) if logic == "AND" else any(r)
+                    passed = evaluate(cond)
                 if passed:
                     self.output = st.value_of(value)
                     break

@@ -185,3 +185,64 @@ def test_initial_geodetic_latitude_of_TestInitialConditions(oracle, rel):
             lon, lat, alt_m = env.pose(0)[:3]        # position/lat-geod-deg and position/h-sl-ft * 0.3048, as AircraftSimulator caches them
             assert round(lat - (lat0 + float(dlat)), places) == 0
             assert abs(alt_m / 0.3048 - h) < 1e-5    # h_sl goes through radius - sea-level radius at 2e7 ft: 1e-5 ft is fp64's floor there
+
+
+def _golden_module(name):
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    spec = importlib.util.spec_from_file_location(name, os.path.join(here, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("case,min_expectations", [("TestGain.test_conditions", 80), ("TestSwitch.test_conditions", 33), ("TestSwitch.test_nested", 6),
+                                                   ("TestFunctions.test_functions", 28)])
+def test_generic_component_reading_passes_the_references_component_tests(case, min_expectations):
+    """The fixture fcs_run() is held to (f16_fcs_check.npz) is the generic interpreter's reading of <switch>, <pure_gain>, <summer>,
+    <fcs_function>. The reference holds JSBSim's own unit tests of those component types with their system files (TestGain.py / gain.xml,
+    TestSwitch.py / switch.xml, TestFunctions.py / function.xml): tests/golden/make_jsbsim_components.py ran them as they are against the
+    interpreter and logged what they set, when they ran the FDM and what they asserted. Replayed here on the stored (tokenised) system
+    file with the same `Component` class: every expectation holds at the test's own criterion (assertEqual exact, assertAlmostEqual
+    7 places)."""
+    import json
+    comp = _golden_module("make_jsbsim_components")
+    rec = json.loads(str(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jsbsim_components.npz"))[case]))
+    sysm = comp.System(rec["tree"])
+    assert sysm.uncovered == rec["uncovered"]
+    n = 0
+    for ev in rec["events"]:
+        if ev[0] == "set":
+            sysm.st.set(ev[1], ev[2])
+        elif ev[0] == "run":
+            sysm.run()
+        else:
+            _, name, want, places, delta = ev
+            got = sysm.st.get(name)
+            if delta is not None:
+                assert abs(got - want) <= delta, (name, got, want)
+            elif places is None:
+                assert got == want, (name, got, want)
+            else:
+                assert round(abs(got - want), places) == 0, (name, got, want)
+            n += 1
+    assert n >= min_expectations
+
+
+def test_fcs_fixture_is_what_the_generic_interpreter_produces_today(fcs):
+    """The interpreter was extended after the fixture was written (nested <test> groups, for TestSwitch): its reading of the F-16's own
+    section must not have moved. Needs the reference's f16.xml: runs in the build container, skipped on the GPU box."""
+    gen = _golden_module("make_f16_fcs_check")
+    if not os.path.exists(gen.F16):
+        pytest.skip("the reference's f16.xml is not on this machine")
+    fc = next(gen.find_all(gen.parse(gen.F16), "flight_control"))
+    for seq in (0, 5, 13, 37, 63):                      # (5, 13, 37: sequences that start with the gear already up)
+        ctl = gen.F16FlightControl(fc)
+        if fcs["gear_pos0"][seq] == 0.0:
+            ctl.st.set("gear/gear-pos-norm", 0.0)
+        X = gen.expand_inputs(fcs["knots"][seq], fcs["linear"][seq])
+        for t in range(gen.NT):
+            y = ctl.tick(dict(zip(gen.IN_PROPS, X[t])))
+            assert np.array_equal(np.asarray(y), fcs["out_full"][seq, t]), (seq, t)
