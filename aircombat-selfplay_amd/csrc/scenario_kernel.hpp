@@ -304,7 +304,11 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
         wg_sync();                                  // the geometry is in LDS
         if (live) store_flight(P.F, P.I, P.D, c.N, n, in.s);   // (LATE_STORE: ordered before the environment wave's episode reset by the barrier below)
         if (!c.legacy_obs) build_rows(q);
-        wg_sync();                                  // the rows are in LDS (the environment wave adds the missile block and sends them)
+        wg_sync();                                  // the rows are in LDS (the environment wave adds the missile block, or the reset rows)
+        if (!c.legacy_obs) {
+          wg_sync();                                // the rows are final: this wave sends them while the environment wave stores its state
+          emit_obs_rows(P, lds_out, c.obs_dim, lane);
+        }
       }
     };
     pair_flight_wave<RAWP, decltype(rows_tail), ROWS_BY_FLIGHT>(P, c, T, LP, lane, n, live, in, rows_tail);   // (rows_tail ends in two barriers)
@@ -859,6 +863,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
       for (int k = 0; k < OBS; ++k) ob[k] = tobs[k];
     }
   }
+  if (ROWS_BY_FLIGHT && row_direct) wg_sync();          // the rows in LDS are final: the flight wave sends them
   if (live) {
     if (!PAIR) store_state(P.F, P.I, P.D, N, n, s, t);
     else {   // the flight wave has stored the flown state (ordered before this by the barrier): an episode reset overwrites it
@@ -873,7 +878,8 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   AC_CLKE(67);
   // (WVR uses the first 15 of the 21 slots; the *_RWR variants append two reserved zero slots)
   reward = poison_if(nonfinite, reward);
-  if (row_direct) emit_rows(P, lds_out, c.obs_dim, lane, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);
+  if (row_direct && ROWS_BY_FLIGHT) emit_scalars(P, lane, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);   // (the rows: the flight wave, above)
+  else if (row_direct) emit_rows(P, lds_out, c.obs_dim, lane, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);
   else emit_outputs(P, lds_out, c.obs_dim, lane, ob, reward, done, A, step_out, last_code, 0, all_done ? 1 : 0);
   AC_CLKE(68);
 }
