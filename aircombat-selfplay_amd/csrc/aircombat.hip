@@ -478,6 +478,29 @@ __device__ __forceinline__ void small_sincos(double d, double* s, double* c) {
   *s = d * (1.0 + d2 * (-1.0 / 6.0 + d2 * (1.0 / 120.0 + d2 * (-1.0 / 5040.0 + d2 * (1.0 / 362880.0)))));
   *c = 1.0 + d2 * (-0.5 + d2 * (1.0 / 24.0 + d2 * (-1.0 / 720.0 + d2 * (1.0 / 40320.0))));
 }
+// fp32 sine of a turn rate (|x| up to a few pi): nearest multiple of pi off in two pieces, odd Taylor polynomial to y^11 on [-pi/2, pi/2]
+// (truncation 6e-8; v_sin_f32 alone is 4e-7 absolute, which the reference-area term of the drag would see as 1e-5 relative)
+__device__ __forceinline__ float sin_rate(float x) {
+  const float n = rintf(x * 0.318309886f);
+  float y = fmaf(-n, 3.14159274f, x);
+  y = fmaf(-n, -8.74227766e-8f, y);
+  const float t = y * y;
+  float p = -2.50521084e-8f;               // -1/11!
+  p = fmaf(p, t, 2.75573192e-6f);          //  1/9!
+  p = fmaf(p, t, -1.98412698e-4f);         // -1/7!
+  p = fmaf(p, t, 8.33333333e-3f);          //  1/5!
+  p = fmaf(p, t, -1.66666667e-1f);         // -1/3!
+  const float r = fmaf(y * t, p, y);
+  return ((int)n & 1) ? -r : r;
+}
+// What stays in fp64 and what does not. A munition's STATE is integrated in fp64 -- position, speed, pitch / heading and the velocity
+// vector rebuilt from them by the angle-addition formulas, the clock, the mass -- and so are the line of sight, the range that the 5 m
+// fuse, the receding count and `dprev` see, and the proportional-navigation demands with the two turn rates they give (near a pass the
+// demands hinge on centimetres: taking them in fp32 was measured, 2v2 "closing" parity case 1.05 -> 12.2 times the observation bound).
+// The DRAG side of a tick -- geodetic height, air density, reference area from the two turn rates, thrust minus drag, dv/dt -- is fp32:
+// it only moves the speed (1e-7 relative on an acceleration of a few g: millimetres over a flight; the parity cases use the same
+// fraction of their bounds with it, tools/diag/missile_drift.py), and it held a third of the update's fp64 instructions, whose
+// reciprocal / square root / exp / sin are 8-15 instruction sequences where fp32 has one each: scenario1 28.9 -> 26.4 us per step.
 __device__ __forceinline__ void missile_run(MslD& m, const MslParam& P, double tx, double ty, double tz, double tvx, double tvy, double tvz,
                                             bool target_alive, const DevCfg& c) {
   const double dt = 1.0 / 60.0;
@@ -505,24 +528,25 @@ __device__ __forceinline__ void missile_run(MslD& m, const MslParam& P, double t
     m.status = MSL_MISS;
   } else {
     m.px += dt * m.vx; m.py += dt * m.vy; m.pz += dt * m.vz;
-    const double alt = missile_height(m.px, m.py, m.pz, c);
-    const double Tt = burning ? g * (double)P.Isp * (double)P.dm : 0.0;
-    const double sd = fx::sin(m.dth), sp = fx::sin(m.dph);
-    const double D0 = P.Diameter, L0 = P.Length;
-    const double S = 3.14159265358979323846 * 0.25 * D0 * D0 + fx::sqrt(sd * sd + sp * sp) * D0 * L0;
-    const double rho = 1.225 * fx::exp(-alt * (1.0 / 9300.0));
-    const double D = 0.5 * (double)P.cD * S * rho * vm * vm;
-    const double nx = (Tt - D) * fx::rcp(m.m * g);
+    // ---- drag and dv/dt (simulatior.py:578-590), fp32
+    const float gf = P.g, fvm = (float)vm;
+    const float alt = missile_height((float)m.px, (float)m.py, (float)m.pz, c);
+    const float Tt = burning ? gf * P.Isp * P.dm : 0.0f;
+    const float sd = sin_rate((float)m.dth), sp = sin_rate((float)m.dph);
+    const float S = 3.14159265358979323846f * 0.25f * P.Diameter * P.Diameter + sqrtf(sd * sd + sp * sp) * P.Diameter * P.Length;
+    const float rho = 1.225f * __expf(-alt * (1.0f / 9300.0f));
+    const float D = 0.5f * P.cD * S * rho * fvm * fvm;
+    const float nx = (Tt - D) / ((float)m.m * gf);
     double st, ct, sps, cps;   // of the CURRENT theta, psi
     if (k == 1) { fx::sincos(m.theta, &st, &ct); fx::sincos(m.psi, &sps, &cps); }
     else {
       const double hxy = fx::sqrt(hxy2), ih = fx::rcp(hxy);
       st = m.vz * ivm; ct = hxy * ivm; cps = m.vx * ih; sps = m.vy * ih;
     }
-    const double dv = g * (nx - st);
+    const float dv = gf * (nx - (float)st);
     m.dph = g * ivm * (ny * fx::rcp(ct));
     m.dth = g * ivm * (nz - ct);
-    const double v = vm + dt * dv;
+    const double v = vm + dt * (double)dv;
     const double dps = dt * m.dph, dts = dt * m.dth;
     m.psi += dps; m.theta += dts;
     double s2, c2, s3, c3;
