@@ -508,15 +508,20 @@ __device__ __forceinline__ void missile_run(MslD& m, const MslParam& P, double t
   m.t = (double)k * dt;
   const bool burning = k < P.k_burnout;
   const double g = P.g, t_max = P.t_max, nyz_max = P.nyz_max;
+  // (every length comes with its reciprocal from the one refined rsqrt seed: 1 / Rxy^2 = (1 / Rxy)^2, 1 / (R^2 Rxy) = (1 / R)^2 (1 / Rxy);
+  //  cos(asin(vz / v)) IS hxy / v)
   const double hxy2 = m.vx * m.vx + m.vy * m.vy;
-  const double vm = fx::sqrt(hxy2 + m.vz * m.vz);
-  const double ivm = fx::rcp(vm);
-  const double cth = fx::sqrt(fmax(0.0, 1.0 - (m.vz * ivm) * (m.vz * ivm)));  // cos(asin(dz/v))
+  double vm, ivm, hxy = 0.0, ih = 0.0;
+  fx::sqrt_both(hxy2 + m.vz * m.vz, &vm, &ivm);
+  if (hxy2 > 0.0) fx::sqrt_both(hxy2, &hxy, &ih);
+  const double cth = hxy * ivm;
   const double ddx = tx - m.px, ddy = ty - m.py, ddz = tz - m.pz;
-  const double Rxy2 = ddx * ddx + ddy * ddy, Rxy = fx::sqrt(Rxy2);
-  const double R2 = Rxy2 + ddz * ddz, Rxyz = fx::sqrt(R2);
-  const double dbeta = ((tvy - m.vy) * ddx - (tvx - m.vx) * ddy) * fx::rcp(Rxy2);
-  const double deps = ((tvz - m.vz) * Rxy2 - ddz * (ddx * (tvx - m.vx) + ddy * (tvy - m.vy))) * fx::rcp(R2 * Rxy);
+  const double Rxy2 = ddx * ddx + ddy * ddy, R2 = Rxy2 + ddz * ddz;
+  double Rxy, iRxy, Rxyz, iR;
+  fx::sqrt_both(Rxy2, &Rxy, &iRxy);
+  fx::sqrt_both(R2, &Rxyz, &iR);
+  const double dbeta = ((tvy - m.vy) * ddx - (tvx - m.vx) * ddy) * (iRxy * iRxy);
+  const double deps = ((tvz - m.vz) * Rxy2 - ddz * (ddx * (tvx - m.vx) + ddy * (tvy - m.vy))) * (iR * iR * iRxy);
   const double K = fmax((double)P.K * (t_max - m.t) * (1.0 / t_max), 0.0);
   const double ny = m_clamp(-nyz_max, K * vm * (1.0 / g) * cth * dbeta, nyz_max);
   const double nz = m_clamp(-nyz_max, K * vm * (1.0 / g) * deps + cth, nyz_max);
@@ -539,10 +544,7 @@ __device__ __forceinline__ void missile_run(MslD& m, const MslParam& P, double t
     const float nx = (Tt - D) / ((float)m.m * gf);
     double st, ct, sps, cps;   // of the CURRENT theta, psi
     if (k == 1) { fx::sincos(m.theta, &st, &ct); fx::sincos(m.psi, &sps, &cps); }
-    else {
-      const double hxy = fx::sqrt(hxy2), ih = fx::rcp(hxy);
-      st = m.vz * ivm; ct = hxy * ivm; cps = m.vx * ih; sps = m.vy * ih;
-    }
+    else { st = m.vz * ivm; ct = cth; cps = m.vx * ih; sps = m.vy * ih; }
     const float dv = gf * (nx - (float)st);
     m.dph = g * ivm * (ny * fx::rcp(ct));
     m.dth = g * ivm * (nz - ct);

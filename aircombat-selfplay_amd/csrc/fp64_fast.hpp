@@ -30,6 +30,12 @@ __device__ __forceinline__ double sqrt(double x) {          // x >= 0
   const double y = fma(fma(-s, s, x), 0.5 * r, s);
   return x > 0.0 ? y : 0.0;
 }
+// sqrt(x) and 1 / sqrt(x) from the one refined seed (x > 0): the callers that divide by a length they also need
+__device__ __forceinline__ void sqrt_both(double x, double* s_out, double* r_out) {
+  const double r = rsqrt(x), s = x * r;
+  *s_out = fma(fma(-s, s, x), 0.5 * r, s);
+  *r_out = r;
+}
 // sin for |x| up to a few pi (the per-second turn rates of a missile: |x| <= 3.4): reduction by the nearest multiple of pi in two
 // pieces, Taylor series to x^21 on [-pi/2, pi/2] (truncation 3e-16)
 __device__ __forceinline__ double sin(double x) {
