@@ -195,10 +195,12 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   static_assert(FORM != FORM_ONE && (FORM == FORM_PAIR || A == 2), "no launch path for this (A, form)");
   constexpr bool SPLIT = FORM == FORM_SPLIT, QUAD = FORM == FORM_QUAD, PAIR = FORM == FORM_PAIR || QUAD;   // (the quad form's environment wave runs the pair form's code)
   constexpr bool MULTI = SD::MULTI;
-  // pair form, who makes the fp64 geodetic reduction of each tick's pose (1.4 k cycles): the flight wave (8.8 k cycles per substep with it).
-  // Handing it to this wave pays while at most one dict entry per aircraft flies (4.8 k -> 6.2 k here, 8.8 k -> 7.4 k there) and costs
-  // with two (7.5 k -> 8.9 k here):
-  constexpr bool RAWP = false;   // (measured round 3 with true: 2v2 34.2 -> 36.9 us, 4v4 39.7 -> 42.4 us on the bench workload, where most aircraft keep two dict entries flying)
+  // pair form, who makes the fp64 geodetic reduction of each tick's pose (1.4 k cycles): THIS wave, from the raw ECI pose the flight wave posts
+  // (the 1v1 missile tasks' arrangement). The flight wave's substep is 7.4 k cycles without it; this wave's is 1.4 k + 2.4 k per dict entry in
+  // flight + 1.2 k, i.e. even with two entries per aircraft it is no longer than the flight wave's. (Measured before the munition update was
+  // lightened -- 3.1 k per entry -- the same switch lost: 2v2 34.2 -> 36.9 us; after it: 33.9 -> 32.3 us, 4v4 37.5 -> 37.2 us.) The 256-register
+  // builds for grids beyond one wave per SIMD keep the reduction on the flight wave: there this wave already spills.
+  constexpr bool RAWP = WPE == 1;
   constexpr int OBS = SD::OBS;
   constexpr int NE = SD::NE;
   constexpr int MS = 2;  // munition slots (uids) per aircraft
