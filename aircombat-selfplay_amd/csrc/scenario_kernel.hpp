@@ -7,8 +7,10 @@
 //
 // Lane layout: the A aircraft of an env in A adjacent lanes (ego team first). Every aircraft owns two munition slots — the
 // two uids "agent+2", "agent+1" that env._tempsims can hold for it (an AIM-9M launched after an AIM-120B with the same
-// remaining-count reuses the uid and replaces the dict entry) — and two chaff release events. Anything another aircraft
-// needs (target pose, missile pose, chaff clouds, statuses) is fetched from the owning lane with __shfl.
+// remaining-count reuses the uid and replaces the dict entry) — and two chaff release events. What another aircraft
+// needs DURING the substeps (target pose and status) is fetched from the owning lane with __shfl; what the aircraft of an env
+// exchange after the last substep (poses, munition entries, gun hits, chaff counts, the missile warning) and the chaff clouds go
+// through LDS rows of the environment wave (xp_* / cl_* below).
 #pragma once
 
 // extension state of the scenario tasks, SoA [field][N]. The counters and flags the reference keeps in Python attributes (remaining rounds per
