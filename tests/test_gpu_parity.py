@@ -335,7 +335,7 @@ def test_scenario_weapon_tasks_match_oracle(pkg, oracle, task, per_side, geometr
         same = (done == rdone).all(axis=(1, 2))
         assert same.all(), (step, done[..., 0], rdone[..., 0])
         # every element to its own bound (x3 for 330 open-loop steps of the munitions, in fp64 against fp32 target poses: 1.6x measured at worst; rewards x4: 0.1x)
-        assert_obs(obs, robs, float(os.environ.get("AC_DIAG_WEAPON_OBS_SCALE", 3.0)), (task, geometry, step), label=f"weapons {task} x{per_side} {geometry} rwr{rwr}")
+        assert_obs(obs, robs, 3.0, (task, geometry, step), label=f"weapons {task} x{per_side} {geometry} rwr{rwr}")
         rt = bound(rrew, robs)
         if A > 2:
             rt = team_max(rt, A)
