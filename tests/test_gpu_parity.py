@@ -10,8 +10,6 @@ Open-loop pieces inside these tests (ten free steps between re-synchronisations,
 open-loop for hundreds of steps) are held to 2-4x those bounds; free flight proper -- no re-synchronisation at all, 600 steps -- has its own
 stated envelopes in tests/test_gpu_open_loop.py.
 """
-import os
-
 import numpy as np
 import pytest
 
