@@ -188,6 +188,14 @@ __global__ void mp_walk_selftest_kernel(int* mismatches, unsigned long long comb
   if (env < combos && holds && a.prev_mine != 0 && a.prev_mine != inc_id) atomicAdd(mismatches + 1, 1);   // cases where the remembered missile is another agent's
 }
 
+// the value of the other lane of an aligned lane pair (quad_perm [1,0,3,2]: v_mov_b32_dpp, full rate, all lanes active at the call sites)
+__device__ __forceinline__ int pair_swap(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ float pair_swap(float v) { return __int_as_float(pair_swap(__float_as_int(v))); }
+__device__ __forceinline__ double pair_swap(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)pair_swap((int)(unsigned)b), hi = (unsigned)pair_swap((int)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 // (cycle stamps of the wave that runs the environment layer: wave 3 in the quad form, wave 0 otherwise)
 #define AC_CLKE(i) AC_CLKW(QUAD ? 3 : 0, i)
 template <int A, int WPE, int FORM = FORM_ONE>
@@ -414,14 +422,26 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
       }
     };
     if (fly) {
+    // 1v1: both munition slots of an aircraft can only be aimed at the other aircraft of the pair, the neighbouring lane -- one
+    // quad-permute (a VALU move, no LDS crossbar trip) per value for both slots instead of a ds_bpermute per value and slot
+    double pn = 0, pe = 0, pu = 0; float pvn = 0, pve = 0, pvd = 0; int pst = 0;
+    if (A == 2) {
+      pn = pair_swap(pr.n64); pe = pair_swap(pr.e64); pu = pair_swap(pr.u64);
+      pvn = pair_swap(pr.vn); pve = pair_swap(pr.ve); pvd = pair_swap(pr.vd); pst = pair_swap(t.status);
+    }
 #pragma unroll
     for (int k = 0; k < MS; ++k) {
       const int tg = ms[k].order & 15;               // target slot lives in the low bits of `order`
       const bool used = ms[k].status != MSL_INACTIVE;
-      const int src = base + (used ? tg : slot);
-      tx[k] = __shfl(pr.n64, src); ty[k] = __shfl(pr.e64, src); tz[k] = __shfl(pr.u64, src);
-      tvx[k] = (double)__shfl(pr.vn, src); tvy[k] = (double)__shfl(pr.ve, src); tvz[k] = (double)__shfl(pr.vd, src);
-      talive[k] = __shfl(t.status, src) == AC_ALIVE;
+      if (A == 2) {                                   // (an unused slot's values are never looked at)
+        tx[k] = pn; ty[k] = pe; tz[k] = pu; tvx[k] = (double)pvn; tvy[k] = (double)pve; tvz[k] = (double)pvd;
+        talive[k] = pst == AC_ALIVE;
+      } else {
+        const int src = base + (used ? tg : slot);
+        tx[k] = __shfl(pr.n64, src); ty[k] = __shfl(pr.e64, src); tz[k] = __shfl(pr.u64, src);
+        tvx[k] = (double)__shfl(pr.vn, src); tvy[k] = (double)__shfl(pr.ve, src); tvz[k] = (double)__shfl(pr.vd, src);
+        talive[k] = __shfl(t.status, src) == AC_ALIVE;
+      }
       hit_pos[k] = 0x7fffffff;
       if (MULTI && used && talive[k] && ms[k].status != MSL_MISS) {   // the fuse test of run(), exactly as missile_run makes it
         const double ddx = tx[k] - ms[k].px, ddy = ty[k] - ms[k].py, ddz = tz[k] - ms[k].pz;
