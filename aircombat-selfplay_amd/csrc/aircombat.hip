@@ -240,6 +240,35 @@ __device__ __forceinline__ void store_msl(R* MF, int* MI, int N, int n, int slot
   AC_AT(i, MI_status) = m.status; AC_AT(i, MI_recede) = (m.dpos << 10) | (m.model << 9) | m.recede; AC_AT(i, MI_order) = m.order;
 }
 
+// a munition entry that did not move this step: its clock, `dprev`, status and receding count are all that changed
+template <typename R>
+__device__ __forceinline__ void store_msl_clock(R* MF, int* MI, int N, int n, int slot, const MslT<R>& m) {
+  AC_LANE_INDEX(n);
+  R* f = MF + (size_t)slot * NMF * N;
+  int* i = MI + (size_t)slot * NMI * N;
+  AC_AT(f, MF_t) = m.t; AC_AT(f, MF_dprev) = m.dprev;
+  AC_AT(i, MI_status) = m.status; AC_AT(i, MI_recede) = (m.dpos << 10) | (m.model << 9) | m.recede;
+}
+// the task record: the step counter and the three potentials change every step and are always written; the other eleven words (status,
+// blood, the launch bookkeeping) change a few times per episode and are written together, under ONE test, when any of them differs from
+// what was loaded (`was`)
+__device__ __forceinline__ void store_task_changed(float* F, int* I, int N, int n, const Task& t, const Task& was) {
+  AC_LANE_INDEX(n);
+  AC_AT(I, FI_cur_step) = t.cur_step;
+  AC_AT(F, FF_pre_posture) = t.pre_posture; AC_AT(F, FF_pre_altitude) = t.pre_altitude; AC_AT(F, FF_pre_event) = t.pre_event;
+  const bool rare = __float_as_int(t.bloods) != __float_as_int(was.bloods) || __float_as_int(t.pre_shoot) != __float_as_int(was.pre_shoot) ||
+                    t.status != was.status || t.die_flag != was.die_flag || t.remaining != was.remaining || t.pre_remaining != was.pre_remaining ||
+                    t.shoot_action != was.shoot_action || t.last_missile != was.last_missile || t.last_shoot_time != was.last_shoot_time ||
+                    t.lock_bits != was.lock_bits || t.lock_pos != was.lock_pos;
+  if (rare) {
+    AC_AT(F, FF_bloods) = t.bloods; AC_AT(F, FF_pre_shoot) = t.pre_shoot;
+    AC_AT(I, FI_status) = t.status; AC_AT(I, FI_die_flag) = t.die_flag; AC_AT(I, FI_remaining) = t.remaining; AC_AT(I, FI_pre_remaining) = t.pre_remaining;
+    AC_AT(I, FI_shoot_action) = t.shoot_action; AC_AT(I, FI_last_missile) = t.last_missile; AC_AT(I, FI_last_shoot_time) = t.last_shoot_time;
+    AC_AT(I, FI_lock_bits) = t.lock_bits; AC_AT(I, FI_lock_pos) = t.lock_pos;
+  }
+}
+static_assert(FI_cur_step - FI_status == 9 && FF_pre_shoot - FF_bloods == 4, "store_task_changed lists the task record's fifteen fields by hand");
+
 // task.reset() of the hierarchical tasks clears _inner_rnn_states (singlecombat_task.py:258-262)
 __device__ __forceinline__ void zero_controller_state(const DevPtrs& P, int N, int n, bool live) {
   if (P.H && live) {
@@ -501,7 +530,9 @@ __device__ __forceinline__ float sin_rate(float x) {
 // it only moves the speed (1e-7 relative on an acceleration of a few g: millimetres over a flight; the parity cases use the same
 // fraction of their bounds with it, tools/diag/missile_drift.py), and it held a third of the update's fp64 instructions, whose
 // reciprocal / square root / exp / sin are 8-15 instruction sequences where fp32 has one each: scenario1 28.9 -> 26.4 us per step.
-__device__ __forceinline__ void missile_run(MslD& m, const MslParam& P, double tx, double ty, double tz, double tvx, double tvy, double tvz,
+// Returns whether the entry MOVED (took the state-transition branch): a finished entry that stands still only advances its clock, its
+// receding count and `dprev`, and the caller writes back just those.
+__device__ __forceinline__ bool missile_run(MslD& m, const MslParam& P, double tx, double ty, double tz, double tvx, double tvy, double tvz,
                                             bool target_alive, const DevCfg& c) {
   const double dt = 1.0 / 60.0;
   const int k = (int)rint(m.t * 60.0) + 1;
@@ -561,7 +592,9 @@ __device__ __forceinline__ void missile_run(MslD& m, const MslParam& P, double t
     }
     m.vx = v * c2 * c3; m.vy = v * c2 * s3; m.vz = v * s2;
     if (burning) m.m -= dt * (double)P.dm;
+    return true;
   }
+  return false;
 }
 
 // Stage the 7 KB table pack into LDS: every lane issues all of its 16-byte global loads before the first LDS store, so
