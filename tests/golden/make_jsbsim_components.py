@@ -142,6 +142,15 @@ def load(name, events, holder):
     return mod
 
 
+def prune(tree, uncovered):
+    """The tokenised system file without the components the interpreter does not cover."""
+    def keep(node):
+        return not (isinstance(node, list) and len(node) == 4 and isinstance(node[1], dict) and node[1].get("name") in uncovered)
+    def walk(node):
+        return [node[0], node[1], [walk(c) for c in node[2] if keep(c)], node[3]]
+    return walk(tree)
+
+
 def main():
     out = {}
     for script, cls, methods in (("TestGain", "TestGain", ["test_conditions"]), ("TestSwitch", "TestSwitch", ["test_conditions", "test_nested"]),
@@ -154,7 +163,9 @@ def main():
             n_exp = sum(1 for e in events if e[0] == "expect")
             names = sorted({e[1] for e in events if e[0] == "expect"})
             key = f"{script}.{meth}"
-            out[key] = np.array(json.dumps({"file": holder["file"], "tree": holder["tree"], "events": events, "uncovered": holder["uncovered"],
+            # (only the components the interpreter covers travel with the fixture: the rest of the test's system file is not needed to replay it)
+            tree = prune(holder["tree"], set(holder["uncovered"]))
+            out[key] = np.array(json.dumps({"file": holder["file"], "tree": tree, "events": events, "uncovered": holder["uncovered"],
                                             "skipped": holder.get("skipped", 0)}))
             print(f"{key}: {n_exp} expectations hold on {len(names)} properties ({', '.join(names)}); "
                   f"{holder.get('skipped', 0)} assertions on properties outside the F-16's component set not covered: {holder['uncovered']}")
