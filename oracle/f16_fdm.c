@@ -581,6 +581,13 @@ static void pilot_accel(const double cg[3], const double eye[3], const double bo
 void f16_test_pilot_accel(const double* cg, const double* eye, const double* body_accel, const double* pqridot, const double* pqri, double* out3) {
   pilot_accel(cg, eye, body_accel, pqridot, pqri, out3);
 }
+/* wind -> body (S/models/FGAuxiliary.cpp:256-264) */
+static void wind_to_body(double alpha, double beta, double Tw2b[9]) {
+  double ca = cos(alpha), sa = sin(alpha), cb = cos(beta), sb = sin(beta);
+  Tw2b[0] = ca * cb; Tw2b[1] = -ca * sb; Tw2b[2] = -sa;
+  Tw2b[3] = sb;      Tw2b[4] = cb;       Tw2b[5] = 0.0;
+  Tw2b[6] = sa * cb; Tw2b[7] = -sa * sb; Tw2b[8] = ca;
+}
 static void auxiliary_run(F16State* s) {
   for (int i = 0; i < 3; i++) s->aero_pqr[i] = s->pqr[i];
   double u = s->uvw[0], v = s->uvw[1], w = s->uvw[2];
@@ -591,9 +598,7 @@ static void auxiliary_run(F16State* s) {
     s->beta = atan2(v, sqrt(mUW));
     if (mUW >= 1E-6) s->alpha = atan2(w, u);
   }
-  double ca = cos(s->alpha), sa = sin(s->alpha), cb = cos(s->beta), sb = sin(s->beta);
-  double Tw2b[9] = {ca * cb, -ca * sb, -sa, sb, cb, 0.0, sa * cb, -sa * sb, ca};
-  memcpy(s->Tw2b, Tw2b, sizeof Tw2b);
+  wind_to_body(s->alpha, s->beta, s->Tw2b);
   s->qbar = 0.5 * s->rho * Vt2;
   s->mach = s->vt / s->snd;
   s->vg = sqrt(s->vel_ned[0] * s->vel_ned[0] + s->vel_ned[1] * s->vel_ned[1]);
@@ -706,6 +711,12 @@ void f16_test_turbine_run(double* io, double throttle_pos, double sigma, double 
   turbine_calculate(&s, dt);
   io[0] = s.n1; io[1] = s.n2; io[2] = s.n2norm;
 }
+/* moment about the CG of a body-axis force acting at a structural location (FGForce::GetBodyForces, S/models/propulsion/FGForce.cpp) */
+static void force_moment_about_cg(const double cg[3], const double loc[3], const double f[3], double m[3]) {
+  double r[3];
+  struct_to_body(cg, loc, r);
+  cross3(r, f, m);
+}
 /* FGPropulsion::Run + ConsumeFuel (S/models/FGPropulsion.cpp:113-258), FGTank::Drain (S/models/propulsion/FGTank.cpp:281-294) */
 static void propulsion_run(F16State* s, double dt) {
   double thrust = turbine_calculate(s, dt);
@@ -721,10 +732,14 @@ static void propulsion_run(F16State* s, double dt) {
   }
   /* direct thruster along body x acting at the structural origin (f16.xml:259-270; FGForce.cpp GetBodyForces) */
   const double loc[3] = {F16_THRUSTER_X, F16_THRUSTER_Y, F16_THRUSTER_Z};
-  double r[3];
-  struct_to_body(s->cg, loc, r);
   s->f_prop[0] = thrust; s->f_prop[1] = 0; s->f_prop[2] = 0;
-  cross3(r, s->f_prop, s->m_prop);
+  force_moment_about_cg(s->cg, loc, s->f_prop, s->m_prop);
+}
+/* test hook: the moment about the CG (structural inches) of a body-axis force applied at the F-16 thruster's location, through the
+ * function propulsion_run uses. Pinned by the reference's CheckMomentsUpdate.py:66-76 (a force at the structural origin). */
+void f16_test_thruster_moment(const double* cg, const double* force3, double* m3) {
+  const double loc[3] = {F16_THRUSTER_X, F16_THRUSTER_Y, F16_THRUSTER_Z};
+  force_moment_about_cg(cg, loc, force3, m3);
 }
 
 /* ------------------------------------------------------------------ FGAerodynamics::Run (S/models/FGAerodynamics.cpp:132-300), f16.xml:994-1925 */
@@ -781,18 +796,30 @@ static void aero_axis_sums(const F16State* s, double* o) {
   n += qS * bw * a * dr * TAB1(CNDR_M, M);
   o[0] = D; o[1] = Y; o[2] = L; o[3] = l; o[4] = m; o[5] = n;
 }
+/* the axis sums -> body-axis force and moment about the CG: DRAG / SIDE / LIFT are wind-axis natives with drag and lift sign-flipped,
+ * rotated by Tw2b (S/models/FGAerodynamics.cpp:205-216); the moments are taken at the aerodynamic reference point and moved to the CG
+ * with r x F (:280) */
+static void aero_frame(const double cg[3], const double rp[3], const double Tw2b[9], const double o[6], double f_aero[3], double m_aero[3]) {
+  const double D = o[0], Y = o[1], L = o[2], l = o[3], m = o[4], n = o[5];
+  double fw[3] = {-D, Y, -L};
+  mv3(Tw2b, fw, f_aero);
+  double rpb[3], mx[3];
+  struct_to_body(cg, rp, rpb);
+  cross3(rpb, f_aero, mx);
+  m_aero[0] = l + mx[0]; m_aero[1] = m + mx[1]; m_aero[2] = n + mx[2];
+}
 static void aerodynamics_run(F16State* s) {
   double o[6];
   aero_axis_sums(s, o);
-  const double D = o[0], Y = o[1], L = o[2], l = o[3], m = o[4], n = o[5];
-  /* wind axes: drag and lift sign-flipped, rotated by Tw2b (:205-212) */
-  double fw[3] = {-D, Y, -L};
-  mv3(s->Tw2b, fw, s->f_aero);
   const double rp[3] = {F16_AERORP_X, F16_AERORP_Y, F16_AERORP_Z};
-  double rpb[3], mx[3];
-  struct_to_body(s->cg, rp, rpb);
-  cross3(rpb, s->f_aero, mx);
-  s->m_aero[0] = l + mx[0]; s->m_aero[1] = m + mx[1]; s->m_aero[2] = n + mx[2];
+  aero_frame(s->cg, rp, s->Tw2b, o, s->f_aero, s->m_aero);
+}
+/* test hook: aerodynamics_run's frame handling for given (alpha, beta), CG and reference point (structural inches) and the six axis
+ * sums, through the very wind_to_body() / aero_frame() the tick uses. Pinned by the reference's TestAeroFuncFrame.py testAeroFrame. */
+void f16_test_aero_frame(double alpha, double beta, const double* cg, const double* rp, const double* sums6, double* f3, double* m3) {
+  double Tw2b[9];
+  wind_to_body(alpha, beta, Tw2b);
+  aero_frame(cg, rp, Tw2b, sums6, f3, m3);
 }
 
 /* test hook: the axis sums for given property values, in the order of tests/golden/make_f16_aero_check.py's PROPS (alpha, beta,

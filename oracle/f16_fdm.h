@@ -107,6 +107,8 @@ double f16_kinemat(double out, double in, const double* detents, const double* t
 void f16_test_fcs(double* st18, const double* in17, double* out16);
 void f16_test_massbalance(const double* tanks4, const double* pm2, const double* cg_tanks, double* out31);
 void f16_test_pilot_accel(const double* cg, const double* eye, const double* body_accel, const double* pqridot, const double* pqri, double* out3);
+void f16_test_aero_frame(double alpha, double beta, const double* cg, const double* rp, const double* sums6, double* f3, double* m3);
+void f16_test_thruster_moment(const double* cg, const double* force3, double* m3);
 
 #ifdef __cplusplus
 }

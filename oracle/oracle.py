@@ -115,6 +115,10 @@ def lib():
         L.f16_test_massbalance.restype = None
         L.f16_test_pilot_accel.argtypes = [dp] * 6
         L.f16_test_pilot_accel.restype = None
+        L.f16_test_aero_frame.argtypes = [C.c_double, C.c_double] + [dp] * 5
+        L.f16_test_aero_frame.restype = None
+        L.f16_test_thruster_moment.argtypes = [dp] * 3
+        L.f16_test_thruster_moment.restype = None
         L.or_posture_orientation.argtypes = [C.c_double] * 2
         L.or_posture_orientation.restype = C.c_double
         L.or_posture_range.argtypes = [C.c_double]

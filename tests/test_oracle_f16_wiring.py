@@ -187,6 +187,52 @@ def test_initial_geodetic_latitude_of_TestInitialConditions(oracle, rel):
             assert abs(alt_m / 0.3048 - h) < 1e-5    # h_sl goes through radius - sea-level radius at 2e7 ft: 1e-5 ft is fp64's floor there
 
 
+def test_aerodynamic_force_frame_and_moment_transfer_of_TestAeroFuncFrame(oracle, rel):
+    """TestAeroFuncFrame.testAeroFrame (the DRAG / SIDE / LIFT axis form of f16.xml:994-1925), 256 random frames: the body-axis force is
+    Tw2b * diag(-1, 1, -1) * (DRAG, SIDE, LIFT), the moment is the (ROLL, PITCH, YAW) sums taken at the reference point plus
+    cross((cg - rp) / 12 with y negated, Fb) — aerodynamics_run's wind_to_body() / aero_frame() at the test's own 7 places. A sign flip
+    of either arm of the cross product, of the lift / drag negation or of one Tw2b element fails it (checked below on the numbers)."""
+    L = oracle.lib()
+    X, fb, mb = rel["aeroframe_inputs"], rel["aeroframe_fb"], rel["aeroframe_mb"]
+    places = int(rel["aeroframe_places"])
+    assert len(X) >= 200 and np.array_equal(rel["aeroframe_fw"], X[:, 8:11])            # forces/fw*-aero-lbs ARE the axis sums
+    f, fp = dbl(np.zeros(3))
+    m, mp = dbl(np.zeros(3))
+    for x, wf, wm in zip(X, fb, mb):
+        L.f16_test_aero_frame(x[0], x[1], dbl(x[2:5])[1], dbl(x[5:8])[1], dbl(x[8:14])[1], fp, mp)
+        assert all(round(a - b, places) == 0 for a, b in zip(f, wf)), (x, f, wf)          # assertAlmostEqual(places=7)
+        assert all(round(a - b, places) == 0 for a, b in zip(m, wm)), (x, m, wm)
+    # the fixture discriminates: each of these wrong readings misses the recorded numbers by far more than the criterion
+    x, wf, wm = X[0], fb[0], mb[0]
+    ca, sa, cb, sb = np.cos(x[0]), np.sin(x[0]), np.cos(x[1]), np.sin(x[1])
+    T = np.array([[ca * cb, -ca * sb, -sa], [sb, cb, 0.0], [sa * cb, -sa * sb, ca]])
+    arm = np.array([x[2] - x[5], x[6] - x[3], x[4] - x[7]]) / 12.0
+    right = T @ (np.array([-1.0, 1.0, -1.0]) * x[8:11])
+    assert np.abs(right - wf).max() < 1e-7 and np.abs(x[11:14] + np.cross(arm, right) - wm).max() < 1e-6
+    assert np.abs(T @ x[8:11] - wf).max() > 1.0                                          # drag / lift not negated
+    assert np.abs(T.T @ (np.array([-1.0, 1.0, -1.0]) * x[8:11]) - wf).max() > 1.0        # Tb2w instead of Tw2b
+    assert np.abs(x[11:14] + np.cross(-arm, right) - wm).max() > 1.0                     # rp - cg instead of cg - rp
+    assert np.abs(x[11:14] + np.cross(arm * [1, -1, 1], right) - wm).max() > 1.0         # structural y not negated
+
+
+def test_moment_of_a_force_at_the_structural_origin_of_CheckMomentsUpdate(oracle, rel, fcs):
+    """CheckMomentsUpdate.test_moments_update: a force applied at the structural origin with the CG at (CGx, CGz) gives
+    My = Fx * CGz - Fz * CGx (CG in feet, delta 1e-7). The F-16's thruster sits at the structural origin (f16.xml:259-270; the generic
+    reading's thruster_xyz == 0 is asserted in test_metrics_mass_and_tank_constants_of_both_headers), so this is propulsion_run's moment arm."""
+    L = oracle.lib()
+    assert list(fcs["mass|thruster_xyz"]) == [0.0, 0.0, 0.0]
+    X, want, delta = rel["origin_force_inputs"], rel["origin_force_my"], float(rel["origin_force_delta"])
+    assert len(X) >= 200
+    m, mp = dbl(np.zeros(3))
+    for (fx, fz, cgx, cgz), my in zip(X, want):
+        L.f16_test_thruster_moment(dbl([cgx, 0.0, cgz])[1], dbl([fx, 0.0, fz])[1], mp)
+        assert abs(m[1] - my) <= delta, (fx, fz, cgx, cgz, m, my)
+        assert abs(-m[1] - my) > 1e-3 or abs(my) < 1e-3                                  # the opposite arm misses it
+    # the thrust itself is along body x only: its pitching moment is thrust * CGz / 12 (a 5.1 in arm on the as-shipped loading)
+    L.f16_test_thruster_moment(dbl([-193.0, 0.0, -5.1])[1], dbl([10000.0, 0.0, 0.0])[1], mp)
+    assert abs(m[1] - 10000.0 * (-5.1 / 12.0)) < 1e-9 and m[0] == 0.0 and abs(m[2]) == 0.0
+
+
 def _golden_module(name):
     import sys
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
