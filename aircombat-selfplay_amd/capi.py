@@ -84,6 +84,8 @@ SIGNATURES = {
     "ac_reset": (C.c_int, [_p, _p]),
     "ac_step": (C.c_int, [_p, _p, _p, _p, _p, _p]),
     "ac_host_buffers": (C.c_int, [_p, C.c_int32, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
+    "ac_host_set_detach": (C.c_int, [_p, C.c_int32]),
+    "ac_host_set_free": (None, [_p, _p, _p, _p, _p]),
     "ac_step_host_async": (C.c_int, [_p, C.c_int32]),
     "ac_step_host_wait": (C.c_int, [_p]),
     "ac_step_host": (C.c_int, [_p, C.c_int32]),

@@ -126,7 +126,8 @@ struct DevPtrs {
   float* obs; float* rew; uint8_t* done; int* info;        // outputs, rows padded to whole workgroups (64 aircraft)
   float* obs2; float* rew2; uint8_t* done2; int* info2;    // second copy of the outputs (pinned host memory mapped into the device:
                                                            // ac_step_host), or null
-  int* err;                              // one word of page-locked host memory: 1 + index of an aircraft whose state or reward went non-finite
+  int* err;                              // one word of page-locked host memory, 0 = healthy: (own state probe << 30) | (0x3fffffff - index) of the aircraft
+                                         // whose state or reward went non-finite, merged with a system-scope max (emit_scalars)
 };
 
 // ------------------------------------------------------------------------------------------------ non-finite guard
@@ -138,7 +139,9 @@ struct DevPtrs {
 __device__ __forceinline__ bool nonfinite_probe(float veci, float pqr, float h_sl_ft, float np_max) {
   return !(fabsf(veci + pqr + h_sl_ft + np_max) < INFINITY);
 }
-__device__ __forceinline__ float poison_if(bool bad, float reward) { return bad ? __int_as_float(0x7fc00000) : reward; }
+// (a NaN with payload 1: emit_scalars tells "this aircraft's own state probe fired" from a reward that merely inherited a NaN -- the
+// opponent's posture term of a NaN pose is NaN as well -- and reports the aircraft that is actually at fault)
+__device__ __forceinline__ float poison_if(bool bad, float reward) { return bad ? __int_as_float(0x7fc00001) : reward; }
 
 // ------------------------------------------------------------------------------------------------ device helpers
 // Field f of lane n at byte offset (f*N + n)*sizeof from ONE wave-uniform base pointer: the offset is a 32-bit lane value (one VALU
@@ -699,7 +702,12 @@ __device__ __forceinline__ void emit_scalars(const DevPtrs& P, int lane, float r
   // (current_step < 65536 is checked by ac_create; the turn count saturates at its field's 127 -- the reference's increment_size list has 15 stages)
   const int packed = (i0 & 0xFFFF) | ((i1 & 0xFF) << 16) | (min(i2, 127) << 24) | ((i3 & 1) << 31);
   const size_t n = blk * 64 + lane;
-  if (!(fabsf(reward) < INFINITY)) *(volatile int*)P.err = (int)n + 1;   // (any of the offending lanes wins; the host keeps it sticky)
+  if (!(fabsf(reward) < INFINITY)) {
+    // One winner whatever the hardware's store order: a system-scope max on the page-locked word. An aircraft whose OWN probe fired
+    // (poison_if's payload) outranks one whose reward only inherited the NaN; within a rank the lowest aircraft index wins.
+    const int own = ((__float_as_int(reward) & 0x7fffffff) == 0x7fc00001) ? 1 : 0;
+    __hip_atomic_fetch_max(P.err, (own << 30) | (0x3fffffff - (int)n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 #pragma unroll
   for (int set = 1; set >= 0; --set) {
     float* rew = set ? P.rew2 : P.rew; uint8_t* dn = set ? P.done2 : P.done; int* info = set ? P.info2 : P.info;
@@ -1558,6 +1566,7 @@ __global__ void init_kernel_nvn(InitArgs ia, DevCfg c, const float* tab, float* 
 #include "scenario_kernel.hpp"
 #include "controller_common.hpp"
 #include "controller_split_kernel.hpp"
+#include "controller8_kernel.hpp"
 #include "heading_kernel.hpp"
 
 // reset(): every env takes the template (SubprocVecEnv.reset -> env.reset(), env_base.py:98-113)
@@ -1603,6 +1612,8 @@ struct ac_env {
   float* d_XF; int* d_XI;                // scenario-task extension state
   float* d_low;                          // hierarchical tasks: low-level action buffer (the controller's output, the step kernel's input)
   float* d_ctlWs;                        // controller weights as bf16 pieces (controller_split_kernel.hpp)
+  float* d_ctlWs8;                       // the same in the eight-wave kernel's tiling (controller8_kernel.hpp)
+  bool ctl8;                             // which controller kernel the handle launches (AIRCOMBAT_CTL8=0/1; default: the eight-wave one)
   HeadingPtrs hp; HeadingCfg hc;         // HeadingTask: targets, check clock, numpy-PCG64 state per env
   int act_low;                           // width of the low-level action the step kernels decode
   hipEvent_t ev0, ev1;
@@ -1610,10 +1621,11 @@ struct ac_env {
   bool mark_mid;
   hipEvent_t ev_order;                   // stream-ordering hand-shake with the caller's streams (ac_order_after / ac_order_before)
   // ac_step_host: two library-owned sets of pinned host buffers mapped into the device (actions in; obs, rewards, dones, info out)
-  struct HostSet { float* act; float* obs; float* rew; uint8_t* done; int* info; } hs[2];
-  bool have_hs;
+  struct HostSet { float* act; float* obs; float* rew; uint8_t* done; int* info; } hs[AC_HOST_SETS];   // allocated on first use (ac_host_buffers)
+  bool have_hs[AC_HOST_SETS];
   int* err_host;                         // P.err: one word of page-locked host memory the step kernels write on a non-finite state (sticky until ac_reset)
   int err_sticky;
+  int* count_host;                       // ac_munitions_in_flight's counter: one page-locked, device-mapped word allocated with the handle
   bool timing;
   bool quad_waves;                       // the 1v1 tasks with munitions up to one workgroup per CU: three FDM waves + the environment wave (FORM 3 / FORM_QUAD)
   bool split_waves;                      // SingleCombat below one wave per SIMD: three waves per 64 aircraft (step_kernel_1v1<.., SPLIT>)
@@ -1633,7 +1645,7 @@ static void geodetic2ecef_m(double lat_deg, double lon_deg, double alt, double* 
 static int check_nonfinite(ac_env* h, const char* who) {
   if (h->err_host && *(volatile int*)h->err_host) h->err_sticky = *(volatile int*)h->err_host;
   if (!h->err_sticky) return 0;
-  const int n = std::min(h->err_sticky - 1, h->N - 1);
+  const int n = std::max(0, std::min(0x3fffffff - (h->err_sticky & 0x3fffffff), h->N - 1));   // emit_scalars: (own probe << 30) | (0x3fffffff - aircraft)
   char msg[192];
   snprintf(msg, sizeof msg, "%s: JSBSim failed. Non-finite state or reward in env %d, agent %d (ac_reset clears the condition)", who, n / h->A, n % h->A);
   return fail(msg);
@@ -1648,12 +1660,16 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
   dim3 block(64), grid((h->N + 63) / 64);
   if (h->cfg.hierarchical) {   // [3,5,3] (+ weapon bits) -> control indices, then the ordinary step on those
     if (!h->d_ctlWs) return fail("hierarchical task: ac_load_controller has not been called");
-    ctl::Args a{h->d_ctlWs, p.actions, p.obs, p.H, h->d_low, h->N, h->obs_dim, h->act_dim, h->act_low,
+    ctl::Args a{h->d_ctlWs, h->d_ctlWs8, p.actions, p.obs, p.H, h->d_low, h->N, h->obs_dim, h->act_dim, h->act_low,
                 h->cfg.use_baseline, h->A, h->cfg.n_ego, h->cfg.use_artillery,
                 (float)h->cfg.agent_interaction_steps / (float)h->cfg.sim_freq, p.man_step, p.man_h0, p, h->dc};
     // (the scripted opponents' inputs -- use_baseline -- are computed inside that instantiation of the kernel)
-    if (h->cfg.use_baseline) hipLaunchKernelGGL(controller_split_kernel<true>, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
-    else hipLaunchKernelGGL(controller_split_kernel<false>, dim3((h->N + ctl::MT - 1) / ctl::MT), dim3(256), 0, h->stream, a);
+    const dim3 cgrid((h->N + ctl::MT - 1) / ctl::MT);
+    if (h->ctl8) {   // eight waves per 32-aircraft tile (controller8_kernel.hpp); AIRCOMBAT_CTL8=0 pins the four-wave kernel it replaced
+      if (h->cfg.use_baseline) hipLaunchKernelGGL(controller8_kernel<true>, cgrid, dim3(512), 0, h->stream, a);
+      else hipLaunchKernelGGL(controller8_kernel<false>, cgrid, dim3(512), 0, h->stream, a);
+    } else if (h->cfg.use_baseline) hipLaunchKernelGGL(controller_split_kernel<true>, cgrid, dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL(controller_split_kernel<false>, cgrid, dim3(256), 0, h->stream, a);
     HIP_OK(hipGetLastError());
     if (h->mark_mid) HIP_OK(hipEventRecord(h->ev_mid, h->stream));
     p.actions = h->d_low;
@@ -1790,6 +1806,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     const bool ticks_only = cfg->task == AC_TASK_SINGLECOMBAT || cfg->task == AC_TASK_MULTICOMBAT || cfg->task == AC_TASK_HEADING ||
                             cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER;
     h->split_waves = ticks_only && (e ? (e[0] == '1') : (wgs <= 512));
+    const char* ce = getenv("AIRCOMBAT_CTL8");
+    h->ctl8 = ce ? (ce[0] == '1') : true;
     const char* qe = getenv("AIRCOMBAT_QUAD");   // 0 / 1 overrides the choice of the quad form
     const bool munitions_1v1 = cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE || cfg->task == AC_TASK_SCENARIO1;
     h->quad_waves = munitions_1v1 && (qe ? (qe[0] == '1') : (wgs <= 256));
@@ -1843,6 +1861,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   HIP_OK(hipHostMalloc((void**)&h->err_host, sizeof(int), hipHostMallocDefault));
   *h->err_host = 0; h->err_sticky = 0;
   h->dp.err = h->err_host;
+  HIP_OK(hipHostMalloc((void**)&h->count_host, sizeof(int), hipHostMallocDefault));
   const size_t N = (size_t)h->N;
   DevPtrs& p = h->dp;
   HIP_OK(hipMalloc(&p.F, sizeof(float) * NF * N));
@@ -1935,11 +1954,12 @@ int ac_destroy(ac_env_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->dp.F, h->dp.I, h->dp.D, h->dp.MF, h->dp.MD, h->dp.MI, h->dp.obs, h->dp.rew, h->dp.done, h->dp.info,
-                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_ctlWs, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
+                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_ctlWs, h->d_ctlWs8, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
   for (void* b : bufs) (void)hipFree(b);
-  if (h->have_hs)
-    for (auto& hs : h->hs) { (void)hipHostFree(hs.act); (void)hipHostFree(hs.obs); (void)hipHostFree(hs.rew); (void)hipHostFree(hs.done); (void)hipHostFree(hs.info); }
+  for (int k = 0; k < AC_HOST_SETS; ++k)
+    if (h->have_hs[k]) ac_host_set_free(h->hs[k].act, h->hs[k].obs, h->hs[k].rew, h->hs[k].done, h->hs[k].info);   // (a detached set is the caller's)
   if (h->err_host) (void)hipHostFree(h->err_host);
+  if (h->count_host) (void)hipHostFree(h->count_host);
   (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); (void)hipEventDestroy(h->ev_order); (void)hipEventDestroy(h->ev_mid);
   (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1979,24 +1999,22 @@ int ac_step(ac_env_t* h, const float* actions, float* obs, float* rewards, uint8
 // writes a second copy of its outputs there (whole 16-byte vectors, emit_outputs): no H2D / D2H copy commands, no staging, one
 // launch and one completion wait per step. Two buffer sets, so the arrays of step t stay untouched while step t+1 runs.
 int ac_host_buffers(ac_env_t* h, int32_t set, float** actions, float** obs, float** rewards, uint8_t** dones, int32_t** info) {
-  if (!h || set < 0 || set > 1) return fail("ac_host_buffers: bad argument");
+  if (!h || set < 0 || set >= AC_HOST_SETS) return fail("ac_host_buffers: bad argument (sets 0 .. AC_HOST_SETS - 1)");
   HIP_OK(hipSetDevice(h->device));
-  if (!h->have_hs) {
+  ac_env::HostSet& hs = h->hs[set];
+  if (!h->have_hs[set]) {
     const size_t Npad = ((size_t)h->N + 63) / 64 * 64;
-    for (auto& hs : h->hs) {
-      // hipHostMallocDefault: page-locked, mapped into the device's address space, coherent (kernel stores are visible to the host
-      // once the kernel has completed)
-      HIP_OK(hipHostMalloc((void**)&hs.act, sizeof(float) * Npad * h->act_dim, hipHostMallocDefault));
-      HIP_OK(hipHostMalloc((void**)&hs.obs, sizeof(float) * Npad * h->obs_dim, hipHostMallocDefault));
-      HIP_OK(hipHostMalloc((void**)&hs.rew, sizeof(float) * Npad, hipHostMallocDefault));
-      HIP_OK(hipHostMalloc((void**)&hs.done, Npad, hipHostMallocDefault));
-      HIP_OK(hipHostMalloc((void**)&hs.info, sizeof(int) * (Npad / h->A), hipHostMallocDefault));
-      memset(hs.act, 0, sizeof(float) * Npad * h->act_dim); memset(hs.obs, 0, sizeof(float) * Npad * h->obs_dim);
-      memset(hs.rew, 0, sizeof(float) * Npad); memset(hs.done, 0, Npad); memset(hs.info, 0, sizeof(int) * (Npad / h->A));
-    }
-    h->have_hs = true;
+    // hipHostMallocDefault: page-locked, mapped into the device's address space, coherent (kernel stores are visible to the host
+    // once the kernel has completed)
+    HIP_OK(hipHostMalloc((void**)&hs.act, sizeof(float) * Npad * h->act_dim, hipHostMallocDefault));
+    HIP_OK(hipHostMalloc((void**)&hs.obs, sizeof(float) * Npad * h->obs_dim, hipHostMallocDefault));
+    HIP_OK(hipHostMalloc((void**)&hs.rew, sizeof(float) * Npad, hipHostMallocDefault));
+    HIP_OK(hipHostMalloc((void**)&hs.done, Npad, hipHostMallocDefault));
+    HIP_OK(hipHostMalloc((void**)&hs.info, sizeof(int) * (Npad / h->A), hipHostMallocDefault));
+    memset(hs.act, 0, sizeof(float) * Npad * h->act_dim); memset(hs.obs, 0, sizeof(float) * Npad * h->obs_dim);
+    memset(hs.rew, 0, sizeof(float) * Npad); memset(hs.done, 0, Npad); memset(hs.info, 0, sizeof(int) * (Npad / h->A));
+    h->have_hs[set] = true;
   }
-  const ac_env::HostSet& hs = h->hs[set];
   if (actions) *actions = hs.act;
   if (obs) *obs = hs.obs;
   if (rewards) *rewards = hs.rew;
@@ -2004,9 +2022,22 @@ int ac_host_buffers(ac_env_t* h, int32_t set, float** actions, float** obs, floa
   if (info) *info = hs.info;
   return 0;
 }
+// A set whose arrays the caller still holds when the VecEnv closes (the reference's step() returns arrays the caller owns for good,
+// env_wrappers.py:276-282): the handle gives the set up -- ac_destroy leaves it alone -- and the holder frees it when the last array is gone.
+int ac_host_set_detach(ac_env_t* h, int32_t set) {
+  if (!h || set < 0 || set >= AC_HOST_SETS || !h->have_hs[set]) return fail("ac_host_set_detach: no such set");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));     // no step may still be writing into it
+  h->have_hs[set] = false;
+  memset(&h->hs[set], 0, sizeof h->hs[set]);
+  return 0;
+}
+void ac_host_set_free(void* actions, void* obs, void* rewards, void* dones, void* info) {
+  (void)hipHostFree(actions); (void)hipHostFree(obs); (void)hipHostFree(rewards); (void)hipHostFree(dones); (void)hipHostFree(info);
+}
 int ac_step_host_async(ac_env_t* h, int32_t set) {
-  if (!h || set < 0 || set > 1) return fail("ac_step_host_async: bad argument");
-  if (!h->have_hs) return fail("ac_step_host_async: call ac_host_buffers first");
+  if (!h || set < 0 || set >= AC_HOST_SETS) return fail("ac_step_host_async: bad argument");
+  if (!h->have_hs[set]) return fail("ac_step_host_async: call ac_host_buffers for this set first");
   HIP_OK(hipSetDevice(h->device));
   return launch_step(h, nullptr, set);
 }
@@ -2213,21 +2244,21 @@ __global__ void munitions_in_flight_kernel(DevPtrs P, DevCfg c, int* out) {
     for (int k = 0; k < c.msl_slots; ++k) cnt += P.MI[((size_t)k * NMI + MI_status) * (size_t)N + n] == MSL_LAUNCHED;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(out, cnt);
+  if ((threadIdx.x & 63) == 0 && cnt) __hip_atomic_fetch_add(out, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (`out` is page-locked host memory)
 }
 int ac_munitions_in_flight(ac_env_t* h, int32_t* count) {
   if (!h || !count) return fail("ac_munitions_in_flight: null argument");
   *count = 0;
   if (!h->dc.msl_slots || !h->dp.MI) return 0;
   HIP_OK(hipSetDevice(h->device));
-  int* d_out;
-  HIP_OK(hipMalloc(&d_out, sizeof(int)));
-  HIP_OK(hipMemsetAsync(d_out, 0, sizeof(int), h->stream));
-  hipLaunchKernelGGL(munitions_in_flight_kernel, dim3((h->N + 63) / 64), dim3(64), 0, h->stream, h->dp, h->dc, d_out);
+  // the counter lives with the handle (no allocation, no device-wide synchronisation in a call): cleared and added to on the handle's
+  // stream, read after one wait for that stream
+  HIP_OK(hipStreamSynchronize(h->stream));
+  *(volatile int*)h->count_host = 0;
+  hipLaunchKernelGGL(munitions_in_flight_kernel, dim3((h->N + 63) / 64), dim3(64), 0, h->stream, h->dp, h->dc, h->count_host);
   HIP_OK(hipGetLastError());
   HIP_OK(hipStreamSynchronize(h->stream));
-  HIP_OK(hipMemcpy(count, d_out, sizeof(int), hipMemcpyDeviceToHost));
-  HIP_OK(hipFree(d_out));
+  *count = *(volatile int*)h->count_host;
   return 0;
 }
 int ac_seed_envs(ac_env_t* h, const uint64_t* states) {
@@ -2300,6 +2331,33 @@ int ac_load_controller(ac_env_t* h, const float* weights, int64_t n) {
     tiles_s(S_WA, B_WA, NH, 128, 128, 5); copy_s(S_BA, B_BA, NH);
     if (!h->d_ctlWs) HIP_OK(hipMalloc(&h->d_ctlWs, sizeof(float) * B_END));
     HIP_OK(hipMemcpy(h->d_ctlWs, e.data(), sizeof(float) * B_END, hipMemcpyHostToDevice));
+  }
+  {   // the eight-wave kernel's tiling: tile(c) = the 16 columns 16 c .. 16 c + 15 = K/32 k-steps x 3 pieces x 64 lanes x 8 values,
+      // element (s, p, lane, i) = piece p of W[j = 16 c + lane % 16][k = 32 s + 8 (lane / 16) + i]
+    using namespace ctl8;
+    std::vector<float> e(C_END, 0.0f);
+    unsigned short* e16 = reinterpret_cast<unsigned short*>(e.data());
+    auto tiles_s = [&](int src, int dst, int J, int K, int Kpad, int ntiles) {
+      for (int c = 0; c < ntiles; ++c)
+        for (int st = 0; st < Kpad / 32; ++st)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int i = 0; i < 8; ++i) {
+              const int k = 32 * st + 8 * (lane / 16) + i, j = 16 * c + lane % 16;
+              unsigned pc[3];
+              ctls::split3((j < J && k < K) ? weights[src + j * K + k] : 0.0f, pc[0], pc[1], pc[2]);
+              for (int pp = 0; pp < 3; ++pp)
+                e16[(size_t)dst * 2 + ((((size_t)c * (Kpad / 32) + st) * 3 + pp) * 64 + lane) * 8 + i] = (unsigned short)pc[pp];
+            }
+    };
+    auto copy_s = [&](int src, int dst, int cnt) { for (int i = 0; i < cnt; ++i) e[dst + i] = weights[src + i]; };
+    tiles_s(S_W1, C_W1, 128, 12, 32, 8); copy_s(S_B1, C_B1, 128); copy_s(S_G1, C_G1, 128); copy_s(S_BE1, C_BE1, 128);
+    tiles_s(S_W2, C_W2, 128, 128, 128, 8); copy_s(S_B2, C_B2, 128); copy_s(S_G2, C_G2, 128); copy_s(S_BE2, C_BE2, 128);
+    // (W_ih / W_hh rows are gate-major: r 0..127, z 128..255, n 256..383, so tile 8 g + u is columns 128 g + 16 u .. + 15 = tile index c of the stacked matrix)
+    tiles_s(S_WIH, C_WIH, 384, 128, 128, 24); tiles_s(S_WHH, C_WHH, 384, 128, 128, 24); copy_s(S_BIH, C_BIH, 384); copy_s(S_BHH, C_BHH, 384);
+    copy_s(S_G3, C_G3, 128); copy_s(S_BE3, C_BE3, 128);
+    tiles_s(S_WA, C_WA, NH, 128, 128, 10); copy_s(S_BA, C_BA, NH);
+    if (!h->d_ctlWs8) HIP_OK(hipMalloc(&h->d_ctlWs8, sizeof(float) * C_END));
+    HIP_OK(hipMemcpy(h->d_ctlWs8, e.data(), sizeof(float) * C_END, hipMemcpyHostToDevice));
   }
   return 0;
 }

@@ -1,0 +1,367 @@
+// The low-level controller kernel, eight-wave form (network, arguments: controller_common.hpp; the bf16-piece arithmetic -- every fp32
+// product as six exact bf16 x bf16 terms accumulated in fp32 -- and its helpers: controller_split_kernel.hpp, whose four-wave kernel this
+// one replaces on every grid).
+//
+// Why eight waves. The four-wave kernel put ONE wave on each SIMD of a CU: 378 registers of weight prefetch per wave, and a wave issues
+// in order -- so every weight load, every LDS read and every LayerNorm / gate / argmax instruction was time the SIMD's matrix pipe stood
+// idle (round 3's counters: pipe busy 12.9 k of a wave's 38.8 k cycles; sharing a weight stream between two tiles, two workgroups per CU
+// in lockstep and a software pipeline of two tiles all measured within 3 % of it). Here a workgroup is still one 32-aircraft tile, but
+// EIGHT waves, two per SIMD, each owning 16 of a layer's output columns (v_mfma_f32_16x16x32_bf16: M = 16 aircraft x N = 16 columns x
+// K = 32 per instruction, two M-tiles per wave): the two waves of a SIMD run the same phase on different columns, so one's load issue and
+// LDS waits sit under the other's matrix instructions, and the vector phases (LayerNorm, gate algebra, argmax, staging) are spread over
+// twice the lanes. A operands are read from the LDS planes per k-step (two M-tiles x three pieces = six ds_read_b128 per 36 matrix
+// instructions) instead of living in 96 registers, weight pieces stream through a three-stage ring of one k-step each: <= 256 registers,
+// no scratch.
+//
+// Weight tiles for this form (ac_load_controller): tile(c, K) = the 16 output columns 16 c .. 16 c + 15 of a layer = K/32 k-steps x
+// 3 pieces x 64 lanes x 8 bf16; element (s, p, lane, i) = piece p of W[j = 16 c + lane % 16][k = 32 s + 8 (lane / 16) + i] (the B
+// operand map of the 16x16x32 instruction: lane l holds B[k = 8 (l >> 4) + i][col = l & 15]).
+#pragma once
+
+namespace ctl8 {
+using ctl::HID; using ctl::NH; using ctl::NHP; using ctl::MT; using ctl::LS;
+using ctls::KS; using ctls::PLANE; using ctls::RS; using ctls::bf16x8; using ctls::split3_pair;
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int tile_floats(int K) { return (K / 32) * 3 * 64 * 4; }   // in floats (a uint4 = 8 bf16 = 4 floats)
+enum : int {
+  C_W1 = 0,                                  // K = 32 (12 padded), 8 tiles
+  C_W2 = C_W1 + 8 * tile_floats(32),         // K = 128, 8 tiles
+  C_WIH = C_W2 + 8 * tile_floats(128),       // 24 tiles: gate g (r, z, n), unit tile u -> tile 8 g + u
+  C_WHH = C_WIH + 24 * tile_floats(128),     // 24 tiles
+  C_WA = C_WHH + 24 * tile_floats(128),      // 10 tiles (columns 153..159 zero)
+  C_B1 = C_WA + 10 * tile_floats(128), C_G1 = C_B1 + 128, C_BE1 = C_G1 + 128,
+  C_B2 = C_BE1 + 128, C_G2 = C_B2 + 128, C_BE2 = C_G2 + 128,
+  C_BIH = C_BE2 + 128, C_BHH = C_BIH + 384, C_G3 = C_BHH + 384, C_BE3 = C_G3 + 128,
+  C_BA = C_BE3 + 128,                        // [160]
+  C_END = C_BA + NHP
+};
+__device__ __forceinline__ floatx4 splat4(float v) { floatx4 a = {v, v, v, v}; return a; }
+__device__ __forceinline__ floatx4 mf(const uint4& a, const uint4& b, floatx4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+// result layout of a 16x16 tile: acc[i] is (row = 4 (lane / 16) + i, column = lane % 16)
+__device__ __forceinline__ int c_row(int mt, int i, int lane) { return 16 * mt + 4 * (lane >> 4) + i; }
+
+// A operands of one k-step for this lane: [M-tile][piece] = planes[piece][row = 16 mt + lane % 16][k = 32 s + 8 (lane / 16) .. + 7]
+struct AF { uint4 a[2][3]; };
+__device__ __forceinline__ void load_af(const unsigned short* planes, int lane, int s, AF& A) {
+  const unsigned short* base = planes + (lane & 15) * KS + 8 * (lane >> 4) + 32 * s;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) A.a[mt][p] = *reinterpret_cast<const uint4*>(base + p * PLANE + 16 * mt * KS);
+}
+struct BS { uint4 b[3]; };   // one k-step of one 16-column tile: the three pieces
+__device__ __forceinline__ void load_bs(const uint4* __restrict__ t4 /* tile + lane */, int s, BS& B) {
+#pragma unroll
+  for (int p = 0; p < 3; ++p) B.b[p] = t4[(s * 3 + p) * 64];
+}
+template <int K>
+struct BT { BS s[K / 32]; };
+template <int K>
+__device__ __forceinline__ void prefetch_bt(const float* __restrict__ tile, int lane, BT<K>& B) {
+  const uint4* t4 = reinterpret_cast<const uint4*>(tile) + lane;
+#pragma unroll
+  for (int s = 0; s < K / 32; ++s) load_bs(t4, s, B.s[s]);
+}
+// one k-step of one tile on three accumulation chains per M-tile (the 2^-16 terms, the 2^-8 terms, the leading term), like mma1 of the
+// four-wave kernel
+#define CTL8_STEP(lo, mid, acc, A, B)                                                                                     \
+  do {                                                                                                                    \
+    lo[0] = mf(A.a[0][2], B.b[0], lo[0]); lo[1] = mf(A.a[1][2], B.b[0], lo[1]);                                           \
+    mid[0] = mf(A.a[0][1], B.b[0], mid[0]); mid[1] = mf(A.a[1][1], B.b[0], mid[1]);                                       \
+    acc[0] = mf(A.a[0][0], B.b[0], acc[0]); acc[1] = mf(A.a[1][0], B.b[0], acc[1]);                                       \
+    lo[0] = mf(A.a[0][0], B.b[2], lo[0]); lo[1] = mf(A.a[1][0], B.b[2], lo[1]);                                           \
+    mid[0] = mf(A.a[0][0], B.b[1], mid[0]); mid[1] = mf(A.a[1][0], B.b[1], mid[1]);                                       \
+    lo[0] = mf(A.a[0][1], B.b[1], lo[0]); lo[1] = mf(A.a[1][1], B.b[1], lo[1]);                                           \
+  } while (0)
+// a whole K = 128 layer for this wave's 16 columns: the weight tile is in registers (asked for a phase earlier), the A operands come
+// from the planes one k-step ahead of their use
+__device__ __forceinline__ void layer128(const BT<HID>& B, const unsigned short* planes, int lane, floatx4 (&acc)[2]) {
+  floatx4 lo[2] = {splat4(0.0f), splat4(0.0f)}, mid[2] = {splat4(0.0f), splat4(0.0f)};
+  AF A[2];
+  load_af(planes, lane, 0, A[0]);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (s + 1 < 4) load_af(planes, lane, s + 1, A[(s + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    CTL8_STEP(lo, mid, acc, A[s & 1], B.s[s]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[mt][i] += mid[mt][i] + lo[mt][i];
+}
+// the GRU's k-steps: three gate tiles of this wave's 16 hidden units, the six terms smallest first into one accumulator per (gate, M-tile)
+#define CTL8_GRU_TERM(a0, a1, a2, A, pa, B, pb)                                                                           \
+  do {                                                                                                                    \
+    a0[0] = mf(A.a[0][pa], B[0].b[pb], a0[0]); a1[0] = mf(A.a[0][pa], B[1].b[pb], a1[0]); a2[0] = mf(A.a[0][pa], B[2].b[pb], a2[0]); \
+    a0[1] = mf(A.a[1][pa], B[0].b[pb], a0[1]); a1[1] = mf(A.a[1][pa], B[1].b[pb], a1[1]); a2[1] = mf(A.a[1][pa], B[2].b[pb], a2[1]); \
+  } while (0)
+#define CTL8_GRU_STEP(a0, a1, a2, A, B)                                                                                   \
+  do {                                                                                                                    \
+    CTL8_GRU_TERM(a0, a1, a2, A, 2, B, 0); CTL8_GRU_TERM(a0, a1, a2, A, 0, B, 2); CTL8_GRU_TERM(a0, a1, a2, A, 1, B, 1);   \
+    CTL8_GRU_TERM(a0, a1, a2, A, 1, B, 0); CTL8_GRU_TERM(a0, a1, a2, A, 0, B, 1); CTL8_GRU_TERM(a0, a1, a2, A, 0, B, 0);   \
+  } while (0)
+__device__ __forceinline__ void ring_load(const float* __restrict__ W, int w, int lane, int st, BS (&dst)[3]) {
+  const int TF = tile_floats(HID);
+  const float* base = W + (st < 4 ? C_WIH : C_WHH);
+#pragma unroll
+  for (int g = 0; g < 3; ++g) load_bs(reinterpret_cast<const uint4*>(base + (8 * g + w) * TF) + lane, st & 3, dst[g]);
+}
+// eight consecutive features of one aircraft -> the three planes (one 16-byte LDS store per plane)
+__device__ __forceinline__ void write_planes8(unsigned short* planes, int row, int k0, const float (&v)[8]) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) split3_pair(v[2 * q], v[2 * q + 1], h[q], m[q], l[q]);
+  *reinterpret_cast<uint4*>(planes + 0 * PLANE + row * KS + k0) = make_uint4(h[0], h[1], h[2], h[3]);
+  *reinterpret_cast<uint4*>(planes + 1 * PLANE + row * KS + k0) = make_uint4(m[0], m[1], m[2], m[3]);
+  *reinterpret_cast<uint4*>(planes + 2 * PLANE + row * KS + k0) = make_uint4(l[0], l[1], l[2], l[3]);
+}
+// torch.nn.LayerNorm(128) (eps 1e-5, biased variance) of buf[row][k] (fp32, row stride RS) into the three bf16 planes the next layer's
+// A operands are read from. Thread = (aircraft = tid / 16, part = tid % 16) owns features 8 part .. 8 part + 7; the sixteen parts of an
+// aircraft sit in adjacent lanes: mean and variance are four butterfly steps each, no partial sums through LDS.
+__device__ __forceinline__ float group16_sum(float v) {
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  return v;
+}
+__device__ __forceinline__ void layer_norm_planes(const float* buf, unsigned short* planes, const float* __restrict__ g, const float* __restrict__ b, int tid) {
+  const int row = tid >> 4, part = tid & 15;
+  const float4 g0 = *reinterpret_cast<const float4*>(g + 8 * part), g1 = *reinterpret_cast<const float4*>(g + 8 * part + 4);   // (from L2: behind the reductions)
+  const float4 b0 = *reinterpret_cast<const float4*>(b + 8 * part), b1 = *reinterpret_cast<const float4*>(b + 8 * part + 4);
+  const float4 x0 = *reinterpret_cast<const float4*>(buf + row * RS + 8 * part), x1 = *reinterpret_cast<const float4*>(buf + row * RS + 8 * part + 4);
+  float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+  const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  const float m = group16_sum(((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) * (1.0f / HID);
+  float v = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { x[q] -= m; v = fmaf(x[q], x[q], v); }
+  const float is = rsqrtf(group16_sum(v) * (1.0f / HID) + 1e-5f);
+  float y[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) y[q] = fmaf(x[q] * is, gg[q], bb[q]);
+  write_planes8(planes, row, 8 * part, y);
+  __syncthreads();
+}
+}  // namespace ctl8
+
+// SCRIPTED: the handle has scripted opponents (`use_baseline`); their state -> pose code is compiled into that instantiation only.
+template <bool SCRIPTED>
+__global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
+  using namespace ctl8;
+  using ctl::sigmoid_f; using ctl::tanh_f;
+  __shared__ __attribute__((aligned(16))) unsigned short PA[3 * PLANE];   // activations as bf16 planes [piece][aircraft][k]
+  __shared__ __attribute__((aligned(16))) unsigned short PH[3 * PLANE];   // the GRU state likewise; the head logits (fp32 [160][LS]) later
+  __shared__ __attribute__((aligned(16))) float stg[HID * LS];   // a layer's fp32 outputs [aircraft][k] (row stride RS) on their way to LayerNorm
+  __shared__ __attribute__((aligned(16))) float hbuf[MT * RS];   // GRU state of the 32 aircraft, fp32 [aircraft][unit] (gate algebra)
+  static_assert(MT * RS <= HID * LS, "staging rows fit");
+  static_assert(sizeof(unsigned short) * 3 * PLANE >= sizeof(float) * NHP * LS, "the logits reuse the GRU-state planes");
+  float* lg = reinterpret_cast<float*>(PH);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave 0..7: output columns 16 w .. 16 w + 15 of every 128-wide layer
+  const int i0 = blockIdx.x * MT;
+  const float* __restrict__ W = a.Ws8;
+  const int col = lane & 15;
+
+  // ---- stage. Loads return in the order they were asked for: the 12 controller inputs first (layer 1 waits for nothing else), then
+  // layer 1's weights, the GRU state (first needed by the GRU) and layer 2's weights.
+  AC_CLK(200);
+  BT<32> b1;
+  BT<HID> b2;
+  const int srow = tid & 31, spart = tid >> 5;   // staging: thread = (aircraft, 8-feature part)
+  const int sn = min(i0 + srow, a.N - 1);
+  float x[16];
+  if (spart == 0) {
+    const float* hi = a.hi + (size_t)sn * a.act_hi;
+    const float* ob = a.obs + (size_t)sn * a.obs_dim;
+    const int slot = sn % a.A;
+    if (SCRIPTED && a.use_baseline && slot >= a.n_ego) {
+      // the enemy team is flown by BaselineAgent k: its 12 inputs come from the geometry (no action row is read for it)
+      float xs[12];
+      ctl::scripted_inputs(a, sn, xs);
+#pragma unroll
+      for (int k = 0; k < 12; ++k) x[k] = xs[k];
+    } else {
+      const int c0 = (int)hi[0], c1 = (int)hi[1], c2 = (int)hi[2];
+      // singlecombat_task.py:217-219, 235-241: below 3500 m the altitude choice is overridden by "climb"
+      x[0] = (ob[0] * 5000.0f < 3500.0f) ? 0.1f : (c0 == 0 ? 0.1f : (c0 == 1 ? 0.0f : -0.1f));
+      x[1] = (float)(c1 - 2) * 0.26179938779914943f;   // {-pi/6, -pi/12, 0, pi/12, pi/6}
+      x[2] = c2 == 0 ? 0.05f : (c2 == 1 ? 0.0f : -0.05f);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) x[3 + k] = ob[k];
+    }
+    x[12] = 0.0f; x[13] = 0.0f; x[14] = 0.0f; x[15] = 0.0f;   // (k 12..31 of the one 32-k step are zero)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  prefetch_bt<32>(W + C_W1 + w * tile_floats(32), lane, b1);
+  float hv[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) hv[f] = a.H[(size_t)(spart * 8 + f) * a.N + sn];
+  prefetch_bt<HID>(W + C_W2 + w * tile_floats(HID), lane, b2);
+  __builtin_amdgcn_sched_barrier(0);
+  if (spart == 0) {
+    const float lo8[8] = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]}, hi8[8] = {x[8], x[9], x[10], x[11], 0.0f, 0.0f, 0.0f, 0.0f};
+    write_planes8(PA, srow, 0, lo8); write_planes8(PA, srow, 8, hi8);
+  } else if (spart <= 2) {   // zero k 16..31 of the three planes
+    const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(PA + p * PLANE + srow * KS + 8 * (spart + 1)) = z;
+  }
+  __syncthreads();
+
+  AC_CLK(201);
+  // ---- MLP layer 1: Linear(12, 128) + ReLU + LayerNorm; wave w owns output columns 16 w .. 16 w + 15
+  {
+    AF A;
+    load_af(PA, lane, 0, A);
+    const float bias = W[C_B1 + w * 16 + col];
+    floatx4 acc[2] = {splat4(bias), splat4(bias)}, lo[2] = {splat4(0.0f), splat4(0.0f)}, mid[2] = {splat4(0.0f), splat4(0.0f)};
+    CTL8_STEP(lo, mid, acc, A, b1.s[0]);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) stg[c_row(mt, i, lane) * RS + w * 16 + col] = fmaxf(acc[mt][i] + (mid[mt][i] + lo[mt][i]), 0.0f);
+  }
+  {   // the GRU state has arrived behind layer 1: fp32 for the gate algebra, bf16 planes for the products
+    *reinterpret_cast<float4*>(hbuf + srow * RS + spart * 8) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+    *reinterpret_cast<float4*>(hbuf + srow * RS + spart * 8 + 4) = make_float4(hv[4], hv[5], hv[6], hv[7]);
+    write_planes8(PH, srow, spart * 8, hv);
+  }
+  __syncthreads();
+  AC_CLK(202);
+  layer_norm_planes(stg, PA, W + C_G1, W + C_BE1, tid);
+  AC_CLK(203);
+  // ---- MLP layer 2
+  {
+    const float bias = W[C_B2 + w * 16 + col];
+    floatx4 acc[2] = {splat4(bias), splat4(bias)};
+    layer128(b2, PA, lane, acc);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) stg[c_row(mt, i, lane) * RS + w * 16 + col] = fmaxf(acc[mt][i], 0.0f);
+  }
+  BS ring[3][3];   // [stage][gate]: the GRU's first two k-steps, behind LayerNorm 2
+  ring_load(W, w, lane, 0, ring[0]);
+  ring_load(W, w, lane, 1, ring[1]);
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  AC_CLK(204);
+  layer_norm_planes(stg, PA, W + C_G2, W + C_BE2, tid);
+  AC_CLK(205);
+  // ---- GRU cell (torch gate order r, z, n): wave w owns hidden units 16 w .. 16 w + 15, i.e. gate tiles w, 8 + w, 16 + w
+  BT<HID> bh;
+  BS b5;
+  {
+    const float bir = W[C_BIH + 0 * 128 + w * 16 + col], biz = W[C_BIH + 1 * 128 + w * 16 + col], bin = W[C_BIH + 2 * 128 + w * 16 + col];
+    const float bhr = W[C_BHH + 0 * 128 + w * 16 + col], bhz = W[C_BHH + 1 * 128 + w * 16 + col], bhn = W[C_BHH + 2 * 128 + w * 16 + col];
+    floatx4 ir[2] = {splat4(bir), splat4(bir)}, iz[2] = {splat4(biz), splat4(biz)}, in_[2] = {splat4(bin), splat4(bin)};
+    floatx4 hr[2] = {splat4(bhr), splat4(bhr)}, hz[2] = {splat4(bhz), splat4(bhz)}, hn[2] = {splat4(bhn), splat4(bhn)};
+    {
+      AF A[2];
+      load_af(PA, lane, 0, A[0]);
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        // (the scheduling fences keep the loads where they are written: left alone, the machine scheduler sinks every weight load
+        // to just in front of its first use to save registers, which serialises an L2 round trip with every k-step)
+        if (st + 2 < 8) ring_load(W, w, lane, st + 2, ring[(st + 2) % 3]);
+        if (st + 1 < 8) load_af(st + 1 < 4 ? PA : PH, lane, (st + 1) & 3, A[(st + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st < 4) CTL8_GRU_STEP(ir, iz, in_, A[st & 1], ring[st % 3]);
+        else CTL8_GRU_STEP(hr, hz, hn, A[st & 1], ring[st % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // the heads' weights (this wave's tile and its k-step of the ninth / tenth), behind the gate algebra and LayerNorm 3
+    prefetch_bt<HID>(W + C_WA + w * tile_floats(HID), lane, bh);
+    load_bs(reinterpret_cast<const uint4*>(W + C_WA + (8 + (w & 1)) * tile_floats(HID)) + lane, w >> 1, b5);
+    __builtin_amdgcn_sched_barrier(0);
+    AC_CLK(206);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = c_row(mt, i, lane), unit = w * 16 + col;
+        const float rg = sigmoid_f(ir[mt][i] + hr[mt][i]);
+        const float zg = sigmoid_f(iz[mt][i] + hz[mt][i]);
+        // (explicit fused multiply-adds: which products the compiler fuses on its own depends on the code around them, and two builds of
+        // this kernel would differ by an ulp)
+        const float ng = tanh_f(fmaf(rg, hn[mt][i], in_[mt][i]));
+        const float hnew = fmaf(zg, hbuf[row * RS + unit], (1.0f - zg) * ng);
+        stg[row * RS + unit] = hnew;
+      }
+  }
+  __syncthreads();
+  AC_CLK(207);
+  {   // the new hidden state goes out row-contiguous (128-byte runs per feature) from LDS; thread = (row, 8-feature part)
+    const int row = tid & 31, part = tid >> 5, n = i0 + row;
+    if (n < a.N) {
+      const float4 h0 = *reinterpret_cast<const float4*>(stg + row * RS + part * 8), h1 = *reinterpret_cast<const float4*>(stg + row * RS + part * 8 + 4);
+      const float hh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+      for (int f = 0; f < 8; ++f) a.H[(size_t)(part * 8 + f) * a.N + n] = hh[f];
+    }
+  }
+  AC_CLK(208);
+  layer_norm_planes(stg, PA, W + C_G3, W + C_BE3, tid);
+  AC_CLK(209);
+  // ---- heads: 153 logits = ten 16-column tiles; wave w takes tile w, and one k-step of tile 8 + (w & 1) (logits 128 .. 159)
+  {
+    const float bias = W[C_BA + w * 16 + col];
+    floatx4 acc[2] = {splat4(bias), splat4(bias)};
+    layer128(bh, PA, lane, acc);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lg[(w * 16 + col) * LS + c_row(mt, i, lane)] = acc[mt][i];   // (the GRU-state planes under lg were last read before two barriers)
+    // tiles 8 and 9: their K range is split over four waves each (k-step w >> 1); the partial sums go to stg (free by now) and are added
+    // in a fixed order below
+    {
+      AF A;
+      load_af(PA, lane, w >> 1, A);
+      floatx4 part[2] = {splat4(0.0f), splat4(0.0f)}, lo[2] = {splat4(0.0f), splat4(0.0f)}, mid[2] = {splat4(0.0f), splat4(0.0f)};
+      CTL8_STEP(lo, mid, part, A, b5);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stg[((w >> 1) * 32 + (w & 1) * 16 + col) * LS + c_row(mt, i, lane)] = part[mt][i] + (mid[mt][i] + lo[mt][i]);
+    }
+  }
+  __syncthreads();
+  AC_CLK(210);
+  // logits 128 .. 152 = bias + the four K-partials, summed in a fixed order (25 columns x 32 aircraft over 512 threads)
+  for (int e = tid; e < 25 * 32; e += 512) {
+    const int q = e >> 5, row = e & 31;
+    lg[(128 + q) * LS + row] = (((W[C_BA + 128 + q] + stg[q * LS + row]) + stg[(32 + q) * LS + row]) + stg[(64 + q) * LS + row]) + stg[(96 + q) * LS + row];
+  }
+  __syncthreads();
+  AC_CLK(211);
+  {   // argmax: wave = (head, half of the rows), lane = (quarter of the head's logits, row): first maximum, like torch argmax
+    const int head = w >> 1, row = 16 * (w & 1) + (lane & 15), quarter = lane >> 4;
+    const int off = head * 41, cnt = (head == 3) ? 30 : 41;
+    const int j0 = 11 * quarter;
+    // (quarter 0 starts from logit 0 like the sequential scan does; the others from -inf, so that a NaN logit is skipped, not adopted)
+    float best = quarter == 0 ? lg[off * LS + row] : -INFINITY;
+    int bi = quarter == 0 ? 0 : cnt;
+    for (int j = j0 + (quarter == 0 ? 1 : 0); j < min(cnt, j0 + 11); ++j) {
+      const float v = lg[(off + j) * LS + row];
+      if (v > best) { best = v; bi = j; }
+    }
+    // the later quarter only wins with a strictly larger value (its indices are all higher)
+#pragma unroll
+    for (int d = 16; d <= 32; d <<= 1) {
+      const float v2 = __shfl_down(best, d);
+      const int i2 = __shfl_down(bi, d);
+      if (v2 > best) { best = v2; bi = i2; }
+    }
+    const int nn = i0 + row;
+    if (quarter == 0 && nn < a.N) a.low[(size_t)nn * a.act_low + head] = (float)bi;
+    if (quarter == 1 && head == 0 && nn < a.N) {   // weapon bits ride along unchanged
+      const bool scripted = a.use_baseline && (nn % a.A) >= a.n_ego;   // scenario1_task.py:42-48: bits [0,0,0,0], or all ones with artillery
+      for (int k = 4; k < a.act_low; ++k)
+        a.low[(size_t)nn * a.act_low + k] = scripted ? (a.use_artillery ? 1.0f : 0.0f) : a.hi[(size_t)nn * a.act_hi + (k - 1)];
+    }
+  }
+  AC_CLK(212);
+}

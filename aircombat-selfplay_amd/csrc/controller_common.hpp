@@ -29,6 +29,7 @@ enum : int {
 
 struct Args {
   const float* Ws;         // the weights as bf16 pieces, tiled for controller_split_kernel (controller_split_kernel.hpp)
+  const float* Ws8;        // the same, tiled for controller8_kernel (16-column tiles, 32-k steps: controller8_kernel.hpp)
   const float* hi;         // [N][act_hi]: 3 high-level choices (+ weapon bits passed through)
   const float* obs;        // [N][obs_dim]: observation of the CURRENT state (last step's / the reset's output)
   float* H;                // [128][N] GRU state

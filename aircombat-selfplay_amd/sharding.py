@@ -45,3 +45,22 @@ def max_over_ranks(values, dist=None, device="cpu"):
 def barrier(dist=None):
     if dist is not None:
         dist.barrier()
+
+
+def rank_census(dist=None, device="cpu", device_ordinal=0, pci_bus_id=0, agent_steps=0.0):
+    """What makes an N > 1 bench line self-proving: every rank adds a 1, its device ordinal, its GPU's PCI bus id and the agent-steps
+    it ran into its own slot of one SUM all-reduce on the job's process group (RCCL on GPUs). Returns {"ranks_reporting": how many
+    ranks took part in the collective, "devices": [{"rank", "device", "pci_bus_id"} ...], "agent_steps_per_rank": [...]};
+    a rank that never joined leaves its slot empty (and the collective would not have completed)."""
+    rank, world, _ = dist_env()
+    if dist is None:
+        return {"ranks_reporting": 1, "devices": [{"rank": 0, "device": int(device_ordinal), "pci_bus_id": int(pci_bus_id)}],
+                "agent_steps_per_rank": [float(agent_steps)]}
+    import torch
+    t = torch.zeros(world, 4, dtype=torch.float64, device=device)
+    t[rank, 0], t[rank, 1], t[rank, 2], t[rank, 3] = 1.0, float(device_ordinal), float(pci_bus_id), float(agent_steps)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t = t.cpu()
+    return {"ranks_reporting": int(t[:, 0].sum().item()),
+            "devices": [{"rank": r, "device": int(t[r, 1].item()), "pci_bus_id": int(t[r, 2].item())} for r in range(world) if t[r, 0] > 0],
+            "agent_steps_per_rank": [float(t[r, 3].item()) for r in range(world)]}

@@ -7,14 +7,19 @@ Mirrors ``SubprocVecEnv`` / ``DummyVecEnv`` of the reference (envs/env_wrappers.
 (the buffers cast to float32 on insert, algorithms/utils/buffer.py:52-58).
 
 Ownership of what ``step`` returns. The reference hands back fresh arrays every step (``np.stack``, env_wrappers.py:276-282), so a
-caller may keep ``obs`` / ``dones`` / ``infos`` of step t for as long as it likes. That is the default here too: ``step`` returns
-copies. ``copy=False`` (constructor argument; bench.py uses it, INTEGRATION.md section 3 describes it) returns live views of the
-library's two alternating page-locked buffer sets instead: valid until the step after next overwrites them, and never after
+caller may keep ``obs`` / ``dones`` / ``infos`` of step t for as long as it likes. That is the default here too (``copy=True``), and
+it costs no copy in the usual rollout loop: the library keeps a small ring of page-locked result sets (the step kernel writes its
+outputs straight into one), and ``step`` picks a set whose arrays NOBODY outside holds any more -- the caller's names, slices, views,
+tensors made from them all count as holding (reference counts) -- so an array the caller still has is never written again. When the
+caller hoards more results than the ring has sets, ``step`` falls back to handing out fresh copies. The arrays outlive ``close()``
+(a set still held then is detached from the handle and freed with its last array). ``copy=False`` (constructor argument) returns
+live views of two alternating sets instead, without any check: valid until the step after next overwrites them, never after
 ``close()``. A non-finite aircraft state surfaces as ``RuntimeError`` (the reference's ``RuntimeError("JSBSim failed.")``,
 core/simulatior.py:223-225; its ``pdb`` NaN trap in ``_pack``, env_base.py:277-281, is not reproduced).
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -128,6 +133,32 @@ def _spaces():
 CONTROLLER_WEIGHTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "baseline_actor.f32")
 
 
+RING_SETS = 4        # result sets the default mode cycles through (the library allows AC_HOST_SETS = 8; one more is the staging set)
+
+
+class _HostSetOwner:
+    """One set of the library's page-locked buffers. While the handle lives the library owns the memory; a set whose arrays the caller
+    still holds at close() is detached (ac_host_set_detach) and this object frees it when the last array referring to it is gone."""
+
+    def __init__(self, lib, ptrs):
+        self.lib, self.ptrs, self.detached = lib, [p.value for p in ptrs], False
+
+    def __del__(self):
+        if self.detached:
+            try:
+                self.lib.ac_host_set_free(*self.ptrs)
+            except Exception:       # interpreter shutdown: the process's memory goes with it
+                pass
+
+
+class _Mapped:
+    """Array-interface view of one buffer of a set; numpy keeps it (and through it the set's owner) alive as the arrays' base."""
+
+    def __init__(self, owner, ptr, shape, typestr):
+        self.owner = owner
+        self.__array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 3}
+
+
 class HipVecEnv:
     """E parallel 1v1 air-combat envs advanced by one HIP kernel launch per ``step``."""
 
@@ -171,32 +202,70 @@ class HipVecEnv:
             self.action_space = Tuple([MultiDiscrete([41, 41, 41, 30]), MultiDiscrete([2, 2, 2, 2])])
         else:
             self.action_space = MultiDiscrete([41, 41, 41, 30])
-        E, A = self.num_envs, self.num_agents
-        # Two sets of page-locked host buffers owned by the library and mapped into the device (ac_host_buffers): the step kernel
-        # reads the actions from, and writes observations / rewards / dones / info into, the set of the step. step() alternates the
-        # sets, so what it returns stays untouched while the next step runs (the reference returns fresh arrays,
-        # env_wrappers.py:276-282, and its callers copy them into their buffers right away, runner/jsbsim_runner.py:104).
+        # Sets of page-locked host buffers owned by the library and mapped into the device (ac_host_buffers): the step kernel reads
+        # the actions from, and writes observations / rewards / dones / info into, the set of the step. copy=False alternates two
+        # sets, so what step() returns stays untouched while the next step runs; the default mode cycles through a ring of sets and
+        # only steps into one whose arrays the caller has dropped (module docstring).
         self._sets = []
         for k in range(2):
-            ptrs = [C.c_void_p() for _ in range(5)]
-            self.lib.check(self.lib.ac_host_buffers(self._h, k, *[C.byref(p) for p in ptrs]), "ac_host_buffers")
-
-            def arr(ptr, shape, ctype):
-                n = int(np.prod(shape))
-                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).reshape(shape)
-
-            self._sets.append({
-                "actions": arr(ptrs[0], (E, A, self.act_dim), C.c_float),
-                "obs": arr(ptrs[1], (E, A, self.obs_dim), C.c_float),
-                "rew": arr(ptrs[2], (E, A, 1), C.c_float),
-                "done": arr(ptrs[3], (E, A, 1), C.c_uint8).view(np.bool_),     # the kernel writes 0 / 1
-                "info": arr(ptrs[4], (E,), C.c_int32),
-            })
+            self._add_set()
         self._cur = 0
+        self._pending = None
+        self._staging = None         # default mode's fallback: a set that is never handed out (results are copied out of it)
         self._actions = self._sets[0]["actions"]
         # what step() hands back for each set, built once: the arrays are views of fixed buffers, and LazyInfos reads its codes when asked
         self._results = [self._result(st) for st in self._sets]
         self._step_host = self.lib.ac_step_host
+        self._ref0 = self._refs(self._sets[0])   # what a set's arrays count when only this object holds them
+
+    def _add_set(self):
+        k = len(self._sets)
+        E, A = self.num_envs, self.num_agents
+        ptrs = [C.c_void_p() for _ in range(5)]
+        self.lib.check(self.lib.ac_host_buffers(self._h, k, *[C.byref(p) for p in ptrs]), "ac_host_buffers")
+        owner = _HostSetOwner(self.lib, ptrs)
+
+        def arr(ptr, shape, typestr):
+            return np.asarray(_Mapped(owner, ptr.value, shape, typestr))
+
+        st = {"actions": arr(ptrs[0], (E, A, self.act_dim), "<f4"), "owner": owner, "index": k,
+              # (kept in ONE tuple and nowhere else, so that their reference counts tell whether anybody outside holds them; the info
+              # words count too: the LazyInfos handed out with a step reads them when it is asked)
+              "out": (arr(ptrs[1], (E, A, self.obs_dim), "<f4"), arr(ptrs[2], (E, A, 1), "<f4"), arr(ptrs[3], (E, A, 1), "|b1"),   # the kernel writes 0 / 1
+                      arr(ptrs[4], (E,), "<i4"))}
+        self._sets.append(st)
+        return st
+
+    def _held(self, st):
+        """Does anybody outside this object hold one of the set's result arrays (a name, a slice, a view, a tensor sharing its memory)?"""
+        return self._refs(st) != self._ref0
+
+    @staticmethod
+    def _refs(st):
+        t = st["out"]
+        return sys.getrefcount(t[0]), sys.getrefcount(t[1]), sys.getrefcount(t[2]), sys.getrefcount(t[3])
+
+    def _next_set(self):
+        """copy=False: the other one of two sets. Default: the next set of the ring that nobody holds, one more set while the ring may
+        grow, else the staging set (its results are then copied out, like the reference's np.stack)."""
+        if not self.copy:
+            self._cur ^= 1
+            return self._sets[self._cur], False
+        n = len(self._sets)
+        for i in range(1, n + 1):
+            st = self._sets[(self._cur + i) % n]
+            if not self._held(st):
+                self._cur = st["index"]
+                return st, False
+        if n < RING_SETS:
+            st = self._add_set()
+            self._results.append(self._result(st))
+            self._cur = st["index"]
+            return st, False
+        if self._staging is None:
+            self._staging = self._add_set()
+            self._sets.pop()                     # (not part of the ring)
+        return self._staging, True
 
     # ---- reference surface
     def seed(self, seed=None):
@@ -215,49 +284,62 @@ class HipVecEnv:
 
     def reset(self):
         self._assert_not_closed()
-        obs = self._sets[self._cur]["obs"]
+        obs = np.empty((self.num_envs, self.num_agents, self.obs_dim), dtype=np.float32)     # the caller's own, like the reference's np.stack
         self.lib.check(self.lib.ac_reset(self._h, obs.ctypes.data), "ac_reset")
-        return obs.copy()
+        return obs
+
+    def _hand_over(self, actions):
+        """Pick the set of this step and put the actions into its mapped buffer (the kernel reads them from there)."""
+        st, staged = self._next_set()
+        dst = st["actions"]
+        a = actions if isinstance(actions, np.ndarray) else np.asarray(actions, dtype=np.float32)
+        if a.shape != dst.shape:
+            a = a.reshape(dst.shape)  # nested lists [E][A][act_dim] from the runners
+        np.copyto(dst, a)
+        return st, staged
 
     def step_async(self, actions):
         """SubprocVecEnv.step_async (env_wrappers.py:269-273): hand the actions over and start the step."""
         self._assert_not_closed()
-        self._cur ^= 1
-        dst = self._sets[self._cur]["actions"]
-        a = actions if isinstance(actions, np.ndarray) else np.asarray(actions, dtype=np.float32)
-        if a.shape != dst.shape:
-            a = a.reshape(dst.shape)  # nested lists [E][A][act_dim] from the runners
-        np.copyto(dst, a)             # into the mapped buffer the kernel reads
-        self.lib.check(self.lib.ac_step_host_async(self._h, self._cur), "ac_step_host_async")
+        self._pending = self._hand_over(actions)
+        self.lib.check(self.lib.ac_step_host_async(self._h, self._pending[0]["index"]), "ac_step_host_async")
         self.waiting = True
 
     def step_wait(self):
-        """SubprocVecEnv.step_wait (env_wrappers.py:275-282): fresh float32 arrays (the buffers cast on insert,
+        """SubprocVecEnv.step_wait (env_wrappers.py:275-282): float32 arrays the caller owns (the buffers cast on insert,
         algorithms/utils/buffer.py:52-58), or with copy=False views of the step's buffer set, valid until the step after next."""
         self._assert_not_closed()
         self.lib.check(self.lib.ac_step_host_wait(self._h), "ac_step_host_wait")
         self.waiting = False
-        return self._fresh(self._cur) if self.copy else self._results[self._cur]
+        st, staged = self._pending
+        return self._returned(st, staged)
+
+    def _returned(self, st, staged):
+        if not self.copy:
+            return self._results[st["index"]]
+        return self._fresh(st) if staged else self._owned(st)
 
     def _result(self, st):
-        return st["obs"], st["rew"], st["done"], LazyInfos(st["info"])
+        o = st["out"]
+        return o[0], o[1], o[2], LazyInfos(o[3])
 
-    def _fresh(self, cur):
-        st = self._sets[cur]
-        return st["obs"].copy(), st["rew"].copy(), st["done"].copy(), LazyInfos(st["info"], snapshot=True)
+    def _owned(self, st):
+        """The set's arrays themselves: nobody else held them when the step began, and they are not written again while the caller does
+        (the info words included: the LazyInfos keeps them, and with them the set, for as long as the caller keeps it)."""
+        o = st["out"]
+        return o[0], o[1], o[2], LazyInfos(o[3])
+
+    def _fresh(self, st):
+        o = st["out"]
+        return o[0].copy(), o[1].copy(), o[2].copy(), LazyInfos(o[3], snapshot=True)
 
     def step(self, actions):
         """VecEnv.step = step_async + step_wait (env_wrappers.py:30-42), through one library call."""
         assert not self.closed, "Trying to operate on a HipVecEnv after calling close()"
-        cur = self._cur = self._cur ^ 1
-        dst = self._sets[cur]["actions"]
-        a = actions if isinstance(actions, np.ndarray) else np.asarray(actions, dtype=np.float32)
-        if a.shape != dst.shape:
-            a = a.reshape(dst.shape)
-        np.copyto(dst, a)
-        if self._step_host(self._h, cur) != 0:
+        st, staged = self._hand_over(actions)
+        if self._step_host(self._h, st["index"]) != 0:
             self.lib.check(-1, "ac_step_host")      # RuntimeError: a HIP failure, or a non-finite aircraft state ("JSBSim failed.")
-        return self._fresh(cur) if self.copy else self._results[cur]
+        return self._returned(st, staged)
 
     def render(self, mode="txt", filepath="./JSBSimRecording.txt.acmi", env=0):
         """BaseEnv.render (env_base.py:207-250) for one env (the reference renders through DummyVecEnv, i.e. env 0): appends one
@@ -337,10 +419,16 @@ class HipVecEnv:
 
     def close(self):
         """Frees the handle and its page-locked buffers. With copy=False the views handed out earlier point into those buffers: they
-        must not be read after close() (with the default copy=True nothing the caller holds refers to library memory)."""
+        must not be read after close(). In the default mode the arrays a caller still holds stay valid: their set is detached from the
+        handle first and freed when the last of them is gone."""
         if self.closed:
             return
-        self._sets, self._results = [], []           # views of library-owned memory: dropped before the handle frees it
+        if self.copy:
+            for st in self._sets:
+                if self._held(st):
+                    self.lib.check(self.lib.ac_host_set_detach(self._h, st["index"]), "ac_host_set_detach")
+                    st["owner"].detached = True
+        self._sets, self._results, self._staging, self._pending = [], [], None, None    # views of library-owned memory: dropped before the handle frees it
         self._actions = None
         self.lib.ac_destroy(self._h)
         self._h = None
@@ -467,13 +555,17 @@ class HipShareVecEnv(HipVecEnv):
         return obs, self._share(obs)
 
     def _result(self, st):
-        obs = st["obs"]
-        return obs, self._share(obs), st["rew"], st["done"], LazyInfos(st["info"])
+        o = st["out"]
+        return o[0], self._share(o[0]), o[1], o[2], LazyInfos(o[3])
 
-    def _fresh(self, cur):
-        st = self._sets[cur]
-        obs = st["obs"].copy()
-        return obs, self._share(obs), st["rew"].copy(), st["done"].copy(), LazyInfos(st["info"], snapshot=True)
+    def _owned(self, st):
+        o = st["out"]
+        return o[0], self._share(o[0]), o[1], o[2], LazyInfos(o[3])
+
+    def _fresh(self, st):
+        o = st["out"]
+        obs = o[0].copy()
+        return obs, self._share(obs), o[1].copy(), o[2].copy(), LazyInfos(o[3], snapshot=True)
 
 
 class MultiDeviceVecEnv:
@@ -504,16 +596,31 @@ class MultiDeviceVecEnv:
         self._pool = ThreadPoolExecutor(max_workers=len(self.parts))
         self._pending = None
 
+    def _share(self, obs):
+        E, A, D = obs.shape
+        return np.broadcast_to(obs.reshape(E, 1, A * D), (E, A, A * D))
+
     def _cat(self, results):
+        """One set of arrays for the caller: every column of the parts' results concatenated along the env axis, except share_obs,
+        which is rebuilt as the broadcast view of the concatenated observations (the parts' share_obs are broadcast views themselves:
+        concatenating them would materialise A copies of every row -- 66 MB per device and step at 4096 envs x 8 aircraft x 504)."""
         cols = list(zip(*results))
-        out = [np.concatenate(c, axis=0) for c in cols[:-1]]
-        return tuple(out) + (LazyInfos(np.concatenate([i._codes for i in cols[-1]], axis=0)),)
+        obs = np.concatenate(cols[0], axis=0)
+        rest = [np.concatenate(c, axis=0) for c in cols[(2 if self.share else 1):-1]]
+        infos = LazyInfos(np.concatenate([i._codes for i in cols[-1]], axis=0))
+        return ((obs, self._share(obs)) if self.share else (obs,)) + tuple(rest) + (infos,)
 
     def reset(self):
-        res = [p.reset() for p in self.parts]
-        if self.share:
-            return tuple(np.concatenate(c, axis=0) for c in zip(*res))
-        return np.concatenate(res, axis=0)
+        obs = np.concatenate([(p.reset()[0] if self.share else p.reset()) for p in self.parts], axis=0)
+        return (obs, self._share(obs)) if self.share else obs
+
+    def render(self, mode="txt", filepath="./JSBSimRecording.txt.acmi", env=0):
+        """BaseEnv.render for env `env` of the whole batch: the part that owns that env writes the frame (env_wrappers.py:167-169
+        renders through DummyVecEnv, i.e. env 0 -- always the first part's)."""
+        for p, (s, c) in zip(self.parts, self.blocks):
+            if s <= env < s + c:
+                return p.render(mode=mode, filepath=filepath, env=env - s)
+        raise IndexError(f"env {env} of {self.num_envs}")
 
     def step_async(self, actions):
         a = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self.num_agents, self.act_dim)

@@ -12,9 +12,10 @@ over the whole batch: 6 FDM ticks per aircraft + observation / reward / terminat
 4v4, as shipped: [3,5,3] + four weapon bits through the low-level controller kernel), same contract, 4096 envs per GPU.
 
 ``value`` is SURVEY 8(d)'s metric: agent-steps per second of ``VecEnv.step(numpy actions) -> numpy obs / rewards / dones / infos`` at
-the Python boundary, every ctypes call and every byte that crosses PCIe included, with the VecEnv in its zero-copy mode
-(``copy=False``: step() returns views of the library's page-locked buffers; ``default_copy_mode`` reports the same leg with the default
-fresh arrays). The same step with the actions and the outputs resident in HBM (``step_device``) is reported beside it as
+the Python boundary, every ctypes call and every byte that crosses PCIe included, with the VecEnv in its DEFAULT mode (``copy=True``:
+step() returns arrays the caller owns, like the reference's np.stack -- handed out without a copy from a ring of page-locked result
+sets that is only ever stepped into where the caller has dropped the previous arrays; ``value_mode`` says so in the line, and
+``zero_copy_views_mode`` reports the same leg with ``copy=False``, the unchecked views of two alternating sets). The same step with the actions and the outputs resident in HBM (``step_device``) is reported beside it as
 ``device_resident``; the ``roofline`` of the dominant kernel is measured on that back-to-back device-resident leg with HIP events on
 the launch stream. At N = 1 the line also carries ``configs`` (BASELINE C3 / C4 / C5 as shipped = hierarchical, and in the
 control-index form, one GPU's 4096-env shard each), a steady-state leg, a saturating-batch leg and the CPU baseline in SURVEY 8(d)'s
@@ -39,9 +40,16 @@ VALU_PER_AGENT_STEP = {"one_wave": 8379.0, "three_wave": 9386.0}
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
+def action_bytes(env):
+    """SURVEY 8(d) prices the action row at 16-28 B: the four control indices (16 B: C2 593, C3 617, C4 689, C5 785 B per agent-step are
+    quoted with that; the weapon bits of the control-index form are not priced), or the as-shipped hierarchical row of 4 * act_dim
+    ([3,5,3] + up to four weapon bits: 12-28 B, floored at 16)."""
+    return float(min(28, max(16, 4 * env.act_dim))) if env.hierarchical else 16.0
+
+
 def algorithmic_bytes(env, missiles_in_flight=0.0):
-    """512 B state + action + 4 * obs_dim + reward + done per agent-step (+ 192 B per live missile-step)."""
-    return 512.0 + 4.0 * env.act_dim + 4.0 * env.obs_dim + 5.0 + 192.0 * missiles_in_flight
+    """512 B state + action (16-28 B) + 4 * obs_dim + reward + done per agent-step (+ 192 B per live missile-step)."""
+    return 512.0 + action_bytes(env) + 4.0 * env.obs_dim + 5.0 + 192.0 * missiles_in_flight
 
 
 def boundary_bytes(env):
@@ -85,10 +93,12 @@ def host_leg(env, pool, steps, warmup, sync_all=None):
         env.step(pool[i % n])
     if sync_all:
         sync_all()
+    res = None
     t0 = time.perf_counter()
     for i in range(steps):
-        env.step(pool[(warmup + i) % n])
+        res = env.step(pool[(warmup + i) % n])     # (kept in a name like a rollout loop does: step t's arrays are alive while step t + 1 runs)
     t1 = time.perf_counter()
+    del res
     if sync_all:
         sync_all()
     return t1 - t0
@@ -133,11 +143,9 @@ def host_launch_ms(env, pool, steps=200):
     ev = C.c_float()
     dll = env.lib.dll
     for i in range(steps + 20):
-        cur = env._cur = env._cur ^ 1
-        dst = env._sets[cur]["actions"]
-        np.copyto(dst, pool[i % len(pool)].reshape(dst.shape))
+        st, _ = env._hand_over(pool[i % len(pool)])      # the set VecEnv.step would pick, actions copied into its mapped buffer
         env.lib.check(env.lib.ac_timing_begin(env._h), "ac_timing_begin")
-        env.lib.check(dll.ac_step_host_async(env._h, cur), "ac_step_host_async")
+        env.lib.check(dll.ac_step_host_async(env._h, st["index"]), "ac_step_host_async")
         env.lib.check(env.lib.ac_timing_end(env._h, C.byref(ev)), "ac_timing_end")
         if i >= 20:
             tot += ev.value
@@ -189,7 +197,7 @@ def config_leg(pkg, np, torch, name, task, per_side, envs, device_id, hierarchic
     roofline, and how much of the boundary step is the step's bytes crossing PCIe."""
     cfg = pkg.default_config(task, hierarchical=hierarchical) if per_side == 1 else pkg.default_nvn_config(per_side, task=task, hierarchical=hierarchical)
     cls = pkg.HipShareVecEnv if cfg.n_agents > 2 else pkg.HipVecEnv
-    env = cls(cfg, envs, device_id=device_id, seed=1, copy=False)
+    env = cls(cfg, envs, device_id=device_id, seed=1)       # default mode: arrays the caller owns (ring of page-locked result sets)
     env.reset()
     rng = np.random.default_rng(20250321)
     pool = action_pool(np, rng, env, 16)
@@ -388,7 +396,7 @@ def main():
         env = StubVecEnv(None, E, seed=seed, agents=2 * (args.per_side or 1), hierarchical=args.hierarchical)
     else:
         cls = pkg.HipShareVecEnv if cfg.n_agents > 2 else pkg.HipVecEnv
-        env = cls(cfg, E, device_id=local_rank, seed=seed, copy=False)
+        env = cls(cfg, E, device_id=local_rank, seed=seed)     # default mode (copy=True): what a caller who reads INTEGRATION.md section 3 gets
     A = env.num_agents
     env.reset()
 
@@ -440,6 +448,14 @@ def main():
             elapsed = dev_wall
     red = pkg.sharding.max_over_ranks([elapsed, dev_wall or 0.0, kernel_ms or 0.0], dist, device=red_dev)
     elapsed, dev_wall, kernel_ms = red
+    # who took part: one SUM all-reduce on the job's group (RCCL for N > 1 on GPUs) with every rank's device ordinal, PCI bus id and work
+    pci = 0
+    if torch is not None:
+        try:
+            pci = int(torch.cuda.get_device_properties(local_rank).pci_bus_id)
+        except (AttributeError, RuntimeError):
+            pci = 0
+    census = pkg.sharding.rank_census(dist, device=red_dev, device_ordinal=local_rank, pci_bus_id=pci, agent_steps=float(E) * env.num_agents * args.steps)
 
     if not args.stub_env:
         for _ in range(args.checksum_calls):
@@ -461,9 +477,13 @@ def main():
             "metric": "agent-steps/sec", "value": agent_steps / elapsed, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.stub_env else "stub (control-flow rehearsal, not a measurement)",
+            "value_mode": "default VecEnv (copy=True): step() returns arrays the caller owns, handed out without a copy from a ring of page-locked result sets "
+                          "that is only stepped into where the caller has dropped the previous arrays; zero_copy_views_mode = the same leg with copy=False",
+            "ranks_reporting": census["ranks_reporting"], "devices": census["devices"], "agent_steps_per_rank": census["agent_steps_per_rank"],
+            "collective_backend": None if dist is None else ("gloo" if cpu_group else "nccl (RCCL)"),
             "config": {"workload": workload, "task": args.task, "envs_per_gpu": E, "aircraft_per_env": A, "fdm_ticks_per_step": 6,
                        "hierarchical": bool(args.hierarchical),
-                       "boundary": "VecEnv.step(numpy) -> numpy views of page-locked buffers (copy=False), PCIe inclusive (SURVEY 8d)" if not args.device_only else "device-resident (--device-only)",
+                       "boundary": "VecEnv.step(numpy) -> numpy arrays the caller owns (default copy=True), PCIe inclusive (SURVEY 8d)" if not args.device_only else "device-resident (--device-only)",
                        "actions": ("uniform random MultiDiscrete[3,5,3] (+ Bernoulli(0.05) weapon bits)" if args.hierarchical else "uniform random MultiDiscrete[41,41,41,30]") + ", a new host batch every step",
                        "auto_reset": True, "parallelism": f"env-block x{world}", "seed_of_rank0_block": seed,
                        "setup_steps": SETUP_STEPS},
@@ -528,13 +548,26 @@ def main():
                 bn = host_leg(env, [hold], 500, 50)
                 result["benign_actions"] = {"value": E * A * 500 / bn, "unit": "agent-steps/s", "ms_per_step": bn / 500 * 1e3,
                                             "note": "same boundary, every aircraft holds the straight-fly action: no early crashes in the mix"}
-                # and what the default copy=True mode (fresh arrays per step, like the reference's np.stack) costs on the same boundary
+                # the same boundary with copy=False: unchecked views of two alternating sets (what `value` was measured with up to round 3)
+                vw = pkg.HipVecEnv(cfg, E, device_id=local_rank, seed=seed, copy=False)
+                vw.reset()
+                zc = host_leg(vw, pool, 500, 50)
+                result["zero_copy_views_mode"] = {"value": E * A * 500 / zc, "unit": "agent-steps/s", "ms_per_step": zc / 500 * 1e3,
+                                                  "note": "VecEnv(copy=False): step() returns live views of two alternating page-locked sets, no ownership check"}
+                vw.close()
+                # and a caller that hoards every result (more live result sets than the ring has): step() falls back to fresh copies
                 env.reset()
-                env.copy = True
-                cp = host_leg(env, pool, 500, 50)
-                env.copy = False
-                result["default_copy_mode"] = {"value": E * A * 500 / cp, "unit": "agent-steps/s", "ms_per_step": cp / 500 * 1e3,
-                                               "note": "VecEnv.step with its default copy=True: obs / rewards / dones copied out of the page-locked buffers into fresh arrays every step"}
+                hoard = []
+                for i in range(50):
+                    hoard.append(env.step(pool[i % len(pool)]))
+                t0 = time.perf_counter()
+                for i in range(300):
+                    hoard.append(env.step(pool[i % len(pool)]))
+                hd = time.perf_counter() - t0
+                del hoard
+                result["hoarding_caller_copy_fallback"] = {"value": E * A * 300 / hd, "unit": "agent-steps/s", "ms_per_step": hd / 300 * 1e3,
+                                                           "note": "a caller that keeps EVERY step's arrays alive: the ring has no free set, step() copies the results out of a staging set "
+                                                                   "(the outputs were just written by the GPU, so the copy reads them cache-cold: tools/diag/host_copy_bench.py)"}
         env.close()
         if plain and not args.no_configs and not profiling:
             legs = [("C3 SingleCombat 1v1 shoot-missile", "singlecombat_shoot", 1), ("C3 Scenario1 (gun, AIM-9M, AIM-120B, chaff)", "scenario1", 1),

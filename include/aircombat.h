@@ -116,7 +116,7 @@ int ac_reset(ac_env_t* h, float* obs);
  * terminal reward/done, like worker() does (env_wrappers.py:191-204). */
 int ac_step(ac_env_t* h, const float* actions, float* obs, float* rewards, uint8_t* dones, int32_t* info);
 
-/* Zero-copy form of the same step for the VecEnv shim: the library owns two sets of page-locked host buffers that are mapped into
+/* Zero-copy form of the same step for the VecEnv shim: the library owns up to AC_HOST_SETS sets of page-locked host buffers that are mapped into
  * the device (rows padded to a multiple of 64 aircraft); the step kernel reads the actions of set `set` straight from host memory
  * and writes obs / rewards / dones / info of the step into the same set -- no copy commands. The caller fills the action buffer,
  * calls ac_step_host_async (= SubprocVecEnv.step_async, R/envs/env_wrappers.py:269-273) and ac_step_host_wait (= step_wait,
@@ -128,7 +128,13 @@ int ac_step(ac_env_t* h, const float* actions, float* obs, float* rewards, uint8
 #define AC_INFO_DONE_CODE(w) ((int32_t)(((uint32_t)(w) >> 16) & 0xFFu))
 #define AC_INFO_TURN_COUNTS(w) ((int32_t)(((uint32_t)(w) >> 24) & 0x7Fu))
 #define AC_INFO_WAS_RESET(w) ((int32_t)((uint32_t)(w) >> 31))
+#define AC_HOST_SETS 8   /* sets 0 .. 7, each allocated by its first ac_host_buffers call */
 int ac_host_buffers(ac_env_t* h, int32_t set, float** actions, float** obs, float** rewards, uint8_t** dones, int32_t** info);
+/* SubprocVecEnv.step_wait hands the caller arrays it owns for good (np.stack, env_wrappers.py:276-282). The shim gets the same without a
+ * copy by handing out a set's arrays only while nobody holds that set's previous ones; a set still held when the VecEnv closes is
+ * detached (ac_destroy no longer frees it, the handle can no longer step into it) and freed by its holder with ac_host_set_free. */
+int ac_host_set_detach(ac_env_t* h, int32_t set);
+void ac_host_set_free(void* actions, void* obs, void* rewards, void* dones, void* info);
 int ac_step_host_async(ac_env_t* h, int32_t set);
 int ac_step_host_wait(ac_env_t* h);
 int ac_step_host(ac_env_t* h, int32_t set);   /* both in one call: VecEnv.step (env_wrappers.py:30-42) */

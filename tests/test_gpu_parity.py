@@ -270,10 +270,68 @@ def test_nvn_multicombat_matches_oracle(pkg, oracle, per_side):
     env.close()
 
 
+@pytest.mark.parametrize("task,per_side", [("multiplecombat", 2), ("scenario_nvn", 2), ("scenario_nvn", 4)])
+def test_shipped_nvn_spawn_exactly_head_on(pkg, oracle, task, per_side):
+    """The spawn of the shipped NvN YAMLs as it is (scenario2_nvn.yaml / scenario3_nvn.yaml: both teams on one meridian, exactly
+    head-on), no stagger, the first 30 steps with the straight-fly action, flight state re-synchronised each step. Aircraft k of each
+    team faces enemy k at TA = pi - 8.7e-4, AO = 8.7e-4 (two aircraft at one altitude 11 km apart see each other R / 2 R_earth below
+    the horizon: the 3-D angles never reach the singular point itself), on the steep flank of PostureReward's atanh(1 - 2 TA / pi)
+    (posture_reward.py:26-75; slope 1 / (pi - TA) = 1150 per rad) where an fp32 cosine resolves pi - TA to 8 %. Held here: (1) the
+    potential the reset seeds (`pre_posture`, the device's own bookkeeping) is the oracle's to 2 %; (2) every observation element and
+    every reward to its bound, the ill-conditioned ones (the side flag where the cross product vanishes, the posture term where its
+    slope is large) widened by exactly the conditioning obs_bounds / RewardBound state; from the third step on (pi - TA has grown to
+    4e-3: the aircraft settle onto their angle of attack) the plain bounds must do."""
+    cfg = pkg.default_nvn_config(per_side, task=task)
+    A, E = 2 * per_side, 3
+    env = pkg.HipShareVecEnv(cfg, E, seed=9)
+    ref = oracle.OracleVecEnv(oracle.config_from_ac(cfg), E, chaff_seed=9)
+    obs, _ = env.reset()
+    robs = ref.reset()
+    names = env.lib.state_field_names()
+    ix = {nm: k for k, nm in enumerate(names) if nm}
+    fdm_fields = np.array([k for k, nm in enumerate(names) if nm and not nm.startswith("x_") and nm not in
+                           ("bloods", "pre_posture", "pre_altitude", "pre_event", "pre_shoot", "status", "die_flag", "remaining", "pre_remaining",
+                            "shoot_action", "last_missile", "last_shoot_time", "lock_bits", "lock_pos", "cur_step")])
+    o_en = 9 + 6 * (per_side - 1)
+    assert 5e-4 < np.pi - robs[0, 0, o_en + 3] < 1.2e-3 and robs[0, 0, o_en + 2] < 1.2e-3      # enemy 0 of aircraft 0: head-on but for the earth's curvature
+    assert_obs(obs, robs, 1.0, (task, "reset"))
+    worst_seed = 0.0
+    for a in range(A):
+        g, o = env.get_state(0, a)[ix["pre_posture"]], ref.envs[0].export_state(a)[ix["pre_posture"]]
+        worst_seed = max(worst_seed, abs(g - o) / abs(o))
+        assert abs(g - o) <= 0.02 * abs(o) and abs(o) > 1.0, (a, g, o)      # (1): the seeded potential sits on the reference's floor
+    bound = RewardBound(cfg.posture_scale, o_en, per_side, 2.0)
+    bound(np.zeros((E, A, 1)), robs)                                        # the reset's geometry is the first step's "previous" one
+    act = np.tile(np.array([20, 19, 20, 0] + [0] * (env.act_dim - 4), dtype=np.float32), (E, A, 1))
+    used = 0.0
+    for step in range(30):
+        for e in range(E):
+            for a in range(A):
+                v = env.get_state(e, a)
+                v[fdm_fields] = ref.envs[e].export_state(a)[fdm_fields]
+                env.set_state(e, a, v)
+        obs, share, rew, done, info = env.step(act)
+        robs, rrew, rdone, rinfo = ref.step(act)
+        assert (done == rdone).all() and not done.any()
+        assert_obs(obs, robs, 2.0, (task, step), label=f"shipped spawn {task} x{per_side}")
+        rt = team_max(bound(rrew, robs), A)
+        bad = np.abs(rew - rrew) > rt
+        assert not bad.any(), (step, np.argwhere(bad)[:4].tolist(), rew[bad][:4], rrew[bad][:4], rt[bad][:4])
+        if step >= 2:       # from here on nothing is singular any more: the plain one-step bound must do (x2)
+            plain = 2.0 * (5e-3 + 1e-3 * np.abs(rrew))
+            assert (np.abs(rew - rrew) <= plain).all(), (step, np.abs(rew - rrew).max())
+            used = max(used, float((np.abs(rew - rrew) / plain).max()))
+    import parity_util
+    print(f"shipped spawn {task} x{per_side}: seeded potential within {worst_seed:.4f} of the oracle's; from step 2 on the plain 2x reward bound is used to "
+          f"{used:.3f}, the 2x observation bound to {parity_util.USED.get(f'shipped spawn {task} x{per_side}', 0.0):.3f}")
+    env.close()
+
+
 @pytest.mark.parametrize("task,per_side,geometry,rwr", [("scenario1", 1, "closing", 0), ("scenario1", 1, "tail", 0),
                                                         ("scenario_nvn", 2, "closing", 0), ("scenario_nvn", 4, "closing", 0),
                                                         ("scenario1", 1, "closing", 1), ("scenario_nvn", 2, "closing", 1),
-                                                        ("scenario_nvn", 2, "closing", 2)])
+                                                        ("scenario_nvn", 2, "closing", 2), ("scenario_nvn", 4, "closing", 1),
+                                                        ("scenario_nvn", 4, "closing", 2)])
 def test_scenario_weapon_tasks_match_oracle(pkg, oracle, task, per_side, geometry, rwr):
     """Scenario1 (1v1) / Scenario2_NvN (2v2) / Scenario3_NvN (4v4): gun, AIM-120B / AIM-9M with uid reuse, chaff + keyed decoy
     draws, eleven reward terms with their shared references, env-family order of rewards and terminations. The aircraft state
@@ -316,7 +374,8 @@ def test_scenario_weapon_tasks_match_oracle(pkg, oracle, task, per_side, geometr
     rng = np.random.default_rng(11)
     launched = 0
     seen = {"gun": False, "chaff": False, "shotdown": False}
-    bound = RewardBound(cfg.posture_scale, 9 + 6 * (A // 2 - 1) if (A > 2 and not cfg.legacy_obs) else 9, max(1, A // 2), 4.0)
+    # (the 21-value legacy observation carries ONE enemy block, the paired enemy's: the conditioning of the others' posture terms is not in it)
+    bound = RewardBound(cfg.posture_scale, 9 + 6 * (A // 2 - 1) if (A > 2 and not cfg.legacy_obs) else 9, 1 if cfg.legacy_obs else max(1, A // 2), 4.0)
     for step in range(150 if rwr else 330):
         for e in range(E):
             for a in range(A):
@@ -565,6 +624,11 @@ def _lowlevel_controller_parity(pkg, oracle, task, baseline, E=6, sample=None, p
     flip_gaps = []
     worst_hid = {False: 0.0, True: 0.0}
     hi = np.stack([rng.integers(0, n, size=(E, A)) for n in (3, 5, 3)], axis=-1).astype(np.float32)
+    # rewards of the as-shipped action space: the same per-element bound as the control-index weapon tests (x4: munitions fly open loop)
+    nvn_blocks = A > 2 and not cfg.legacy_obs
+    bound = RewardBound(cfg.posture_scale, 9 + 6 * (A // 2 - 1) if nvn_blocks else 9, max(1, A // 2) if nvn_blocks else 1, 4.0)
+    tainted = np.zeros(S, dtype=bool)      # an env whose control indices once differed carries its own potentials until it resets
+    rew_used, rew_compared = 0.0, 0
     for step in range(steps):
         if step % 7 == 0:   # hold a high-level choice for a while, like a policy acting at 10 Hz
             hi = np.stack([rng.integers(0, n, size=(E, A)) for n in (3, 5, 3)], axis=-1).astype(np.float32)
@@ -605,8 +669,21 @@ def _lowlevel_controller_parity(pkg, oracle, task, baseline, E=6, sample=None, p
         assert ok.all(), (step, done[..., 0], rdone[..., 0])
         good = same_env & (done == rdone).all(axis=(1, 2))
         assert_obs(obs[good], robs[good], 2.0, (task, step), label=f"hier {task} E={E}")   # (measured: 0.7x the base bound at worst)
+        rt = bound(rrew, robs)
+        if A > 2:
+            rt = team_max(rt, A)
+        tainted |= ~same_env
+        cmp = good & ~tainted
+        bad = (np.abs(rew - rrew) > rt) & cmp[:, None, None]
+        assert not bad.any(), (task, step, np.argwhere(bad)[:4].tolist(), rew[bad][:4], rrew[bad][:4], rt[bad][:4])
+        if cmp.any():
+            rew_used = max(rew_used, float((np.abs(rew - rrew) / rt)[cmp].max()))
+            rew_compared += int(cmp.sum()) * A
+        tainted &= ~np.array([bool(rinfo[k][3]) for k in range(S)])      # a reset clears the potentials on both sides
     import parity_util
-    print("fraction of the 2x observation bound used:", round(parity_util.USED.get(f"hier {task} E={E}", 0.0), 3))
+    print("fraction of the 2x observation bound used:", round(parity_util.USED.get(f"hier {task} E={E}", 0.0), 3),
+          f"; rewards: {rew_compared} compared, fraction of the 4x bound used {rew_used:.3f}")
+    assert rew_compared >= S * A * steps // 2, (rew_compared, S * A * steps)
     print(f"{task} E={E} A={A}: {calls} controller outputs compared, {flips} differ from the oracle's argmax, oracle logit gaps there: "
           f"{[float(f'{g:.2e}') for g in sorted(flip_gaps)]}"
           f"; worst |d hidden| learned {worst_hid[False]:.2e} scripted {worst_hid[True]:.2e}")
@@ -619,6 +696,11 @@ def test_hierarchical_scenario_nvn_as_shipped(pkg, oracle, per_side):
     """BASELINE C4 / C5 as shipped: Scenario2_NvN (2v2) / Scenario3_NvN (4v4, A = 8) with the [3,5,3] + four weapon bits action of
     scenario2_task.py:14,225 / scenario3_nvn.yaml through the controller kernel, small batch, every env compared."""
     _lowlevel_controller_parity(pkg, oracle, "scenario_nvn", 0, E=5, per_side=per_side, steps=90)
+
+
+# multiples of the one-step bounds (module docstring) the single-aircraft tasks are held to (round 3 ran them at 10x; measured: heading
+# 0.003x / 0.001x, approach 0.63x / 0.002x of the observation / reward bound)
+HEADING_OBS_X, HEADING_REW_X = 2.0, 1.0
 
 
 def test_heading_task_numpy_stream_on_device(pkg, oracle):
@@ -640,6 +722,7 @@ def test_heading_task_numpy_stream_on_device(pkg, oracle):
     fdm_fields = np.array([k for k, nm in enumerate(names) if nm and not nm.startswith("x_") and nm not in task_fields])
     rng = np.random.default_rng(4)
     resets = turns = 0
+    used_obs = used_rew = 0.0
     for step in range(340):
         for e in range(E):
             v = env.get_state(e, 0)
@@ -653,8 +736,10 @@ def test_heading_task_numpy_stream_on_device(pkg, oracle):
                 o = refs[e].reset()
                 resets += 1
             assert bool(done[e, 0, 0]) == bool(d[0]), (step, e)
-            assert obs_close(obs[e], o, 10.0).all(), (step, e, obs[e], o)
-            assert abs(rew[e, 0, 0] - r[0]) <= 10 * (5e-3 + 1e-3 * abs(r[0])), (step, e, rew[e, 0, 0], r[0])
+            used_obs = max(used_obs, float((np.abs(obs[e] - o) / (2e-4 + 2e-4 * np.abs(o))).max()))
+            used_rew = max(used_rew, abs(rew[e, 0, 0] - r[0]) / (5e-3 + 1e-3 * abs(r[0])))
+            assert obs_close(obs[e], o, HEADING_OBS_X).all(), (step, e, obs[e], o)
+            assert abs(rew[e, 0, 0] - r[0]) <= HEADING_REW_X * (5e-3 + 1e-3 * abs(r[0])), (step, e, rew[e, 0, 0], r[0])
             hs = env.get_heading_state(e)
             out = np.zeros(8)
             refs[e].L.or_env_heading_get(refs[e].p, out.ctypes.data_as(__import__("ctypes").POINTER(__import__("ctypes").c_double)))
@@ -664,6 +749,7 @@ def test_heading_task_numpy_stream_on_device(pkg, oracle):
             turns = max(turns, int(hs[5]))
             if i[1] == 8:
                 assert info[e].get("heading_turn_counts") == int(i[2])
+    print(f"heading: worst multiple of the one-step bounds used: observation {used_obs:.2f}x, reward {used_rew:.2f}x")
     assert resets >= 3 and turns >= 1, (resets, turns)
     env.close()
 
@@ -687,6 +773,7 @@ def test_approach_task_on_device(pkg, oracle):
     fdm_fields = np.array([k for k, nm in enumerate(names) if nm and not nm.startswith("x_") and nm not in task_fields])
     targets0 = [env.get_heading_state(e)[1:4].copy() for e in range(E)]
     codes, resets = set(), 0
+    used_obs = used_rew = 0.0
     for step in range(420):
         for e in range(E):
             v = env.get_state(e, 0)
@@ -702,12 +789,18 @@ def test_approach_task_on_device(pkg, oracle):
                 resets += 1
                 targets0[e] = env.get_heading_state(e)[1:4].copy()
             assert bool(done[e, 0, 0]) == bool(d[0]), (step, e)
-            assert obs_close(obs[e], o, 10.0).all(), (step, e, obs[e], o)
-            assert abs(rew[e, 0, 0] - r[0]) <= 10 * (5e-3 + 1e-3 * abs(r[0])), (step, e, rew[e, 0, 0], r[0])
+            used_obs = max(used_obs, float((np.abs(obs[e] - o) / (2e-4 + 2e-4 * np.abs(o))).max()))
+            used_rew = max(used_rew, abs(rew[e, 0, 0] - r[0]) / (5e-3 + 1e-3 * abs(r[0])))
+            assert obs_close(obs[e], o, HEADING_OBS_X).all(), (step, e, obs[e], o)
+            assert abs(rew[e, 0, 0] - r[0]) <= HEADING_REW_X * (5e-3 + 1e-3 * abs(r[0])), (step, e, rew[e, 0, 0], r[0])
             hs = env.get_heading_state(e)
             assert (hs[1:4] == targets0[e]).all() and int(hs[5]) == 0          # no UnreachHeading: targets never move
+    print(f"approach: worst multiple of the one-step bounds used: observation {used_obs:.2f}x, reward {used_rew:.2f}x")
     assert resets >= E and codes <= {1, 2, 3}, (resets, codes)                 # crash-type endings only (LowAltitude / ExtremeState / Overload)
     env.close()
+
+
+WVR_REW_X = 3.0      # (round 3: 10x; measured 1.70x for WVRTask's eight terms -- the gun-track terms difference R sin(AO) of consecutive steps --, 0.09x for Maneuver)
 
 
 @pytest.mark.parametrize("task", ["wvr_lowlevel", "maneuver_lowlevel"])
@@ -733,6 +826,7 @@ def test_wvr_task_gun_only(pkg, oracle, task):
     fdm_fields = np.array([k for k, nm in enumerate(names) if nm and not nm.startswith("x_") and nm not in task_fields])
     rng = np.random.default_rng(31)
     shot = resets = 0
+    used_rew = 0.0
     for step in range(260):
         for e in range(E):
             for a in range(2):
@@ -745,7 +839,8 @@ def test_wvr_task_gun_only(pkg, oracle, task):
         assert (done == rdone).all(), (step, done[..., 0], rdone[..., 0])
         ok = nvn_obs_close(obs, robs)
         assert ok.all(), (step, np.argwhere(~ok)[:4], obs[~ok][:4], robs[~ok][:4])
-        assert (np.abs(rew - rrew) <= 10 * (5e-3 + 1e-3 * np.abs(rrew))).all(), (step, rew.ravel(), rrew.ravel())
+        used_rew = max(used_rew, float((np.abs(rew - rrew) / (5e-3 + 1e-3 * np.abs(rrew))).max()))
+        assert (np.abs(rew - rrew) <= WVR_REW_X * (5e-3 + 1e-3 * np.abs(rrew))).all(), (step, rew.ravel(), rrew.ravel())
         for e in range(E):
             resets += int(rinfo[e][3])
             shot += int(rinfo[e][1]) == 4          # Maneuver_curriculum: SafeReturn reports the shot-down aircraft and the env ends
@@ -754,6 +849,7 @@ def test_wvr_task_gun_only(pkg, oracle, task):
                     g, o = env.get_state(e, a), ref.envs[e].export_state(a)
                     assert abs(g[ix["bloods"]] - o[ix["bloods"]]) < 1e-3 and g[ix["status"]] == o[ix["status"]], (step, e, a)
                     shot += int(o[ix["status"]] == 2)
+    print(f"{task}: worst multiple of the one-step reward bound used: {used_rew:.2f}x")
     assert shot > 0 and resets >= E
     env.close()
 
@@ -985,6 +1081,39 @@ def test_multi_device_vec_env_matches_one_handle(pkg, task):
             assert a.shape == b.shape and (a == b).all(), step
         assert list(o1[-1]) == list(o2[-1])
     one.close(); many.close()
+
+
+def test_multi_device_share_obs_is_a_view_and_render_delegates(pkg, tmp_path):
+    """BASELINE C5's shape (4v4, observation 63, share_obs 8 x 504) over two handles: share_obs of the joined result is the broadcast
+    view of the joined observations (its base is the [E, A, 63] array, nothing A-fold is materialised), and render(env=i) is written by
+    the part that owns env i -- the same text a single handle over all envs writes for that env."""
+    cfg = pkg.default_nvn_config(4, task="scenario_nvn")
+    E = 10
+    many = pkg.MultiDeviceVecEnv(cfg, E, device_ids=[0, 0], seed=5)
+    one = pkg.HipShareVecEnv(cfg, E, seed=5)
+    obs, share = many.reset()
+    one.reset()
+    assert obs.shape == (E, 8, 63) and share.shape == (E, 8, 504)
+    act = np.tile(np.array([20, 19, 20, 0, 0, 0, 0, 0], dtype=np.float32), (E, 8, 1))
+    for step in range(3):
+        obs, share, rew, done, infos = many.step(act)
+        o1 = one.step(act)
+        assert (obs == o1[0]).all() and (share == o1[1]).all() and (rew == o1[2]).all()
+        assert share.base is not None and not share.flags.owndata and not share.flags.writeable
+        assert share.strides[1] == 0 and np.shares_memory(share, obs)          # broadcast over the agent axis of the observations themselves
+        assert obs.nbytes == E * 8 * 63 * 4
+        for env in (0, 7):                                                     # env 7 lives in the second part (blocks 5 + 5)
+            many.render(filepath=str(tmp_path / f"many{env}.acmi"), env=env) if step == 0 else None
+    for env in (0, 7):
+        fresh = pkg.HipShareVecEnv(cfg, E, seed=5)
+        fresh.reset()
+        fresh.step(act)
+        fresh.render(filepath=str(tmp_path / f"one{env}.acmi"), env=env)
+        fresh.close()
+        assert open(tmp_path / f"many{env}.acmi", encoding="utf-8-sig").read() == open(tmp_path / f"one{env}.acmi", encoding="utf-8-sig").read()
+    with pytest.raises(IndexError):
+        many.render(filepath=str(tmp_path / "x.acmi"), env=E)
+    many.close(); one.close()
 
 
 @pytest.mark.parametrize("substeps", [1, 3, 12])

@@ -89,6 +89,10 @@ def test_bench_control_flow_two_ranks_under_torchrun(tmp_path):
     assert abs(r["value"] - 2 * 64 * 2 * 30 / (r["ms_per_step"] * 1e-3 * 30)) < 1e-6 * r["value"]   # whole-job agent-steps / max-over-ranks time
     assert r["ms_per_step"] >= 0.2                                                        # the stand-in sleeps 0.2 ms per step
     assert "stub" in r["data"]
+    # the line proves who took part: one SUM all-reduce on the job's group carried every rank's 1, device ordinal and work
+    assert r["ranks_reporting"] == 2 and [d["rank"] for d in r["devices"]] == [0, 1] and [d["device"] for d in r["devices"]] == [0, 1]
+    assert r["agent_steps_per_rank"] == [64 * 2 * 30.0] * 2 and sum(r["agent_steps_per_rank"]) == 2 * 64 * 2 * 30
+    assert r["collective_backend"] == "gloo"
 
 
 @pytest.mark.parametrize("per_side,world", [(2, 2), (4, 2)])
@@ -117,6 +121,7 @@ def test_bench_multi_gpu_configs_c4_c5_under_torchrun(tmp_path, per_side, world)
     assert r["stub"]["agents"] == A and r["stub"]["act_dim"] == 7 and r["stub"]["steps_taken"] == 25
     assert ("C4" if per_side == 2 else "C5") in r["config"]["workload"] and "as shipped" in r["config"]["workload"]
     assert abs(r["value"] - world * 32 * A * 20 / (r["ms_per_step"] * 1e-3 * 20)) < 1e-6 * r["value"]
+    assert r["ranks_reporting"] == world and len(r["devices"]) == world and r["agent_steps_per_rank"] == [32.0 * A * 20] * world
 
 
 def test_bench_rank_seed_blocks_do_not_overlap(pkg):
