@@ -617,12 +617,16 @@ struct TableCopy {
       v[k] = (i < NV) ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  __device__ __forceinline__ void commit(float* lds) {
+  __device__ __forceinline__ void write(float* lds) {
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       int i = threadIdx.x + k * THREADS;
       if (i < NV) reinterpret_cast<float4*>(lds)[i] = v[k];
     }
+  }
+  __device__ __forceinline__ void commit(float* lds) {
+    write(lds);
+    AC_CLKW(0, 120); AC_CLKW(1, 121); AC_CLKW(2, 122);     // (scratch builds: when each wave of workgroup 0 reaches the barrier)
     __syncthreads();
   }
 };
@@ -828,17 +832,34 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
   // loads behind them, and the LDS copy of the tables waits (in-order vmcnt) for the table loads alone.
   const float* act = P.actions + (size_t)nn * c.act_dim;
   float4 a4;
+  ActionRow arow;                        // three-wave form: the systems wave's action row (asked for late, waited for by hand)
   float shoot_raw = 0.0f;
   if (SPLIT) {
     TableCopy<192> tc;
     tc.issue(P.tab);
+    AC_CLKW(0, 123);
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     s = State{}; t = Task{};
-    if (role == 0) { load_flight_role<0>(P.F, P.I, P.D, N, nn, s); load_task(P.F, P.I, N, nn, t); }
+    if (role == 0) { load_flight_role<0>(P.F, P.I, P.D, N, nn, s); AC_CLKW(0, 124); load_task(P.F, P.I, N, nn, t); AC_CLKW(0, 125); }
     else if (role == 1) load_flight_role<1>(P.F, P.I, P.D, N, nn, s);
     else { load_flight_role<2>(P.F, P.I, P.D, N, nn, s); t.status = P.I[(size_t)FI_status * N + nn]; }
-    a4 = load_controls(act, c.act_dim);   // last: loads return in order, and this one may come from host memory (ac_step_host)
-    tc.commit(lds_tab);
+    // The action row may live in mapped host memory (ac_step_host): a read across PCIe takes ~5 k cycles, and the CU's vector memory
+    // path returns loads in the order they were issued ACROSS its waves -- a state load issued behind it, by any wave of the
+    // workgroup, waits those 5 k cycles too (measured: the dynamics wave, which asks for the most, reached the table barrier at 8-10 k
+    // cycles instead of 3 k; profiles/round4_cycle_stamps.txt). So: a bare barrier (no wait for memory) once every wave has ISSUED
+    // its state loads; then the tables go to LDS (the compiler's waits are for its own loads, all older than the row), and only then
+    // the one wave that decodes the commands -- the systems wave, after B1 of the first tick -- asks for the row, with a load whose
+    // wait is placed by hand (ActionRow).
+    __builtin_amdgcn_s_barrier();
+    tc.write(lds_tab);
+    a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // every load the compiler knows of has landed -- on every path, so that no compiler-placed `s_waitcnt vmcnt(0)` for a state field is
+    // left anywhere behind this point (the counter counts all loads: it would wait for the row as well) -- before the one it does not
+    // know of is issued
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the wave's own state, one round trip like the tables
+    if (role == 1) arow.issue(act);
+    AC_CLKW(0, 120); AC_CLKW(1, 121); AC_CLKW(2, 122);
+    __syncthreads();                      // (LDS visibility; loads in flight are not waited for)
   } else if (QUAD) {
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0 dynamics, 1 systems, 2 kinematics, 3 environment
     TableCopy<256> tc;
@@ -890,7 +911,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
   constexpr bool OBS_BY_KIN = SPLIT && TASK == AC_TASK_SINGLECOMBAT;
   if (SPLIT) {   // helper waves: run their part of every substep (the systems wave decodes the commands it integrates)
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (split_helper_wave(s, t, T, L, l, c.substeps, &a4)) {
+    if (split_helper_wave(s, t, T, L, l, c.substeps, nullptr, nullptr, &arow)) {
       if (OBS_BY_KIN && role == 2) {
         using namespace mail;
         wg_sync();                                   // the dynamics wave has posted the final pose

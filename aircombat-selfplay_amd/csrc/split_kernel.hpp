@@ -76,7 +76,18 @@ __device__ __forceinline__ void wg_sync() {
 // `raw`: the aircraft's action row still on its way (in a step through ac_step_host it crosses PCIe: about three times the latency of
 // the state loads it was issued behind). The commands are this wave's alone to integrate and first needed after B1 of the first tick,
 // so they are decoded there and the other two waves start the tick without waiting for them.
-__device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::Tab& T, float (*M)[64], int l, int substeps, const float4* raw = nullptr) {
+// `row`: the same row asked for by ActionRow::issue and possibly still in flight: then the wait for it is HERE, after B1 of the first tick.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct ActionRow {
+  f32x4 v;
+  // One 16-byte load the compiler does not know about: it cannot put a wait for it (or a copy of its registers) anywhere before take().
+  // With a plain load the optimiser hoisted the loop-invariant decode, and the wait with it, in front of B1 -- and a row that comes
+  // from mapped host memory (ac_step_host) takes ~5 k cycles across PCIe (profiles/round4_cycle_stamps.txt).
+  __device__ __forceinline__ void issue(const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
+  __device__ __forceinline__ void take() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory"); }
+};
+__device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::Tab& T, float (*M)[64], int l, int substeps, const float4* raw = nullptr,
+                                             ActionRow* row = nullptr) {
   using namespace mail;
   f16::DynVars km{};
   f16::sys_mass(s, km);
@@ -86,7 +97,13 @@ __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::
     f16::Surf sf{};
     AC_CLKW(1, 64 + sub * 8);
     wg_sync();                                             // B1: this tick's attitude is known
-    if (raw && sub == 0) {                                 // normalize_action (singlecombat_task.py:141-153), property bounds catalog.py:189-197
+    if (row && sub == 0) {                                 // normalize_action (singlecombat_task.py:141-153), property bounds catalog.py:189-197
+      row->take();
+      s.da = f16::clampf(-1.0f, row->v.x / 20.0f - 1.0f, 1.0f);
+      s.de = f16::clampf(-1.0f, row->v.y / 20.0f - 1.0f, 1.0f);
+      s.dr = f16::clampf(-1.0f, row->v.z / 20.0f - 1.0f, 1.0f);
+      s.thr = f16::clampf(0.0f, row->v.w / 58.0f + 0.4f, 0.9f);
+    } else if (raw && sub == 0) {
       s.da = f16::clampf(-1.0f, raw->x / 20.0f - 1.0f, 1.0f);
       s.de = f16::clampf(-1.0f, raw->y / 20.0f - 1.0f, 1.0f);
       s.dr = f16::clampf(-1.0f, raw->z / 20.0f - 1.0f, 1.0f);
@@ -215,10 +232,10 @@ struct SplitLds {
 // wave (wave 0) gets false. Commands (s.da .. s.thr) must be decoded before the call, or handed over as the raw action row.
 template <bool QUAD = false, bool POSE = false>
 __device__ __forceinline__ bool split_helper_wave(f16::State& s, Task& t, const f16::Tab& T, SplitLds& L, int l, int substeps, const float4* raw = nullptr,
-                                                  const DevCfg* cfg = nullptr) {
+                                                  const DevCfg* cfg = nullptr, ActionRow* row = nullptr) {
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (role == 2) { kinematics_wave<QUAD, POSE>(s, t, T, L.M, L.MD, l, substeps, cfg); return true; }   // (a caller with work left for this wave tests the role itself)
-  if (role == 1) { systems_wave(s, t, T, L.M, l, substeps, raw); return true; }
+  if (role == 1) { systems_wave(s, t, T, L.M, l, substeps, raw, row); return true; }
   return false;
 }
 // One substep of the dynamics wave (three workgroup barriers inside; every lane of the wave must call it). Returns whether this
