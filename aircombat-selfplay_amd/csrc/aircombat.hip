@@ -53,6 +53,48 @@ enum {
   NI
 };
 enum { ND = 3 };
+// ---- storage. The names above are the EXTERNAL state vector (ac_get_state / ac_set_state, the oracle's state bridge). In HBM an aircraft's
+// 75 32-bit words live in 19 groups of four: group g of aircraft n is the 16 bytes at S4[g * N + n], so every state access of a wave is one
+// dwordx4 instruction moving one contiguous 1 KB (round 3 moved a dword per lane per instruction: 173 loads + 90 stores per workgroup in the
+// BASELINE kernel, ~28 issue cycles each). Groups are cut by who reads them in the three-wave form -- 0-3 what the systems wave owns,
+// 4-6 the air data it reads (with the two flight ints), 6-10 what the kinematics wave reads, 11-14 the dynamics wave's alone -- and 15-18
+// are the task record (the environment layer's: group 15 changes every step, 16-18 a few times per episode). The fp64 position: (rx, ry)
+// as one 16-byte pair at D2[n], rz at D[2 N + n].
+enum : int {
+  SW_tef = 0, SW_pin_r, SW_pin_p, SW_pin_y,
+  SW_pi_r, SW_pi_p, SW_pi_y, SW_ail,
+  SW_elev, SW_sbdeg, SW_n1, SW_n2,
+  SW_n2norm, SW_ff, SW_tank0, SW_tank1,
+  SW_alpha, SW_mach, SW_qc, SW_vg,
+  SW_ap, SW_aq, SW_ar, SW_npy,
+  SW_npz, SW_npx, SW_eng, SW_ticks,
+  SW_vx, SW_vy, SW_vz, SW_q0,
+  SW_q1, SW_q2, SW_q3, SW_wp,
+  SW_wq, SW_wr, SW_hv1x, SW_hv1y,
+  SW_hv1z, SW_hv2x, SW_hv2y, SW_hv2z,
+  SW_ha1x, SW_ha1y, SW_ha1z, SW_wdx,
+  SW_wdy, SW_wdz, SW_aix, SW_aiy,
+  SW_aiz, SW_bax, SW_bay, SW_baz,
+  SW_da, SW_de, SW_dr, SW_thr,
+  SW_pre_posture, SW_pre_altitude, SW_pre_event, SW_cur_step,          // group 15
+  SW_bloods, SW_status, SW_die_flag, SW_pre_shoot,                     // group 16
+  SW_remaining, SW_pre_remaining, SW_shoot_action, SW_last_missile,    // group 17
+  SW_last_shoot_time, SW_lock_bits, SW_lock_pos, SW_pad,               // group 18 (the pad word stays 0)
+  NSW
+};
+enum { NSG = NSW / 4, SG_TASK0 = 15 };
+static_assert(NSW == 76 && SW_pre_posture == 4 * SG_TASK0, "19 groups: 15 flight, 4 task");
+// storage word of every external field, in the external order
+static const int kSlotF[NF] = {
+#define X(n) SW_##n,
+    AC_F_FIELDS(X) AC_TF_FIELDS(X)
+#undef X
+};
+static const int kSlotI[NI] = {SW_eng, SW_ticks,
+#define X(n) SW_##n,
+                               AC_TI_FIELDS(X)
+#undef X
+};
 // missile slot fields
 enum { MF_px, MF_py, MF_pz, MF_vx, MF_vy, MF_vz, MF_theta, MF_psi, MF_t, MF_m, MF_dth, MF_dph, MF_dprev, NMF };
 enum { MI_status, MI_recede, MI_order, NMI };
@@ -150,65 +192,80 @@ __device__ __forceinline__ float poison_if(bool bad, float reward) { return bad 
 #define AC_LANE_INDEX(n) const unsigned un_ = (unsigned)(n), uN_ = (unsigned)N
 #define AC_AT(base, f) \
   (*(decltype(base))((char*)(base) + (size_t)((unsigned)(f) * (uN_ * (unsigned)sizeof(*(base))) + un_ * (unsigned)sizeof(*(base)))))
+// group g of lane n of the state storage (16 bytes), and one word of it (byte offsets stay below 2^32: 19 groups x 16 B x 2^23 aircraft)
+#define AC_GRP(S, g) (*reinterpret_cast<float4*>((char*)(S) + (size_t)((unsigned)(g) * (uN_ * 16u) + un_ * 16u)))
+#define AC_WORD(S, w) (*reinterpret_cast<int*>((char*)(S) + (size_t)((unsigned)((w) >> 2) * (uN_ * 16u) + un_ * 16u + 4u * (unsigned)((w) & 3))))
+__device__ __forceinline__ int state_word(const float* S, int w, int N, int n) { AC_LANE_INDEX(n); return AC_WORD(S, w); }
+// the flight groups that hold four floats (group 6 = npz, npx and the two ints is written out by hand)
+#define AC_FLIGHT_GROUPS(G)                                                                                                       \
+  G(0, tef, pin_r, pin_p, pin_y) G(1, pi_r, pi_p, pi_y, ail) G(2, elev, sbdeg, n1, n2) G(3, n2norm, ff, tank0, tank1)               \
+  G(4, alpha, mach, qc, vg) G(5, ap, aq, ar, npy) G(7, vx, vy, vz, q0) G(8, q1, q2, q3, wp) G(9, wq, wr, hv1x, hv1y)                \
+  G(10, hv1z, hv2x, hv2y, hv2z) G(11, ha1x, ha1y, ha1z, wdx) G(12, wdy, wdz, aix, aiy) G(13, aiz, bax, bay, baz) G(14, da, de, dr, thr)
+static_assert(SW_alpha == 16 && SW_npz == 24 && SW_vx == 28 && SW_ha1x == 44 && SW_da == 56, "AC_FLIGHT_GROUPS follows the SW_ order");
+__device__ __forceinline__ void load_position(const double* D, int N, int n, State& s) {
+  const double2 xy = *reinterpret_cast<const double2*>((const char*)D + (size_t)((unsigned)n * 16u));
+  s.rx = xy.x; s.ry = xy.y;
+  s.rz = D[2 * (size_t)N + n];
+}
+__device__ __forceinline__ void store_position(double* D, int N, int n, const State& s) {
+  *reinterpret_cast<double2*>((char*)D + (size_t)((unsigned)n * 16u)) = make_double2(s.rx, s.ry);
+  D[2 * (size_t)N + n] = s.rz;
+}
 // the flight-dynamics part of an aircraft's state (what the FDM tick reads and writes) ...
-__device__ __forceinline__ void load_flight(const float* F, const int* I, const double* D, int N, int n, State& s) {
-  AC_LANE_INDEX(n);
-#define X(f) s.f = AC_AT(F, FF_##f);
-  AC_F_FIELDS(X)
-#undef X
-  s.eng = AC_AT(I, FI_eng); s.ticks = AC_AT(I, FI_ticks);
-  s.rx = AC_AT(D, 0); s.ry = AC_AT(D, 1); s.rz = AC_AT(D, 2);
-}
-__device__ __forceinline__ void store_flight(float* F, int* I, double* D, int N, int n, const State& s) {
-  AC_LANE_INDEX(n);
-#define X(f) AC_AT(F, FF_##f) = s.f;
-  AC_F_FIELDS(X)
-#undef X
-  AC_AT(I, FI_eng) = s.eng; AC_AT(I, FI_ticks) = s.ticks;
-  AC_AT(D, 0) = s.rx; AC_AT(D, 1) = s.ry; AC_AT(D, 2) = s.rz;
-}
-// The three-wave form: each wave asks only for what its share of the tick reads (the 64 aircraft's state would otherwise cross the
-// L2 -> CU path three times at the start of every step). ROLE 0 = dynamics wave: everything except the fields the systems wave owns
-// and hands over at the end (dynamics_wave_finish); 1 = systems wave: what sys_mass / sys_fcs / sys_engine read; 2 = kinematics wave:
-// what kin_position / kin_attitude / locate read.
-constexpr bool ac_sys_owned(int f) {
-  return f == FF_tef || f == FF_pin_r || f == FF_pin_p || f == FF_pin_y || f == FF_pi_r || f == FF_pi_p || f == FF_pi_y || f == FF_ail ||
-         f == FF_elev || f == FF_sbdeg || f == FF_n1 || f == FF_n2 || f == FF_n2norm || f == FF_ff || f == FF_tank0 || f == FF_tank1;
-}
-constexpr bool ac_sys_reads(int f) {
-  return ac_sys_owned(f) || f == FF_alpha || f == FF_mach || f == FF_qc || f == FF_vg || f == FF_ap || f == FF_aq || f == FF_ar || f == FF_npy || f == FF_npz;
-}
-constexpr bool ac_kin_reads(int f) {
-  return f == FF_vx || f == FF_vy || f == FF_vz || f == FF_q0 || f == FF_q1 || f == FF_q2 || f == FF_q3 || f == FF_wp || f == FF_wq || f == FF_wr ||
-         f == FF_hv1x || f == FF_hv1y || f == FF_hv1z || f == FF_hv2x || f == FF_hv2y || f == FF_hv2z;
+// ROLE -1: all of it. Three-wave form: each wave asks only for what its share of the tick reads (the 64 aircraft's state would otherwise
+// cross the L2 -> CU path three times at the start of every step). ROLE 0 = dynamics wave: everything except the groups the systems wave
+// owns and hands over at the end (dynamics_wave_finish); 1 = systems wave: what sys_mass / sys_fcs / sys_engine read; 2 = kinematics
+// wave: what kin_position / kin_attitude / locate read.
+constexpr bool ac_role_reads(int role, int g) {
+  return role < 0 || (role == 0 ? g >= 4 : (role == 1 ? g <= 6 : (g >= 6 && g <= 10)));
 }
 template <int ROLE>
 __device__ __forceinline__ void load_flight_role(const float* F, const int* I, const double* D, int N, int n, State& s) {
+  (void)I;
   AC_LANE_INDEX(n);
-#define X(f) if (ROLE == 0 ? !ac_sys_owned(FF_##f) : (ROLE == 1 ? ac_sys_reads(FF_##f) : ac_kin_reads(FF_##f))) s.f = AC_AT(F, FF_##f);
-  AC_F_FIELDS(X)
-#undef X
-  if (ROLE == 1) s.eng = AC_AT(I, FI_eng);
-  if (ROLE != 1) { s.ticks = AC_AT(I, FI_ticks); s.rx = AC_AT(D, 0); s.ry = AC_AT(D, 1); s.rz = AC_AT(D, 2); }
+#define G(g, a, b, c, d) if (ac_role_reads(ROLE, g)) { const float4 v = AC_GRP(F, g); s.a = v.x; s.b = v.y; s.c = v.z; s.d = v.w; }
+  AC_FLIGHT_GROUPS(G)
+#undef G
+  if (ac_role_reads(ROLE, 6)) {
+    const float4 v = AC_GRP(F, 6);
+    s.npz = v.x; s.npx = v.y; s.eng = __float_as_int(v.z); s.ticks = __float_as_int(v.w);
+  }
+  if (ROLE != 1) load_position(D, N, n, s);
 }
-// ... and the task bookkeeping (what the environment layer reads and writes)
-__device__ __forceinline__ void load_task(const float* F, const int* I, int N, int n, Task& t) {
+__device__ __forceinline__ void load_flight(const float* F, const int* I, const double* D, int N, int n, State& s) { load_flight_role<-1>(F, I, D, N, n, s); }
+__device__ __forceinline__ void store_flight(float* F, int* I, double* D, int N, int n, const State& s) {
+  (void)I;
   AC_LANE_INDEX(n);
-#define X(f) t.f = AC_AT(F, FF_##f);
-  AC_TF_FIELDS(X)
-#undef X
-#define X(f) t.f = AC_AT(I, FI_##f);
-  AC_TI_FIELDS(X)
-#undef X
+#define G(g, a, b, c, d) AC_GRP(F, g) = make_float4(s.a, s.b, s.c, s.d);
+  AC_FLIGHT_GROUPS(G)
+#undef G
+  AC_GRP(F, 6) = make_float4(s.npz, s.npx, __int_as_float(s.eng), __int_as_float(s.ticks));
+  store_position(D, N, n, s);
+}
+// ... and the task bookkeeping (what the environment layer reads and writes): groups 15-18
+__device__ __forceinline__ void load_task(const float* F, const int* I, int N, int n, Task& t) {
+  (void)I;
+  AC_LANE_INDEX(n);
+  const float4 a = AC_GRP(F, SG_TASK0), b = AC_GRP(F, SG_TASK0 + 1), c = AC_GRP(F, SG_TASK0 + 2), d = AC_GRP(F, SG_TASK0 + 3);
+  t.pre_posture = a.x; t.pre_altitude = a.y; t.pre_event = a.z; t.cur_step = __float_as_int(a.w);
+  t.bloods = b.x; t.status = __float_as_int(b.y); t.die_flag = __float_as_int(b.z); t.pre_shoot = b.w;
+  t.remaining = __float_as_int(c.x); t.pre_remaining = __float_as_int(c.y); t.shoot_action = __float_as_int(c.z); t.last_missile = __float_as_int(c.w);
+  t.last_shoot_time = __float_as_int(d.x); t.lock_bits = __float_as_int(d.y); t.lock_pos = __float_as_int(d.z);
+}
+__device__ __forceinline__ void store_task_group0(float* F, int N, int n, const Task& t) {
+  AC_LANE_INDEX(n);
+  AC_GRP(F, SG_TASK0) = make_float4(t.pre_posture, t.pre_altitude, t.pre_event, __int_as_float(t.cur_step));
+}
+__device__ __forceinline__ void store_task_rare(float* F, int N, int n, const Task& t) {
+  AC_LANE_INDEX(n);
+  AC_GRP(F, SG_TASK0 + 1) = make_float4(t.bloods, __int_as_float(t.status), __int_as_float(t.die_flag), t.pre_shoot);
+  AC_GRP(F, SG_TASK0 + 2) = make_float4(__int_as_float(t.remaining), __int_as_float(t.pre_remaining), __int_as_float(t.shoot_action), __int_as_float(t.last_missile));
+  AC_GRP(F, SG_TASK0 + 3) = make_float4(__int_as_float(t.last_shoot_time), __int_as_float(t.lock_bits), __int_as_float(t.lock_pos), 0.0f);
 }
 __device__ __forceinline__ void store_task(float* F, int* I, int N, int n, const Task& t) {
-  AC_LANE_INDEX(n);
-#define X(f) AC_AT(F, FF_##f) = t.f;
-  AC_TF_FIELDS(X)
-#undef X
-#define X(f) AC_AT(I, FI_##f) = t.f;
-  AC_TI_FIELDS(X)
-#undef X
+  (void)I;
+  store_task_group0(F, N, n, t);
+  store_task_rare(F, N, n, t);
 }
 __device__ __forceinline__ void load_state(const float* F, const int* I, const double* D, int N, int n, State& s, Task& t) {
   load_flight(F, I, D, N, n, s);
@@ -252,25 +309,18 @@ __device__ __forceinline__ void store_msl_clock(R* MF, int* MI, int N, int n, in
   AC_AT(f, MF_t) = m.t; AC_AT(f, MF_dprev) = m.dprev;
   AC_AT(i, MI_status) = m.status; AC_AT(i, MI_recede) = (m.dpos << 10) | (m.model << 9) | m.recede;
 }
-// the task record: the step counter and the three potentials change every step and are always written; the other eleven words (status,
-// blood, the launch bookkeeping) change a few times per episode and are written together, under ONE test, when any of them differs from
-// what was loaded (`was`)
+// the task record: the step counter and the three potentials (group 15) change every step and are always written; the other eleven words
+// (status, blood, the launch bookkeeping: groups 16-18) change a few times per episode and are written together, under ONE test, when any
+// of them differs from what was loaded (`was`)
 __device__ __forceinline__ void store_task_changed(float* F, int* I, int N, int n, const Task& t, const Task& was) {
-  AC_LANE_INDEX(n);
-  AC_AT(I, FI_cur_step) = t.cur_step;
-  AC_AT(F, FF_pre_posture) = t.pre_posture; AC_AT(F, FF_pre_altitude) = t.pre_altitude; AC_AT(F, FF_pre_event) = t.pre_event;
+  (void)I;
+  store_task_group0(F, N, n, t);
   const bool rare = __float_as_int(t.bloods) != __float_as_int(was.bloods) || __float_as_int(t.pre_shoot) != __float_as_int(was.pre_shoot) ||
                     t.status != was.status || t.die_flag != was.die_flag || t.remaining != was.remaining || t.pre_remaining != was.pre_remaining ||
                     t.shoot_action != was.shoot_action || t.last_missile != was.last_missile || t.last_shoot_time != was.last_shoot_time ||
                     t.lock_bits != was.lock_bits || t.lock_pos != was.lock_pos;
-  if (rare) {
-    AC_AT(F, FF_bloods) = t.bloods; AC_AT(F, FF_pre_shoot) = t.pre_shoot;
-    AC_AT(I, FI_status) = t.status; AC_AT(I, FI_die_flag) = t.die_flag; AC_AT(I, FI_remaining) = t.remaining; AC_AT(I, FI_pre_remaining) = t.pre_remaining;
-    AC_AT(I, FI_shoot_action) = t.shoot_action; AC_AT(I, FI_last_missile) = t.last_missile; AC_AT(I, FI_last_shoot_time) = t.last_shoot_time;
-    AC_AT(I, FI_lock_bits) = t.lock_bits; AC_AT(I, FI_lock_pos) = t.lock_pos;
-  }
+  if (rare) store_task_rare(F, N, n, t);
 }
-static_assert(FI_cur_step - FI_status == 9 && FF_pre_shoot - FF_bloods == 4, "store_task_changed lists the task record's fifteen fields by hand");
 
 // task.reset() of the hierarchical tasks clears _inner_rnn_states (singlecombat_task.py:258-262)
 __device__ __forceinline__ void zero_controller_state(const DevPtrs& P, int N, int n, bool live) {
@@ -842,7 +892,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
     s = State{}; t = Task{};
     if (role == 0) { load_flight_role<0>(P.F, P.I, P.D, N, nn, s); AC_CLKW(0, 124); load_task(P.F, P.I, N, nn, t); AC_CLKW(0, 125); }
     else if (role == 1) load_flight_role<1>(P.F, P.I, P.D, N, nn, s);
-    else { load_flight_role<2>(P.F, P.I, P.D, N, nn, s); t.status = P.I[(size_t)FI_status * N + nn]; }
+    else { load_flight_role<2>(P.F, P.I, P.D, N, nn, s); t.status = state_word(P.F, SW_status, N, nn); }
     // The action row may live in mapped host memory (ac_step_host): a read across PCIe takes ~5 k cycles, and the CU's vector memory
     // path returns loads in the order they were issued ACROSS its waves -- a state load issued behind it, by any wave of the
     // workgroup, waits those 5 k cycles too (measured: the dynamics wave, which asks for the most, reached the table barrier at 8-10 k
@@ -865,12 +915,12 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
     TableCopy<256> tc;
     tc.issue(P.tab);
     s = State{}; t = Task{};
-    if (role == 0) { load_flight_role<0>(P.F, P.I, P.D, N, nn, s); t.status = P.I[(size_t)FI_status * N + nn]; }
+    if (role == 0) { load_flight_role<0>(P.F, P.I, P.D, N, nn, s); t.status = state_word(P.F, SW_status, N, nn); }
     else if (role == 1) load_flight_role<1>(P.F, P.I, P.D, N, nn, s);
-    else if (role == 2) { load_flight_role<2>(P.F, P.I, P.D, N, nn, s); t.status = P.I[(size_t)FI_status * N + nn]; }
+    else if (role == 2) { load_flight_role<2>(P.F, P.I, P.D, N, nn, s); t.status = state_word(P.F, SW_status, N, nn); }
     else {   // the environment wave owns the task bookkeeping; the status word of every missile slot and the tick count come with it
       load_task(P.F, P.I, N, nn, t);
-      s.ticks = P.I[(size_t)FI_ticks * N + nn];
+      s.ticks = state_word(P.F, SW_ticks, N, nn);
 #pragma unroll
       for (int k = 0; k < MSLOTS; ++k) pre_st[k] = P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn];
       if (TASK == AC_TASK_SHOOT_MISSILE) shoot_raw = act[4];
@@ -906,12 +956,25 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
     tc.commit(lds_tab);
   }
   AC_CLK(1);
+  const Task was = t;   // the task record as loaded: groups 16-18 are written back only where they changed (store_task_changed)
   // Three-wave form: after the last tick the kinematics wave stays and builds the observation rows from the pose the dynamics wave
   // posts (two more barriers between those two waves), while the dynamics wave runs terminations, rewards and the state stores.
   constexpr bool OBS_BY_KIN = SPLIT && TASK == AC_TASK_SINGLECOMBAT;
   if (SPLIT) {   // helper waves: run their part of every substep (the systems wave decodes the commands it integrates)
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (split_helper_wave(s, t, T, L, l, c.substeps, nullptr, nullptr, &arow)) {
+      if (OBS_BY_KIN && role == 1) {                 // the systems wave, idle after its last tick: the two geometry rewards of the final pose
+        using namespace mail;
+        wg_sync();                                   // the dynamics wave has posted the final pose
+        Props q;
+        q.alt_m = L.M[T_PR][l]; q.ub = L.M[T_PR + 5][l];
+        q.n = L.M[T_PR + 9][l]; q.e = L.M[T_PR + 10][l]; q.u = L.M[T_PR + 11][l];
+        q.vn = L.M[T_PR + 12][l]; q.ve = L.M[T_PR + 13][l]; q.vd = L.M[T_PR + 14][l];
+        const Enemy Eq = exchange_1v1(q);
+        L.M[T_RALT][l] = altitude_raw(q, c);
+        L.M[T_RPOS][l] = posture_raw(q, Eq);
+        wg_sync();                                   // read by the dynamics wave behind this barrier (its terminations ran meanwhile)
+      }
       if (OBS_BY_KIN && role == 2) {
         using namespace mail;
         wg_sync();                                   // the dynamics wave has posted the final pose
@@ -926,7 +989,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
         observe_1v1<TASK>(q, Eq, none, obq);
         wg_sync();                                   // ... and whether the env ends its episode: then the template's observation goes out
         if (L.M[T_DONE][l] != 0.0f) {
-          const float* tobs = (const float*)(P.tF + (size_t)NF * 2) + slot * OBS;
+          const float* tobs = (const float*)(P.tF + (size_t)NSW * 2) + slot * OBS;
 #pragma unroll
           for (int k = 0; k < OBS; ++k) obq[k] = tobs[k];
         }
@@ -1157,7 +1220,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
     L.M[mail::T_DONE][l] = all_done ? 1.0f : 0.0f;
     wg_sync();                                       // the kinematics wave sends the rows (the template's if the episode ends)
   } else if (all_done) {
-    const float* tobs = (const float*)(P.tF + (size_t)NF * 2) + slot * OBS;  // template observation follows the template fields
+    const float* tobs = (const float*)(P.tF + (size_t)NSW * 2) + slot * OBS;  // template observation follows the template fields
 #pragma unroll
     for (int k = 0; k < OBS; ++k) ob[k] = tobs[k];
   }
@@ -1168,8 +1231,9 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
   const bool evaluates = !t.die_flag;
   if (evaluates) {
     t.die_flag = (t.status != AC_ALIVE) ? 1 : 0;
-    float r_alt = potential(altitude_raw(pr, c), c.altitude_scale, c.altitude_pot, t.pre_altitude);
-    float r_pos = potential(posture_raw(pr, E), c.posture_scale, c.posture_pot, t.pre_posture);
+    // (three-wave SingleCombat: the systems wave evaluated the two geometry terms from the posted pose while this wave ran the terminations)
+    float r_alt = potential(OBS_BY_KIN ? L.M[mail::T_RALT][l] : altitude_raw(pr, c), c.altitude_scale, c.altitude_pot, t.pre_altitude);
+    float r_pos = potential(OBS_BY_KIN ? L.M[mail::T_RPOS][l] : posture_raw(pr, E), c.posture_scale, c.posture_pot, t.pre_posture);
     float ev = ((t.status != AC_ALIVE) ? -200.0f : 0.0f) + 200.0f * (float)my_hits;  // event_driven_reward.py:15-34
     float r_ev = potential(ev, c.event_scale, c.event_pot, t.pre_event);
     reward = r_alt + r_pos + r_ev;
@@ -1226,10 +1290,10 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
   }
   AC_CLK(53);
   if (live) {
-    if (!PAIR) store_state(P.F, P.I, P.D, N, n, s, t);
+    if (!PAIR) { store_flight(P.F, P.I, P.D, N, n, s); store_task_changed(P.F, P.I, N, n, t, was); }
     else {   // the flight wave has stored the flown state (ordered before this by the barrier): an episode reset overwrites it
       if (all_done) store_flight(P.F, P.I, P.D, N, n, s);
-      store_task(P.F, P.I, N, n, t);
+      store_task_changed(P.F, P.I, N, n, t, was);
     }
     if (HAS_MSL) {
 #pragma unroll
@@ -1336,6 +1400,7 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
   tc.issue(P.tab);
   const float4 a4 = load_controls(P.actions + (size_t)nn * c.act_dim, c.act_dim);
   load_state(P.F, P.I, P.D, N, nn, s, t);
+  const Task was = t;
   tc.commit(lds_tab);
   t.cur_step += 1;
   s.da = clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);   // multiplecombat_task.py:137-145
@@ -1431,11 +1496,12 @@ __global__ __launch_bounds__(SPLIT ? 192 : 64, WPE) void step_kernel_nvn(DevPtrs
   if (all_done) {
     load_state(P.tF, P.tI, P.tD, A, slot, s, t);
     zero_controller_state(P, N, n, live);
-    const float* tobs = P.tF + (size_t)NF * A + slot * OBS;
+    const float* tobs = P.tF + (size_t)NSW * A + slot * OBS;
     for (int k = 0; k < ow; ++k) orow[k] = tobs[k];
   }
   if (live) {
-    store_state(P.F, P.I, P.D, N, n, s, t);
+    store_flight(P.F, P.I, P.D, N, n, s);
+    store_task_changed(P.F, P.I, N, n, t, was);
   }
   emit_rows(P, lds_out, ow, l, poison_if(nonfinite, reward), done, A, step_out, last_code, 0, all_done ? 1 : 0);
 }
@@ -1551,7 +1617,7 @@ __global__ void init_kernel_1v1(InitArgs ia, DevCfg c, const float* tab, float* 
   if (c.posture_pot) t.pre_posture = posture_raw(pr, E) * c.posture_scale;
   if (threadIdx.x < 2) {
     store_state(tF, tI, tD, 2, slot, s, t);
-    float* tobs = tF + (size_t)NF * 2 + slot * OBS;
+    float* tobs = tF + (size_t)NSW * 2 + slot * OBS;
     for (int k = 0; k < OBS; ++k) tobs[k] = ob[k];
   }
 }
@@ -1579,7 +1645,7 @@ __global__ void init_kernel_nvn(InitArgs ia, DevCfg c, const float* tab, float* 
   if (c.posture_pot) t.pre_posture = posture * c.posture_scale;
   if (threadIdx.x < A) {
     store_state(tF, tI, tD, A, slot, s, t);
-    float* tobs = tF + (size_t)NF * A + slot * OBS;
+    float* tobs = tF + (size_t)NSW * A + slot * OBS;
     for (int k = 0; k < OBS; ++k) tobs[k] = ob[k];
   }
 }
@@ -1605,7 +1671,7 @@ __global__ void reset_all_kernel(DevPtrs P, DevCfg c) {
     else { Msl m{}; m.status = MSL_INACTIVE; store_msl(P.MF, P.MI, N, n, k, m); }
   }
   const int TOBS = c.tobs;   // the template holds the kernel family's own layout; RWR appends two zero slots, WVR uses the first 15
-  const float* tobs = P.tF + (size_t)NF * c.A + slot * TOBS;
+  const float* tobs = P.tF + (size_t)NSW * c.A + slot * TOBS;
   for (int k = 0; k < OBS; ++k) P.obs[(size_t)n * OBS + k] = (k < TOBS) ? tobs[k] : 0.0f;
   zero_controller_state(P, N, n, true);
   P.rew[n] = 0.0f; P.done[n] = 0;
@@ -1885,8 +1951,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   HIP_OK(hipHostMalloc((void**)&h->count_host, sizeof(int), hipHostMallocDefault));
   const size_t N = (size_t)h->N;
   DevPtrs& p = h->dp;
-  HIP_OK(hipMalloc(&p.F, sizeof(float) * NF * N));
-  HIP_OK(hipMalloc(&p.I, sizeof(int) * NI * N));
+  HIP_OK(hipMalloc(&p.F, sizeof(float) * NSW * N));   // 19 groups of four words per aircraft, ints among them (see SW_*)
+  p.I = reinterpret_cast<int*>(p.F);                  // (the same storage: kept as a name for the signatures that take the pair)
   HIP_OK(hipMalloc(&p.D, sizeof(double) * ND * N));
   const size_t ms = c.msl_slots > 0 ? (size_t)c.msl_slots : 1;
   HIP_OK(hipMalloc(&p.MF, sizeof(float) * ms * NMF * N));
@@ -1906,8 +1972,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   for (int i = 0; i < F16_PACK_LEN; ++i) tab[i] = (float)F16_PACK[i];
   HIP_OK(hipMalloc(&h->d_tab, sizeof(float) * F16_PACK_LEN));
   HIP_OK(hipMemcpy(h->d_tab, tab.data(), sizeof(float) * F16_PACK_LEN, hipMemcpyHostToDevice));
-  HIP_OK(hipMalloc(&h->d_tF, sizeof(float) * ((size_t)NF * h->A + (size_t)h->A * tmpl_obs)));
-  HIP_OK(hipMalloc(&h->d_tI, sizeof(int) * NI * h->A));
+  HIP_OK(hipMalloc(&h->d_tF, sizeof(float) * ((size_t)NSW * h->A + (size_t)h->A * tmpl_obs)));
+  h->d_tI = reinterpret_cast<int*>(h->d_tF);
   HIP_OK(hipMalloc(&h->d_tD, sizeof(double) * ND * h->A));
   if (scenario) {
     HIP_OK(hipMalloc(&h->d_XF, sizeof(float) * NXF * N));
@@ -1974,8 +2040,8 @@ int ac_destroy(ac_env_t* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  void* bufs[] = {h->dp.F, h->dp.I, h->dp.D, h->dp.MF, h->dp.MD, h->dp.MI, h->dp.obs, h->dp.rew, h->dp.done, h->dp.info,
-                  h->d_actions, h->d_tab, h->d_tF, h->d_tI, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_ctlWs, h->d_ctlWs8, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
+  void* bufs[] = {h->dp.F, h->dp.D, h->dp.MF, h->dp.MD, h->dp.MI, h->dp.obs, h->dp.rew, h->dp.done, h->dp.info,
+                  h->d_actions, h->d_tab, h->d_tF, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_ctlWs, h->d_ctlWs8, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
   for (void* b : bufs) (void)hipFree(b);
   for (int k = 0; k < AC_HOST_SETS; ++k)
     if (h->have_hs[k]) ac_host_set_free(h->hs[k].act, h->hs[k].obs, h->hs[k].rew, h->hs[k].done, h->hs[k].info);   // (a detached set is the caller's)
@@ -2144,6 +2210,9 @@ int ac_step_timed_device(ac_env_t* h, const float* d_actions, float* controller_
 }
 
 // state vector layout: rx ry rz | float fields | task floats | eng ticks | task ints   (names: ac_state_field_name)
+// where a word of the external vector lives in the device's group storage (SW_*), and the fp64 position (a pair + rz)
+static float* storage_word(float* S, int w, size_t N, size_t n) { return S + (((size_t)(w >> 2) * N + n) * 4 + (size_t)(w & 3)); }
+static double* position_word(double* D, int f, size_t N, size_t n) { return f < 2 ? D + 2 * n + f : D + 2 * N + n; }
 static int check_idx(ac_env_t* h, int env, int agent) {
   if (!h) return fail("null handle");
   if (env < 0 || env >= h->E || agent < 0 || agent >= h->A) return fail("env/agent index out of range");
@@ -2155,9 +2224,9 @@ int ac_get_state(ac_env_t* h, int32_t env, int32_t agent, double* out) {
   HIP_OK(hipStreamSynchronize(h->stream));
   const size_t N = h->N, n = (size_t)env * h->A + agent;
   int k = 0;
-  for (int f = 0; f < ND; ++f) { double v; HIP_OK(hipMemcpy(&v, h->dp.D + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
-  for (int f = 0; f < NF; ++f) { float v; HIP_OK(hipMemcpy(&v, h->dp.F + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
-  for (int f = 0; f < NI; ++f) { int v; HIP_OK(hipMemcpy(&v, h->dp.I + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
+  for (int f = 0; f < ND; ++f) { double v; HIP_OK(hipMemcpy(&v, position_word(h->dp.D, f, N, n), sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
+  for (int f = 0; f < NF; ++f) { float v; HIP_OK(hipMemcpy(&v, storage_word(h->dp.F, kSlotF[f], N, n), sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
+  for (int f = 0; f < NI; ++f) { int v; HIP_OK(hipMemcpy(&v, storage_word(h->dp.F, kSlotI[f], N, n), sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
   if (h->d_XF) {  // read-only tail: scenario-task extension (weapon counters, chaff clouds, shared reward references)
     {   // the fourteen counters / flags live in two packed words (scenario_kernel.hpp: ext_pack0 / ext_pack1); reported one by one
       int w[NXI];
@@ -2179,9 +2248,9 @@ int ac_set_state(ac_env_t* h, int32_t env, int32_t agent, const double* in) {
   HIP_OK(hipStreamSynchronize(h->stream));
   const size_t N = h->N, n = (size_t)env * h->A + agent;
   int k = 0;
-  for (int f = 0; f < ND; ++f) { double v = in[k++]; HIP_OK(hipMemcpy(h->dp.D + f * N + n, &v, sizeof v, hipMemcpyHostToDevice)); }
-  for (int f = 0; f < NF; ++f) { float v = (float)in[k++]; HIP_OK(hipMemcpy(h->dp.F + f * N + n, &v, sizeof v, hipMemcpyHostToDevice)); }
-  for (int f = 0; f < NI; ++f) { int v = (int)llround(in[k++]); HIP_OK(hipMemcpy(h->dp.I + f * N + n, &v, sizeof v, hipMemcpyHostToDevice)); }
+  for (int f = 0; f < ND; ++f) { double v = in[k++]; HIP_OK(hipMemcpy(position_word(h->dp.D, f, N, n), &v, sizeof v, hipMemcpyHostToDevice)); }
+  for (int f = 0; f < NF; ++f) { float v = (float)in[k++]; HIP_OK(hipMemcpy(storage_word(h->dp.F, kSlotF[f], N, n), &v, sizeof v, hipMemcpyHostToDevice)); }
+  for (int f = 0; f < NI; ++f) { int v = (int)llround(in[k++]); HIP_OK(hipMemcpy(storage_word(h->dp.F, kSlotI[f], N, n), &v, sizeof v, hipMemcpyHostToDevice)); }
   return 0;
 }
 int ac_set_status(ac_env_t* h, int32_t env, int32_t agent, int32_t status) {
@@ -2191,7 +2260,7 @@ int ac_set_status(ac_env_t* h, int32_t env, int32_t agent, int32_t status) {
   HIP_OK(hipStreamSynchronize(h->stream));
   const size_t N = h->N, n = (size_t)env * h->A + agent;
   int v = status;
-  HIP_OK(hipMemcpy(h->dp.I + (size_t)FI_status * N + n, &v, sizeof v, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(storage_word(h->dp.F, SW_status, N, n), &v, sizeof v, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -2231,9 +2300,16 @@ __global__ void state_checksum_kernel(DevPtrs P, DevCfg c, unsigned long long* o
       z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 27; z *= 0x94D049BB133111EBULL; z ^= z >> 31;
       return z;
     };
-    for (int f = 0; f < NF; ++f) acc += mix((unsigned long long)__float_as_uint(P.F[(size_t)f * N + n]), f);
-    for (int f = 0; f < NI; ++f) acc += mix((unsigned long long)(unsigned)P.I[(size_t)f * N + n], NF + f);
-    for (int f = 0; f < ND; ++f) acc += mix((unsigned long long)__double_as_longlong(P.D[(size_t)f * N + n]), NF + NI + f);
+    for (int g = 0; g < NSG; ++g) {   // the step kernels' own access pattern: one 16-byte group per lane and instruction
+      const float4 v = reinterpret_cast<const float4*>(P.F)[(size_t)g * N + n];
+      acc += mix((unsigned long long)__float_as_uint(v.x), 4 * g) + mix((unsigned long long)__float_as_uint(v.y), 4 * g + 1) +
+             mix((unsigned long long)__float_as_uint(v.z), 4 * g + 2) + mix((unsigned long long)__float_as_uint(v.w), 4 * g + 3);
+    }
+    {
+      const double2 xy = reinterpret_cast<const double2*>(P.D)[n];
+      acc += mix((unsigned long long)__double_as_longlong(xy.x), NSW) + mix((unsigned long long)__double_as_longlong(xy.y), NSW + 1) +
+             mix((unsigned long long)__double_as_longlong(P.D[2 * (size_t)N + n]), NSW + 2);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);

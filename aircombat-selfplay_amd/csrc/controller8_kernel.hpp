@@ -126,9 +126,9 @@ __device__ __forceinline__ float group16_sum(float v) {
   v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
   return v;
 }
-__device__ __forceinline__ void layer_norm_planes(const float* buf, unsigned short* planes, const float* __restrict__ g, const float* __restrict__ b, int tid) {
+__device__ __forceinline__ void layer_norm_planes(const float* buf, unsigned short* planes, const float* g, const float* b, int tid) {
   const int row = tid >> 4, part = tid & 15;
-  const float4 g0 = *reinterpret_cast<const float4*>(g + 8 * part), g1 = *reinterpret_cast<const float4*>(g + 8 * part + 4);   // (from L2: behind the reductions)
+  const float4 g0 = *reinterpret_cast<const float4*>(g + 8 * part), g1 = *reinterpret_cast<const float4*>(g + 8 * part + 4);   // (scale / shift: staged in LDS with the biases)
   const float4 b0 = *reinterpret_cast<const float4*>(b + 8 * part), b1 = *reinterpret_cast<const float4*>(b + 8 * part + 4);
   const float4 x0 = *reinterpret_cast<const float4*>(buf + row * RS + 8 * part), x1 = *reinterpret_cast<const float4*>(buf + row * RS + 8 * part + 4);
   float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
@@ -163,6 +163,13 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
   const int i0 = blockIdx.x * MT;
   const float* __restrict__ W = a.Ws8;
   const int col = lane & 15;
+  // every bias and LayerNorm scale / shift (1952 floats behind the weight tiles) goes to LDS with the first loads: read from L2 where it is
+  // used, each of them put a whole round trip in front of its phase's first matrix instruction (layer 2 took 3.9 k cycles for 1.5 k of matrix work)
+  __shared__ __attribute__((aligned(16))) float prm[C_END - C_B1];
+  static_assert((C_END - C_B1) % 4 == 0 && (C_END - C_B1) / 4 <= 512 && C_B1 % 4 == 0, "one float4 per thread");
+#define CTL8_PRM(i) prm[(i) - C_B1]            /* W[i] for the vectors, from LDS */
+  float4 prm4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < (C_END - C_B1) / 4) prm4 = reinterpret_cast<const float4*>(W + C_B1)[tid];
 
   // ---- stage. Loads return in the order they were asked for: the 12 controller inputs first (layer 1 waits for nothing else), then
   // layer 1's weights, the GRU state (first needed by the GRU) and layer 2's weights.
@@ -200,6 +207,7 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
   for (int f = 0; f < 8; ++f) hv[f] = a.H[(size_t)(spart * 8 + f) * a.N + sn];
   prefetch_bt<HID>(W + C_W2 + w * tile_floats(HID), lane, b2);
   __builtin_amdgcn_sched_barrier(0);
+  if (tid < (C_END - C_B1) / 4) reinterpret_cast<float4*>(prm)[tid] = prm4;
   if (spart == 0) {
     const float lo8[8] = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]}, hi8[8] = {x[8], x[9], x[10], x[11], 0.0f, 0.0f, 0.0f, 0.0f};
     write_planes8(PA, srow, 0, lo8); write_planes8(PA, srow, 8, hi8);
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
   {
     AF A;
     load_af(PA, lane, 0, A);
-    const float bias = W[C_B1 + w * 16 + col];
+    const float bias = CTL8_PRM(C_B1 + w * 16 + col);
     floatx4 acc[2] = {splat4(bias), splat4(bias)}, lo[2] = {splat4(0.0f), splat4(0.0f)}, mid[2] = {splat4(0.0f), splat4(0.0f)};
     CTL8_STEP(lo, mid, acc, A, b1.s[0]);
 #pragma unroll
@@ -230,11 +238,11 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
   }
   __syncthreads();
   AC_CLK(202);
-  layer_norm_planes(stg, PA, W + C_G1, W + C_BE1, tid);
+  layer_norm_planes(stg, PA, prm + (C_G1 - C_B1), prm + (C_BE1 - C_B1), tid);
   AC_CLK(203);
   // ---- MLP layer 2
   {
-    const float bias = W[C_B2 + w * 16 + col];
+    const float bias = CTL8_PRM(C_B2 + w * 16 + col);
     floatx4 acc[2] = {splat4(bias), splat4(bias)};
     layer128(b2, PA, lane, acc);
 #pragma unroll
@@ -248,14 +256,14 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   AC_CLK(204);
-  layer_norm_planes(stg, PA, W + C_G2, W + C_BE2, tid);
+  layer_norm_planes(stg, PA, prm + (C_G2 - C_B1), prm + (C_BE2 - C_B1), tid);
   AC_CLK(205);
   // ---- GRU cell (torch gate order r, z, n): wave w owns hidden units 16 w .. 16 w + 15, i.e. gate tiles w, 8 + w, 16 + w
   BT<HID> bh;
   BS b5;
   {
-    const float bir = W[C_BIH + 0 * 128 + w * 16 + col], biz = W[C_BIH + 1 * 128 + w * 16 + col], bin = W[C_BIH + 2 * 128 + w * 16 + col];
-    const float bhr = W[C_BHH + 0 * 128 + w * 16 + col], bhz = W[C_BHH + 1 * 128 + w * 16 + col], bhn = W[C_BHH + 2 * 128 + w * 16 + col];
+    const float bir = CTL8_PRM(C_BIH + 0 * 128 + w * 16 + col), biz = CTL8_PRM(C_BIH + 1 * 128 + w * 16 + col), bin = CTL8_PRM(C_BIH + 2 * 128 + w * 16 + col);
+    const float bhr = CTL8_PRM(C_BHH + 0 * 128 + w * 16 + col), bhz = CTL8_PRM(C_BHH + 1 * 128 + w * 16 + col), bhn = CTL8_PRM(C_BHH + 2 * 128 + w * 16 + col);
     floatx4 ir[2] = {splat4(bir), splat4(bir)}, iz[2] = {splat4(biz), splat4(biz)}, in_[2] = {splat4(bin), splat4(bin)};
     floatx4 hr[2] = {splat4(bhr), splat4(bhr)}, hz[2] = {splat4(bhz), splat4(bhz)}, hn[2] = {splat4(bhn), splat4(bhn)};
     {
@@ -304,11 +312,11 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
     }
   }
   AC_CLK(208);
-  layer_norm_planes(stg, PA, W + C_G3, W + C_BE3, tid);
+  layer_norm_planes(stg, PA, prm + (C_G3 - C_B1), prm + (C_BE3 - C_B1), tid);
   AC_CLK(209);
   // ---- heads: 153 logits = ten 16-column tiles; wave w takes tile w, and one k-step of tile 8 + (w & 1) (logits 128 .. 159)
   {
-    const float bias = W[C_BA + w * 16 + col];
+    const float bias = CTL8_PRM(C_BA + w * 16 + col);
     floatx4 acc[2] = {splat4(bias), splat4(bias)};
     layer128(bh, PA, lane, acc);
 #pragma unroll
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
   // logits 128 .. 152 = bias + the four K-partials, summed in a fixed order (25 columns x 32 aircraft over 512 threads)
   for (int e = tid; e < 25 * 32; e += 512) {
     const int q = e >> 5, row = e & 31;
-    lg[(128 + q) * LS + row] = (((W[C_BA + 128 + q] + stg[q * LS + row]) + stg[(32 + q) * LS + row]) + stg[(64 + q) * LS + row]) + stg[(96 + q) * LS + row];
+    lg[(128 + q) * LS + row] = (((CTL8_PRM(C_BA + 128 + q) + stg[q * LS + row]) + stg[(32 + q) * LS + row]) + stg[(64 + q) * LS + row]) + stg[(96 + q) * LS + row];
   }
   __syncthreads();
   AC_CLK(211);
@@ -365,3 +373,4 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
   }
   AC_CLK(212);
 }
+#undef CTL8_PRM

@@ -59,7 +59,7 @@ __device__ __forceinline__ void pair_post_final(PairLds& L, int l, const f16::St
 struct PairFlightIn { f16::State s; int status0; float4 a4; };
 __device__ __forceinline__ void pair_flight_load(const DevPtrs& P, const DevCfg& c, int nn, PairFlightIn& in) {
   load_flight(P.F, P.I, P.D, c.N, nn, in.s);
-  in.status0 = P.I[(size_t)FI_status * c.N + nn];
+  in.status0 = state_word(P.F, SW_status, c.N, nn);
   in.a4 = load_controls(P.actions + (size_t)nn * c.act_dim, c.act_dim);
 }
 // `tail(pp)`: work for this wave after its final values are posted and the flight state is stored, while the environment wave runs the

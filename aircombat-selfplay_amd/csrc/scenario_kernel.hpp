@@ -259,9 +259,9 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   int mst[MS] = {MSL_INACTIVE, MSL_INACTIVE};
   if (fdm_role) {   // each FDM wave asks for the state fields its share of the tick reads (load_flight_role), and the action row
     s = State{}; t = Task{};
-    if (wave == 0) { load_flight_role<0>(P.F, P.I, P.D, N, nn, s); t.status = P.I[(size_t)FI_status * N + nn]; }
+    if (wave == 0) { load_flight_role<0>(P.F, P.I, P.D, N, nn, s); t.status = state_word(P.F, SW_status, N, nn); }
     else if (wave == 1) load_flight_role<1>(P.F, P.I, P.D, N, nn, s);
-    else { load_flight_role<2>(P.F, P.I, P.D, N, nn, s); t.status = P.I[(size_t)FI_status * N + nn]; }
+    else { load_flight_role<2>(P.F, P.I, P.D, N, nn, s); t.status = state_word(P.F, SW_status, N, nn); }
     a4 = load_controls(act, c.act_dim);
   } else if (!flight_role) {
     a4 = load_controls(act, c.act_dim);
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
 #pragma unroll
     for (int k = 0; k < MS; ++k) { ms[k] = MslD{}; ms[k].status = MSL_INACTIVE; }
     msl_moved = (1 << MS) - 1;
-    const float* tobs = P.tF + (size_t)NF * A + slot * OBS;
+    const float* tobs = P.tF + (size_t)NSW * A + slot * OBS;
     if (row_direct) { float* orow = lds_out + lane * c.obs_dim; for (int k = 0; k < OBS; ++k) orow[k] = tobs[k]; }
     else {
 #pragma unroll
@@ -978,7 +978,7 @@ __global__ void init_kernel_scenario(InitArgs ia, DevCfg c, const float* tab, fl
   if (c.posture_pot) t.pre_posture = posture * c.posture_scale;
   if (threadIdx.x < A) {
     store_state(tF, tI, tD, A, slot, s, t);
-    float* tobs = tF + (size_t)NF * A + slot * OBS;
+    float* tobs = tF + (size_t)NSW * A + slot * OBS;
     for (int k = 0; k < OBS; ++k) tobs[k] = ob[k];
   }
 }

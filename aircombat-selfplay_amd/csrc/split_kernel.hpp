@@ -32,7 +32,8 @@ enum { RUNF,                                                       // dynamics -
        QP_F = G_NED + 8, QP_F_N = 9,                                // quad form with reduced poses: altitude [m] and the local frame of tick k in rows QP_F + 9 (k & 1) ..
        T_PR = QP_F + 2 * QP_F_N, T_PR_N = 15,                       // three-wave SingleCombat: dynamics -> kinematics after the last tick, the pose
        T_DONE = T_PR + T_PR_N,                                      //   the observation is built from, and whether the env ends its episode
-       ROWS = T_DONE + 1 };
+       T_RALT = T_DONE + 1, T_RPOS,                                 // systems -> dynamics before the second of those barriers: AltitudeReward / PostureReward of the final pose, unscaled
+       ROWS = T_RPOS + 1 };
 // fp64 rows: ECI position of tick k in rows GD_R + 3 (k & 1) .. (double-buffered: the kinematics wave is one tick ahead), ECEF
 // position and geodetic cosines of the step's last substep
 // (quad form with reduced poses: the NEU position of tick k in rows GD_QP + 3 (k & 1) ..)
