@@ -1701,6 +1701,7 @@ struct ac_env {
   float* d_ctlWs;                        // controller weights as bf16 pieces (controller_split_kernel.hpp)
   float* d_ctlWs8;                       // the same in the eight-wave kernel's tiling (controller8_kernel.hpp)
   bool ctl8;                             // which controller kernel the handle launches (AIRCOMBAT_CTL8=0/1; default: the eight-wave one)
+  int ctl_rows;                          // aircraft per controller workgroup pinned by AIRCOMBAT_CTL_ROWS=32/64 (0: chosen per grid)
   HeadingPtrs hp; HeadingCfg hc;         // HeadingTask: targets, check clock, numpy-PCG64 state per env
   int act_low;                           // width of the low-level action the step kernels decode
   hipEvent_t ev0, ev1;
@@ -1752,9 +1753,15 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
                 (float)h->cfg.agent_interaction_steps / (float)h->cfg.sim_freq, p.man_step, p.man_h0, p, h->dc};
     // (the scripted opponents' inputs -- use_baseline -- are computed inside that instantiation of the kernel)
     const dim3 cgrid((h->N + ctl::MT - 1) / ctl::MT);
-    if (h->ctl8) {   // eight waves per 32-aircraft tile (controller8_kernel.hpp); AIRCOMBAT_CTL8=0 pins the four-wave kernel it replaced
-      if (h->cfg.use_baseline) hipLaunchKernelGGL(controller8_kernel<true>, cgrid, dim3(512), 0, h->stream, a);
-      else hipLaunchKernelGGL(controller8_kernel<false>, cgrid, dim3(512), 0, h->stream, a);
+    if (h->ctl8) {   // eight waves per tile (controller8_kernel.hpp); AIRCOMBAT_CTL8=0 pins the four-wave kernel it replaced
+      // 32 aircraft per workgroup while that leaves no CU with two tiles to do one after the other; 64 beyond (AIRCOMBAT_CTL_ROWS pins it)
+      const int rows = h->ctl_rows ? h->ctl_rows : ((h->N + 31) / 32 > 256 ? 64 : 32);
+      const dim3 g8((h->N + rows - 1) / rows);
+      if (rows == 64) {
+        if (h->cfg.use_baseline) hipLaunchKernelGGL((controller8_kernel<true, 4>), g8, dim3(512), 0, h->stream, a);
+        else hipLaunchKernelGGL((controller8_kernel<false, 4>), g8, dim3(512), 0, h->stream, a);
+      } else if (h->cfg.use_baseline) hipLaunchKernelGGL((controller8_kernel<true, 2>), g8, dim3(512), 0, h->stream, a);
+      else hipLaunchKernelGGL((controller8_kernel<false, 2>), g8, dim3(512), 0, h->stream, a);
     } else if (h->cfg.use_baseline) hipLaunchKernelGGL(controller_split_kernel<true>, cgrid, dim3(256), 0, h->stream, a);
     else hipLaunchKernelGGL(controller_split_kernel<false>, cgrid, dim3(256), 0, h->stream, a);
     HIP_OK(hipGetLastError());
@@ -1895,6 +1902,8 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     h->split_waves = ticks_only && (e ? (e[0] == '1') : (wgs <= 512));
     const char* ce = getenv("AIRCOMBAT_CTL8");
     h->ctl8 = ce ? (ce[0] == '1') : true;
+    const char* cr = getenv("AIRCOMBAT_CTL_ROWS");
+    h->ctl_rows = cr ? (atoi(cr) == 64 ? 64 : 32) : 0;
     const char* qe = getenv("AIRCOMBAT_QUAD");   // 0 / 1 overrides the choice of the quad form
     const bool munitions_1v1 = cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE || cfg->task == AC_TASK_SCENARIO1;
     h->quad_waves = munitions_1v1 && (qe ? (qe[0] == '1') : (wgs <= 256));

@@ -42,14 +42,27 @@ __device__ __forceinline__ floatx4 mf(const uint4& a, const uint4& b, floatx4 ac
 // result layout of a 16x16 tile: acc[i] is (row = 4 (lane / 16) + i, column = lane % 16)
 __device__ __forceinline__ int c_row(int mt, int i, int lane) { return 16 * mt + 4 * (lane >> 4) + i; }
 
-// A operands of one k-step for this lane: [M-tile][piece] = planes[piece][row = 16 mt + lane % 16][k = 32 s + 8 (lane / 16) .. + 7]
-struct AF { uint4 a[2][3]; };
-__device__ __forceinline__ void load_af(const unsigned short* planes, int lane, int s, AF& A) {
+// A operands of one k-step for this lane: [M-tile][piece] = planes[piece][row = 16 mt + lane % 16][k = 32 s + 8 (lane / 16) .. + 7].
+// MTL = M-tiles per wave: 2 (32 aircraft per workgroup) or 4 (64: the grids with more tiles than CUs, where a workgroup's fixed costs --
+// first round trip, barriers, the latency-bound LayerNorm / gate / argmax phases -- are shared by twice the aircraft and every weight
+// piece loaded feeds twice the matrix instructions).
+template <int MTL>
+struct Geo8 {
+  static constexpr int R = 16 * MTL;               // aircraft per workgroup
+  static constexpr int PLN = R * KS;               // bf16 per plane
+  static constexpr int LSR = R + 1;                // row stride of the [feature][aircraft] buffers (odd: column writes spread over the banks)
+  static constexpr int TPR = 512 / R;              // threads per aircraft in the row-wise phases (16 or 8)
+  static constexpr int FPT = HID / TPR;            // features per thread there (8 or 16)
+};
+template <int MTL>
+struct AF { uint4 a[MTL][3]; };
+template <int MTL>
+__device__ __forceinline__ void load_af(const unsigned short* planes, int lane, int s, AF<MTL>& A) {
   const unsigned short* base = planes + (lane & 15) * KS + 8 * (lane >> 4) + 32 * s;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) A.a[mt][p] = *reinterpret_cast<const uint4*>(base + p * PLANE + 16 * mt * KS);
+    for (int p = 0; p < 3; ++p) A.a[mt][p] = *reinterpret_cast<const uint4*>(base + p * Geo8<MTL>::PLN + 16 * mt * KS);
 }
 struct BS { uint4 b[3]; };   // one k-step of one 16-column tile: the three pieces
 __device__ __forceinline__ void load_bs(const uint4* __restrict__ t4 /* tile + lane */, int s, BS& B) {
@@ -66,44 +79,58 @@ __device__ __forceinline__ void prefetch_bt(const float* __restrict__ tile, int 
 }
 // one k-step of one tile on three accumulation chains per M-tile (the 2^-16 terms, the 2^-8 terms, the leading term), like mma1 of the
 // four-wave kernel
-#define CTL8_STEP(lo, mid, acc, A, B)                                                                                     \
-  do {                                                                                                                    \
-    lo[0] = mf(A.a[0][2], B.b[0], lo[0]); lo[1] = mf(A.a[1][2], B.b[0], lo[1]);                                           \
-    mid[0] = mf(A.a[0][1], B.b[0], mid[0]); mid[1] = mf(A.a[1][1], B.b[0], mid[1]);                                       \
-    acc[0] = mf(A.a[0][0], B.b[0], acc[0]); acc[1] = mf(A.a[1][0], B.b[0], acc[1]);                                       \
-    lo[0] = mf(A.a[0][0], B.b[2], lo[0]); lo[1] = mf(A.a[1][0], B.b[2], lo[1]);                                           \
-    mid[0] = mf(A.a[0][0], B.b[1], mid[0]); mid[1] = mf(A.a[1][0], B.b[1], mid[1]);                                       \
-    lo[0] = mf(A.a[0][1], B.b[1], lo[0]); lo[1] = mf(A.a[1][1], B.b[1], lo[1]);                                           \
-  } while (0)
+template <int MTL>
+__device__ __forceinline__ void step3(floatx4 (&lo)[MTL], floatx4 (&mid)[MTL], floatx4 (&acc)[MTL], const AF<MTL>& A, const BS& B) {
+#pragma unroll
+  for (int mt = 0; mt < MTL; ++mt) lo[mt] = mf(A.a[mt][2], B.b[0], lo[mt]);
+#pragma unroll
+  for (int mt = 0; mt < MTL; ++mt) mid[mt] = mf(A.a[mt][1], B.b[0], mid[mt]);
+#pragma unroll
+  for (int mt = 0; mt < MTL; ++mt) acc[mt] = mf(A.a[mt][0], B.b[0], acc[mt]);
+#pragma unroll
+  for (int mt = 0; mt < MTL; ++mt) lo[mt] = mf(A.a[mt][0], B.b[2], lo[mt]);
+#pragma unroll
+  for (int mt = 0; mt < MTL; ++mt) mid[mt] = mf(A.a[mt][0], B.b[1], mid[mt]);
+#pragma unroll
+  for (int mt = 0; mt < MTL; ++mt) lo[mt] = mf(A.a[mt][1], B.b[1], lo[mt]);
+}
 // a whole K = 128 layer for this wave's 16 columns: the weight tile is in registers (asked for a phase earlier), the A operands come
-// from the planes one k-step ahead of their use
-__device__ __forceinline__ void layer128(const BT<HID>& B, const unsigned short* planes, int lane, floatx4 (&acc)[2]) {
-  floatx4 lo[2] = {splat4(0.0f), splat4(0.0f)}, mid[2] = {splat4(0.0f), splat4(0.0f)};
-  AF A[2];
-  load_af(planes, lane, 0, A[0]);
+// from the planes one k-step ahead of their use (MTL = 2) or as they are needed (MTL = 4: registers)
+template <int MTL>
+__device__ __forceinline__ void layer128(const BT<HID>& B, const unsigned short* planes, int lane, floatx4 (&acc)[MTL]) {
+  floatx4 lo[MTL], mid[MTL];
+#pragma unroll
+  for (int mt = 0; mt < MTL; ++mt) { lo[mt] = splat4(0.0f); mid[mt] = splat4(0.0f); }
+  constexpr int NB = MTL == 2 ? 2 : 1;
+  AF<MTL> A[NB];
+  load_af<MTL>(planes, lane, 0, A[0]);
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    if (s + 1 < 4) load_af(planes, lane, s + 1, A[(s + 1) & 1]);
+    if (NB == 2 && s + 1 < 4) load_af<MTL>(planes, lane, s + 1, A[(s + 1) % NB]);
     __builtin_amdgcn_sched_barrier(0);
-    CTL8_STEP(lo, mid, acc, A[s & 1], B.s[s]);
+    step3<MTL>(lo, mid, acc, A[s % NB], B.s[s]);
     __builtin_amdgcn_sched_barrier(0);
+    if (NB == 1 && s + 1 < 4) load_af<MTL>(planes, lane, s + 1, A[0]);
   }
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[mt][i] += mid[mt][i] + lo[mt][i];
 }
-// the GRU's k-steps: three gate tiles of this wave's 16 hidden units, the six terms smallest first into one accumulator per (gate, M-tile)
-#define CTL8_GRU_TERM(a0, a1, a2, A, pa, B, pb)                                                                           \
-  do {                                                                                                                    \
-    a0[0] = mf(A.a[0][pa], B[0].b[pb], a0[0]); a1[0] = mf(A.a[0][pa], B[1].b[pb], a1[0]); a2[0] = mf(A.a[0][pa], B[2].b[pb], a2[0]); \
-    a0[1] = mf(A.a[1][pa], B[0].b[pb], a0[1]); a1[1] = mf(A.a[1][pa], B[1].b[pb], a1[1]); a2[1] = mf(A.a[1][pa], B[2].b[pb], a2[1]); \
-  } while (0)
-#define CTL8_GRU_STEP(a0, a1, a2, A, B)                                                                                   \
-  do {                                                                                                                    \
-    CTL8_GRU_TERM(a0, a1, a2, A, 2, B, 0); CTL8_GRU_TERM(a0, a1, a2, A, 0, B, 2); CTL8_GRU_TERM(a0, a1, a2, A, 1, B, 1);   \
-    CTL8_GRU_TERM(a0, a1, a2, A, 1, B, 0); CTL8_GRU_TERM(a0, a1, a2, A, 0, B, 1); CTL8_GRU_TERM(a0, a1, a2, A, 0, B, 0);   \
-  } while (0)
+// the GRU's k-steps: three gate tiles of this wave's 16 hidden units; one term of the six, all gates and M-tiles
+template <int MTL>
+__device__ __forceinline__ void gru_term(floatx4 (&a0)[MTL], floatx4 (&a1)[MTL], floatx4 (&a2)[MTL], const AF<MTL>& A, int pa, const BS (&B)[3], int pb) {
+#pragma unroll
+  for (int mt = 0; mt < MTL; ++mt) {
+    a0[mt] = mf(A.a[mt][pa], B[0].b[pb], a0[mt]); a1[mt] = mf(A.a[mt][pa], B[1].b[pb], a1[mt]); a2[mt] = mf(A.a[mt][pa], B[2].b[pb], a2[mt]);
+  }
+}
+// the six terms smallest first into one accumulator per (gate, M-tile)
+template <int MTL>
+__device__ __forceinline__ void gru_step(floatx4 (&a0)[MTL], floatx4 (&a1)[MTL], floatx4 (&a2)[MTL], const AF<MTL>& A, const BS (&B)[3]) {
+  gru_term<MTL>(a0, a1, a2, A, 2, B, 0); gru_term<MTL>(a0, a1, a2, A, 0, B, 2); gru_term<MTL>(a0, a1, a2, A, 1, B, 1);
+  gru_term<MTL>(a0, a1, a2, A, 1, B, 0); gru_term<MTL>(a0, a1, a2, A, 0, B, 1); gru_term<MTL>(a0, a1, a2, A, 0, B, 0);
+}
 __device__ __forceinline__ void ring_load(const float* __restrict__ W, int w, int lane, int st, BS (&dst)[3]) {
   const int TF = tile_floats(HID);
   const float* base = W + (st < 4 ? C_WIH : C_WHH);
@@ -111,60 +138,92 @@ __device__ __forceinline__ void ring_load(const float* __restrict__ W, int w, in
   for (int g = 0; g < 3; ++g) load_bs(reinterpret_cast<const uint4*>(base + (8 * g + w) * TF) + lane, st & 3, dst[g]);
 }
 // eight consecutive features of one aircraft -> the three planes (one 16-byte LDS store per plane)
-__device__ __forceinline__ void write_planes8(unsigned short* planes, int row, int k0, const float (&v)[8]) {
+template <int MTL>
+__device__ __forceinline__ void write_planes8(unsigned short* planes, int row, int k0, const float* v) {
   unsigned h[4], m[4], l[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) split3_pair(v[2 * q], v[2 * q + 1], h[q], m[q], l[q]);
-  *reinterpret_cast<uint4*>(planes + 0 * PLANE + row * KS + k0) = make_uint4(h[0], h[1], h[2], h[3]);
-  *reinterpret_cast<uint4*>(planes + 1 * PLANE + row * KS + k0) = make_uint4(m[0], m[1], m[2], m[3]);
-  *reinterpret_cast<uint4*>(planes + 2 * PLANE + row * KS + k0) = make_uint4(l[0], l[1], l[2], l[3]);
+  *reinterpret_cast<uint4*>(planes + 0 * Geo8<MTL>::PLN + row * KS + k0) = make_uint4(h[0], h[1], h[2], h[3]);
+  *reinterpret_cast<uint4*>(planes + 1 * Geo8<MTL>::PLN + row * KS + k0) = make_uint4(m[0], m[1], m[2], m[3]);
+  *reinterpret_cast<uint4*>(planes + 2 * Geo8<MTL>::PLN + row * KS + k0) = make_uint4(l[0], l[1], l[2], l[3]);
 }
-// torch.nn.LayerNorm(128) (eps 1e-5, biased variance) of buf[row][k] (fp32, row stride RS) into the three bf16 planes the next layer's
-// A operands are read from. Thread = (aircraft = tid / 16, part = tid % 16) owns features 8 part .. 8 part + 7; the sixteen parts of an
-// aircraft sit in adjacent lanes: mean and variance are four butterfly steps each, no partial sums through LDS.
-__device__ __forceinline__ float group16_sum(float v) {
-  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+// Sum over the adjacent lanes of an aircraft (16 or 8), the same value in all of them, with data-parallel-primitive moves (a few cycles
+// each; __shfl_xor compiles to ds_bpermute_b32, an LDS round trip of ~100 cycles, eight of them in a dependent chain per LayerNorm): pairs
+// and quads by quad_perm, the two quads of a half row by row_half_mirror (lane i <-> 7 - i), the two halves by row_mirror (i <-> 15 - i).
+// Every lane adds its own and its partner's partial sum, which are the same two numbers on both sides: all lanes end bit-identical.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int LANES>
+__device__ __forceinline__ float group_sum(float v) {
+  v += dpp_f<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += dpp_f<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  v += dpp_f<0x141>(v);   // row_half_mirror
+  if (LANES == 16) v += dpp_f<0x140>(v);   // row_mirror
   return v;
 }
+// torch.nn.LayerNorm(128) (eps 1e-5, biased variance) of buf[row][k] (fp32, row stride RS) into the three bf16 planes the next layer's
+// A operands are read from. Thread = (aircraft = tid / TPR, part = tid % TPR) owns FPT consecutive features; the parts of an aircraft sit
+// in adjacent lanes: mean and variance are a few DPP steps each, no partial sums through LDS. Scale / shift come from LDS (staged).
+template <int MTL>
 __device__ __forceinline__ void layer_norm_planes(const float* buf, unsigned short* planes, const float* g, const float* b, int tid) {
-  const int row = tid >> 4, part = tid & 15;
-  const float4 g0 = *reinterpret_cast<const float4*>(g + 8 * part), g1 = *reinterpret_cast<const float4*>(g + 8 * part + 4);   // (scale / shift: staged in LDS with the biases)
-  const float4 b0 = *reinterpret_cast<const float4*>(b + 8 * part), b1 = *reinterpret_cast<const float4*>(b + 8 * part + 4);
-  const float4 x0 = *reinterpret_cast<const float4*>(buf + row * RS + 8 * part), x1 = *reinterpret_cast<const float4*>(buf + row * RS + 8 * part + 4);
-  float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-  const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-  const float m = group16_sum(((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) * (1.0f / HID);
+  constexpr int TPR = Geo8<MTL>::TPR, FPT = Geo8<MTL>::FPT;
+  const int row = tid / TPR, part = tid % TPR;
+  float x[FPT], gg[FPT], bb[FPT];
+#pragma unroll
+  for (int q = 0; q < FPT / 4; ++q) {
+    const float4 xv = *reinterpret_cast<const float4*>(buf + row * RS + FPT * part + 4 * q);
+    const float4 gv = *reinterpret_cast<const float4*>(g + FPT * part + 4 * q), bv = *reinterpret_cast<const float4*>(b + FPT * part + 4 * q);
+    x[4 * q] = xv.x; x[4 * q + 1] = xv.y; x[4 * q + 2] = xv.z; x[4 * q + 3] = xv.w;
+    gg[4 * q] = gv.x; gg[4 * q + 1] = gv.y; gg[4 * q + 2] = gv.z; gg[4 * q + 3] = gv.w;
+    bb[4 * q] = bv.x; bb[4 * q + 1] = bv.y; bb[4 * q + 2] = bv.z; bb[4 * q + 3] = bv.w;
+  }
+  float sum = 0.0f;
+#pragma unroll
+  for (int q = 0; q < FPT / 8; ++q) sum += ((x[8 * q] + x[8 * q + 1]) + (x[8 * q + 2] + x[8 * q + 3])) + ((x[8 * q + 4] + x[8 * q + 5]) + (x[8 * q + 6] + x[8 * q + 7]));
+  const float m = group_sum<TPR>(sum) * (1.0f / HID);
   float v = 0.0f;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { x[q] -= m; v = fmaf(x[q], x[q], v); }
-  const float is = rsqrtf(group16_sum(v) * (1.0f / HID) + 1e-5f);
-  float y[8];
+  for (int q = 0; q < FPT; ++q) { x[q] -= m; v = fmaf(x[q], x[q], v); }
+  const float is = rsqrtf(group_sum<TPR>(v) * (1.0f / HID) + 1e-5f);
+  float y[FPT];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) y[q] = fmaf(x[q] * is, gg[q], bb[q]);
-  write_planes8(planes, row, 8 * part, y);
+  for (int q = 0; q < FPT; ++q) y[q] = fmaf(x[q] * is, gg[q], bb[q]);
+#pragma unroll
+  for (int q = 0; q < FPT / 8; ++q) write_planes8<MTL>(planes, row, FPT * part + 8 * q, y + 8 * q);
   __syncthreads();
+}
+// the fp32 GRU state of (aircraft row, unit) back from its three bf16 planes: hi + mid + lo is the fp32 value exactly (that is how the
+// planes were made), so no fp32 copy of the state is kept in LDS
+template <int MTL>
+__device__ __forceinline__ float plane_value(const unsigned short* planes, int row, int unit) {
+  const unsigned short* p = planes + row * KS + unit;
+  const float hi = __uint_as_float((unsigned)p[0] << 16), mid = __uint_as_float((unsigned)p[Geo8<MTL>::PLN] << 16), lo = __uint_as_float((unsigned)p[2 * Geo8<MTL>::PLN] << 16);
+  return (hi + mid) + lo;
 }
 }  // namespace ctl8
 
 // SCRIPTED: the handle has scripted opponents (`use_baseline`); their state -> pose code is compiled into that instantiation only.
-template <bool SCRIPTED>
+// MTL: 16-row M-tiles per wave = aircraft per workgroup / 16 (2 or 4).
+template <bool SCRIPTED, int MTL>
 __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
   using namespace ctl8;
   using ctl::sigmoid_f; using ctl::tanh_f;
-  __shared__ __attribute__((aligned(16))) unsigned short PA[3 * PLANE];   // activations as bf16 planes [piece][aircraft][k]
-  __shared__ __attribute__((aligned(16))) unsigned short PH[3 * PLANE];   // the GRU state likewise; the head logits (fp32 [160][LS]) later
-  __shared__ __attribute__((aligned(16))) float stg[HID * LS];   // a layer's fp32 outputs [aircraft][k] (row stride RS) on their way to LayerNorm
-  __shared__ __attribute__((aligned(16))) float hbuf[MT * RS];   // GRU state of the 32 aircraft, fp32 [aircraft][unit] (gate algebra)
-  static_assert(MT * RS <= HID * LS, "staging rows fit");
-  static_assert(sizeof(unsigned short) * 3 * PLANE >= sizeof(float) * NHP * LS, "the logits reuse the GRU-state planes");
+  using G = Geo8<MTL>;
+  constexpr int R = G::R, PLN = G::PLN, LSR = G::LSR, TPR = G::TPR, FPT = G::FPT;
+  __shared__ __attribute__((aligned(16))) unsigned short PA[3 * PLN];   // activations as bf16 planes [piece][aircraft][k]
+  __shared__ __attribute__((aligned(16))) unsigned short PH[3 * PLN];   // the GRU state likewise; the head logits (fp32 [160][LSR]) later
+  __shared__ __attribute__((aligned(16))) float stg[R * RS];            // a layer's fp32 outputs [aircraft][k] (row stride RS) on their way to LayerNorm
+  static_assert(4 * 32 * LSR <= R * RS, "the head partials of tiles 8 and 9 fit the staging buffer");
+  static_assert(sizeof(unsigned short) * 3 * PLN >= sizeof(float) * NHP * LSR, "the logits reuse the GRU-state planes");
   float* lg = reinterpret_cast<float*>(PH);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave 0..7: output columns 16 w .. 16 w + 15 of every 128-wide layer
-  const int i0 = blockIdx.x * MT;
+  const int i0 = blockIdx.x * R;
   const float* __restrict__ W = a.Ws8;
   const int col = lane & 15;
-  // every bias and LayerNorm scale / shift (1952 floats behind the weight tiles) goes to LDS with the first loads: read from L2 where it is
-  // used, each of them put a whole round trip in front of its phase's first matrix instruction (layer 2 took 3.9 k cycles for 1.5 k of matrix work)
+  // every bias and LayerNorm scale / shift (1952 floats behind the weight tiles) goes to LDS with the first loads
   __shared__ __attribute__((aligned(16))) float prm[C_END - C_B1];
   static_assert((C_END - C_B1) % 4 == 0 && (C_END - C_B1) / 4 <= 512 && C_B1 % 4 == 0, "one float4 per thread");
 #define CTL8_PRM(i) prm[(i) - C_B1]            /* W[i] for the vectors, from LDS */
@@ -176,7 +235,7 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
   AC_CLK(200);
   BT<32> b1;
   BT<HID> b2;
-  const int srow = tid & 31, spart = tid >> 5;   // staging: thread = (aircraft, 8-feature part)
+  const int srow = tid % R, spart = tid / R;     // staging: thread = (aircraft, FPT-feature part)
   const int sn = min(i0 + srow, a.N - 1);
   float x[16];
   if (spart == 0) {
@@ -202,83 +261,92 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
   }
   __builtin_amdgcn_sched_barrier(0);
   prefetch_bt<32>(W + C_W1 + w * tile_floats(32), lane, b1);
-  float hv[8];
+  float hv[FPT];
 #pragma unroll
-  for (int f = 0; f < 8; ++f) hv[f] = a.H[(size_t)(spart * 8 + f) * a.N + sn];
+  for (int f = 0; f < FPT; ++f) hv[f] = a.H[(size_t)(spart * FPT + f) * a.N + sn];
   prefetch_bt<HID>(W + C_W2 + w * tile_floats(HID), lane, b2);
   __builtin_amdgcn_sched_barrier(0);
   if (tid < (C_END - C_B1) / 4) reinterpret_cast<float4*>(prm)[tid] = prm4;
   if (spart == 0) {
-    const float lo8[8] = {x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]}, hi8[8] = {x[8], x[9], x[10], x[11], 0.0f, 0.0f, 0.0f, 0.0f};
-    write_planes8(PA, srow, 0, lo8); write_planes8(PA, srow, 8, hi8);
+    const float hi8[8] = {x[8], x[9], x[10], x[11], 0.0f, 0.0f, 0.0f, 0.0f};
+    write_planes8<MTL>(PA, srow, 0, x); write_planes8<MTL>(PA, srow, 8, hi8);
   } else if (spart <= 2) {   // zero k 16..31 of the three planes
     const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(PA + p * PLANE + srow * KS + 8 * (spart + 1)) = z;
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(PA + p * PLN + srow * KS + 8 * (spart + 1)) = z;
   }
   __syncthreads();
 
   AC_CLK(201);
   // ---- MLP layer 1: Linear(12, 128) + ReLU + LayerNorm; wave w owns output columns 16 w .. 16 w + 15
   {
-    AF A;
-    load_af(PA, lane, 0, A);
+    AF<MTL> A;
+    load_af<MTL>(PA, lane, 0, A);
     const float bias = CTL8_PRM(C_B1 + w * 16 + col);
-    floatx4 acc[2] = {splat4(bias), splat4(bias)}, lo[2] = {splat4(0.0f), splat4(0.0f)}, mid[2] = {splat4(0.0f), splat4(0.0f)};
-    CTL8_STEP(lo, mid, acc, A, b1.s[0]);
+    floatx4 acc[MTL], lo[MTL], mid[MTL];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTL; ++mt) { acc[mt] = splat4(bias); lo[mt] = splat4(0.0f); mid[mt] = splat4(0.0f); }
+    step3<MTL>(lo, mid, acc, A, b1.s[0]);
+#pragma unroll
+    for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) stg[c_row(mt, i, lane) * RS + w * 16 + col] = fmaxf(acc[mt][i] + (mid[mt][i] + lo[mt][i]), 0.0f);
   }
-  {   // the GRU state has arrived behind layer 1: fp32 for the gate algebra, bf16 planes for the products
-    *reinterpret_cast<float4*>(hbuf + srow * RS + spart * 8) = make_float4(hv[0], hv[1], hv[2], hv[3]);
-    *reinterpret_cast<float4*>(hbuf + srow * RS + spart * 8 + 4) = make_float4(hv[4], hv[5], hv[6], hv[7]);
-    write_planes8(PH, srow, spart * 8, hv);
+  {   // the GRU state has arrived behind layer 1: as the three bf16 planes (the products read them; the gate algebra adds them up again)
+#pragma unroll
+    for (int q = 0; q < FPT / 8; ++q) write_planes8<MTL>(PH, srow, spart * FPT + 8 * q, hv + 8 * q);
   }
   __syncthreads();
   AC_CLK(202);
-  layer_norm_planes(stg, PA, prm + (C_G1 - C_B1), prm + (C_BE1 - C_B1), tid);
+  layer_norm_planes<MTL>(stg, PA, prm + (C_G1 - C_B1), prm + (C_BE1 - C_B1), tid);
   AC_CLK(203);
   // ---- MLP layer 2
   {
     const float bias = CTL8_PRM(C_B2 + w * 16 + col);
-    floatx4 acc[2] = {splat4(bias), splat4(bias)};
-    layer128(b2, PA, lane, acc);
+    floatx4 acc[MTL];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTL; ++mt) acc[mt] = splat4(bias);
+    layer128<MTL>(b2, PA, lane, acc);
+#pragma unroll
+    for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) stg[c_row(mt, i, lane) * RS + w * 16 + col] = fmaxf(acc[mt][i], 0.0f);
   }
-  BS ring[3][3];   // [stage][gate]: the GRU's first two k-steps, behind LayerNorm 2
+  constexpr int RING = MTL == 2 ? 3 : 2;   // stages of the weight ring (one k-step each): two ahead, or one where the accumulators leave no room
+  BS ring[RING][3];   // [stage][gate]: the GRU's first k-steps, behind LayerNorm 2
   ring_load(W, w, lane, 0, ring[0]);
-  ring_load(W, w, lane, 1, ring[1]);
+  if (RING == 3) ring_load(W, w, lane, 1, ring[1]);
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   AC_CLK(204);
-  layer_norm_planes(stg, PA, prm + (C_G2 - C_B1), prm + (C_BE2 - C_B1), tid);
+  layer_norm_planes<MTL>(stg, PA, prm + (C_G2 - C_B1), prm + (C_BE2 - C_B1), tid);
   AC_CLK(205);
-  // ---- GRU cell (torch gate order r, z, n): wave w owns hidden units 16 w .. 16 w + 15, i.e. gate tiles w, 8 + w, 16 + w
+  // ---- GRU cell (torch gate order r, z, n): wave w owns hidden units 16 w .. 16 w + 15, i.e. gate tiles w, 8 + w, 16 + w.
+  // r and z only ever need W_ih x + W_hh h summed, so each has ONE accumulator for both products; the n gate keeps them apart (r * (W_hn h + b_hn)).
   BT<HID> bh;
   BS b5;
   {
-    const float bir = CTL8_PRM(C_BIH + 0 * 128 + w * 16 + col), biz = CTL8_PRM(C_BIH + 1 * 128 + w * 16 + col), bin = CTL8_PRM(C_BIH + 2 * 128 + w * 16 + col);
-    const float bhr = CTL8_PRM(C_BHH + 0 * 128 + w * 16 + col), bhz = CTL8_PRM(C_BHH + 1 * 128 + w * 16 + col), bhn = CTL8_PRM(C_BHH + 2 * 128 + w * 16 + col);
-    floatx4 ir[2] = {splat4(bir), splat4(bir)}, iz[2] = {splat4(biz), splat4(biz)}, in_[2] = {splat4(bin), splat4(bin)};
-    floatx4 hr[2] = {splat4(bhr), splat4(bhr)}, hz[2] = {splat4(bhz), splat4(bhz)}, hn[2] = {splat4(bhn), splat4(bhn)};
+    const float br = CTL8_PRM(C_BIH + 0 * 128 + w * 16 + col) + CTL8_PRM(C_BHH + 0 * 128 + w * 16 + col);
+    const float bz = CTL8_PRM(C_BIH + 1 * 128 + w * 16 + col) + CTL8_PRM(C_BHH + 1 * 128 + w * 16 + col);
+    const float bin = CTL8_PRM(C_BIH + 2 * 128 + w * 16 + col), bhn = CTL8_PRM(C_BHH + 2 * 128 + w * 16 + col);
+    floatx4 gr[MTL], gz[MTL], in_[MTL], hn[MTL];
+#pragma unroll
+    for (int mt = 0; mt < MTL; ++mt) { gr[mt] = splat4(br); gz[mt] = splat4(bz); in_[mt] = splat4(bin); hn[mt] = splat4(bhn); }
     {
-      AF A[2];
-      load_af(PA, lane, 0, A[0]);
+      constexpr int NB = MTL == 2 ? 2 : 1;
+      AF<MTL> A[NB];
+      load_af<MTL>(PA, lane, 0, A[0]);
 #pragma unroll
       for (int st = 0; st < 8; ++st) {
         // (the scheduling fences keep the loads where they are written: left alone, the machine scheduler sinks every weight load
         // to just in front of its first use to save registers, which serialises an L2 round trip with every k-step)
-        if (st + 2 < 8) ring_load(W, w, lane, st + 2, ring[(st + 2) % 3]);
-        if (st + 1 < 8) load_af(st + 1 < 4 ? PA : PH, lane, (st + 1) & 3, A[(st + 1) & 1]);
+        if (st + RING - 1 < 8) ring_load(W, w, lane, st + RING - 1, ring[(st + RING - 1) % RING]);
+        if (NB == 2 && st + 1 < 8) load_af<MTL>(st + 1 < 4 ? PA : PH, lane, (st + 1) & 3, A[(st + 1) % NB]);
         __builtin_amdgcn_sched_barrier(0);
-        if (st < 4) CTL8_GRU_STEP(ir, iz, in_, A[st & 1], ring[st % 3]);
-        else CTL8_GRU_STEP(hr, hz, hn, A[st & 1], ring[st % 3]);
+        if (st < 4) gru_step<MTL>(gr, gz, in_, A[st % NB], ring[st % RING]);
+        else gru_step<MTL>(gr, gz, hn, A[st % NB], ring[st % RING]);
         __builtin_amdgcn_sched_barrier(0);
+        if (NB == 1 && st + 1 < 8) load_af<MTL>(st + 1 < 4 ? PA : PH, lane, (st + 1) & 3, A[0]);
       }
     }
     // the heads' weights (this wave's tile and its k-step of the ninth / tenth), behind the gate algebra and LayerNorm 3
@@ -287,85 +355,94 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
     __builtin_amdgcn_sched_barrier(0);
     AC_CLK(206);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = c_row(mt, i, lane), unit = w * 16 + col;
-        const float rg = sigmoid_f(ir[mt][i] + hr[mt][i]);
-        const float zg = sigmoid_f(iz[mt][i] + hz[mt][i]);
+        const float rg = sigmoid_f(gr[mt][i]);
+        const float zg = sigmoid_f(gz[mt][i]);
         // (explicit fused multiply-adds: which products the compiler fuses on its own depends on the code around them, and two builds of
         // this kernel would differ by an ulp)
         const float ng = tanh_f(fmaf(rg, hn[mt][i], in_[mt][i]));
-        const float hnew = fmaf(zg, hbuf[row * RS + unit], (1.0f - zg) * ng);
+        const float hnew = fmaf(zg, plane_value<MTL>(PH, row, unit), (1.0f - zg) * ng);
         stg[row * RS + unit] = hnew;
       }
   }
   __syncthreads();
   AC_CLK(207);
-  {   // the new hidden state goes out row-contiguous (128-byte runs per feature) from LDS; thread = (row, 8-feature part)
-    const int row = tid & 31, part = tid >> 5, n = i0 + row;
+  {   // the new hidden state goes out row-contiguous (runs of R floats per feature) from LDS; thread = (row, FPT-feature part)
+    const int row = tid % R, part = tid / R, n = i0 + row;
     if (n < a.N) {
-      const float4 h0 = *reinterpret_cast<const float4*>(stg + row * RS + part * 8), h1 = *reinterpret_cast<const float4*>(stg + row * RS + part * 8 + 4);
-      const float hh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
-      for (int f = 0; f < 8; ++f) a.H[(size_t)(part * 8 + f) * a.N + n] = hh[f];
+      for (int q = 0; q < FPT / 4; ++q) {
+        const float4 h4 = *reinterpret_cast<const float4*>(stg + row * RS + part * FPT + 4 * q);
+        a.H[(size_t)(part * FPT + 4 * q + 0) * a.N + n] = h4.x; a.H[(size_t)(part * FPT + 4 * q + 1) * a.N + n] = h4.y;
+        a.H[(size_t)(part * FPT + 4 * q + 2) * a.N + n] = h4.z; a.H[(size_t)(part * FPT + 4 * q + 3) * a.N + n] = h4.w;
+      }
     }
   }
   AC_CLK(208);
-  layer_norm_planes(stg, PA, prm + (C_G3 - C_B1), prm + (C_BE3 - C_B1), tid);
+  layer_norm_planes<MTL>(stg, PA, prm + (C_G3 - C_B1), prm + (C_BE3 - C_B1), tid);
   AC_CLK(209);
   // ---- heads: 153 logits = ten 16-column tiles; wave w takes tile w, and one k-step of tile 8 + (w & 1) (logits 128 .. 159)
   {
     const float bias = CTL8_PRM(C_BA + w * 16 + col);
-    floatx4 acc[2] = {splat4(bias), splat4(bias)};
-    layer128(bh, PA, lane, acc);
+    floatx4 acc[MTL];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTL; ++mt) acc[mt] = splat4(bias);
+    layer128<MTL>(bh, PA, lane, acc);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) lg[(w * 16 + col) * LS + c_row(mt, i, lane)] = acc[mt][i];   // (the GRU-state planes under lg were last read before two barriers)
+    for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lg[(w * 16 + col) * LSR + c_row(mt, i, lane)] = acc[mt][i];   // (the GRU-state planes under lg were last read before two barriers)
     // tiles 8 and 9: their K range is split over four waves each (k-step w >> 1); the partial sums go to stg (free by now) and are added
     // in a fixed order below
     {
-      AF A;
-      load_af(PA, lane, w >> 1, A);
-      floatx4 part[2] = {splat4(0.0f), splat4(0.0f)}, lo[2] = {splat4(0.0f), splat4(0.0f)}, mid[2] = {splat4(0.0f), splat4(0.0f)};
-      CTL8_STEP(lo, mid, part, A, b5);
+      AF<MTL> A;
+      load_af<MTL>(PA, lane, w >> 1, A);
+      floatx4 part[MTL], lo[MTL], mid[MTL];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MTL; ++mt) { part[mt] = splat4(0.0f); lo[mt] = splat4(0.0f); mid[mt] = splat4(0.0f); }
+      step3<MTL>(lo, mid, part, A, b5);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stg[((w >> 1) * 32 + (w & 1) * 16 + col) * LS + c_row(mt, i, lane)] = part[mt][i] + (mid[mt][i] + lo[mt][i]);
+      for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stg[((w >> 1) * 32 + (w & 1) * 16 + col) * LSR + c_row(mt, i, lane)] = part[mt][i] + (mid[mt][i] + lo[mt][i]);
     }
   }
   __syncthreads();
   AC_CLK(210);
-  // logits 128 .. 152 = bias + the four K-partials, summed in a fixed order (25 columns x 32 aircraft over 512 threads)
-  for (int e = tid; e < 25 * 32; e += 512) {
-    const int q = e >> 5, row = e & 31;
-    lg[(128 + q) * LS + row] = (((CTL8_PRM(C_BA + 128 + q) + stg[q * LS + row]) + stg[(32 + q) * LS + row]) + stg[(64 + q) * LS + row]) + stg[(96 + q) * LS + row];
+  // logits 128 .. 152 = bias + the four K-partials, summed in a fixed order (25 columns x R aircraft over 512 threads)
+  for (int e = tid; e < 25 * R; e += 512) {
+    const int q = e / R, row = e % R;
+    lg[(128 + q) * LSR + row] = (((CTL8_PRM(C_BA + 128 + q) + stg[q * LSR + row]) + stg[(32 + q) * LSR + row]) + stg[(64 + q) * LSR + row]) + stg[(96 + q) * LSR + row];
   }
   __syncthreads();
   AC_CLK(211);
-  {   // argmax: wave = (head, half of the rows), lane = (quarter of the head's logits, row): first maximum, like torch argmax
-    const int head = w >> 1, row = 16 * (w & 1) + (lane & 15), quarter = lane >> 4;
+  {   // argmax: wave = (head, half of the rows), lane = (part of the head's logits, row): first maximum, like torch argmax
+    constexpr int RW = R / 2, SPLIT = 64 / RW, PER = (41 + SPLIT - 1) / SPLIT;   // rows per wave, parts per head (4 or 2), logits per part (11 or 21)
+    const int head = w >> 1, row = RW * (w & 1) + (lane % RW), part = lane / RW;
     const int off = head * 41, cnt = (head == 3) ? 30 : 41;
-    const int j0 = 11 * quarter;
-    // (quarter 0 starts from logit 0 like the sequential scan does; the others from -inf, so that a NaN logit is skipped, not adopted)
-    float best = quarter == 0 ? lg[off * LS + row] : -INFINITY;
-    int bi = quarter == 0 ? 0 : cnt;
-    for (int j = j0 + (quarter == 0 ? 1 : 0); j < min(cnt, j0 + 11); ++j) {
-      const float v = lg[(off + j) * LS + row];
-      if (v > best) { best = v; bi = j; }
-    }
-    // the later quarter only wins with a strictly larger value (its indices are all higher)
+    const int j0 = PER * part;
+    float lv[PER];
 #pragma unroll
-    for (int d = 16; d <= 32; d <<= 1) {
+    for (int jj = 0; jj < PER; ++jj) lv[jj] = (j0 + jj < cnt) ? lg[(off + j0 + jj) * LSR + row] : -INFINITY;   // independent LDS reads
+    // (part 0 starts from logit 0 like the sequential scan does; the others from -inf, so that a NaN logit is skipped, not adopted)
+    float best = part == 0 ? lv[0] : -INFINITY;
+    int bi = part == 0 ? 0 : cnt;
+#pragma unroll
+    for (int jj = 0; jj < PER; ++jj)
+      if (!(part == 0 && jj == 0) && lv[jj] > best) { best = lv[jj]; bi = j0 + jj; }
+    // the later part only wins with a strictly larger value (its indices are all higher)
+#pragma unroll
+    for (int d = RW; d <= 32; d <<= 1) {
       const float v2 = __shfl_down(best, d);
       const int i2 = __shfl_down(bi, d);
       if (v2 > best) { best = v2; bi = i2; }
     }
     const int nn = i0 + row;
-    if (quarter == 0 && nn < a.N) a.low[(size_t)nn * a.act_low + head] = (float)bi;
-    if (quarter == 1 && head == 0 && nn < a.N) {   // weapon bits ride along unchanged
+    if (part == 0 && nn < a.N) a.low[(size_t)nn * a.act_low + head] = (float)bi;
+    if (part == 1 && head == 0 && nn < a.N) {   // weapon bits ride along unchanged
       const bool scripted = a.use_baseline && (nn % a.A) >= a.n_ego;   // scenario1_task.py:42-48: bits [0,0,0,0], or all ones with artillery
       for (int k = 4; k < a.act_low; ++k)
         a.low[(size_t)nn * a.act_low + k] = scripted ? (a.use_artillery ? 1.0f : 0.0f) : a.hi[(size_t)nn * a.act_hi + (k - 1)];

@@ -569,6 +569,15 @@ def test_hierarchical_tasks_lowlevel_controller(pkg, oracle, task, baseline):
     _lowlevel_controller_parity(pkg, oracle, task, baseline)
 
 
+@pytest.mark.parametrize("rows,task,baseline", [("64", "scenario1", 0), ("64", "scenario_nvn", 1), ("32", "scenario_nvn", 0), ("64", "hierarchical_singlecombat", 2)])
+def test_controller_workgroup_shapes_match_oracle(pkg, oracle, monkeypatch, rows, task, baseline):
+    """controller8_kernel runs 32 aircraft per workgroup up to one tile per CU and 64 beyond (two or four 16-row matrix tiles per wave,
+    the same weight stream); AIRCOMBAT_CTL_ROWS pins the shape so that both meet the oracle on a small batch too (ragged: 6 envs = 12
+    or 24 aircraft in a 32- or 64-row tile), scripted opponents included."""
+    monkeypatch.setenv("AIRCOMBAT_CTL_ROWS", rows)
+    _lowlevel_controller_parity(pkg, oracle, task, baseline, steps=60)
+
+
 FLIP_GAP = 1e-4     # an argmax index that differs from the oracle's must sit on a top-two logit gap below this in the oracle's own fp64 logits
 
 

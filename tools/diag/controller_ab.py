@@ -17,26 +17,30 @@ import aircombat_selfplay_amd as pkg
 E = 4096
 ROUNDS, STEPS = 5, 200
 cases = [("scenario1", 1), ("scenario_nvn", 2), ("scenario_nvn", 4)]
+FORMS = (("0", "four-wave 32 rows", "32"), ("1", "eight-wave 32 rows", "32"), ("1", "eight-wave 64 rows", "64"))
 rng = np.random.default_rng(0)
 for task, per_side in cases:
     envs = {}
-    for form in ("0", "1"):
+    for form, name, rows in FORMS:
         os.environ["AIRCOMBAT_CTL8"] = form
+        os.environ["AIRCOMBAT_CTL_ROWS"] = rows
+        form = name
         cfg = pkg.default_config(task, hierarchical=True) if per_side == 1 else pkg.default_nvn_config(per_side, task=task, hierarchical=True)
         cls = pkg.HipShareVecEnv if cfg.n_agents > 2 else pkg.HipVecEnv
         envs[form] = cls(cfg, E, seed=1, copy=False)
         envs[form].reset()
-    A = envs["0"].num_agents
+    first = FORMS[0][1]
+    A = envs[first].num_agents
     pool = []
     for _ in range(8):
         a = np.stack([rng.integers(0, n, size=(E, A)) for n in (3, 5, 3)], axis=-1).astype(np.float32)
-        a = np.concatenate([a, (rng.random((E, A, envs["0"].act_dim - 3)) < 0.05).astype(np.float32)], axis=-1)
+        a = np.concatenate([a, (rng.random((E, A, envs[first].act_dim - 3)) < 0.05).astype(np.float32)], axis=-1)
         pool.append(torch.from_numpy(a).cuda())
     ptrs = [t.data_ptr() for t in pool]
-    res = {"0": [], "1": []}
+    res = {nm: [] for _, nm, _ in FORMS}
     ctl, stp = C.c_float(), C.c_float()
     for r in range(ROUNDS + 1):
-        for form in ("0", "1"):
+        for _, form, _ in FORMS:
             env = envs[form]
             tc = ts = 0.0
             for i in range(STEPS):
@@ -44,11 +48,12 @@ for task, per_side in cases:
                 tc += ctl.value; ts += stp.value
             if r:
                 res[form].append((tc / STEPS * 1e3, ts / STEPS * 1e3))
-    for form, name in (("0", "four-wave"), ("1", "eight-wave")):
+    for _, form, _ in FORMS:
+        name = form
         c = sorted(x[0] for x in res[form]); s = sorted(x[1] for x in res[form])
-        print(f"{task} x{per_side} ({E * A} aircraft) {name:10s}: controller median {c[len(c) // 2]:6.2f} us (min {c[0]:6.2f})   step kernel median {s[len(s) // 2]:6.2f} us")
+        print(f"{task} x{per_side} ({E * A} aircraft) {name:18s}: controller median {c[len(c) // 2]:6.2f} us (min {c[0]:6.2f})   step kernel median {s[len(s) // 2]:6.2f} us")
     # the two forms must drive the same episode: same observations after the same actions (argmax near-ties aside)
-    o0, o1 = envs["0"].device_tensors()[1].cpu().numpy(), envs["1"].device_tensors()[1].cpu().numpy()
+    o0, o1 = envs[FORMS[0][1]].device_tensors()[1].cpu().numpy(), envs[FORMS[-1][1]].device_tensors()[1].cpu().numpy()
     print(f"    observations of the two handles after {(ROUNDS + 1) * STEPS} steps: {100.0 * np.mean(np.all(o0 == o1, axis=-1)):.2f} % of the aircraft rows identical")
     for env in envs.values():
         env.close()
