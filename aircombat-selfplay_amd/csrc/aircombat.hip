@@ -53,7 +53,7 @@ enum {
   NI
 };
 enum { ND = 3 };
-// ---- storage. The names above are the EXTERNAL state vector (ac_get_state / ac_set_state, the oracle's state bridge). In HBM an aircraft's
+// ---- storage. The names above are the EXTERNAL state vector (ac_get_state / ac_set_state and what the tests exchange through them). In HBM an aircraft's
 // 75 32-bit words live in 19 groups of four: group g of aircraft n is the 16 bytes at S4[g * N + n], so every state access of a wave is one
 // dwordx4 instruction moving one contiguous 1 KB (round 3 moved a dword per lane per instruction: 173 loads + 90 stores per workgroup in the
 // BASELINE kernel, ~28 issue cycles each). Groups are cut by who reads them in the three-wave form -- 0-3 what the systems wave owns,
@@ -1652,7 +1652,7 @@ __global__ void init_kernel_nvn(InitArgs ia, DevCfg c, const float* tab, float* 
 
 #include "scenario_kernel.hpp"
 #include "controller_common.hpp"
-#include "controller_split_kernel.hpp"
+#include "controller_pieces.hpp"
 #include "controller8_kernel.hpp"
 #include "heading_kernel.hpp"
 
@@ -1698,9 +1698,7 @@ struct ac_env {
   float* d_tF; int* d_tI; double* d_tD;
   float* d_XF; int* d_XI;                // scenario-task extension state
   float* d_low;                          // hierarchical tasks: low-level action buffer (the controller's output, the step kernel's input)
-  float* d_ctlWs;                        // controller weights as bf16 pieces (controller_split_kernel.hpp)
-  float* d_ctlWs8;                       // the same in the eight-wave kernel's tiling (controller8_kernel.hpp)
-  bool ctl8;                             // which controller kernel the handle launches (AIRCOMBAT_CTL8=0/1; default: the eight-wave one)
+  float* d_ctlWs8;                       // controller weights as bf16 pieces in the kernel's tiling (controller8_kernel.hpp)
   int ctl_rows;                          // aircraft per controller workgroup pinned by AIRCOMBAT_CTL_ROWS=32/64 (0: chosen per grid)
   HeadingPtrs hp; HeadingCfg hc;         // HeadingTask: targets, check clock, numpy-PCG64 state per env
   int act_low;                           // width of the low-level action the step kernels decode
@@ -1747,14 +1745,13 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
   }
   dim3 block(64), grid((h->N + 63) / 64);
   if (h->cfg.hierarchical) {   // [3,5,3] (+ weapon bits) -> control indices, then the ordinary step on those
-    if (!h->d_ctlWs) return fail("hierarchical task: ac_load_controller has not been called");
-    ctl::Args a{h->d_ctlWs, h->d_ctlWs8, p.actions, p.obs, p.H, h->d_low, h->N, h->obs_dim, h->act_dim, h->act_low,
+    if (!h->d_ctlWs8) return fail("hierarchical task: ac_load_controller has not been called");
+    ctl::Args a{h->d_ctlWs8, p.actions, p.obs, p.H, h->d_low, h->N, h->obs_dim, h->act_dim, h->act_low,
                 h->cfg.use_baseline, h->A, h->cfg.n_ego, h->cfg.use_artillery,
                 (float)h->cfg.agent_interaction_steps / (float)h->cfg.sim_freq, p.man_step, p.man_h0, p, h->dc};
     // (the scripted opponents' inputs -- use_baseline -- are computed inside that instantiation of the kernel)
-    const dim3 cgrid((h->N + ctl::MT - 1) / ctl::MT);
-    if (h->ctl8) {   // eight waves per tile (controller8_kernel.hpp); AIRCOMBAT_CTL8=0 pins the four-wave kernel it replaced
-      // 32 aircraft per workgroup while that leaves no CU with two tiles to do one after the other; 64 beyond (AIRCOMBAT_CTL_ROWS pins it)
+    {   // eight waves per tile (controller8_kernel.hpp): 32 aircraft per workgroup while that leaves no CU with two tiles to do one
+        // after the other, 64 beyond (AIRCOMBAT_CTL_ROWS pins it for tests)
       const int rows = h->ctl_rows ? h->ctl_rows : ((h->N + 31) / 32 > 256 ? 64 : 32);
       const dim3 g8((h->N + rows - 1) / rows);
       if (rows == 64) {
@@ -1762,8 +1759,7 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
         else hipLaunchKernelGGL((controller8_kernel<false, 4>), g8, dim3(512), 0, h->stream, a);
       } else if (h->cfg.use_baseline) hipLaunchKernelGGL((controller8_kernel<true, 2>), g8, dim3(512), 0, h->stream, a);
       else hipLaunchKernelGGL((controller8_kernel<false, 2>), g8, dim3(512), 0, h->stream, a);
-    } else if (h->cfg.use_baseline) hipLaunchKernelGGL(controller_split_kernel<true>, cgrid, dim3(256), 0, h->stream, a);
-    else hipLaunchKernelGGL(controller_split_kernel<false>, cgrid, dim3(256), 0, h->stream, a);
+    }
     HIP_OK(hipGetLastError());
     if (h->mark_mid) HIP_OK(hipEventRecord(h->ev_mid, h->stream));
     p.actions = h->d_low;
@@ -1900,8 +1896,6 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     const bool ticks_only = cfg->task == AC_TASK_SINGLECOMBAT || cfg->task == AC_TASK_MULTICOMBAT || cfg->task == AC_TASK_HEADING ||
                             cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER;
     h->split_waves = ticks_only && (e ? (e[0] == '1') : (wgs <= 512));
-    const char* ce = getenv("AIRCOMBAT_CTL8");
-    h->ctl8 = ce ? (ce[0] == '1') : true;
     const char* cr = getenv("AIRCOMBAT_CTL_ROWS");
     h->ctl_rows = cr ? (atoi(cr) == 64 ? 64 : 32) : 0;
     const char* qe = getenv("AIRCOMBAT_QUAD");   // 0 / 1 overrides the choice of the quad form
@@ -2050,7 +2044,7 @@ int ac_destroy(ac_env_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->dp.F, h->dp.D, h->dp.MF, h->dp.MD, h->dp.MI, h->dp.obs, h->dp.rew, h->dp.done, h->dp.info,
-                  h->d_actions, h->d_tab, h->d_tF, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_ctlWs, h->d_ctlWs8, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
+                  h->d_actions, h->d_tab, h->d_tF, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_ctlWs8, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
   for (void* b : bufs) (void)hipFree(b);
   for (int k = 0; k < AC_HOST_SETS; ++k)
     if (h->have_hs[k]) ac_host_set_free(h->hs[k].act, h->hs[k].obs, h->hs[k].rew, h->hs[k].done, h->hs[k].info);   // (a detached set is the caller's)
@@ -2412,33 +2406,7 @@ int ac_load_controller(ac_env_t* h, const float* weights, int64_t n) {
   if (!h->cfg.hierarchical) return fail("ac_load_controller: the handle was not created with cfg.hierarchical");
   if (n != S_END) return fail("ac_load_controller: expected 137753 floats (layout of tools/export_baseline_actor.py)");
   HIP_OK(hipSetDevice(h->device));
-  {   // the weights as bf16 pieces: tile(c) = K/16 chunks x 3 pieces x 64 lanes x 8 values, element (g, p, lane, i) = piece p of
-      // W[j = 32 c + lane % 32][k = 16 g + 8 (lane / 32) + i]
-    using namespace ctls;
-    std::vector<float> e(B_END, 0.0f);
-    unsigned short* e16 = reinterpret_cast<unsigned short*>(e.data());
-    auto tiles_s = [&](int src, int dst, int J, int K, int Kpad, int ntiles) {
-      for (int c = 0; c < ntiles; ++c)
-        for (int g = 0; g < Kpad / 16; ++g)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int i = 0; i < 8; ++i) {
-              const int k = 16 * g + 8 * (lane / 32) + i, j = 32 * c + lane % 32;
-              unsigned pc[3];
-              split3((j < J && k < K) ? weights[src + j * K + k] : 0.0f, pc[0], pc[1], pc[2]);
-              for (int pp = 0; pp < 3; ++pp)
-                e16[(size_t)dst * 2 + ((((size_t)c * (Kpad / 16) + g) * 3 + pp) * 64 + lane) * 8 + i] = (unsigned short)pc[pp];
-            }
-    };
-    auto copy_s = [&](int src, int dst, int cnt) { for (int i = 0; i < cnt; ++i) e[dst + i] = weights[src + i]; };
-    tiles_s(S_W1, B_W1, 128, 12, 16, 4); copy_s(S_B1, B_B1, 128); copy_s(S_G1, B_G1, 128); copy_s(S_BE1, B_BE1, 128);
-    tiles_s(S_W2, B_W2, 128, 128, 128, 4); copy_s(S_B2, B_B2, 128); copy_s(S_G2, B_G2, 128); copy_s(S_BE2, B_BE2, 128);
-    tiles_s(S_WIH, B_WIH, 384, 128, 128, 12); tiles_s(S_WHH, B_WHH, 384, 128, 128, 12); copy_s(S_BIH, B_BIH, 384); copy_s(S_BHH, B_BHH, 384);
-    copy_s(S_G3, B_G3, 128); copy_s(S_BE3, B_BE3, 128);
-    tiles_s(S_WA, B_WA, NH, 128, 128, 5); copy_s(S_BA, B_BA, NH);
-    if (!h->d_ctlWs) HIP_OK(hipMalloc(&h->d_ctlWs, sizeof(float) * B_END));
-    HIP_OK(hipMemcpy(h->d_ctlWs, e.data(), sizeof(float) * B_END, hipMemcpyHostToDevice));
-  }
-  {   // the eight-wave kernel's tiling: tile(c) = the 16 columns 16 c .. 16 c + 15 = K/32 k-steps x 3 pieces x 64 lanes x 8 values,
+  {   // the weights as bf16 pieces in the kernel's tiling: tile(c) = the 16 columns 16 c .. 16 c + 15 = K/32 k-steps x 3 pieces x 64 lanes x 8 values,
       // element (s, p, lane, i) = piece p of W[j = 16 c + lane % 16][k = 32 s + 8 (lane / 16) + i]
     using namespace ctl8;
     std::vector<float> e(C_END, 0.0f);

@@ -1,6 +1,6 @@
 // The low-level controller kernel, eight-wave form (network, arguments: controller_common.hpp; the bf16-piece arithmetic -- every fp32
-// product as six exact bf16 x bf16 terms accumulated in fp32 -- and its helpers: controller_split_kernel.hpp, whose four-wave kernel this
-// one replaces on every grid).
+// product as six exact bf16 x bf16 terms accumulated in fp32 -- and its helpers: controller_pieces.hpp; the four-wave kernel of rounds
+// 2-3 that this one replaced on every grid is in the history).
 //
 // Why eight waves. The four-wave kernel put ONE wave on each SIMD of a CU: 378 registers of weight prefetch per wave, and a wave issues
 // in order -- so every weight load, every LDS read and every LayerNorm / gate / argmax instruction was time the SIMD's matrix pipe stood
@@ -20,7 +20,7 @@
 
 namespace ctl8 {
 using ctl::HID; using ctl::NH; using ctl::NHP; using ctl::MT; using ctl::LS;
-using ctls::KS; using ctls::PLANE; using ctls::RS; using ctls::bf16x8; using ctls::split3_pair;
+using ctls::KS; using ctls::RS; using ctls::bf16x8; using ctls::split3_pair;
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int tile_floats(int K) { return (K / 32) * 3 * 64 * 4; }   // in floats (a uint4 = 8 bf16 = 4 floats)
 enum : int {

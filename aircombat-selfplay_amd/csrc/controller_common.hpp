@@ -5,13 +5,11 @@
 // (delta altitude, delta heading, delta speed) + the first nine values of the aircraft's current observation; the four argmax
 // indices become the control indices the step kernel decodes. Included by aircombat.hip.
 //
-// This file: what the controller kernel (controller_split_kernel.hpp) shares with the host side -- network dimensions, the layout of the
-// exported weight blob, the kernel's arguments -- and the inputs of the scripted opponents. One workgroup = 32 aircraft (the M of a
-// 32 x 32 matrix-core tile) x 4 waves; each wave owns 32-column tiles of a layer's outputs (one tile of the 128-wide layers, the six gate
-// tiles of its 32 GRU units, one or two of the five head tiles).
-// (History: round 1 ran the GEMMs on v_mfma_f32_32x32x2_f32, 27 us per call at 8192 aircraft; the bf16-piece form replaced it in
-// round 2 at 20 us and the fp32 kernel was removed in round 3. A first version with lane = aircraft and wave-uniform weights through the
-// scalar cache took 257 us: every s_load missed.)
+// This file: what the controller kernel (controller8_kernel.hpp) shares with the host side -- network dimensions, the layout of the
+// exported weight blob, the kernel's arguments -- and the inputs of the scripted opponents. One workgroup = 32 or 64 aircraft x 8 waves;
+// each wave owns 16 columns of a layer's outputs (controller8_kernel.hpp).
+// (History in controller_pieces.hpp. A first version with lane = aircraft and wave-uniform weights through the scalar cache took 257 us:
+// every s_load missed.)
 #pragma once
 
 namespace ctl {
@@ -28,8 +26,7 @@ enum : int {
 };
 
 struct Args {
-  const float* Ws;         // the weights as bf16 pieces, tiled for controller_split_kernel (controller_split_kernel.hpp)
-  const float* Ws8;        // the same, tiled for controller8_kernel (16-column tiles, 32-k steps: controller8_kernel.hpp)
+  const float* Ws8;        // the weights as bf16 pieces, tiled for controller8_kernel (16-column tiles, 32-k steps: controller8_kernel.hpp)
   const float* hi;         // [N][act_hi]: 3 high-level choices (+ weapon bits passed through)
   const float* obs;        // [N][obs_dim]: observation of the CURRENT state (last step's / the reset's output)
   float* H;                // [128][N] GRU state
@@ -72,7 +69,7 @@ __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f / (__expf(
 }  // namespace ctl
 
 // Inputs of a scripted opponent (`use_baseline`; aircraft n of the enemy team): BaselineAgent.get_observation (baseline.py:45-63) on the
-// geometry of PursueAgent / ManeuverAgent. controller_split_kernel<true> computes them while it stages its inputs.
+// geometry of PursueAgent / ManeuverAgent. controller8_kernel<true, .> computes them while it stages its inputs.
 namespace ctl {
 __device__ __forceinline__ void scripted_inputs(const Args& a, int n, float (&x)[12]) {
   // (singlecombat_task.py:224-228, scenario1_task.py:41-49, scenario2_task.py:49-58)

@@ -177,7 +177,7 @@ def roofline(env, task, kernel_ms, hierarchical=False, controller_ms=None, step_
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
            "traffic": traffic, "traffic_committed_pmc": traffic,
            "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc passes of this workload (profiles/pmc_traffic.json); NOT measured in this run",
-           "kernel": "step kernel of the task" + (" + controller_split_kernel" if hierarchical else ""), "kernel_ms": kernel_ms,
+           "kernel": "step kernel of the task" + (" + controller8_kernel" if hierarchical else ""), "kernel_ms": kernel_ms,
            "algorithmic_bytes_per_launch": algo, "algorithmic_bytes_per_agent_step": algorithmic_bytes(env, missiles),
            "munitions_in_flight_per_aircraft": missiles}
     if traffic:

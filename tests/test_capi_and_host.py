@@ -241,7 +241,7 @@ def test_acmi_records_match_the_reference_log_text(pkg):
 
 
 def test_controller_products_split_into_exact_bf16_pieces(pkg):
-    """The arithmetic claim behind controller_split_kernel (host side of it, no GPU): x = hi + mid + lo EXACTLY with three bf16 pieces
+    """The arithmetic claim behind controller8_kernel (host side of it, no GPU): x = hi + mid + lo EXACTLY with three bf16 pieces
     (round-to-nearest each, 8 significant bits, low 16 bits of the float pattern clear), for normal floats of every sign and magnitude
     the network sees; and the six kept product terms reproduce the exact product to within one fp32 ulp (worst case)."""
     import ctypes as C

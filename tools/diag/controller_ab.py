@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The controller kernel's two forms side by side in ONE process on one device (interleaved rounds: cdna_hip_programming.md rule 24):
-controller8_kernel (eight waves per 32-aircraft tile, AIRCOMBAT_CTL8=1) against the four-wave controller_split_kernel (=0), at the three
+controller8_kernel with 32 and with 64 aircraft per workgroup (AIRCOMBAT_CTL_ROWS; the four-wave kernel of rounds 2-3 it was first measured
+against here -- 22.7 / 39.2 / 74.5 us -- is gone), at the three
 batches BASELINE's as-shipped configs call it with: 8192 aircraft (C3 scenario1), 16 384 (C4 2v2), 32 768 (C5 4v4). HIP events around the
 controller kernel and the step kernel of every device-resident step (ac_step_timed_device)."""
 import ctypes as C
@@ -17,12 +18,11 @@ import aircombat_selfplay_amd as pkg
 E = 4096
 ROUNDS, STEPS = 5, 200
 cases = [("scenario1", 1), ("scenario_nvn", 2), ("scenario_nvn", 4)]
-FORMS = (("0", "four-wave 32 rows", "32"), ("1", "eight-wave 32 rows", "32"), ("1", "eight-wave 64 rows", "64"))
+FORMS = (("1", "32 rows per workgroup", "32"), ("1", "64 rows per workgroup", "64"))
 rng = np.random.default_rng(0)
 for task, per_side in cases:
     envs = {}
     for form, name, rows in FORMS:
-        os.environ["AIRCOMBAT_CTL8"] = form
         os.environ["AIRCOMBAT_CTL_ROWS"] = rows
         form = name
         cfg = pkg.default_config(task, hierarchical=True) if per_side == 1 else pkg.default_nvn_config(per_side, task=task, hierarchical=True)

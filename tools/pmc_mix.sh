@@ -11,7 +11,7 @@ import csv,glob,collections
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for p in glob.glob("$out/pmc/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(p)):
-        if "step_kernel" in r["Kernel_Name"] or "controller_split_kernel" in r["Kernel_Name"]:
+        if "step_kernel" in r["Kernel_Name"] or "controller8_kernel" in r["Kernel_Name"]:
             acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,d in acc.items():
     print(k)
