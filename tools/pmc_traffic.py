@@ -3,7 +3,8 @@
 into HBM bytes per launch of the step kernel, following MI355X_MICROARCH.md's HBM section: both counters are memory-side
 request tallies in KB; WRITE_SIZE is exact for dword-per-lane stores; FETCH_SIZE is only calibrated by the guide for 16-B
 streaming reads (where it reports half), so it is calibrated here on the state-digest kernel, which reads a known byte count
-(324 B per aircraft) with the step kernel's own 4-B-per-lane SoA pattern.
+(328 B per aircraft since round 4: 19 groups of 16 B + the 24-B fp64 position) with the step kernel's own 16-B-per-lane group pattern
+(rounds 1-3: 324 B, 4 B per lane).
 
 usage: pmc_traffic.py <fetch_dir> <write_dir> --task singlecombat --envs 4096 --agents 2 [--out profiles/pmc_traffic.json]"""
 import argparse
@@ -13,7 +14,7 @@ import json
 import os
 from collections import defaultdict
 
-STATE_READ_BYTES = 4 * 63 + 4 * 12 + 8 * 3
+STATE_READ_BYTES = 16 * 19 + 8 * 3
 
 
 def per_kernel(directory, counter):

@@ -2,7 +2,7 @@
 # the PMC traffic passes of tools/pmc_traffic_tasks.sh for the scenario tasks alone (after a change to their state record)
 set -e
 out=gpurun_out/${1:-pmc_sc}
-round=${2:-3}
+round=${2:-4}
 mkdir -p $out
 export TMPDIR=/tmp
 cp profiles/pmc_traffic.json $out/pmc_traffic.json

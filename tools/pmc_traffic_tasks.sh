@@ -3,7 +3,7 @@
 # -> $out/pmc_traffic.json (copy to profiles/).   usage (inside gpurun): bash tools/pmc_traffic_tasks.sh <tag> <round>
 set -e
 out=gpurun_out/${1:-pmc_tasks}
-round=${2:-3}
+round=${2:-4}
 mkdir -p $out
 export TMPDIR=/tmp
 cp profiles/pmc_traffic.json $out/pmc_traffic.json
