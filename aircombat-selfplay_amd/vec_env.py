@@ -233,8 +233,12 @@ class HipVecEnv:
               # words count too: the LazyInfos handed out with a step reads them when it is asked)
               "out": (arr(ptrs[1], (E, A, self.obs_dim), "<f4"), arr(ptrs[2], (E, A, 1), "<f4"), arr(ptrs[3], (E, A, 1), "|b1"),   # the kernel writes 0 / 1
                       arr(ptrs[4], (E,), "<i4"))}
+        self._extend_set(st)
         self._sets.append(st)
         return st
+
+    def _extend_set(self, st):
+        """Hook for subclasses that hand out one more array per set (HipShareVecEnv: the share_obs view)."""
 
     def _held(self, st):
         """Does anybody outside this object hold one of the set's result arrays (a name, a slice, a view, a tensor sharing its memory)?"""
@@ -243,7 +247,9 @@ class HipVecEnv:
     @staticmethod
     def _refs(st):
         t = st["out"]
-        return sys.getrefcount(t[0]), sys.getrefcount(t[1]), sys.getrefcount(t[2]), sys.getrefcount(t[3])
+        if len(t) == 4:
+            return sys.getrefcount(t[0]), sys.getrefcount(t[1]), sys.getrefcount(t[2]), sys.getrefcount(t[3])
+        return sys.getrefcount(t[0]), sys.getrefcount(t[1]), sys.getrefcount(t[2]), sys.getrefcount(t[3]), sys.getrefcount(t[4])
 
     def _next_set(self):
         """copy=False: the other one of two sets. Default: the next set of the ring that nobody holds, one more set while the ring may
@@ -554,13 +560,18 @@ class HipShareVecEnv(HipVecEnv):
         obs = super().reset()
         return obs, self._share(obs)
 
+    def _extend_set(self, st):
+        # the broadcast view of the set's observations, built once (np.broadcast_to + reshape cost ~4 us per step) and counted like the
+        # set's other arrays: a caller holding only share_obs holds the set
+        st["out"] = st["out"] + (self._share(st["out"][0]),)
+
     def _result(self, st):
         o = st["out"]
-        return o[0], self._share(o[0]), o[1], o[2], LazyInfos(o[3])
+        return o[0], o[4], o[1], o[2], LazyInfos(o[3])
 
     def _owned(self, st):
         o = st["out"]
-        return o[0], self._share(o[0]), o[1], o[2], LazyInfos(o[3])
+        return o[0], o[4], o[1], o[2], LazyInfos(o[3])
 
     def _fresh(self, st):
         o = st["out"]
