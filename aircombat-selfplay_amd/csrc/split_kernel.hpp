@@ -87,11 +87,6 @@ struct ActionRow {
   __device__ __forceinline__ void issue(const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
   __device__ __forceinline__ void take() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory"); }
 };
-// EARLY: the flight-control channels that read last tick's values only run BEFORE B1 (where this wave used to idle ~770 cycles while the
-// dynamics wave integrated rates and velocity), so that B1 -> B2 -- where the dynamics wave waited ~190 cycles for this wave -- keeps the
-// pitch channel alone. Who flies a tick is only known after B1 (a status can change between substeps), so the six state words those
-// channels advance are put back where the run flag says "grounded". Not for the first tick when its commands are still on their way.
-template <bool EARLY = true>
 __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::Tab& T, float (*M)[64], int l, int substeps, const float4* raw = nullptr,
                                              ActionRow* row = nullptr) {
   using namespace mail;
@@ -101,10 +96,6 @@ __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::
   (void)t;
   for (int sub = 0; sub < substeps; ++sub) {
     f16::Surf sf{};
-    float elev_sched = 0.0f;
-    const bool early = EARLY && !(sub == 0 && (raw || row));
-    const float b_tef = s.tef, b_pinr = s.pin_r, b_pir = s.pi_r, b_ail = s.ail, b_piny = s.pin_y, b_piy = s.pi_y;
-    if (early) f16::sys_fcs_early(s, sf, elev_sched);
     AC_CLKW(1, 64 + sub * 8);
     wg_sync();                                             // B1: this tick's attitude is known
     if (row && sub == 0) {                                 // normalize_action (singlecombat_task.py:141-153), property bounds catalog.py:189-197
@@ -120,10 +111,8 @@ __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::
       s.thr = f16::clampf(0.0f, raw->w / 58.0f + 0.4f, 0.9f);
     }
     const bool run = M[RUNF][l] != 0.0f;                   // the dynamics wave decides who flies (status can change between substeps)
-    if (early && !run) { s.tef = b_tef; s.pin_r = b_pinr; s.pi_r = b_pir; s.ail = b_ail; s.pin_y = b_piny; s.pi_y = b_piy; }
     if (run) {
-      if (!early) f16::sys_fcs_early(s, sf, elev_sched);
-      f16::sys_fcs_late(s, M[CTH][l], M[VB][l], sf, elev_sched);
+      f16::sys_fcs(s, M[CTH][l], M[VB][l], sf);
       M[S_AIL][l] = sf.aileron_rad; M[S_FLAP][l] = sf.flaperon_rad; M[S_ELEV][l] = sf.elevator_rad;
       M[S_RUD][l] = sf.rudder_rad;  M[S_LEF][l] = sf.lef_rad;       M[S_SB][l] = sf.sb_rad;
     }
@@ -247,7 +236,7 @@ __device__ __forceinline__ bool split_helper_wave(f16::State& s, Task& t, const 
                                                   const DevCfg* cfg = nullptr, ActionRow* row = nullptr) {
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (role == 2) { kinematics_wave<QUAD, POSE>(s, t, T, L.M, L.MD, l, substeps, cfg); return true; }   // (a caller with work left for this wave tests the role itself)
-  if (role == 1) { systems_wave<!QUAD>(s, t, T, L.M, l, substeps, raw, row); return true; }
+  if (role == 1) { systems_wave(s, t, T, L.M, l, substeps, raw, row); return true; }
   return false;
 }
 // One substep of the dynamics wave (three workgroup barriers inside; every lane of the wave must call it). Returns whether this

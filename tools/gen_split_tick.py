@@ -192,27 +192,10 @@ struct DynVars {
             "  const float aileron_rad = sf.aileron_rad, flaperon_rad = sf.flaperon_rad, rudder_rad = sf.rudder_rad, lef_rad = sf.lef_rad, sb_rad = sf.sb_rad;\n"
             "  const float bw = (float)F16_WINGSPAN, cbar = (float)F16_CHORD;\n  const float* Tb = d.T;\n  (void)Tb;\n"
             + arm + "  float Fx, Fy, Fz, Mx, My, Mz;\n  {\n" + asm + "  }\n" + acc + pub + "}\n\n")
-    # The FCS in two halves. Only the pitch PID (cos(theta)cos(phi)) and the speed brake (body v) read what the dynamics wave posts at B1
-    # of THIS tick; flaps, roll and yaw channels, the elevator schedule, leading-edge flap and throttle run on last tick's auxiliary values
-    # alone, so the systems wave can do them BEFORE B1, where it used to idle ~770 cycles, and B1 -> B2 -- where the dynamics wave waited
-    # ~190 cycles for it -- keeps the pitch channel only. The statements are the same, the channels are independent of each other.
-    i_pe, i_yaw, i_sb = fcs.index("  float pitch_err = "), fcs.index("  // yaw:"), fcs.index("  // speedbrake auto-deploy")
-    fcs_early = fcs[:i_pe] + fcs[i_yaw:i_sb]
-    fcs_late = "  const float alpha_p = s.alpha, qc_p = s.qc;\n" + fcs[i_pe:i_yaw] + fcs[i_sb:]
-    fcs_early = rep(fcs_early, "  float elev_sched = elev_lim * tabc(kElX, kElY, alpha_p);", "  elev_sched = elev_lim * tabc(kElX, kElY, alpha_p);")
-    assert "cthcph" not in fcs_early and "vbody" not in fcs_early and "elevator_rad" not in fcs_early and "sb_rad" not in fcs_early
-    assert "s.da" not in fcs_late and "s.dr" not in fcs_late and "mach_p" not in fcs_late
-    refs = ("  float &aileron_rad = sf.aileron_rad, &flaperon_rad = sf.flaperon_rad, &elevator_rad = sf.elevator_rad, &rudder_rad = sf.rudder_rad,\n"
-            "        &lef_rad = sf.lef_rad, &sb_rad = sf.sb_rad, &throttle_pos = sf.throttle_pos;\n")
-    out += ("// systems wave, part 1a: the flight control system's channels that read last tick's auxiliary values only (flaps, roll, yaw, the\n"
-            "// elevator schedule, leading-edge flap, throttle): can run before B1 of the tick\n"
-            "__device__ __forceinline__ void sys_fcs_early(State& s, Surf& sf, float& elev_sched) {\n" + refs +
-            "  (void)elevator_rad; (void)sb_rad;\n" + fcs_early + "}\n"
-            "// part 1b: the pitch PID and the speed brake (inputs: this tick's cos(theta)cos(phi) and body v, posted by the dynamics wave before B1)\n"
-            "__device__ __forceinline__ void sys_fcs_late(State& s, float cthcph, float vbody, Surf& sf, float elev_sched) {\n" + refs +
-            "  (void)aileron_rad; (void)flaperon_rad; (void)rudder_rad; (void)lef_rad; (void)throttle_pos;\n" + fcs_late + "}\n"
+    out += ("// systems wave, part 1: the flight control system (inputs: last tick's auxiliary values in s, this tick's cos(theta)cos(phi) and body v)\n"
             "__device__ __forceinline__ void sys_fcs(State& s, float cthcph, float vbody, Surf& sf) {\n"
-            "  float elev_sched;\n  sys_fcs_early(s, sf, elev_sched);\n  sys_fcs_late(s, cthcph, vbody, sf, elev_sched);\n}\n\n")
+            "  float &aileron_rad = sf.aileron_rad, &flaperon_rad = sf.flaperon_rad, &elevator_rad = sf.elevator_rad, &rudder_rad = sf.rudder_rad,\n"
+            "        &lef_rad = sf.lef_rad, &sb_rad = sf.sb_rad, &throttle_pos = sf.throttle_pos;\n" + fcs + "}\n\n")
     out += ("// systems wave: mass balance of the coming tick from the tanks the turbine just drew from, and the inverse inertia\n"
             "__device__ __forceinline__ void sys_mass(const State& s, DynVars& k) {\n  F16_DYN_REFS(k);\n" + mass + "  {\n" + cof + "  }\n}\n\n")
     out += ("// systems wave, part 2: turbine and fuel (inputs: this tick's Mach, dynamic pressure, atmosphere and altitude)\n"
