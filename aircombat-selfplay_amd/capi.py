@@ -110,7 +110,7 @@ SIGNATURES = {
     "ac_pin_host_buffer": (C.c_int, [_p, _p, C.c_int64]),
     "ac_unpin_host_buffer": (C.c_int, [_p, _p]),
     "ac_load_controller": (C.c_int, [_p, _p, C.c_int64]),
-    "ac_split_bf16x3": (C.c_int, [_p, C.c_int64, _p, _p, _p]),
+    "ac_split_f16x2": (C.c_int, [_p, C.c_int64, _p, _p]),
     "ac_selftest_missile_walk": (C.c_int, [C.c_int32, _p]),
     "ac_get_controller_state": (C.c_int, [_p, C.c_int32, C.c_int32, _p, _p]),
     "ac_set_controller_state": (C.c_int, [_p, C.c_int32, C.c_int32, _p]),

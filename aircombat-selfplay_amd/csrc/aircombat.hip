@@ -1698,7 +1698,7 @@ struct ac_env {
   float* d_tF; int* d_tI; double* d_tD;
   float* d_XF; int* d_XI;                // scenario-task extension state
   float* d_low;                          // hierarchical tasks: low-level action buffer (the controller's output, the step kernel's input)
-  float* d_ctlWs8;                       // controller weights as bf16 pieces in the kernel's tiling (controller8_kernel.hpp)
+  float* d_ctlWs8;                       // controller weights as fp16 pieces in the kernel's tiling (controller8_kernel.hpp)
   int ctl_rows;                          // aircraft per controller workgroup pinned by AIRCOMBAT_CTL_ROWS=32/64 (0: chosen per grid)
   HeadingPtrs hp; HeadingCfg hc;         // HeadingTask: targets, check clock, numpy-PCG64 state per env
   int act_low;                           // width of the low-level action the step kernels decode
@@ -2406,7 +2406,7 @@ int ac_load_controller(ac_env_t* h, const float* weights, int64_t n) {
   if (!h->cfg.hierarchical) return fail("ac_load_controller: the handle was not created with cfg.hierarchical");
   if (n != S_END) return fail("ac_load_controller: expected 137753 floats (layout of tools/export_baseline_actor.py)");
   HIP_OK(hipSetDevice(h->device));
-  {   // the weights as bf16 pieces in the kernel's tiling: tile(c) = the 16 columns 16 c .. 16 c + 15 = K/32 k-steps x 3 pieces x 64 lanes x 8 values,
+  {   // the weights as fp16 pieces in the kernel's tiling: tile(c) = the 16 columns 16 c .. 16 c + 15 = K/32 k-steps x 2 pieces x 64 lanes x 8 values,
       // element (s, p, lane, i) = piece p of W[j = 16 c + lane % 16][k = 32 s + 8 (lane / 16) + i]
     using namespace ctl8;
     std::vector<float> e(C_END, 0.0f);
@@ -2417,10 +2417,10 @@ int ac_load_controller(ac_env_t* h, const float* weights, int64_t n) {
           for (int lane = 0; lane < 64; ++lane)
             for (int i = 0; i < 8; ++i) {
               const int k = 32 * st + 8 * (lane / 16) + i, j = 16 * c + lane % 16;
-              unsigned pc[3];
-              ctls::split3((j < J && k < K) ? weights[src + j * K + k] : 0.0f, pc[0], pc[1], pc[2]);
-              for (int pp = 0; pp < 3; ++pp)
-                e16[(size_t)dst * 2 + ((((size_t)c * (Kpad / 32) + st) * 3 + pp) * 64 + lane) * 8 + i] = (unsigned short)pc[pp];
+              unsigned pc[NP];
+              ctls::split2((j < J && k < K) ? weights[src + j * K + k] : 0.0f, pc[0], pc[1]);
+              for (int pp = 0; pp < NP; ++pp)
+                e16[(size_t)dst * 2 + ((((size_t)c * (Kpad / 32) + st) * NP + pp) * 64 + lane) * 8 + i] = (unsigned short)pc[pp];
             }
     };
     auto copy_s = [&](int src, int dst, int cnt) { for (int i = 0; i < cnt; ++i) e[dst + i] = weights[src + i]; };
@@ -2435,13 +2435,13 @@ int ac_load_controller(ac_env_t* h, const float* weights, int64_t n) {
   }
   return 0;
 }
-int ac_split_bf16x3(const float* x, int64_t n, float* hi, float* mid, float* lo) {
-  if (!x || !hi || !mid || !lo || n < 0) return fail("ac_split_bf16x3: bad argument");
+int ac_split_f16x2(const float* x, int64_t n, float* hi, float* lo) {
+  if (!x || !hi || !lo || n < 0) return fail("ac_split_f16x2: bad argument");
   for (int64_t i = 0; i < n; ++i) {
-    unsigned p[3];
-    ctls::split3(x[i], p[0], p[1], p[2]);
-    float* out[3] = {hi, mid, lo};
-    for (int k = 0; k < 3; ++k) { const unsigned b = p[k] << 16; memcpy(&out[k][i], &b, 4); }
+    unsigned p[2];
+    ctls::split2(x[i], p[0], p[1]);
+    float* out[2] = {hi, lo};
+    for (int k = 0; k < 2; ++k) { const unsigned short b = (unsigned short)p[k]; _Float16 v; memcpy(&v, &b, 2); out[k][i] = (float)v; }
   }
   return 0;
 }

@@ -1,28 +1,29 @@
-// The low-level controller kernel, eight-wave form (network, arguments: controller_common.hpp; the bf16-piece arithmetic -- every fp32
-// product as six exact bf16 x bf16 terms accumulated in fp32 -- and its helpers: controller_pieces.hpp; the four-wave kernel of rounds
+// The low-level controller kernel, eight-wave form (network, arguments: controller_common.hpp; the piece arithmetic -- every fp32
+// product as three exact fp16 x fp16 terms accumulated in fp32 -- and its helpers: controller_pieces.hpp; the four-wave kernel of rounds
 // 2-3 that this one replaced on every grid is in the history).
 //
 // Why eight waves. The four-wave kernel put ONE wave on each SIMD of a CU: 378 registers of weight prefetch per wave, and a wave issues
 // in order -- so every weight load, every LDS read and every LayerNorm / gate / argmax instruction was time the SIMD's matrix pipe stood
 // idle (round 3's counters: pipe busy 12.9 k of a wave's 38.8 k cycles; sharing a weight stream between two tiles, two workgroups per CU
 // in lockstep and a software pipeline of two tiles all measured within 3 % of it). Here a workgroup is still one 32-aircraft tile, but
-// EIGHT waves, two per SIMD, each owning 16 of a layer's output columns (v_mfma_f32_16x16x32_bf16: M = 16 aircraft x N = 16 columns x
+// EIGHT waves, two per SIMD, each owning 16 of a layer's output columns (v_mfma_f32_16x16x32_f16: M = 16 aircraft x N = 16 columns x
 // K = 32 per instruction, two M-tiles per wave): the two waves of a SIMD run the same phase on different columns, so one's load issue and
 // LDS waits sit under the other's matrix instructions, and the vector phases (LayerNorm, gate algebra, argmax, staging) are spread over
-// twice the lanes. A operands are read from the LDS planes per k-step (two M-tiles x three pieces = six ds_read_b128 per 36 matrix
-// instructions) instead of living in 96 registers, weight pieces stream through a three-stage ring of one k-step each: <= 256 registers,
-// no scratch.
+// twice the lanes. A operands are read from the LDS planes per k-step (two M-tiles x two pieces = four ds_read_b128 per 18 matrix
+// instructions of a GRU k-step) instead of living in registers, weight pieces stream through a three-stage ring of one k-step each:
+// under 200 registers, no scratch.
 //
 // Weight tiles for this form (ac_load_controller): tile(c, K) = the 16 output columns 16 c .. 16 c + 15 of a layer = K/32 k-steps x
-// 3 pieces x 64 lanes x 8 bf16; element (s, p, lane, i) = piece p of W[j = 16 c + lane % 16][k = 32 s + 8 (lane / 16) + i] (the B
+// 2 pieces x 64 lanes x 8 fp16; element (s, p, lane, i) = piece p of W[j = 16 c + lane % 16][k = 32 s + 8 (lane / 16) + i] (the B
 // operand map of the 16x16x32 instruction: lane l holds B[k = 8 (l >> 4) + i][col = l & 15]).
 #pragma once
 
 namespace ctl8 {
 using ctl::HID; using ctl::NH; using ctl::NHP; using ctl::MT; using ctl::LS;
-using ctls::KS; using ctls::RS; using ctls::bf16x8; using ctls::split3_pair;
+using ctls::KS; using ctls::RS;
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-constexpr int tile_floats(int K) { return (K / 32) * 3 * 64 * 4; }   // in floats (a uint4 = 8 bf16 = 4 floats)
+constexpr int NP = 2;                    // pieces per value
+constexpr int tile_floats(int K) { return (K / 32) * NP * 64 * 4; }   // in floats (a uint4 = 8 fp16 = 4 floats)
 enum : int {
   C_W1 = 0,                                  // K = 32 (12 padded), 8 tiles
   C_W2 = C_W1 + 8 * tile_floats(32),         // K = 128, 8 tiles
@@ -37,7 +38,7 @@ enum : int {
 };
 __device__ __forceinline__ floatx4 splat4(float v) { floatx4 a = {v, v, v, v}; return a; }
 __device__ __forceinline__ floatx4 mf(const uint4& a, const uint4& b, floatx4 acc) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ctls::f16x8, a), __builtin_bit_cast(ctls::f16x8, b), acc, 0, 0, 0);
 }
 // result layout of a 16x16 tile: acc[i] is (row = 4 (lane / 16) + i, column = lane % 16)
 __device__ __forceinline__ int c_row(int mt, int i, int lane) { return 16 * mt + 4 * (lane >> 4) + i; }
@@ -49,25 +50,25 @@ __device__ __forceinline__ int c_row(int mt, int i, int lane) { return 16 * mt +
 template <int MTL>
 struct Geo8 {
   static constexpr int R = 16 * MTL;               // aircraft per workgroup
-  static constexpr int PLN = R * KS;               // bf16 per plane
+  static constexpr int PLN = R * KS;               // fp16 per plane
   static constexpr int LSR = R + 1;                // row stride of the [feature][aircraft] buffers (odd: column writes spread over the banks)
   static constexpr int TPR = 512 / R;              // threads per aircraft in the row-wise phases (16 or 8)
   static constexpr int FPT = HID / TPR;            // features per thread there (8 or 16)
 };
 template <int MTL>
-struct AF { uint4 a[MTL][3]; };
+struct AF { uint4 a[MTL][NP]; };
 template <int MTL>
 __device__ __forceinline__ void load_af(const unsigned short* planes, int lane, int s, AF<MTL>& A) {
   const unsigned short* base = planes + (lane & 15) * KS + 8 * (lane >> 4) + 32 * s;
 #pragma unroll
   for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) A.a[mt][p] = *reinterpret_cast<const uint4*>(base + p * Geo8<MTL>::PLN + 16 * mt * KS);
+    for (int p = 0; p < NP; ++p) A.a[mt][p] = *reinterpret_cast<const uint4*>(base + p * Geo8<MTL>::PLN + 16 * mt * KS);
 }
-struct BS { uint4 b[3]; };   // one k-step of one 16-column tile: the three pieces
+struct BS { uint4 b[NP]; };   // one k-step of one 16-column tile: the two pieces
 __device__ __forceinline__ void load_bs(const uint4* __restrict__ t4 /* tile + lane */, int s, BS& B) {
 #pragma unroll
-  for (int p = 0; p < 3; ++p) B.b[p] = t4[(s * 3 + p) * 64];
+  for (int p = 0; p < NP; ++p) B.b[p] = t4[(s * NP + p) * 64];
 }
 template <int K>
 struct BT { BS s[K / 32]; };
@@ -77,30 +78,23 @@ __device__ __forceinline__ void prefetch_bt(const float* __restrict__ tile, int 
 #pragma unroll
   for (int s = 0; s < K / 32; ++s) load_bs(t4, s, B.s[s]);
 }
-// one k-step of one tile on three accumulation chains per M-tile (the 2^-16 terms, the 2^-8 terms, the leading term), like mma1 of the
-// four-wave kernel
+// one k-step of one tile on two accumulation chains per M-tile: the two cross terms (2^-11 of the product) and the leading term
 template <int MTL>
-__device__ __forceinline__ void step3(floatx4 (&lo)[MTL], floatx4 (&mid)[MTL], floatx4 (&acc)[MTL], const AF<MTL>& A, const BS& B) {
+__device__ __forceinline__ void step2(floatx4 (&lo)[MTL], floatx4 (&acc)[MTL], const AF<MTL>& A, const BS& B) {
 #pragma unroll
-  for (int mt = 0; mt < MTL; ++mt) lo[mt] = mf(A.a[mt][2], B.b[0], lo[mt]);
-#pragma unroll
-  for (int mt = 0; mt < MTL; ++mt) mid[mt] = mf(A.a[mt][1], B.b[0], mid[mt]);
+  for (int mt = 0; mt < MTL; ++mt) lo[mt] = mf(A.a[mt][1], B.b[0], lo[mt]);
 #pragma unroll
   for (int mt = 0; mt < MTL; ++mt) acc[mt] = mf(A.a[mt][0], B.b[0], acc[mt]);
 #pragma unroll
-  for (int mt = 0; mt < MTL; ++mt) lo[mt] = mf(A.a[mt][0], B.b[2], lo[mt]);
-#pragma unroll
-  for (int mt = 0; mt < MTL; ++mt) mid[mt] = mf(A.a[mt][0], B.b[1], mid[mt]);
-#pragma unroll
-  for (int mt = 0; mt < MTL; ++mt) lo[mt] = mf(A.a[mt][1], B.b[1], lo[mt]);
+  for (int mt = 0; mt < MTL; ++mt) lo[mt] = mf(A.a[mt][0], B.b[1], lo[mt]);
 }
 // a whole K = 128 layer for this wave's 16 columns: the weight tile is in registers (asked for a phase earlier), the A operands come
 // from the planes one k-step ahead of their use (MTL = 2) or as they are needed (MTL = 4: registers)
 template <int MTL>
 __device__ __forceinline__ void layer128(const BT<HID>& B, const unsigned short* planes, int lane, floatx4 (&acc)[MTL]) {
-  floatx4 lo[MTL], mid[MTL];
+  floatx4 lo[MTL];
 #pragma unroll
-  for (int mt = 0; mt < MTL; ++mt) { lo[mt] = splat4(0.0f); mid[mt] = splat4(0.0f); }
+  for (int mt = 0; mt < MTL; ++mt) lo[mt] = splat4(0.0f);
   constexpr int NB = MTL == 2 ? 2 : 1;
   AF<MTL> A[NB];
   load_af<MTL>(planes, lane, 0, A[0]);
@@ -108,16 +102,16 @@ __device__ __forceinline__ void layer128(const BT<HID>& B, const unsigned short*
   for (int s = 0; s < 4; ++s) {
     if (NB == 2 && s + 1 < 4) load_af<MTL>(planes, lane, s + 1, A[(s + 1) % NB]);
     __builtin_amdgcn_sched_barrier(0);
-    step3<MTL>(lo, mid, acc, A[s % NB], B.s[s]);
+    step2<MTL>(lo, acc, A[s % NB], B.s[s]);
     __builtin_amdgcn_sched_barrier(0);
     if (NB == 1 && s + 1 < 4) load_af<MTL>(planes, lane, s + 1, A[0]);
   }
 #pragma unroll
   for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[mt][i] += mid[mt][i] + lo[mt][i];
+    for (int i = 0; i < 4; ++i) acc[mt][i] += lo[mt][i];
 }
-// the GRU's k-steps: three gate tiles of this wave's 16 hidden units; one term of the six, all gates and M-tiles
+// the GRU's k-steps: three gate tiles of this wave's 16 hidden units; one term of the three, all gates and M-tiles
 template <int MTL>
 __device__ __forceinline__ void gru_term(floatx4 (&a0)[MTL], floatx4 (&a1)[MTL], floatx4 (&a2)[MTL], const AF<MTL>& A, int pa, const BS (&B)[3], int pb) {
 #pragma unroll
@@ -125,10 +119,9 @@ __device__ __forceinline__ void gru_term(floatx4 (&a0)[MTL], floatx4 (&a1)[MTL],
     a0[mt] = mf(A.a[mt][pa], B[0].b[pb], a0[mt]); a1[mt] = mf(A.a[mt][pa], B[1].b[pb], a1[mt]); a2[mt] = mf(A.a[mt][pa], B[2].b[pb], a2[mt]);
   }
 }
-// the six terms smallest first into one accumulator per (gate, M-tile)
+// the three terms smallest first into one accumulator per (gate, M-tile)
 template <int MTL>
 __device__ __forceinline__ void gru_step(floatx4 (&a0)[MTL], floatx4 (&a1)[MTL], floatx4 (&a2)[MTL], const AF<MTL>& A, const BS (&B)[3]) {
-  gru_term<MTL>(a0, a1, a2, A, 2, B, 0); gru_term<MTL>(a0, a1, a2, A, 0, B, 2); gru_term<MTL>(a0, a1, a2, A, 1, B, 1);
   gru_term<MTL>(a0, a1, a2, A, 1, B, 0); gru_term<MTL>(a0, a1, a2, A, 0, B, 1); gru_term<MTL>(a0, a1, a2, A, 0, B, 0);
 }
 __device__ __forceinline__ void ring_load(const float* __restrict__ W, int w, int lane, int st, BS (&dst)[3]) {
@@ -137,15 +130,14 @@ __device__ __forceinline__ void ring_load(const float* __restrict__ W, int w, in
 #pragma unroll
   for (int g = 0; g < 3; ++g) load_bs(reinterpret_cast<const uint4*>(base + (8 * g + w) * TF) + lane, st & 3, dst[g]);
 }
-// eight consecutive features of one aircraft -> the three planes (one 16-byte LDS store per plane)
+// eight consecutive features of one aircraft -> the two planes (one 16-byte LDS store per plane)
 template <int MTL>
 __device__ __forceinline__ void write_planes8(unsigned short* planes, int row, int k0, const float* v) {
-  unsigned h[4], m[4], l[4];
+  unsigned h[4], l[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) split3_pair(v[2 * q], v[2 * q + 1], h[q], m[q], l[q]);
+  for (int q = 0; q < 4; ++q) ctls::split2_pair(v[2 * q], v[2 * q + 1], h[q], l[q]);
   *reinterpret_cast<uint4*>(planes + 0 * Geo8<MTL>::PLN + row * KS + k0) = make_uint4(h[0], h[1], h[2], h[3]);
-  *reinterpret_cast<uint4*>(planes + 1 * Geo8<MTL>::PLN + row * KS + k0) = make_uint4(m[0], m[1], m[2], m[3]);
-  *reinterpret_cast<uint4*>(planes + 2 * Geo8<MTL>::PLN + row * KS + k0) = make_uint4(l[0], l[1], l[2], l[3]);
+  *reinterpret_cast<uint4*>(planes + 1 * Geo8<MTL>::PLN + row * KS + k0) = make_uint4(l[0], l[1], l[2], l[3]);
 }
 // Sum over the adjacent lanes of an aircraft (16 or 8), the same value in all of them, with data-parallel-primitive moves (a few cycles
 // each; __shfl_xor compiles to ds_bpermute_b32, an LDS round trip of ~100 cycles, eight of them in a dependent chain per LayerNorm): pairs
@@ -163,7 +155,7 @@ __device__ __forceinline__ float group_sum(float v) {
   if (LANES == 16) v += dpp_f<0x140>(v);   // row_mirror
   return v;
 }
-// torch.nn.LayerNorm(128) (eps 1e-5, biased variance) of buf[row][k] (fp32, row stride RS) into the three bf16 planes the next layer's
+// torch.nn.LayerNorm(128) (eps 1e-5, biased variance) of buf[row][k] (fp32, row stride RS) into the two fp16 planes the next layer's
 // A operands are read from. Thread = (aircraft = tid / TPR, part = tid % TPR) owns FPT consecutive features; the parts of an aircraft sit
 // in adjacent lanes: mean and variance are a few DPP steps each, no partial sums through LDS. Scale / shift come from LDS (staged).
 template <int MTL>
@@ -194,13 +186,11 @@ __device__ __forceinline__ void layer_norm_planes(const float* buf, unsigned sho
   for (int q = 0; q < FPT / 8; ++q) write_planes8<MTL>(planes, row, FPT * part + 8 * q, y + 8 * q);
   __syncthreads();
 }
-// the fp32 GRU state of (aircraft row, unit) back from its three bf16 planes: hi + mid + lo is the fp32 value exactly (that is how the
-// planes were made), so no fp32 copy of the state is kept in LDS
+// the fp32 GRU state of (aircraft row, unit): two fp16 pieces do not add up to it exactly, so an fp32 copy [aircraft][k] (row stride RS)
+// sits behind the two planes of the state buffer for the gate algebra
 template <int MTL>
-__device__ __forceinline__ float plane_value(const unsigned short* planes, int row, int unit) {
-  const unsigned short* p = planes + row * KS + unit;
-  const float hi = __uint_as_float((unsigned)p[0] << 16), mid = __uint_as_float((unsigned)p[Geo8<MTL>::PLN] << 16), lo = __uint_as_float((unsigned)p[2 * Geo8<MTL>::PLN] << 16);
-  return (hi + mid) + lo;
+__device__ __forceinline__ float state_value(const unsigned short* planes, int row, int unit) {
+  return reinterpret_cast<const float*>(planes + 2 * Geo8<MTL>::PLN)[row * RS + unit];
 }
 }  // namespace ctl8
 
@@ -212,11 +202,12 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
   using ctl::sigmoid_f; using ctl::tanh_f;
   using G = Geo8<MTL>;
   constexpr int R = G::R, PLN = G::PLN, LSR = G::LSR, TPR = G::TPR, FPT = G::FPT;
-  __shared__ __attribute__((aligned(16))) unsigned short PA[3 * PLN];   // activations as bf16 planes [piece][aircraft][k]
-  __shared__ __attribute__((aligned(16))) unsigned short PH[3 * PLN];   // the GRU state likewise; the head logits (fp32 [160][LSR]) later
+  constexpr int PHN = 2 * PLN + 2 * R * RS;                            // two planes + the fp32 copy [aircraft][k] (state_value), in 16-bit units
+  __shared__ __attribute__((aligned(16))) unsigned short PA[NP * PLN];  // activations as piece planes [piece][aircraft][k]
+  __shared__ __attribute__((aligned(16))) unsigned short PH[PHN];       // the GRU state likewise; the head logits (fp32 [160][LSR]) later
   __shared__ __attribute__((aligned(16))) float stg[R * RS];            // a layer's fp32 outputs [aircraft][k] (row stride RS) on their way to LayerNorm
   static_assert(4 * 32 * LSR <= R * RS, "the head partials of tiles 8 and 9 fit the staging buffer");
-  static_assert(sizeof(unsigned short) * 3 * PLN >= sizeof(float) * NHP * LSR, "the logits reuse the GRU-state planes");
+  static_assert(sizeof(unsigned short) * PHN >= sizeof(float) * NHP * LSR && (2 * PLN) % 8 == 0, "the logits reuse the GRU-state planes");
   float* lg = reinterpret_cast<float*>(PH);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave 0..7: output columns 16 w .. 16 w + 15 of every 128-wide layer
@@ -270,10 +261,10 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
   if (spart == 0) {
     const float hi8[8] = {x[8], x[9], x[10], x[11], 0.0f, 0.0f, 0.0f, 0.0f};
     write_planes8<MTL>(PA, srow, 0, x); write_planes8<MTL>(PA, srow, 8, hi8);
-  } else if (spart <= 2) {   // zero k 16..31 of the three planes
+  } else if (spart <= 2) {   // zero k 16..31 of the planes
     const uint4 z = make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(PA + p * PLN + srow * KS + 8 * (spart + 1)) = z;
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<uint4*>(PA + p * PLN + srow * KS + 8 * (spart + 1)) = z;
   }
   __syncthreads();
 
@@ -283,18 +274,22 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
     AF<MTL> A;
     load_af<MTL>(PA, lane, 0, A);
     const float bias = CTL8_PRM(C_B1 + w * 16 + col);
-    floatx4 acc[MTL], lo[MTL], mid[MTL];
+    floatx4 acc[MTL], lo[MTL];
 #pragma unroll
-    for (int mt = 0; mt < MTL; ++mt) { acc[mt] = splat4(bias); lo[mt] = splat4(0.0f); mid[mt] = splat4(0.0f); }
-    step3<MTL>(lo, mid, acc, A, b1.s[0]);
+    for (int mt = 0; mt < MTL; ++mt) { acc[mt] = splat4(bias); lo[mt] = splat4(0.0f); }
+    step2<MTL>(lo, acc, A, b1.s[0]);
 #pragma unroll
     for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) stg[c_row(mt, i, lane) * RS + w * 16 + col] = fmaxf(acc[mt][i] + (mid[mt][i] + lo[mt][i]), 0.0f);
+      for (int i = 0; i < 4; ++i) stg[c_row(mt, i, lane) * RS + w * 16 + col] = fmaxf(acc[mt][i] + lo[mt][i], 0.0f);
   }
-  {   // the GRU state has arrived behind layer 1: as the three bf16 planes (the products read them; the gate algebra adds them up again)
+  {   // the GRU state has arrived behind layer 1: as the two fp16 planes the products read, and in fp32 for the gate algebra
 #pragma unroll
     for (int q = 0; q < FPT / 8; ++q) write_planes8<MTL>(PH, srow, spart * FPT + 8 * q, hv + 8 * q);
+    float* hf = reinterpret_cast<float*>(PH + 2 * PLN);
+#pragma unroll
+    for (int q = 0; q < FPT / 4; ++q)
+      *reinterpret_cast<float4*>(hf + srow * RS + spart * FPT + 4 * q) = make_float4(hv[4 * q], hv[4 * q + 1], hv[4 * q + 2], hv[4 * q + 3]);
   }
   __syncthreads();
   AC_CLK(202);
@@ -312,10 +307,12 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) stg[c_row(mt, i, lane) * RS + w * 16 + col] = fmaxf(acc[mt][i], 0.0f);
   }
-  constexpr int RING = MTL == 2 ? 3 : 2;   // stages of the weight ring (one k-step each): two ahead, or one where the accumulators leave no room
+  // stages of the weight ring (one k-step each): two ahead, or one. (With two fp16 pieces the registers would allow more -- measured: a
+  // fourth stage at 32 rows +1 to +4 %, a third stage and A operands one k-step ahead at 64 rows +1 %: depth is not what the loop waits for.)
+  constexpr int RING = MTL == 2 ? 3 : 2;
   BS ring[RING][3];   // [stage][gate]: the GRU's first k-steps, behind LayerNorm 2
-  ring_load(W, w, lane, 0, ring[0]);
-  if (RING == 3) ring_load(W, w, lane, 1, ring[1]);
+#pragma unroll
+  for (int st = 0; st < RING - 1; ++st) ring_load(W, w, lane, st, ring[st]);
   __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   AC_CLK(204);
@@ -368,7 +365,7 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
         // (explicit fused multiply-adds: which products the compiler fuses on its own depends on the code around them, and two builds of
         // this kernel would differ by an ulp)
         const float ng = tanh_f(fmaf(rg, hn[mt][i], in_[mt][i]));
-        const float hnew = fmaf(zg, plane_value<MTL>(PH, row, unit), (1.0f - zg) * ng);
+        const float hnew = fmaf(zg, state_value<MTL>(PH, row, unit), (1.0f - zg) * ng);
         stg[row * RS + unit] = hnew;
       }
   }
@@ -404,14 +401,14 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
     {
       AF<MTL> A;
       load_af<MTL>(PA, lane, w >> 1, A);
-      floatx4 part[MTL], lo[MTL], mid[MTL];
+      floatx4 part[MTL], lo[MTL];
 #pragma unroll
-      for (int mt = 0; mt < MTL; ++mt) { part[mt] = splat4(0.0f); lo[mt] = splat4(0.0f); mid[mt] = splat4(0.0f); }
-      step3<MTL>(lo, mid, part, A, b5);
+      for (int mt = 0; mt < MTL; ++mt) { part[mt] = splat4(0.0f); lo[mt] = splat4(0.0f); }
+      step2<MTL>(lo, part, A, b5);
 #pragma unroll
       for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stg[((w >> 1) * 32 + (w & 1) * 16 + col) * LSR + c_row(mt, i, lane)] = part[mt][i] + (mid[mt][i] + lo[mt][i]);
+        for (int i = 0; i < 4; ++i) stg[((w >> 1) * 32 + (w & 1) * 16 + col) * LSR + c_row(mt, i, lane)] = part[mt][i] + lo[mt][i];
     }
   }
   __syncthreads();

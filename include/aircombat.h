@@ -191,9 +191,9 @@ int ac_load_controller(ac_env_t* h, const float* weights, int64_t n);
 int ac_get_controller_state(ac_env_t* h, int32_t env, int32_t agent, float* hidden, float* low_action);
 int ac_set_controller_state(ac_env_t* h, int32_t env, int32_t agent, const float* hidden);
 /* Host-side check of the arithmetic behind the controller's GEMMs (no GPU, no handle): every fp32 weight and activation is taken apart
- * into three bf16 pieces, hi + mid + lo == x exactly, and the products run on the bf16 matrix path (controller_split_kernel.hpp). Writes
- * the three pieces of x[0..n) as float32 values (each with at most 8 significant bits). */
-int ac_split_bf16x3(const float* x, int64_t n, float* hi, float* mid, float* lo);
+ * into two fp16 pieces, hi = fp16(x), lo = fp16(x - hi), |x - hi - lo| <= 2^-22 |x|, and the products run on the fp16 matrix path
+ * (controller_pieces.hpp). Writes the two pieces of x[0..n) as float32 values (each with at most 11 significant bits). */
+int ac_split_f16x2(const float* x, int64_t n, float* hi, float* lo);
 /* Device self-test (needs the GPU, no handle): the closed form the NvN kernels use for MissilePostureReward's agent-by-agent walk over its
  * shared remembered missile (missile_posture_reward.py:18-46) against the round-by-round walk, for every combination of agent states
  * of a 2v2 and a 4v4 env. *mismatches receives the number of combinations that differ (0 = the two agree everywhere). */

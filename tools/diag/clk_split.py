@@ -34,5 +34,6 @@ for it in range(80):
             print(f"          systems wave early by {c[b + 1] - c[h]:5d} / {c[b + 3] - c[h + 1]:5d} / {c[b + 5] - c[h + 2]:5d}   "
                   f"kinematics wave early by {c[b + 1] - c[h + 4]:5d} / {c[b + 3] - c[h + 5]:5d} / {c[b + 5] - c[h + 6]:5d}")
         print(f"  finish wait {c[51] - c[50]}  tail (finish -> task.step) {c[52] - c[51]}  task.step {c[53] - c[52]}  stores+outputs {c[54] - c[53]}  total {c[54] - c[0]}")
-        print(f"  task.step: to obs {c[58] - c[52]}  terminations {c[59] - c[58]}  rewards+reset {c[53] - c[59]} | state stores {c[55] - c[53]}  rows to LDS + fence {c[56] - c[55]}  output stores {c[57] - c[56]}  fence {c[54] - c[57]}")
+        # (the observation rows leave from the kinematics wave in this form: the dynamics wave writes the reward / done / info scalars only)
+        print(f"  task.step: to obs {c[58] - c[52]}  terminations {c[59] - c[58]}  rewards+reset {c[53] - c[59]} | state stores {c[55] - c[53]}  reward / done / info scalars {c[54] - c[55]}")
 env.close()
