@@ -10,7 +10,7 @@
 // each) per 32 k of a 16 x 16 tile are 48 cycles where the fp32 instructions take 256.
 //
 // What that costs in parity, measured (tests/test_gpu_parity.py::test_hierarchical_tasks_lowlevel_controller and the as-shipped NvN
-// cases, teacher-forced against the float64 oracle): 0 of 130 000 argmax indices differ; worst |d GRU state| 4.0 - 7.6e-6 per case
+// cases, teacher-forced against the float64 CPU restatement): 0 of 130 000 argmax indices differ; worst |d GRU state| 4.0 - 7.6e-6 per case
 // against 2.8 - 6.1e-6 with three bf16 pieces (24 bits per value, six terms per product: rounds 2 - 4) -- the difference the fp32 flight
 // model's observations feed INTO the network is what both numbers measure, the products' own error (numpy emulation on the golden
 // sequences: 3.1e-6 of the state after 48 steps, 1.3e-5 of a logit; a plain fp32 matmul 6.4e-7 / 2.5e-6; three bf16 pieces 1.1e-7 /
