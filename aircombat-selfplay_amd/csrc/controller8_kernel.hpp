@@ -340,9 +340,9 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
         if (st + RING - 1 < 8) ring_load(W, w, lane, st + RING - 1, ring[(st + RING - 1) % RING]);
         if (NB == 2 && st + 1 < 8) load_af<MTL>(st + 1 < 4 ? PA : PH, lane, (st + 1) & 3, A[(st + 1) % NB]);
         // (Measured and left out: a bare barrier per k-step that keeps the two waves of a SIMD within a k-step of each other. Left alone the
-        // older wave finishes all its products first -- 7.4 k cycles at 32 rows -- and the younger runs on for 6.2 k; in lockstep the pair took
-        // 15.3 k instead of 13.6 k (64 rows: 27.6 k against 24.0 k). The matrix pipe is not what the pair waits for: at two M-tiles per wave a
-        // k-step's 24 KB of weight pieces per CU against 384 cycles of matrix work is exactly the 64 B / clk a CU's L1 fills at.)
+        // older wave finishes all its products first and the younger runs on; in lockstep the pair was slower -- with three pieces 15.3 k
+        // cycles instead of 13.6 k at 32 rows, 27.6 k against 24.0 k at 64. The matrix pipe is not what the pair waits for: the GRU's 384 KB
+        // of weight pieces per workgroup are 6.1 k cycles of the 64 B / clk a CU's L1 fills at, its matrix instructions 2.3 k per wave.)
         __builtin_amdgcn_sched_barrier(0);
         if (st < 4) gru_step<MTL>(gr, gz, in_, A[st % NB], ring[st % RING]);
         else gru_step<MTL>(gr, gz, hn, A[st % NB], ring[st % RING]);

@@ -187,7 +187,7 @@ def roofline(env, task, kernel_ms, hierarchical=False, controller_ms=None, step_
         out["step_kernel"] = {"kernel_ms": step_ms, "achieved": a, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS}
     if hierarchical and controller_ms:
         flop = 2.0 * 137753.0 * env.num_envs * env.num_agents       # BaselineActor: 137 753 multiply-adds per aircraft (weights in baseline_actor.f32)
-        out["controller"] = {"kernel_ms": controller_ms, "bound": "mfma (fp32 products as bf16 pieces) / L2 weight stream", "achieved": flop / (controller_ms * 1e-3) / 1e12,
+        out["controller"] = {"kernel_ms": controller_ms, "bound": "L1 fill of the weight stream (fp32 products as two fp16 pieces on the f16 MFMA)", "achieved": flop / (controller_ms * 1e-3) / 1e12,
                              "unit": "TFLOP/s fp32-equivalent", "flop_per_call": flop}
     return out
 
