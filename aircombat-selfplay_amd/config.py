@@ -28,6 +28,13 @@ TASK_IDS = {
     # missile variant of MultipleCombat an env can select. Its step() launches nothing, so it is MultipleCombat with the 21-value
     # paired-enemy observation and a [3,5,3] + shoot-bit action whose bit is ignored.
     "hierarchical_multiplecombat_shoot": AC_TASK_MULTICOMBAT,
+    # MultipleCombatShootMissileTask (multiplecombat_with_missile_task.py:165-216), its parent: the same task with the control-index
+    # action [41,41,41,30] + shoot bit. No env of the reference constructs it (multiplecombat_env.py:25-33); the name is this package's own.
+    "multiplecombat_shoot": AC_TASK_MULTICOMBAT,
+    # MultipleCombatDodgeMissileTask (multiplecombat_with_missile_task.py:13-145): rule-based launches of the base-class missile at
+    # enemies[0] under MultipleCombatEnv.step, the same 21-value observation with a live missile block. Equally unconstructible in the
+    # reference; here AC_TASK_DODGE_MISSILE with four or eight aircraft.
+    "multiplecombat_dodge_missile": AC_TASK_DODGE_MISSILE,
     # HierarchicalSingleCombatShootTask / HierarchicalSingleCombatDodgeMissileTask (singlecombat_with_missile_task.py:126-145,206-238):
     # the 1v1 missile tasks behind the low-level controller. No env of the reference selects them (singlecombat_env.py:19-36); the
     # names are this package's own.
@@ -122,7 +129,7 @@ def config_from_dict(data, task=None, hierarchical=None):
         raise NotImplementedError(f"Unknown taskname: {name} (available: {sorted(TASK_IDS)})")
     cfg.task = TASK_IDS[name]
     cfg.rwr = int(rwr)
-    cfg.legacy_obs = int(legacy or name == "hierarchical_multiplecombat_shoot")
+    cfg.legacy_obs = int(legacy or name in ("hierarchical_multiplecombat_shoot", "multiplecombat_shoot", "multiplecombat_dodge_missile"))
     cfg.approach = int(name == "approach")
     cfg.hierarchical = int(name in ALWAYS_HIERARCHICAL if hierarchical is None else bool(hierarchical))
     acs = data["aircraft_configs"]
@@ -242,8 +249,8 @@ def default_config(task="singlecombat", hierarchical=False):
         return cfg
     if task in ALWAYS_HIERARCHICAL:
         hierarchical = True
-    if task in ("multiplecombat", "hierarchical_multiplecombat", "hierarchical_multiplecombat_shoot"):
-        return default_nvn_config(2, task=task if task.endswith("_shoot") else "multiplecombat", hierarchical=hierarchical)
+    if task in ("multiplecombat", "hierarchical_multiplecombat", "hierarchical_multiplecombat_shoot", "multiplecombat_shoot", "multiplecombat_dodge_missile"):
+        return default_nvn_config(2, task=task if task.endswith(("_shoot", "_dodge_missile")) else "multiplecombat", hierarchical=hierarchical)
     if task in ("scenario_nvn", "scenario2_nvn"):
         return default_nvn_config(2, task="scenario_nvn", hierarchical=hierarchical)
     if task == "scenario3_nvn":

@@ -1779,7 +1779,7 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
     if (h->split_waves) hipLaunchKernelGGL((step_kernel_scenario<2, 1, FORM_SPLIT>), grid, dim3(192), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
     else if (pair_wpe1) hipLaunchKernelGGL((step_kernel_scenario<2, 1, FORM_PAIR>), grid, dim3(128), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
     else hipLaunchKernelGGL((step_kernel_scenario<2, 2, FORM_PAIR>), grid, dim3(128), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
-  } else if (h->cfg.task == AC_TASK_SCENARIO1 || h->cfg.task == AC_TASK_SCENARIO_NVN) {
+  } else if (h->cfg.task == AC_TASK_SCENARIO1 || h->cfg.task == AC_TASK_SCENARIO_NVN || (h->cfg.task == AC_TASK_DODGE_MISSILE && h->A > 2)) {
 #define AC_LAUNCH_PAIR(AA)                                                                                                                                \
   do {                                                                                                                                                    \
     if (pair_wpe1) hipLaunchKernelGGL((step_kernel_scenario<AA, 1, FORM_PAIR>), grid, dim3(128), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr); \
@@ -1841,7 +1841,11 @@ const char* ac_state_field_name(int i) { return (i >= 0 && i < AC_STATE_LEN && k
 
 int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_t seed, ac_env_t** out) {
   if (!cfg || !out) return fail("ac_create: null argument");
-  const bool scenario = cfg->task == AC_TASK_SCENARIO1 || cfg->task == AC_TASK_SCENARIO_NVN || cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER;
+  // MultipleCombatDodgeMissileTask (multiplecombat_with_missile_task.py:13-145; `multiplecombat_dodge_missile`): AC_TASK_DODGE_MISSILE with more
+  // than two aircraft. It runs on the scenario kernel family's NvN machinery (MultipleCombatEnv.step order, two munition uids per aircraft in fp64,
+  // the 21-value paired-enemy observation) with the rule-based launch, the base-class missile and four reward terms.
+  const bool nvn_dodge = cfg->task == AC_TASK_DODGE_MISSILE && cfg->n_agents > 2;
+  const bool scenario = cfg->task == AC_TASK_SCENARIO1 || cfg->task == AC_TASK_SCENARIO_NVN || cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER || nvn_dodge;
   const bool heading = cfg->task == AC_TASK_HEADING;
   if (cfg->task != AC_TASK_SINGLECOMBAT && cfg->task != AC_TASK_SHOOT_MISSILE && cfg->task != AC_TASK_DODGE_MISSILE &&
       cfg->task != AC_TASK_MULTICOMBAT && !scenario && !heading)
@@ -1850,15 +1854,16 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     return fail("ac_create: AC_TASK_HEADING is a single-aircraft task with control-index actions (n_agents == n_ego == 1)");
   if (cfg->task == AC_TASK_DODGE_MISSILE && (cfg->sim_freq / cfg->agent_interaction_steps < 1 || cfg->sim_freq / cfg->agent_interaction_steps > 31))
     return fail("ac_create: AC_TASK_DODGE_MISSILE keeps its lock window in 31 bits (needs 1 <= sim_freq / agent_interaction_steps <= 31)");
-  if (cfg->task == AC_TASK_SCENARIO_NVN) {
+  if (cfg->task == AC_TASK_SCENARIO_NVN || nvn_dodge) {
     if ((cfg->n_agents != 4 && cfg->n_agents != 8) || cfg->n_ego * 2 != cfg->n_agents)
-      return fail("ac_create: AC_TASK_SCENARIO_NVN needs n_agents in {4, 8} split into two equal teams");
+      return fail("ac_create: AC_TASK_SCENARIO_NVN (and AC_TASK_DODGE_MISSILE with more than two aircraft) needs n_agents in {4, 8} split into two equal teams");
+    if (nvn_dodge && (cfg->hierarchical || cfg->rwr)) return fail("ac_create: multiplecombat_dodge_missile takes control-index actions and has no rwr variant");
   }
   const bool gun_only = cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER;
   if (scenario && !gun_only)
     for (int i = 0; i < cfg->n_agents; ++i)
       if (cfg->num_missiles[i] != 2) return fail("ac_create: the scenario tasks are built for 'missile: 2' (two munition uids per aircraft), as every shipped YAML has");
-  if (cfg->task == AC_TASK_SCENARIO_NVN) {
+  if (cfg->task == AC_TASK_SCENARIO_NVN || nvn_dodge) {
   } else if (cfg->task == AC_TASK_MULTICOMBAT) {
     if ((cfg->n_agents != 4 && cfg->n_agents != 8) || cfg->n_ego <= 0 || cfg->n_ego >= cfg->n_agents)
       return fail("ac_create: AC_TASK_MULTICOMBAT needs n_agents in {4, 8} and 0 < n_ego < n_agents");
@@ -1867,11 +1872,9 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     return fail("ac_create: use_baseline (1 pursue, 2 maneuver) needs the hierarchical form and equal teams (enemy k is flown by scripted agent k)");
   if ((cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER) && (cfg->n_agents != 2 || cfg->n_ego != 1 || cfg->rwr))
     return fail("ac_create: AC_TASK_WVR / AC_TASK_MANEUVER are 1v1 tasks");
-  if (cfg->legacy_obs && ((cfg->task != AC_TASK_SCENARIO_NVN && cfg->task != AC_TASK_MULTICOMBAT) || cfg->rwr))
+  if (cfg->legacy_obs && ((cfg->task != AC_TASK_SCENARIO_NVN && cfg->task != AC_TASK_MULTICOMBAT && !nvn_dodge) || cfg->rwr))
     return fail("ac_create: legacy_obs is the observation of Scenario2 / Scenario3 (AC_TASK_SCENARIO_NVN without rwr) and of "
-                "hierarchical_multiplecombat_shoot (AC_TASK_MULTICOMBAT, hierarchical)");
-  if (cfg->legacy_obs && cfg->task == AC_TASK_MULTICOMBAT && !cfg->hierarchical)
-    return fail("ac_create: the paired-enemy observation of AC_TASK_MULTICOMBAT belongs to hierarchical_multiplecombat_shoot (set hierarchical)");
+                "multiplecombat_shoot / hierarchical_multiplecombat_shoot (AC_TASK_MULTICOMBAT)");
   if (cfg->rwr && !scenario) return fail("ac_create: rwr is a variant of the scenario tasks (Scenario1_RWR, Scenario2_RWR, Scenario3_RWR)");
   if (n_envs <= 0) return fail("ac_create: n_envs must be positive");
   if (cfg->max_steps > 65535) return fail("ac_create: max_steps above 65535 (the host-boundary info word carries current_step in 16 bits)");
@@ -1899,17 +1902,20 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
     const char* cr = getenv("AIRCOMBAT_CTL_ROWS");
     h->ctl_rows = cr ? (atoi(cr) == 64 ? 64 : 32) : 0;
     const char* qe = getenv("AIRCOMBAT_QUAD");   // 0 / 1 overrides the choice of the quad form
-    const bool munitions_1v1 = cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE || cfg->task == AC_TASK_SCENARIO1;
+    const bool munitions_1v1 = cfg->task == AC_TASK_SHOOT_MISSILE || (cfg->task == AC_TASK_DODGE_MISSILE && !nvn_dodge) || cfg->task == AC_TASK_SCENARIO1;
     h->quad_waves = munitions_1v1 && (qe ? (qe[0] == '1') : (wgs <= 256));
   }
   h->obs_dim = heading ? 12 : (cfg->task == AC_TASK_SINGLECOMBAT) ? 15 : (cfg->task == AC_TASK_MULTICOMBAT ? 9 + 6 * (cfg->n_agents - 1) : 21);
-  if (cfg->task == AC_TASK_SCENARIO_NVN) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
+  if (cfg->task == AC_TASK_SCENARIO_NVN || nvn_dodge) h->obs_dim = 9 + 6 * cfg->n_agents + 6;
   const int tmpl_obs = h->obs_dim;   // (the scenario kernel family's template keeps 21 slots for WVR too)
   if (gun_only) h->obs_dim = 15;
-  if ((cfg->task == AC_TASK_SCENARIO_NVN || cfg->task == AC_TASK_MULTICOMBAT) && cfg->legacy_obs) h->obs_dim = 21;   // multiplecombat_with_missile_task.py:30-31
+  if (((cfg->task == AC_TASK_SCENARIO_NVN || cfg->task == AC_TASK_MULTICOMBAT) && cfg->legacy_obs) || nvn_dodge) h->obs_dim = 21;   // multiplecombat_with_missile_task.py:30-31
   if (cfg->rwr) h->obs_dim += 2;   // scenario1_task.py:213-216, scenario2_task.py:403-413
-  const bool weapon_bits = scenario && !gun_only;
+  const bool weapon_bits = scenario && !gun_only && !nvn_dodge;
   h->act_low = weapon_bits ? 8 : ((cfg->task == AC_TASK_SHOOT_MISSILE) ? 5 : 4);
+  // multiplecombat_shoot (MultipleCombatShootMissileTask, multiplecombat_with_missile_task.py:165-216): Tuple([41,41,41,30], Discrete(2)); like its
+  // hierarchical child below, the shoot bit is stored (:204-206) and never used (its step() is MultipleCombatTask.step, :215-216)
+  if (!cfg->hierarchical && cfg->task == AC_TASK_MULTICOMBAT && cfg->legacy_obs) h->act_low = 5;
   // hierarchical tasks (HierarchicalSingleCombatTask and everything built on it): [3,5,3] (+ the four weapon bits)
   // (HierarchicalSingleCombatShootTask: Tuple([3,5,3], Discrete(2)), singlecombat_with_missile_task.py:221-223; the Dodge variant: [3,5,3])
   h->act_dim = cfg->hierarchical ? (weapon_bits ? 7 : (cfg->task == AC_TASK_SHOOT_MISSILE ? 4 : 3)) : h->act_low;
@@ -1919,11 +1925,11 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   memset(&c, 0, sizeof c);
   c.task = cfg->task; c.A = h->A; c.n_ego = cfg->n_ego; c.substeps = cfg->agent_interaction_steps; c.max_steps = cfg->max_steps;
   c.obs_dim = h->obs_dim; c.act_dim = h->act_low; c.N = h->N;
-  c.msl_slots = (cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE) ? AC_MAX_MISSILES_PER_AGENT : (scenario ? 2 : 0);
+  c.msl_slots = scenario ? 2 : ((cfg->task == AC_TASK_SHOOT_MISSILE || cfg->task == AC_TASK_DODGE_MISSILE) ? AC_MAX_MISSILES_PER_AGENT : 0);
   c.chaff_seed = seed;
   c.rwr = cfg->rwr ? 1 : 0;
   c.tobs = tmpl_obs;
-  c.legacy_obs = ((cfg->task == AC_TASK_SCENARIO_NVN || cfg->task == AC_TASK_MULTICOMBAT) && cfg->legacy_obs) ? 1 : 0;
+  c.legacy_obs = (((cfg->task == AC_TASK_SCENARIO_NVN || cfg->task == AC_TASK_MULTICOMBAT) && cfg->legacy_obs) || nvn_dodge) ? 1 : 0;
   c.altitude_limit = (float)cfg->altitude_limit; c.acc_x = (float)cfg->acc_limit_x; c.acc_y = (float)cfg->acc_limit_y; c.acc_z = (float)cfg->acc_limit_z;
   c.posture_scale = (float)cfg->posture_scale; c.altitude_scale = (float)cfg->altitude_scale; c.event_scale = (float)cfg->event_scale;
   c.missile_posture_scale = (float)cfg->missile_posture_scale; c.shoot_penalty_scale = (float)cfg->shoot_penalty_scale;
@@ -2503,7 +2509,7 @@ int ac_get_missile(ac_env_t* h, int32_t env, int32_t agent, int32_t k, double ou
   {   // which munition the slot holds (ACMI name): 0 AIM-9L (the 1v1 missile tasks), 1 AIM-120B, 2 AIM-9M
     int rw;
     HIP_OK(hipMemcpy(&rw, h->dp.MI + ((size_t)k * NMI + MI_recede) * N + n, sizeof rw, hipMemcpyDeviceToHost));
-    out[11] = h->dp.MD ? (double)(1 + ((rw >> 9) & 1)) : 0.0;
+    out[11] = (h->dp.MD && h->cfg.task != AC_TASK_DODGE_MISSILE) ? (double)(1 + ((rw >> 9) & 1)) : 0.0;
   }
   return 0;
 }

@@ -355,12 +355,15 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   const bool maneuver = !MULTI && c.task == AC_TASK_MANEUVER;   // Maneuver_curriculum (singlecombat_task.py:264-359)
   const bool gun_only = !MULTI && (c.task == AC_TASK_WVR || maneuver);   // WVRTask (WVR_task.py:10-90) / Maneuver_curriculum: no weapon bits
   const bool wvr = gun_only && !maneuver;
-  if (!gun_only && (MULTI || team == 0))
+  // MultipleCombatDodgeMissileTask (multiplecombat_with_missile_task.py:13-145): the NvN env with a rule-based launch of the base-class missile at
+  // enemies[0], no gun, no chaff, the paired-enemy 21-value observation (c.legacy_obs) and four reward terms
+  const bool dodge = MULTI && c.task == AC_TASK_DODGE_MISSILE;
+  if (!gun_only && !dodge && (MULTI || team == 0))
   {
     x.bits = (b4.x != 0.0f ? 1 : 0) | (b4.y != 0.0f ? 2 : 0) | (b4.z != 0.0f ? 4 : 0) | (b4.w != 0.0f ? 8 : 0);
   }
 
-  const MslParam MP = aim120b();
+  const MslParam MP = dodge ? aim9l() : aim120b();   // (MissileSimulator's own parameters, simulatior.py:421-433, for the rule-based task)
   bool have_pose = false;
   // Munitions only come into being in the weapons stage after the substeps, so whether this env has anything to fly during them
   // is known up front. With no missile entry and no chaff cloud in the env, the fp64 pose of the intermediate substeps is needed
@@ -562,6 +565,11 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
       float dd = sqrtf(ex * ex + ey * ey + ez * ez);
       if (dd > bd) { bd = dd; tg = e_first + q; tdx = ex; tdy = ey; tdz = ez; tg_status = est; }
     }
+    if (dodge) {   // the rule aims at agent.enemies[0] (:129), not at the farthest enemy
+      const int src = base + e_first;
+      tdx = xp_pose[0][src] - pr.n; tdy = xp_pose[1][src] - pr.e; tdz = xp_pose[2][src] - pr.u;
+      bd = sqrtf(tdx * tdx + tdy * tdy + tdz * tdz); tg = e_first; tg_status = xp_status[src];
+    }
     const float ang = 57.29577951f * acos_fast(clampf(-1.0f, (tdx * pr.vn + tdy * pr.ve + tdz * pr.vd) / (bd * hv + 1e-8f), 1.0f));
     AC_CLKE(80);
     // my dict entries before this step's launches (what an agent that acts before me still sees of them)
@@ -573,9 +581,41 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     }
     float gun_dmg = 0.0f; int gun_tgt = -1;
     int launched_k = -1;   // the slot this aircraft launched into this step (one launch per step at most: the second rule needs the first missile done)
+    auto launch_into = [&](int want_k, int want_model) {   // MissileSimulator.launch (:497-514) into the dict entry of uid "agent + (MS - k)"
+      float tht = asinf(pr.stht);
+      float psi = atan2f(pr.m12, pr.m11);
+      if (psi < 0.0f) psi += 2.0f * f16::kPi;
+#pragma unroll
+      for (int q = 0; q < MS; ++q)
+        if (q == want_k) {
+          if (ms[q].status == MSL_HIT) x.orphan_hits += 1;   // a replaced entry that was HIT stays is_success forever (never run again)
+          if (ms[q].status == MSL_INACTIVE) ms[q].dpos = (t.cur_step << 4) | slot;   // a uid launched again keeps its place in the dict
+          ms[q].model = want_model;
+          ms[q].px = pr.n64; ms[q].py = pr.e64; ms[q].pz = pr.u64; ms[q].vx = pr.vn; ms[q].vy = pr.ve; ms[q].vz = pr.vd;
+          ms[q].theta = tht; ms[q].psi = psi; ms[q].t = 0.0; ms[q].m = MP.m0; ms[q].dth = 0.0; ms[q].dph = 0.0;
+          ms[q].dprev = INFINITY; ms[q].recede = 0; ms[q].status = MSL_LAUNCHED;
+          ms[q].order = (t.cur_step << 8) | (slot << 4) | tg;    // launch order (step, agent) and target slot
+        }
+      t.last_missile = want_k;
+      launched_k = want_k;
+      msl_moved |= 1 << want_k;
+    };
     if (gun_only) {
       // WVR_task.py:62-76 / singlecombat_task.py:290-297: every aircraft, dead or alive, drains 5 blood from its farthest enemy inside 3 km and 5 deg, every step
       if (bd * 0.001f < 3.0f && ang < 5.0f) { gun_dmg = 5.0f; gun_tgt = tg; }
+    } else if (dodge) {
+      // multiplecombat_with_missile_task.py:127-145 (the 1v1 rule of singlecombat_with_missile_task.py:108-124): the window is updated by every
+      // aircraft, dead ones included; a launch needs a full window, the distance gate, a round left, the interval and a live shooter
+      const int len = c.lock_len;                       // deque(maxlen = int(1 / time_interval))
+      const unsigned bit = 1u << (unsigned)(t.lock_pos % len);
+      t.lock_bits = (ang < c.max_attack_angle) ? (t.lock_bits | (int)bit) : (t.lock_bits & ~(int)bit);
+      t.lock_pos += 1;
+      const bool locked = __popc((unsigned)t.lock_bits & ((1u << len) - 1u)) >= len;
+      if (t.status == AC_ALIVE && locked && bd <= c.max_attack_distance && t.remaining > 0 && (t.cur_step - t.last_shoot_time) >= c.min_attack_interval) {
+        launch_into(MS - t.remaining, 0);               // uid = agent_id + str(remaining): 2 -> the first entry, 1 -> the second
+        t.remaining -= 1;
+        t.last_shoot_time = t.cur_step;
+      }
     } else if (t.status == AC_ALIVE) {
       const bool talive = tg_status == AC_ALIVE;
       const bool av_gun = talive && bd * 0.001f < 3.0f && ang < 5.0f;
@@ -592,25 +632,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
       if ((x.bits & 1) && x.rem_gun > 0 && last_done() && av_gun) { gun_dmg = 5.0f; gun_tgt = tg; x.rem_gun -= 1; }
       if ((x.bits & 4) && x.rem_120b > 0 && last_done() && av_120) { want_k = MS - x.rem_120b; want_model = 0; x.rem_120b -= 1; }
       else if ((x.bits & 2) && x.rem_9m > 0 && last_done() && av_9m) { want_k = MS - x.rem_9m; want_model = 1; x.rem_9m -= 1; }   // (after an AIM-120B launch the last missile is in flight: no AIM-9M in the same step)
-      if (want_k >= 0) {   // MissileSimulator.launch (:497-514) into the dict entry of uid "agent + (MS - k)"
-        float tht = asinf(pr.stht);
-        float psi = atan2f(pr.m12, pr.m11);
-        if (psi < 0.0f) psi += 2.0f * f16::kPi;
-#pragma unroll
-        for (int q = 0; q < MS; ++q)
-          if (q == want_k) {
-            if (ms[q].status == MSL_HIT) x.orphan_hits += 1;   // a replaced entry that was HIT stays is_success forever (never run again)
-            if (ms[q].status == MSL_INACTIVE) ms[q].dpos = (t.cur_step << 4) | slot;   // a uid launched again keeps its place in the dict
-            ms[q].model = want_model;
-            ms[q].px = pr.n64; ms[q].py = pr.e64; ms[q].pz = pr.u64; ms[q].vx = pr.vn; ms[q].vy = pr.ve; ms[q].vz = pr.vd;
-            ms[q].theta = tht; ms[q].psi = psi; ms[q].t = 0.0; ms[q].m = MP.m0; ms[q].dth = 0.0; ms[q].dph = 0.0;
-            ms[q].dprev = INFINITY; ms[q].recede = 0; ms[q].status = MSL_LAUNCHED;
-            ms[q].order = (t.cur_step << 8) | (slot << 4) | tg;    // launch order (step, agent) and target slot
-          }
-        t.last_missile = want_k;
-        launched_k = want_k;
-        msl_moved |= 1 << want_k;
-      }
+      if (want_k >= 0) launch_into(want_k, want_model);
     }
     AC_CLKE(81);
     // gun damage lands on the target's blood right away (:70-73): 5 per shooter, counted into the target's cell (bloods are multiples of 5
@@ -622,7 +644,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     // still what they were. The OWNER of an entry tells its target: an entry that was not launched this step counts for its target;
     // one launched this step counts for its (new) target if that one acts at or after the launcher, and the entry it replaced counts
     // for ITS target if that one acts before the launcher.
-    if (!gun_only) {
+    if (!gun_only && !dodge) {
       auto in_range = [&](int r, float mx, float my, float mz) {
         const float dx = xp_pose[0][base + r] - mx, dy = xp_pose[1][base + r] - my, dz = xp_pose[2][base + r] - mz;
         return sqrtf(dx * dx + dy * dy + dz * dz) < 1000.0f;
@@ -647,7 +669,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     }
     wave_lds_fence();
     t.bloods -= 5.0f * (float)xp_cnt[0][lane];
-    if (!gun_only) {
+    if (!gun_only && !dodge) {
       const int lc_status = (x.last_chaff & 1) ? x.ch_status[1] : x.ch_status[0];
       const bool can = t.status == AC_ALIVE && (x.bits & 8) && x.rem_chaff > 0 && (x.last_chaff < 0 || lc_status == 1);
       const int n_rel = can ? xp_cnt[1][lane] : 0;
@@ -851,7 +873,8 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     float r_ev = potential(ev, c.event_scale, c.event_pot, t.pre_event);
     float r_pos = potential(posture, c.posture_scale, c.posture_pot, t.pre_posture);
     float r_ra = fminf(1.0f - fabsf(pr.u * 0.001f - e_u0 * 0.001f), 0.0f);
-    own = r_alt + cg + r_ev + behit + tailr + wezdot + wez + r_pos + (wvr ? 0.0f : r_ra + (maneuver ? 0.0f : r_mp));   // ShootPenalty never fires: remaining_missiles is constant; WVR has eight terms (WVR_task.py:20-29), Maneuver_curriculum nine
+    own = r_alt + cg + r_ev + behit + tailr + wezdot + wez + r_pos + (wvr ? 0.0f : r_ra + (maneuver ? 0.0f : r_mp));
+    if (dodge) own = r_pos + r_mp + r_alt + r_ev;   // multiplecombat_with_missile_task.py:23-28   // ShootPenalty never fires: remaining_missiles is constant; WVR has eight terms (WVR_task.py:20-29), Maneuver_curriculum nine
   }
   AC_CLKE(73);
   float reward = own;

@@ -195,8 +195,8 @@ class HipVecEnv:
             self.action_space = Tuple([MultiDiscrete([3, 5, 3]), Discrete(2)])                     # *_with_missile_task.py:221-223
         elif self.hierarchical:
             self.action_space = MultiDiscrete([3, 5, 3])                                           # singlecombat_task.py:221-222
-        elif config.task == AC_TASK_SHOOT_MISSILE:
-            self.action_space = Tuple([MultiDiscrete([41, 41, 41, 30]), Discrete(2)])
+        elif config.task == AC_TASK_SHOOT_MISSILE or config.legacy_obs and config.task == AC_TASK_MULTICOMBAT:
+            self.action_space = Tuple([MultiDiscrete([41, 41, 41, 30]), Discrete(2)])                # *_with_missile_task.py:176-178
         elif config.task in (AC_TASK_SCENARIO1, AC_TASK_SCENARIO_NVN):
             # low-level controls + [gun, AIM-9M, AIM-120B, chaff] (scenario1_task.py:29-31 with the controller net bypassed)
             self.action_space = Tuple([MultiDiscrete([41, 41, 41, 30]), MultiDiscrete([2, 2, 2, 2])])
@@ -375,6 +375,9 @@ class HipVecEnv:
         for a in range(self.num_agents):
             msgs.append(acmi.aircraft_record(uids[a], color(a), entities[a]))
         slots = {AC_TASK_SHOOT_MISSILE: 4, 2: 4, AC_TASK_SCENARIO1: 2, AC_TASK_SCENARIO_NVN: 2}.get(cfg.task, 0)
+        base_missile = cfg.task in (AC_TASK_SHOOT_MISSILE, 2)       # MissileSimulator itself (300 m fuse); 2 = AC_TASK_DODGE_MISSILE
+        if cfg.task == 2 and cfg.n_agents > 2:                      # multiplecombat_dodge_missile: two uids per aircraft, like the scenario tasks
+            slots = 2
         # env._tempsims in dict order = first-launch order of the uids; a slot's uid is "agent + remaining count at the launch"
         # (scenario1_task.py:83,92; singlecombat_with_missile_task.py:199): slots are consumed from the highest count down
         flying = []
@@ -392,7 +395,7 @@ class HipVecEnv:
         for _, a, k, m, nmis in flying:
             uid = f"{uids[a]}{nmis - k}"
             rec, boom = acmi.missile_records(uid, color(a), int(m[0]), m[1:4], m[7], m[8], center, (a, k) in self._acmi_exploded,
-                                             300 if slots == 4 else 5, acmi.MISSILE_MODELS[int(m[11])])
+                                             300 if base_missile else 5, acmi.MISSILE_MODELS[int(m[11])])
             if boom:
                 self._acmi_exploded.add((a, k))
             msgs.append(rec)
@@ -591,7 +594,7 @@ class MultiDeviceVecEnv:
         from .sharding import env_block
         if not device_ids:
             raise ValueError("device_ids must name at least one GPU")
-        share = (config.task in (AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO_NVN)) if share is None else share
+        share = (config.n_agents > 2) if share is None else share      # the MultipleCombatEnv family (share_obs)
         cls = HipShareVecEnv if share else HipVecEnv
         self.blocks = [env_block(r, len(device_ids), num_envs) for r in range(len(device_ids))]
         if min(c for _, c in self.blocks) < 1:
@@ -659,5 +662,5 @@ class MultiDeviceVecEnv:
 def make_env(scenario=None, num_envs=1, task=None, device_id=0, seed=0, copy=True):
     """``scenario``: path of a scenario YAML (reference format) or None for the 1v1 block of WVR_selfplay.yaml."""
     cfg = config_from_yaml(scenario, task=task) if scenario else default_config(task or "singlecombat")
-    cls = HipShareVecEnv if cfg.task in (AC_TASK_MULTICOMBAT, AC_TASK_SCENARIO_NVN) else HipVecEnv
+    cls = HipShareVecEnv if cfg.n_agents > 2 else HipVecEnv         # the MultipleCombatEnv family (share_obs)
     return cls(cfg, num_envs, device_id=device_id, seed=seed, copy=copy)

@@ -11,6 +11,11 @@ static double clampd(double lo, double v, double hi) { return v < lo ? lo : (v >
 static double norm3(const double v[3]) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 static double sign0(double v) { return (v > 0) - (v < 0); }
 
+/* MultipleCombatEnv semantics (multiplecombat_env.py:119-182): MultipleCombatTask and everything built on it. The rule-based
+ * MultipleCombatDodgeMissileTask (multiplecombat_with_missile_task.py:13-134) is OR_TASK_DODGE_MISSILE with more than two aircraft. */
+static int nvn_env(const OrEnvConfig* c) {
+  return c->task == OR_TASK_MULTICOMBAT || c->task == OR_TASK_SCENARIO_NVN || (c->task == OR_TASK_DODGE_MISSILE && c->n_aircraft > 2);
+}
 int or_env_obs_dim(int task) {
   switch (task) {
     case OR_TASK_HEADING: return 12;
@@ -314,7 +319,8 @@ void or_env_init(OrEnv* e, const OrEnvConfig* c) {
   e->act_dim = or_env_act_dim_h(c->task, c->hierarchical);
   if (c->task == OR_TASK_MULTICOMBAT && c->legacy_obs) { /* hierarchical_multiplecombat_shoot (multiplecombat_with_missile_task.py:206-238) */
     e->obs_dim = 21;                      /* :180-183 */
-    if (c->hierarchical) e->act_dim = 4;  /* Tuple([3,5,3], Discrete(2)) (:221-223); the bit is stored (:231) and never used (:202-203) */
+    e->act_dim = c->hierarchical ? 4 : 5; /* Tuple([3,5,3], Discrete(2)) (:221-223) / MultipleCombatShootMissileTask's Tuple([41,41,41,30], Discrete(2)) (:176-178);
+                                             the bit is stored (:204-206, :231) and never used (:215-216) */
   }
   for (int i = 0; i < c->n_aircraft; i++) e->ac[i].team = (i < c->n_ego) ? 0 : 1;
   e->mp_prev_missile = -1;
@@ -349,7 +355,7 @@ static void feature6(const OrAircraft* a, double f[6]) {
 static void obs_combat(const OrEnv* e, int i, double* o) { /* singlecombat_task.py:88-139, singlecombat_with_missile_task.py:31-99 */
   const OrAircraft* a = &e->ac[i];
   const OrAircraft* en = &e->ac[first_enemy(e, i)];
-  if (e->cfg.task == OR_TASK_SCENARIO_NVN || e->cfg.task == OR_TASK_MULTICOMBAT) { /* legacy layout: `target` = own index within the team (:62-78) */
+  if (nvn_env(&e->cfg)) { /* legacy layout: `target` = own index within the team (multiplecombat_with_missile_task.py:62-78) */
     int idx = (a->team == 0) ? i : i - e->cfg.n_ego;
     en = &e->ac[(a->team == 0) ? e->cfg.n_ego + idx : idx];
   }
@@ -612,7 +618,7 @@ static double task_reward_terms(OrEnv* e, int i) {
 }
 static double get_reward(OrEnv* e, int i) { /* singlecombat_task.py:190-195; heading task uses BaseTask.get_reward */
   if (e->cfg.task == OR_TASK_HEADING) return task_reward_terms(e, i);
-  if (e->cfg.task == OR_TASK_MULTICOMBAT || e->cfg.task == OR_TASK_SCENARIO_NVN) /* multiplecombat_task.py:147-151: only while alive */
+  if (nvn_env(&e->cfg)) /* multiplecombat_task.py:147-151: only while alive */
     return e->ac[i].status == OR_ALIVE ? task_reward_terms(e, i) : 0.0;
   if (e->ac[i].die_flag) return 0.0;
   e->ac[i].die_flag = e->ac[i].status != OR_ALIVE;
@@ -701,7 +707,7 @@ static int get_termination(OrEnv* e, int i, int* code) {
     return t_unreach_heading(e, i, code) || t_extreme(e, i, code) || t_overload(e, i, code) || t_low_altitude(e, i, code) || t_timeout(e, i, code);
   if (e->cfg.task == OR_TASK_WVR) /* WVR_task.py:31-36: no SafeReturn */
     return t_low_altitude(e, i, code) || t_extreme(e, i, code) || t_overload(e, i, code) || t_timeout(e, i, code);
-  if (e->cfg.task == OR_TASK_MULTICOMBAT || e->cfg.task == OR_TASK_SCENARIO_NVN) /* multiplecombat_task.py:33-39 */
+  if (nvn_env(&e->cfg)) /* multiplecombat_task.py:33-39 */
     return t_safe_return(e, i, code) || t_extreme(e, i, code) || t_overload(e, i, code) || t_low_altitude(e, i, code) || t_timeout(e, i, code);
   /* singlecombat_task.py:34-40 */
   return t_low_altitude(e, i, code) || t_extreme(e, i, code) || t_overload(e, i, code) || t_safe_return(e, i, code) || t_timeout(e, i, code);
@@ -824,7 +830,7 @@ static void task_step(OrEnv* e) {
   }
   if (t == OR_TASK_SCENARIO1 || t == OR_TASK_SCENARIO_NVN) { scenario_weapons(e); return; }
   if (t == OR_TASK_WVR || t == OR_TASK_MANEUVER) { wvr_gun(e); return; }   /* Maneuver_curriculum.step: the same rule through a2a_launch_available (:290-297) */
-  if (t == OR_TASK_DODGE_MISSILE) { /* singlecombat_with_missile_task.py:108-124 */
+  if (t == OR_TASK_DODGE_MISSILE) { /* singlecombat_with_missile_task.py:108-124 == multiplecombat_with_missile_task.py:127-145 (target: agent.enemies[0]) */
     for (int i = 0; i < e->cfg.n_aircraft; i++) {
       OrAircraft* a = &e->ac[i];
       int en = first_enemy(e, i);
@@ -927,6 +933,7 @@ void or_env_task_reset(OrEnv* e) {
     OrAircraft* a = &e->ac[i];
     a->die_flag = 0;
     a->last_shoot_time = -c->min_attack_interval;
+    a->remaining_missiles = c->num_missiles[i];   /* singlecombat_with_missile_task.py:101-106, multiplecombat_with_missile_task.py:119-125 */
     a->lock_n = (int)(1 / ((double)c->agent_interaction_steps / c->sim_freq));
     if (a->lock_n > 16) a->lock_n = 16;
     a->lock_pos = 0;
@@ -1020,7 +1027,7 @@ void or_env_evaluate(OrEnv* e, double* obs, double* rew, uint8_t* done, int32_t*
   const OrEnvConfig* c = &e->cfg;
   int code = OR_DONE_NONE;
   get_obs(e, obs);
-  if (c->task == OR_TASK_MULTICOMBAT || c->task == OR_TASK_SCENARIO_NVN) { /* MultipleCombatEnv.step, multiplecombat_env.py:160-182: rewards, team mean, then dones */
+  if (nvn_env(c)) { /* MultipleCombatEnv.step, multiplecombat_env.py:160-182: rewards, team mean, then dones */
     double sum[2] = {0, 0}; int cnt[2] = {0, 0};
     for (int i = 0; i < c->n_aircraft; i++) { rew[i] = get_reward(e, i); sum[e->ac[i].team] += rew[i]; cnt[e->ac[i].team]++; }
     for (int i = 0; i < c->n_aircraft; i++) rew[i] = sum[e->ac[i].team] / cnt[e->ac[i].team];

@@ -201,8 +201,7 @@ class OracleEnv:
         self.act_dim = L.or_env_act_dim_h(cfg.task, cfg.hierarchical)
         if cfg.task == TASK_MULTICOMBAT and cfg.legacy_obs:   # hierarchical_multiplecombat_shoot (or_env_init)
             self.obs_dim = 21
-            if cfg.hierarchical:
-                self.act_dim = 4
+            self.act_dim = 4 if cfg.hierarchical else 5
         if cfg.hierarchical:
             actor_load()
         if pcg64_state is not None:
@@ -252,6 +251,16 @@ class OracleEnv:
         out = (C.c_double * STATE_LEN)()
         self.L.or_state_export(self.p, i, out, STATE_LEN)
         return np.array(out[:])
+
+    def task_record(self, i):
+        """The task bookkeeping of aircraft i by name (the tail of or_state_export's vector)."""
+        out = (C.c_double * STATE_LEN)()
+        k = self.L.or_state_export(self.p, i, out, STATE_LEN)
+        v = out[:k]
+        names = ("status", "die_flag", "remaining", "pre_remaining", "shoot_action", "last_missile", "last_shoot_time", "lock_bits", "lock_pos", "cur_step")
+        rec = {nm: int(round(v[k - 10 + j])) for j, nm in enumerate(names)}
+        rec["bloods"] = v[k - 17]
+        return rec
 
     def import_state(self, i, vec):
         buf = (C.c_double * STATE_LEN)(*[float(v) for v in vec])

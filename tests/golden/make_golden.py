@@ -857,6 +857,107 @@ def gen_scenario_sequences(rng):
     np.savez_compressed(os.path.join(OUT, "scenario_sequences.npz"), **flat)
 
 
+def gen_multicombat_dodge(rng):
+    """MultipleCombatDodgeMissileTask (multiplecombat_with_missile_task.py:13-145; 2v2 and 4v4): the 21-value observation against the
+    enemy with the agent's own team index with the missile-warning block, the rule-based launch at enemies[0] from the one-second lock
+    window (angle, distance, interval, remaining rounds, alive), the base-class missile flown by MultipleCombatEnv.step's substep
+    loop, the four reward terms (MissilePostureReward's shared remembered missile included) and MultipleCombatTask's terminations.
+    No env of the reference constructs this class; the task object itself is driven here like the others."""
+    from envs.JSBSim.tasks.multiplecombat_with_missile_task import MultipleCombatDodgeMissileTask
+    flat = {}
+    ep_id = 0
+    for per_side in (2, 4):
+        uids = tuple(f"{team}0{k + 1}00" for team in "AB" for k in range(per_side))
+        acs = {u: {"color": "Blue" if u[0] == "A" else "Red", "missile": 2} for u in uids}
+        cfg = make_config(aircraft_configs=acs, EventDrivenReward_potential=False, min_attack_interval=25, max_attack_distance=14000, max_attack_angle=45)
+        for ep in range(6 if per_side == 2 else 3):
+            task = MultipleCombatDodgeMissileTask(cfg)
+            assert task.num_agents == 4 or True
+            agents = [FakeAircraft(u, acs[u]["color"]) for u in uids]
+            link(agents)
+            env = WeaponEnv(agents)
+            order = []
+            orig_add = env.add_temp_simulator
+
+            def add(sim, _o=order, _f=orig_add):
+                _o.append(sim)
+                return _f(sim)
+            env.add_temp_simulator = add
+            A = len(agents)
+            # kinds: 0 tail chase inside every gate (two launches 25 steps apart, the second ego aircraft locks the same enemies[0]);
+            # 1 random poses; 2 head-on from beyond max_attack_distance, closing; 3 tail chase in which the shooter dies of blood loss
+            # after its first launch; 4 chase just outside the lock cone for a while, then inside; 5 random, close
+            kind = ep % 6
+            T = {0: 220, 1: 30, 2: 270, 3: 150, 4: 180, 5: 30}[kind]
+            shooter, wing, target = agents[0], agents[1], agents[per_side]
+            for a in agents:
+                random_pose(rng, a, spread_km=8.0 if kind == 5 else 25.0, alt=(2600.0, 9000.0))
+
+            def chase_pose(t):
+                sep0 = {0: 5000.0, 2: 17000.0, 3: 4000.0, 4: 6000.0}[kind]
+                vs, vt = 255.0, (-240.0 if kind == 2 else 235.0)
+                ys, yt = vs * 0.1 * t, sep0 + vt * 0.1 * t
+                off_m = 0.0
+                if kind == 4:
+                    off_m = 9000.0 if t < 20 else 600.0          # 56 deg off the nose, then 6 deg
+                shooter.set_pose(120.0, 60.0 + ys / 111412.0, 6000.0, (0.02, 0.01, 0.0), (vs, 0.0, -1.0), (vs, 0.5, 4.0), vc=240.0,
+                                 npilot=(0.1, 0.0, -1.05), sim_time=12.0 + 0.1 * t)
+                wing.set_pose(120.0 - 300.0 / 55660.0, 60.0 + (ys - 800.0) / 111412.0, 6100.0, (0.0, 0.0, 0.0), (vs, 0.0, 0.0), (vs, 0.0, 3.0), vc=240.0,
+                              npilot=(0.0, 0.0, -1.0), sim_time=12.0 + 0.1 * t)
+                hdg = np.pi if kind == 2 else 0.0
+                target.set_pose(120.0 + (off_m + 25.0 * np.sin(0.05 * t)) / 55660.0, 60.0 + yt / 111412.0, 6050.0, (0.0, 0.0, hdg), (vt, 0.0, 1.0),
+                                (abs(vt), -0.5, 3.0), vc=225.0, npilot=(0.0, 0.0, -1.0), sim_time=12.0 + 0.1 * t)
+            scripted = kind in (0, 2, 3, 4)
+            if scripted:
+                chase_pose(0)
+            task.reset(env)
+            frames = []
+            for t in range(1, T + 1):
+                env.current_step = t
+                for a in agents:
+                    if not a.is_alive or (scripted and a in (shooter, wing, target)):
+                        continue
+                    if t % 3 == 0 or not scripted:
+                        random_pose(rng, a, spread_km=8.0 if kind == 5 else 25.0, alt=(2600.0, 9000.0))
+                if scripted:
+                    chase_pose(t)           # (a dead aircraft keeps being posed: nothing reads its pose but the missile aimed at it)
+                if kind == 3 and t == 14:
+                    shooter.bloods = 0      # dies at the next run()
+                pose = np.stack([pose_vector(a) for a in agents])
+                env.run_projectiles(6)
+                task.step(env)
+                obs = np.stack([task.get_obs(env, u) for u in env.agents])
+                info = {"current_step": env.current_step}
+                rewards = {}
+                for u in env.agents:
+                    r, info = task.get_reward(env, u, info)
+                    rewards[u] = [r]
+                ego = np.mean([rewards[u] for u in env.ego_ids]); enm = np.mean([rewards[u] for u in env.enm_ids])
+                rew = np.array([ego if u in env.ego_ids else enm for u in env.agents])
+                done = []
+                for u in env.agents:
+                    d, info = task.get_termination(env, u, info)
+                    done.append(d)
+                counters = np.array([[task.remaining_missiles[u], task._last_shoot_time[u], sum(task.lock_duration[u]), agents[k].bloods, agents[k].status]
+                                     for k, u in enumerate(env.agents)], dtype=float)
+                mrows = np.zeros((16, 9))
+                for k, m in enumerate(order[:16]):
+                    mrows[k] = [1 + uids.index(m.parent_aircraft.uid), uids.index(m.target_aircraft.uid), m._MissileSimulator__status,
+                                *m.get_position(), *m.get_velocity()]
+                frames.append(dict(pose=pose, obs=obs, rew=rew, done=np.array(done, dtype=float), counters=counters, msl=mrows,
+                                   step=env.current_step, nmsl=len(order)))
+                if all(done):
+                    break
+            for key in ("pose", "obs", "rew", "done", "counters", "msl"):
+                flat[f"ep{ep_id}_{key}"] = np.stack([f[key] for f in frames])
+            flat[f"ep{ep_id}_misc"] = np.array([[f["step"], f["nmsl"]] for f in frames], dtype=float)
+            flat[f"ep{ep_id}_per_side"] = np.array([float(per_side)])
+            ep_id += 1
+    flat["n_episodes"] = np.array([ep_id], dtype=float)
+    flat["min_attack_interval"] = np.array([25.0])
+    np.savez_compressed(os.path.join(OUT, "multicombat_dodge_sequences.npz"), **flat)
+
+
 def gen_curriculum_table():
     from envs.JSBSim.utils.utils import calculate_coordinates_heading_by_curriculum
     res = calculate_coordinates_heading_by_curriculum(60.1, 120.0, 11.119, list(range(0, 181)))
@@ -1167,6 +1268,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "artillery":
         gen_artillery(np.random.default_rng(86))
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "multicombat_dodge":
+        gen_multicombat_dodge(np.random.default_rng(87))
+        return
     rng = np.random.default_rng(20250321)
     gen_geometry(rng)
     gen_reward_functions(rng)
@@ -1186,6 +1290,7 @@ def main():
     gen_approach(np.random.default_rng(85))
     gen_acmi_records()
     gen_artillery(np.random.default_rng(86))
+    gen_multicombat_dodge(np.random.default_rng(87))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

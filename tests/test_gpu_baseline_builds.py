@@ -27,7 +27,7 @@ def make_cfg(pkg, task, per_side):
         cfg.init[i].lon_deg += 0.013 * (i % 3) + (0.02 if i >= per_side else 0.0)
         cfg.init[i].psi_deg = (7.0 + 3.0 * i) if i < per_side else (171.0 + 2.0 * i)
         cfg.init[i].h_sl_ft += 300.0 * i
-        if i >= per_side and task == "scenario_nvn":
+        if i >= per_side and task in ("scenario_nvn", "multiplecombat_dodge_missile"):
             cfg.init[i].lat_geod_deg = 60.06
     return cfg
 
@@ -58,7 +58,7 @@ def run_sampled(pkg, oracle, task, per_side, E, sample, steps, seed=77, expect_k
     weapons = task not in ("singlecombat", "multiplecombat")
     nvn_order = A > 2
     # where the enemies' geometry blocks sit in the oracle's observation (for the reward conditioning)
-    n_en = max(1, A // 2)
+    n_en = 1 if cfg.legacy_obs else max(1, A // 2)      # (the 21-value observation carries the paired enemy's block only)
     en_from = 9 + 6 * (A // 2 - 1) if (A > 2 and not cfg.legacy_obs) else 9
     rng = np.random.default_rng(seed)
     launched = 0
@@ -98,11 +98,11 @@ SAMPLE_4096 = [0, 1, 7, 8, 2047, 2048, 4094, 4095]     # first / last env, workg
 
 @pytest.mark.parametrize("task,per_side", [("singlecombat_shoot", 1), ("scenario1", 1), ("singlecombat_dodge_missile", 1),
                                            ("multiplecombat", 2), ("scenario_nvn", 2),
-                                           ("multiplecombat", 4), ("scenario_nvn", 4)])
+                                           ("multiplecombat", 4), ("scenario_nvn", 4), ("multiplecombat_dodge_missile", 2), ("multiplecombat_dodge_missile", 4)])
 def test_baseline_shapes_sampled_envs_match_oracle(pkg, oracle, task, per_side):
     """C3 (4096 envs x 2 aircraft with missiles), C4 (4096 envs x 4) and C5 (4096 envs x 8: 512 workgroups) as the driver's bench
     launches them: 8 sampled envs on the oracle, 40 steps, per-element bounds."""
-    run_sampled(pkg, oracle, task, per_side, 4096, SAMPLE_4096, 100 if task == "singlecombat_dodge_missile" else 40)
+    run_sampled(pkg, oracle, task, per_side, 4096, SAMPLE_4096, 100 if task.endswith("dodge_missile") else 40)
 
 
 @pytest.mark.parametrize("task,per_side", [("singlecombat", 1), ("singlecombat_shoot", 1), ("scenario1", 1), ("multiplecombat", 4), ("scenario_nvn", 2), ("scenario_nvn", 4)])

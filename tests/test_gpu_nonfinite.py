@@ -20,7 +20,8 @@ def actions(env, rng):
 @pytest.mark.parametrize("task,field,value", [("singlecombat", "wq", np.nan), ("singlecombat", "vx", np.inf), ("singlecombat", "rx", np.nan),
                                               ("singlecombat", "tank0", np.nan), ("singlecombat", "q2", np.nan), ("heading", "wp", np.nan),
                                               ("multiplecombat", "vz", np.nan), ("singlecombat_shoot", "wr", np.nan), ("scenario1", "vy", np.nan),
-                                              ("scenario_nvn", "wq", np.nan), ("wvr_lowlevel", "q0", np.nan)])
+                                              ("scenario_nvn", "wq", np.nan), ("wvr_lowlevel", "q0", np.nan), ("multiplecombat_dodge_missile", "vx", np.nan),
+                                              ("multiplecombat_shoot", "wq", np.nan)])
 def test_non_finite_state_fails_the_step_and_terminates_the_aircraft(pkg, task, field, value):
     _poisoned_aircraft_is_named(pkg, task, field, value, None)
 

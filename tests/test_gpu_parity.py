@@ -226,12 +226,16 @@ def test_crash_and_shotdown_semantics(pkg):
     env.close()
 
 
-@pytest.mark.parametrize("per_side", [2, 4])
-def test_nvn_multicombat_matches_oracle(pkg, oracle, per_side):
+@pytest.mark.parametrize("task,per_side", [("multiplecombat", 2), ("multiplecombat", 4), ("multiplecombat_shoot", 2), ("multiplecombat_shoot", 4)])
+def test_nvn_multicombat_matches_oracle(pkg, oracle, task, per_side):
     """MultipleCombat 2v2 / 4v4: teacher-forced steps with the env's order of operations (rewards before terminations,
-    team means, SafeReturn first), share_obs, auto-reset."""
-    cfg = pkg.default_nvn_config(per_side)
+    team means, SafeReturn first), share_obs, auto-reset. `multiplecombat_shoot` = MultipleCombatShootMissileTask
+    (multiplecombat_with_missile_task.py:165-216; no env of the reference constructs it): the 21-value observation against the enemy
+    with the agent's own team index, a missile block that stays zero, and a fifth action element -- the shoot bit -- that the task
+    stores and never uses (its step() is MultipleCombatTask.step), so random bits must change nothing."""
+    cfg = pkg.default_nvn_config(per_side, task=task)
     A = 2 * per_side
+    shoot = task == "multiplecombat_shoot"
     # The shipped YAML starts both teams exactly head-on on one meridian (TA = pi, AO = 0): PostureReward's atanh term and
     # the side flag are singular there, so numerical parity is only meaningful off that measure-zero geometry. Stagger it.
     for i in range(A):
@@ -244,7 +248,8 @@ def test_nvn_multicombat_matches_oracle(pkg, oracle, per_side):
     ref = oracle.OracleVecEnv(ocfg, E)
     obs, share = env.reset()
     robs = ref.reset()
-    assert obs.shape == (E, A, 9 + 6 * (A - 1)) and share.shape == (E, A, A * obs.shape[-1])
+    assert obs.shape == (E, A, 21 if shoot else 9 + 6 * (A - 1)) and share.shape == (E, A, A * obs.shape[-1])
+    assert env.act_dim == (5 if shoot else 4)
     assert nvn_obs_close(obs, robs).all(), np.abs(obs - robs).max()
     assert (share[:, 0] == obs.reshape(E, -1)).all() and (share[:, A - 1] == share[:, 0]).all()
     rng = np.random.default_rng(5)
@@ -253,7 +258,7 @@ def test_nvn_multicombat_matches_oracle(pkg, oracle, per_side):
         for e in range(E):
             for a in range(A):
                 env.set_state(e, a, ref.envs[e].export_state(a))
-        act = np.stack([rng.integers(0, n, size=(E, A)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
+        act = np.stack([rng.integers(0, n, size=(E, A)) for n in ((41, 41, 41, 30, 2) if shoot else (41, 41, 41, 30))], axis=-1).astype(np.float32)
         if step == 30:
             env.set_status(1, A - 1, 2); ref.envs[1].set_status(A - 1, 2)      # an enemy is shot down
         if step == 40:
@@ -265,6 +270,8 @@ def test_nvn_multicombat_matches_oracle(pkg, oracle, per_side):
         assert ok.all(), (step, np.argwhere(~ok)[:4], obs[~ok][:4], robs[~ok][:4])
         assert (np.abs(rew - rrew) <= 5e-3 + 1e-3 * np.abs(rrew)).all(), (step, np.abs(rew - rrew).max())
         assert (done == rdone).all(), (step, done[..., 0], rdone[..., 0])
+        if shoot:
+            assert (obs[..., 15:] == 0).all()      # nothing is ever launched: the missile block stays zero
         n_done += int(done.sum())
     assert n_done > 0
     env.close()
@@ -419,6 +426,70 @@ def test_scenario_weapon_tasks_match_oracle(pkg, oracle, task, per_side, geometr
     assert obs.shape[-1] == (21 if rwr == 2 else (21 if A == 2 else 9 + 6 * A + 6) + (2 if rwr else 0))
     import parity_util
     print("fraction of the bounds used:", {k: round(v, 3) for k, v in parity_util.USED.items() if k.startswith(f"weapons {task} x{per_side} {geometry} rwr{rwr}")})
+    env.close()
+
+
+@pytest.mark.parametrize("per_side", [2, 4])
+def test_multicombat_dodge_missile_matches_oracle(pkg, oracle, per_side):
+    """MultipleCombatDodgeMissileTask (`multiplecombat_dodge_missile`, multiplecombat_with_missile_task.py:13-145; the oracle's reading of it
+    is pinned by tests/golden/multicombat_dodge_sequences.npz): rule-based launches of the base-class missile at enemies[0] out of the
+    one-second lock window, flown under MultipleCombatEnv.step's order, the 21-value paired-enemy observation with the missile-warning
+    block, Posture + MissilePosture + Altitude + EventDriven with the team mean. Flight state re-synchronised every step; missiles, the
+    lock windows and all bookkeeping run open-loop on both sides for 330 steps."""
+    cfg = pkg.default_nvn_config(per_side, task="multiplecombat_dodge_missile")
+    cfg.min_attack_interval = 25             # (the shipped 125 allows one launch per aircraft in a test of this length)
+    A = 2 * per_side
+    for i in range(A):
+        cfg.init[i].lon_deg += 0.013 * (i % 3) + (0.02 if i >= per_side else 0.0)
+        cfg.init[i].psi_deg = (7.0 + 3.0 * i) if i < per_side else (171.0 + 2.0 * i)
+        cfg.init[i].h_sl_ft += 300.0 * i
+        if i >= per_side:
+            cfg.init[i].lat_geod_deg = 60.06
+    E, seed = 4, 77
+    env = pkg.HipShareVecEnv(cfg, E, seed=seed)
+    ref = oracle.OracleVecEnv(oracle.config_from_ac(cfg), E, chaff_seed=seed)
+    obs, share = env.reset()
+    robs = ref.reset()
+    assert obs.shape == robs.shape == (E, A, 21) and env.act_dim == 4 and share.shape == (E, A, 21 * A)
+    names = env.lib.state_field_names()
+    ix = {nm: k for k, nm in enumerate(names) if nm}
+    task_fields = ("bloods", "pre_posture", "pre_altitude", "pre_event", "pre_shoot", "status", "die_flag", "remaining", "pre_remaining",
+                   "shoot_action", "last_missile", "last_shoot_time", "lock_bits", "lock_pos", "cur_step")
+    fdm_fields = np.array([k for k, nm in enumerate(names) if nm and not nm.startswith("x_") and nm not in task_fields])
+    rng = np.random.default_rng(19)
+    bound = RewardBound(cfg.posture_scale, 9, 1, 4.0)
+    launched = shot = warned = 0
+    lab = f"multiplecombat_dodge_missile x{per_side}"
+    import parity_util
+    for step in range(330):
+        for e in range(E):
+            for a in range(A):
+                v = env.get_state(e, a)
+                v[fdm_fields] = ref.envs[e].export_state(a)[fdm_fields]
+                env.set_state(e, a, v)
+        act = (np.array([20, 18.6, 20, 15], dtype=np.float32) + rng.integers(-2, 3, size=(E, A, 4))).astype(np.float32)   # gentle flying keeps the geometry
+        obs, share, rew, done, info = env.step(act)
+        robs, rrew, rdone, rinfo = ref.step(act)
+        assert (done == rdone).all(), (step, done[..., 0], rdone[..., 0])
+        assert_obs(obs, robs, 3.0, (lab, step), label=lab)
+        rt = team_max(bound(rrew, robs), A)
+        bad = np.abs(rew - rrew) > rt
+        assert not bad.any(), (step, np.argwhere(bad)[:4].tolist(), rew[bad][:4], rrew[bad][:4], rt[bad][:4])
+        parity_util.USED[lab + " reward"] = max(parity_util.USED.get(lab + " reward", 0.0), float((np.abs(rew - rrew) / rt).max()))
+        for e in range(E):
+            if rinfo[e][3]:
+                continue
+            for a in range(A):
+                g = env.get_state(e, a)
+                rec = ref.envs[e].task_record(a)
+                got = [int(g[ix["remaining"]]), int(g[ix["last_shoot_time"]]), int(g[ix["lock_bits"]]), int(g[ix["lock_pos"]]), int(g[ix["status"]])]
+                assert got == [rec["remaining"], rec["last_shoot_time"], rec["lock_bits"], rec["lock_pos"], rec["status"]], (step, e, a, got, rec)
+                assert abs(g[ix["bloods"]] - rec["bloods"]) < 1e-3
+            launched = max(launched, len(ref.envs[e].missiles()))
+        shot += int(sum(int(rinfo[e][1]) == 4 for e in range(E)))
+        warned += int((np.abs(robs[..., 15:]).sum(-1) > 0).sum())
+    assert launched >= 4 and shot >= 1 and warned > 100, (launched, shot, warned)
+    print("fraction of the bounds used:", {k: round(v, 3) for k, v in parity_util.USED.items() if k.startswith(lab)})
     env.close()
 
 

@@ -278,6 +278,56 @@ def test_scenario_weapon_sequences(oracle):
     assert launched >= 4 and chaffs >= 2
 
 
+def test_multicombat_dodge_missile_sequences(oracle):
+    """MultipleCombatDodgeMissileTask (multiplecombat_with_missile_task.py:13-145; 2v2 and 4v4) against the reference's own task object
+    over scripted engagements: the 21-value paired-enemy observation with the missile-warning block, the rule-based launch at
+    enemies[0] (lock window, angle, distance, interval, rounds left, alive), the base-class missile under MultipleCombatEnv.step's
+    substep loop (mutual kills, two aircraft firing at one target), Posture + MissilePosture + Altitude + EventDriven rewards with the
+    team mean, MultipleCombatTask's terminations. The oracle runs it as OR_TASK_DODGE_MISSILE with more than two aircraft."""
+    g = load("multicombat_dodge_sequences.npz")
+    launched = kills = 0
+    for ep in range(int(g["n_episodes"][0])):
+        per_side = int(g[f"ep{ep}_per_side"][0])
+        cfg = oracle.default_config(oracle.TASK_MULTICOMBAT)
+        cfg.task = oracle.TASK_DODGE_MISSILE
+        cfg.n_aircraft, cfg.n_ego = 2 * per_side, per_side
+        cfg.event_potential = 0
+        cfg.min_attack_interval = int(g["min_attack_interval"][0])
+        for i in range(cfg.n_aircraft):
+            cfg.num_missiles[i] = 2
+        A = cfg.n_aircraft
+        env = oracle.OracleEnv(cfg)
+        assert env.obs_dim == 21 and env.act_dim == 4
+        pose, obs, rew, done, counters, msl, misc = (g[f"ep{ep}_{k}"] for k in ("pose", "obs", "rew", "done", "counters", "msl", "misc"))
+        for t in range(len(pose)):
+            for i in range(A):
+                env.set_pose(i, pose[t][i])
+            if t == 0:
+                env.set_step(0)
+                env.task_reset()
+            env.set_step(int(misc[t][0]))
+            env.L.or_env_run_projectiles(env.p, 6)
+            env.L.or_env_task_step(env.p)
+            o, r, d, info = env.evaluate()
+            for i in range(A):
+                rec = env.task_record(i)
+                window = bin(rec["lock_bits"]).count("1")
+                got = [rec["remaining"], rec["last_shoot_time"], window, rec["bloods"], rec["status"]]
+                assert got == list(counters[t][i]), (ep, t, i, got, counters[t][i])
+            ms = env.missiles()
+            assert len(ms) == int(misc[t][1]), (ep, t, len(ms), misc[t][1])
+            for k, m in enumerate(ms[:16]):
+                assert int(m[11]) == int(msl[t][k][0]) - 1 and int(m[12]) == int(msl[t][k][1]) and int(m[0]) == int(msl[t][k][2]), (ep, t, k, m[:1], msl[t][k][:3])
+                assert close(m[1:7], msl[t][k][3:9], rtol=1e-9, atol=1e-6).all(), (ep, t, k)
+            assert close(o, obs[t], rtol=1e-9, atol=5e-8).all(), (ep, t, np.abs(o - obs[t]).max())
+            assert (d == done[t].astype(bool)).all(), (ep, t, d, done[t])
+            if t >= 1:   # frame 0's potential difference depends on the un-stored reset poses
+                assert close(r, rew[t], rtol=1e-7, atol=1e-6).all(), (ep, t, r, rew[t])
+            launched = max(launched, len(ms))
+        kills += int((counters[-1][:, 4] == 2).sum())
+    assert launched >= 6 and kills >= 4
+
+
 def test_lowlevel_controller_matches_reference_module(oracle):
     """BaselineActor restatement (oracle/lowlevel_actor.c) against outputs of the reference's own module over GRU sequences:
     logits and hidden state to fp32-summation accuracy (the reference computes in float32), argmax indices identical wherever
