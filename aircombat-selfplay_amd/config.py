@@ -35,6 +35,7 @@ TASK_IDS = {
     # enemies[0] under MultipleCombatEnv.step, the same 21-value observation with a live missile block. Equally unconstructible in the
     # reference; here AC_TASK_DODGE_MISSILE with four or eight aircraft.
     "multiplecombat_dodge_missile": AC_TASK_DODGE_MISSILE,
+    "hierarchical_multiplecombat_dodge_missile": AC_TASK_DODGE_MISSILE,   # HierarchicalSMultipleCombatDodgeMissileTask (:148-181): [3,5,3] through the controller
     # HierarchicalSingleCombatShootTask / HierarchicalSingleCombatDodgeMissileTask (singlecombat_with_missile_task.py:126-145,206-238):
     # the 1v1 missile tasks behind the low-level controller. No env of the reference selects them (singlecombat_env.py:19-36); the
     # names are this package's own.
@@ -45,7 +46,7 @@ TASK_IDS = {
 # are hierarchical in the reference (scenario1_task.py:11, scenario2_task.py:14); config_from_yaml follows that, while
 # default_config() keeps the control-index form unless asked (tests drive the weapon rules with explicit controls).
 ALWAYS_HIERARCHICAL = ("hierarchical_singlecombat", "hierarchical_multiplecombat", "hierarchical_multiplecombat_shoot",
-                       "hierarchical_singlecombat_shoot", "hierarchical_singlecombat_dodge_missile")
+                       "hierarchical_singlecombat_shoot", "hierarchical_singlecombat_dodge_missile", "hierarchical_multiplecombat_dodge_missile")
 HIERARCHICAL_IN_REFERENCE = ALWAYS_HIERARCHICAL + ("scenario1", "scenario2_nvn", "scenario3_nvn", "scenario1_curriculum",
                                                    "scenario2_nvn_curriculum", "scenario3_nvn_curriculum", "scenario1_rwr",
                                                    "scenario2_rwr", "scenario3_rwr", "scenario1_rwr_curriculum",
@@ -129,7 +130,8 @@ def config_from_dict(data, task=None, hierarchical=None):
         raise NotImplementedError(f"Unknown taskname: {name} (available: {sorted(TASK_IDS)})")
     cfg.task = TASK_IDS[name]
     cfg.rwr = int(rwr)
-    cfg.legacy_obs = int(legacy or name in ("hierarchical_multiplecombat_shoot", "multiplecombat_shoot", "multiplecombat_dodge_missile"))
+    cfg.legacy_obs = int(legacy or name in ("hierarchical_multiplecombat_shoot", "multiplecombat_shoot", "multiplecombat_dodge_missile",
+                                            "hierarchical_multiplecombat_dodge_missile"))
     cfg.approach = int(name == "approach")
     cfg.hierarchical = int(name in ALWAYS_HIERARCHICAL if hierarchical is None else bool(hierarchical))
     acs = data["aircraft_configs"]
@@ -249,7 +251,8 @@ def default_config(task="singlecombat", hierarchical=False):
         return cfg
     if task in ALWAYS_HIERARCHICAL:
         hierarchical = True
-    if task in ("multiplecombat", "hierarchical_multiplecombat", "hierarchical_multiplecombat_shoot", "multiplecombat_shoot", "multiplecombat_dodge_missile"):
+    if task in ("multiplecombat", "hierarchical_multiplecombat", "hierarchical_multiplecombat_shoot", "multiplecombat_shoot", "multiplecombat_dodge_missile",
+                "hierarchical_multiplecombat_dodge_missile"):
         return default_nvn_config(2, task=task if task.endswith(("_shoot", "_dodge_missile")) else "multiplecombat", hierarchical=hierarchical)
     if task in ("scenario_nvn", "scenario2_nvn"):
         return default_nvn_config(2, task="scenario_nvn", hierarchical=hierarchical)

@@ -1857,7 +1857,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   if (cfg->task == AC_TASK_SCENARIO_NVN || nvn_dodge) {
     if ((cfg->n_agents != 4 && cfg->n_agents != 8) || cfg->n_ego * 2 != cfg->n_agents)
       return fail("ac_create: AC_TASK_SCENARIO_NVN (and AC_TASK_DODGE_MISSILE with more than two aircraft) needs n_agents in {4, 8} split into two equal teams");
-    if (nvn_dodge && (cfg->hierarchical || cfg->rwr)) return fail("ac_create: multiplecombat_dodge_missile takes control-index actions and has no rwr variant");
+    if (nvn_dodge && cfg->rwr) return fail("ac_create: multiplecombat_dodge_missile has no rwr variant");
   }
   const bool gun_only = cfg->task == AC_TASK_WVR || cfg->task == AC_TASK_MANEUVER;
   if (scenario && !gun_only)

@@ -634,7 +634,7 @@ def test_artillery_blood_drain_on_device(pkg, oracle):
 
 @pytest.mark.parametrize("task,baseline", [("hierarchical_singlecombat", 0), ("scenario1", 0), ("scenario_nvn", 0),
                                            ("scenario1", 1), ("scenario_nvn", 1), ("hierarchical_singlecombat", 2),
-                                           ("hierarchical_multiplecombat_shoot", 0),
+                                           ("hierarchical_multiplecombat_shoot", 0), ("hierarchical_multiplecombat_dodge_missile", 0),
                                            ("hierarchical_singlecombat_shoot", 0), ("hierarchical_singlecombat_dodge_missile", 0)])
 def test_hierarchical_tasks_lowlevel_controller(pkg, oracle, task, baseline):
     _lowlevel_controller_parity(pkg, oracle, task, baseline)
@@ -677,10 +677,12 @@ def _lowlevel_controller_parity(pkg, oracle, task, baseline, E=6, sample=None, p
     if task in ("scenario1", "hierarchical_singlecombat_shoot", "hierarchical_singlecombat_dodge_missile"):
         cfg.init[1].lon_deg, cfg.init[1].lat_geod_deg, cfg.init[1].psi_deg = 120.02, 60.06, 171.0
         cfg.init[0].psi_deg = 9.0
-    if task == "hierarchical_multiplecombat_shoot":   # off the shipped head-on geometry, where PostureReward's atanh is singular
+    if task in ("hierarchical_multiplecombat_shoot", "hierarchical_multiplecombat_dodge_missile"):   # off the shipped head-on geometry, where PostureReward's atanh is singular
         for i in range(4):
             cfg.init[i].lon_deg += 0.013 * (i % 3) + (0.02 if i >= 2 else 0.0)
             cfg.init[i].psi_deg = (7.0 + 3.0 * i) if i < 2 else (171.0 + 2.0 * i)
+            if task.endswith("dodge_missile") and i >= 2:
+                cfg.init[i].lat_geod_deg = 60.06         # inside max_attack_distance: the rule-based launches happen during the comparison
     A = cfg.n_agents
     sample = list(range(E)) if sample is None else list(sample)
     S = len(sample)
@@ -692,7 +694,7 @@ def _lowlevel_controller_parity(pkg, oracle, task, baseline, E=6, sample=None, p
     robs = ref.reset()
     assert obs[sample].shape == robs.shape
     assert env.act_dim == {"hierarchical_singlecombat": 3, "hierarchical_multiplecombat_shoot": 4, "hierarchical_singlecombat_shoot": 4,
-                           "hierarchical_singlecombat_dodge_missile": 3}.get(task, 7)
+                           "hierarchical_singlecombat_dodge_missile": 3, "hierarchical_multiplecombat_dodge_missile": 3}.get(task, 7)
     if task == "hierarchical_multiplecombat_shoot":   # the only MultipleCombat missile variant an env can select: 21-value paired-enemy
         assert obs.shape == (E, 4, 21)                 # observation, [3,5,3] + a shoot bit that the task stores and never uses
     names = env.lib.state_field_names()
