@@ -34,9 +34,9 @@ sys.path.insert(0, ROOT)
 ENVS_PER_GPU = 4096
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_TINST = 256 * 4 * 32 * 2.4e9 / 1e12   # lane-instructions/s: 256 CUs x 4 SIMD-32 x 2.4 GHz (157.3 TFLOP/s fp32 = 2 flop FMA)
-# SQ_INSTS_VALU per aircraft-step of the SingleCombat kernel (profiles/round3_pmc_mix.txt, tools/pmc_mix.sh): the one-wave form executes
+# SQ_INSTS_VALU per aircraft-step of the SingleCombat kernel (profiles/round4_pmc_mix.txt, tools/pmc_mix.sh): the one-wave form executes
 # the algorithm once per lane; the three-wave form of the BASELINE batch executes the same tick cut in three plus the mailbox traffic
-VALU_PER_AGENT_STEP = {"one_wave": 8379.0, "three_wave": 9386.0}
+VALU_PER_AGENT_STEP = {"one_wave": 8325.0, "three_wave": 9343.0}
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
@@ -513,7 +513,7 @@ def main():
             valu = VALU_PER_AGENT_STEP["three_wave" if (E * A + 63) // 64 <= 512 else "one_wave"]
             result["roofline"]["valu"] = {"achieved": valu * rate / 1e12, "peak": VALU_PEAK_TINST, "unit": "T lane-inst/s",
                                           "frac": valu * rate / 1e12 / VALU_PEAK_TINST,
-                                          "note": "SQ_INSTS_VALU per aircraft-step of the kernel form this batch runs (profiles/round3_pmc_mix.txt) over the measured kernel time"}
+                                          "note": "SQ_INSTS_VALU per aircraft-step of the kernel form this batch runs (profiles/round4_pmc_mix.txt) over the measured kernel time"}
         if not args.device_only and args.steps < 200:
             # a K as short as the driver's (20 steps = 0.8 ms) is one sample of a noisy quantity: the same K-step region repeated, median reported
             reps = sorted(host_leg(env, pool, args.steps, 0, sync_all) for _ in range(31))
