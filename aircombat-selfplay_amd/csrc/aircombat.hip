@@ -1697,6 +1697,7 @@ struct ac_env {
   float* d_tab;
   float* d_tF; int* d_tI; double* d_tD;
   float* d_XF; int* d_XI;                // scenario-task extension state
+  double* d_state_io;                    // ac_get_state / ac_set_state: one aircraft's record on its way through (state_io_kernel)
   float* d_low;                          // hierarchical tasks: low-level action buffer (the controller's output, the step kernel's input)
   float* d_ctlWs8;                       // controller weights as fp16 pieces in the kernel's tiling (controller8_kernel.hpp)
   int ctl_rows;                          // aircraft per controller workgroup pinned by AIRCOMBAT_CTL_ROWS=32/64 (0: chosen per grid)
@@ -1984,6 +1985,7 @@ int ac_create(const ac_config_t* cfg, int32_t n_envs, int32_t device_id, uint64_
   HIP_OK(hipMalloc(&h->d_tF, sizeof(float) * ((size_t)NSW * h->A + (size_t)h->A * tmpl_obs)));
   h->d_tI = reinterpret_cast<int*>(h->d_tF);
   HIP_OK(hipMalloc(&h->d_tD, sizeof(double) * ND * h->A));
+  HIP_OK(hipMalloc(&h->d_state_io, sizeof(double) * 256));
   if (scenario) {
     HIP_OK(hipMalloc(&h->d_XF, sizeof(float) * NXF * N));
     HIP_OK(hipMalloc(&h->d_XI, sizeof(int) * NXI * N));
@@ -2050,7 +2052,7 @@ int ac_destroy(ac_env_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->dp.F, h->dp.D, h->dp.MF, h->dp.MD, h->dp.MI, h->dp.obs, h->dp.rew, h->dp.done, h->dp.info,
-                  h->d_actions, h->d_tab, h->d_tF, h->d_tD, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_ctlWs8, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
+                  h->d_actions, h->d_tab, h->d_tF, h->d_tD, h->d_state_io, h->d_XF, h->d_XI, h->dp.H, h->dp.man_step, h->dp.man_h0, h->d_ctlWs8, h->d_low, h->hp.HD, h->hp.HF, h->hp.HI, h->hp.HR};
   for (void* b : bufs) (void)hipFree(b);
   for (int k = 0; k < AC_HOST_SETS; ++k)
     if (h->have_hs[k]) ac_host_set_free(h->hs[k].act, h->hs[k].obs, h->hs[k].rew, h->hs[k].done, h->hs[k].info);   // (a detached set is the caller's)
@@ -2227,26 +2229,57 @@ static int check_idx(ac_env_t* h, int env, int agent) {
   if (env < 0 || env >= h->E || agent < 0 || agent >= h->A) return fail("env/agent index out of range");
   return 0;
 }
+// One aircraft's record in one launch and one copy (the tests' teacher-forcing reads and writes it for every aircraft of every step: as
+// one small hipMemcpy per word it was most of the GPU suite's run time). io: [ND position doubles][NF floats][NI ints][NXI raw words][NXF floats].
+struct SlotMap { int f[NF]; int i[NI]; };
+constexpr int kStateIoWords = ND + NF + NI + NXI + NXF;
+static_assert(kStateIoWords <= 256, "state_io_kernel: one thread per word of a 256-thread block");
+__global__ void state_io_kernel(float* F, double* D, const float* XF, const int* XI, size_t N, size_t n, double* io, int write, SlotMap m) {
+  const int t = threadIdx.x;
+  if (t < ND) {
+    double* w = t < 2 ? D + 2 * n + t : D + 2 * N + n;
+    if (write) *w = io[t]; else io[t] = *w;
+  } else if (t < ND + NF) {
+    const int sw = m.f[t - ND];
+    float* w = F + (((size_t)(sw >> 2) * N + n) * 4 + (size_t)(sw & 3));
+    if (write) *w = (float)io[t]; else io[t] = (double)*w;
+  } else if (t < ND + NF + NI) {
+    const int sw = m.i[t - ND - NF];
+    int* w = reinterpret_cast<int*>(F + (((size_t)(sw >> 2) * N + n) * 4 + (size_t)(sw & 3)));
+    if (write) *w = (int)llround(io[t]); else io[t] = (double)*w;
+  } else if (!write && t < kStateIoWords) {
+    const int q = t - (ND + NF + NI);
+    if (q < NXI) io[t] = XI ? (double)XI[(size_t)q * N + n] : 0.0;
+    else io[t] = XF ? (double)XF[(size_t)(q - NXI) * N + n] : 0.0;
+  }
+}
+static SlotMap slot_map() {
+  SlotMap m;
+  for (int f = 0; f < NF; ++f) m.f[f] = kSlotF[f];
+  for (int f = 0; f < NI; ++f) m.i[f] = kSlotI[f];
+  return m;
+}
 int ac_get_state(ac_env_t* h, int32_t env, int32_t agent, double* out) {
   if (check_idx(h, env, agent) || !out) return fail("ac_get_state: bad argument");
   HIP_OK(hipSetDevice(h->device));
-  HIP_OK(hipStreamSynchronize(h->stream));
   const size_t N = h->N, n = (size_t)env * h->A + agent;
+  double io[kStateIoWords];
+  hipLaunchKernelGGL(state_io_kernel, dim3(1), dim3(256), 0, h->stream, h->dp.F, h->dp.D, h->d_XF, h->d_XI, N, n, h->d_state_io, 0, slot_map());
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(io, h->d_state_io, sizeof io, hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
   int k = 0;
-  for (int f = 0; f < ND; ++f) { double v; HIP_OK(hipMemcpy(&v, position_word(h->dp.D, f, N, n), sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
-  for (int f = 0; f < NF; ++f) { float v; HIP_OK(hipMemcpy(&v, storage_word(h->dp.F, kSlotF[f], N, n), sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
-  for (int f = 0; f < NI; ++f) { int v; HIP_OK(hipMemcpy(&v, storage_word(h->dp.F, kSlotI[f], N, n), sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
+  for (int f = 0; f < ND + NF + NI; ++f) out[k++] = io[f];
   if (h->d_XF) {  // read-only tail: scenario-task extension (weapon counters, chaff clouds, shared reward references)
     {   // the fourteen counters / flags live in two packed words (scenario_kernel.hpp: ext_pack0 / ext_pack1); reported one by one
-      int w[NXI];
-      for (int f = 0; f < NXI; ++f) HIP_OK(hipMemcpy(&w[f], h->d_XI + f * N + n, sizeof(int), hipMemcpyDeviceToHost));
+      const double* w = io + ND + NF + NI;
       Ext x{};
-      ext_unpack(w[XI_w0], w[XI_w1], x);
+      ext_unpack((int)w[XI_w0], (int)w[XI_w1], x);
       const int v[NXI_UNPACKED] = {x.rem_gun, x.rem_9m, x.rem_120b, x.rem_chaff, x.bits, x.last_chaff, x.orphan_hits, x.mp_prev, x.ref_set,
                                    x.ch_status[0], x.ch_mult[0], x.ch_status[1], x.ch_mult[1], x.n_ch};
       for (int f = 0; f < NXI_UNPACKED; ++f) out[k++] = v[f];
     }
-    for (int f = 0; f < NXF; ++f) { float v; HIP_OK(hipMemcpy(&v, h->d_XF + f * N + n, sizeof v, hipMemcpyDeviceToHost)); out[k++] = v; }
+    for (int f = 0; f < NXF; ++f) out[k++] = io[ND + NF + NI + NXI + f];
   }
   for (; k < AC_STATE_LEN; ++k) out[k] = 0.0;
   return 0;
@@ -2254,12 +2287,11 @@ int ac_get_state(ac_env_t* h, int32_t env, int32_t agent, double* out) {
 int ac_set_state(ac_env_t* h, int32_t env, int32_t agent, const double* in) {
   if (check_idx(h, env, agent) || !in) return fail("ac_set_state: bad argument");
   HIP_OK(hipSetDevice(h->device));
-  HIP_OK(hipStreamSynchronize(h->stream));
   const size_t N = h->N, n = (size_t)env * h->A + agent;
-  int k = 0;
-  for (int f = 0; f < ND; ++f) { double v = in[k++]; HIP_OK(hipMemcpy(position_word(h->dp.D, f, N, n), &v, sizeof v, hipMemcpyHostToDevice)); }
-  for (int f = 0; f < NF; ++f) { float v = (float)in[k++]; HIP_OK(hipMemcpy(storage_word(h->dp.F, kSlotF[f], N, n), &v, sizeof v, hipMemcpyHostToDevice)); }
-  for (int f = 0; f < NI; ++f) { int v = (int)llround(in[k++]); HIP_OK(hipMemcpy(storage_word(h->dp.F, kSlotI[f], N, n), &v, sizeof v, hipMemcpyHostToDevice)); }
+  HIP_OK(hipMemcpyAsync(h->d_state_io, in, sizeof(double) * (ND + NF + NI), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(state_io_kernel, dim3(1), dim3(256), 0, h->stream, h->dp.F, h->dp.D, h->d_XF, h->d_XI, N, n, h->d_state_io, 1, slot_map());
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(h->stream));
   return 0;
 }
 int ac_set_status(ac_env_t* h, int32_t env, int32_t agent, int32_t status) {
@@ -2288,13 +2320,11 @@ __global__ void entity_kernel(DevPtrs P, DevCfg c, int n, double* out) {
 int ac_get_entity(ac_env_t* h, int32_t env, int32_t agent, double out[12]) {
   if (check_idx(h, env, agent) || !out) return fail("ac_get_entity: bad argument");
   HIP_OK(hipSetDevice(h->device));
-  double* d_out;
-  HIP_OK(hipMalloc(&d_out, sizeof(double) * 12));
+  double* d_out = h->d_state_io;   // (the handle's scratch record: no allocation per call)
   hipLaunchKernelGGL(entity_kernel, dim3(1), dim3(64), 0, h->stream, h->dp, h->dc, env * h->A + agent, d_out);
   HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(out, d_out, sizeof(double) * 12, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
-  HIP_OK(hipMemcpy(out, d_out, sizeof(double) * 12, hipMemcpyDeviceToHost));
-  HIP_OK(hipFree(d_out));
   return 0;
 }
 // Order-independent 64-bit digest of the live aircraft state: every lane reads its SoA columns exactly like the step kernel
