@@ -105,6 +105,32 @@ def test_baseline_shapes_sampled_envs_match_oracle(pkg, oracle, task, per_side):
     run_sampled(pkg, oracle, task, per_side, 4096, SAMPLE_4096, 100 if task.endswith("dodge_missile") else 40)
 
 
+@pytest.mark.parametrize("per_side", [2, 4])
+def test_legacy_nvn_batch_every_env_matches_oracle(pkg, oracle, per_side):
+    """C4 / C5 legacy MultipleCombat at 4096 envs (16 384 / 32 768 aircraft), EVERY env against its own oracle env: a different random
+    action stream per env, 10 steps of free flight from the reset, every observation element / reward / done flag compared (the 1v1
+    BASELINE batch likewise: test_gpu_parity.py::test_full_size_batch_every_env_matches_oracle)."""
+    cfg = make_cfg(pkg, "multiplecombat", per_side)
+    A, E = 2 * per_side, 4096
+    env = pkg.HipShareVecEnv(cfg, E, seed=3)
+    ref = oracle.OracleVecEnv(oracle.config_from_ac(cfg), E)
+    obs, _ = env.reset()
+    robs = ref.reset()
+    assert_obs(obs, robs, 1.0, "reset")
+    rng = np.random.default_rng(12)
+    bound = RewardBound(cfg.posture_scale, 9 + 6 * (A // 2 - 1), A // 2, 2.0)
+    for step in range(10):
+        act = actions_for(rng, E, A, 4, gentle=False)
+        obs, _, rew, done, _ = env.step(act)
+        robs, rrew, rdone, _ = ref.step(act)
+        assert (done == rdone).all(), (step, np.argwhere(done != rdone)[:4].tolist())
+        assert_obs(obs, robs, 2.0, ("every env", per_side, step))
+        rt = team_max(bound(rrew, robs), A)
+        bad = np.abs(rew - rrew) > rt
+        assert not bad.any(), (step, np.argwhere(bad)[:4].tolist(), rew[bad][:4], rrew[bad][:4], rt[bad][:4])
+    env.close()
+
+
 @pytest.mark.parametrize("task,per_side", [("singlecombat", 1), ("singlecombat_shoot", 1), ("scenario1", 1), ("multiplecombat", 4), ("scenario_nvn", 2), ("scenario_nvn", 4)])
 def test_saturating_grid_builds_sampled_envs_match_oracle(pkg, oracle, task, per_side):
     """> 1024 workgroups (70 000 aircraft): the two-waves-per-SIMD builds, sampled envs on the oracle."""

@@ -515,6 +515,31 @@ def test_full_size_batch_sampled_envs_match_oracle(pkg, oracle):
     env.close()
 
 
+def test_full_size_batch_every_env_matches_oracle(pkg, oracle):
+    """The BASELINE batch itself (configs[1]: 4096 envs x 2 aircraft), EVERY env against its own oracle env: a different random action
+    stream per env, 12 steps of free flight from the reset (no re-synchronisation), observations / rewards / dones of all 8192
+    aircraft at every step -- not a sample."""
+    cfg = pkg.default_config("singlecombat")
+    E = 4096
+    env = pkg.HipVecEnv(cfg, E)
+    ref = oracle.OracleVecEnv(oracle.config_from_ac(cfg), E)
+    obs, robs = env.reset(), ref.reset()
+    assert obs_close(obs, robs).all()
+    rng = np.random.default_rng(8)
+    worst = 0.0
+    for step in range(12):
+        act = rand_actions(rng, E, 2, 4)
+        obs, rew, done, info = env.step(act)
+        robs, rrew, rdone, rinfo = ref.step(act)
+        assert (done == rdone).all(), (step, np.argwhere(done != rdone)[:4].tolist())
+        ok = obs_close(obs, robs, 2.0)
+        assert ok.all(), (step, np.argwhere(~ok)[:4].tolist(), np.abs(obs - robs).max())
+        assert (np.abs(rew - rrew) <= 2 * (5e-3 + 1e-3 * np.abs(rrew))).all(), (step, np.abs(rew - rrew).max())
+        worst = max(worst, float(np.abs(obs - robs).max()))
+    print(f"4096 envs x 12 steps, every env compared: worst |d obs| {worst:.2e}")
+    env.close()
+
+
 def test_full_size_envs_are_independent_and_deterministic(pkg):
     """Size-independent property at the BASELINE size: with the same actions in every env the 4096 envs stay bit-identical, so
     the order-independent state digest equals 4096 x the digest of a single env stepped the same way (mod 2^64), after resets
