@@ -882,7 +882,8 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
   // loads behind them, and the LDS copy of the tables waits (in-order vmcnt) for the table loads alone.
   const float* act = P.actions + (size_t)nn * c.act_dim;
   float4 a4;
-  ActionRow arow;                        // three-wave form: the systems wave's action row (asked for late, waited for by hand)
+  ActionRow arow;                        // three-wave / quad form: the systems wave's action row (asked for late, waited for by hand)
+  ActionWord aword;                      // pair / quad form of the shoot task: the environment wave's shoot bit, likewise
   float shoot_raw = 0.0f;
   if (SPLIT) {
     TableCopy<192> tc;
@@ -923,18 +924,24 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
       s.ticks = state_word(P.F, SW_ticks, N, nn);
 #pragma unroll
       for (int k = 0; k < MSLOTS; ++k) pre_st[k] = P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn];
-      if (TASK == AC_TASK_SHOOT_MISSILE) shoot_raw = act[4];
     }
-    a4 = load_controls(act, c.act_dim);
-    tc.commit(lds_tab);
-    if (role == 0) { quad_dynamics_wave(P, c, T, LQ, l, n, live, s, t, a4); return; }
-    if (role != 3 && split_helper_wave<true>(s, t, T, LQ.S, l, c.substeps, &a4)) return;
+    // The action row like in the three-wave form above (it may cross PCIe, and loads return in issue order across the CU's waves): a bare
+    // barrier once every wave has issued its state loads, the tables, every known load landed; then the systems wave alone asks for the
+    // control indices (decoded after B1 of the first tick); the environment wave asks for the shoot bit (first needed after the last substep)
+    // once its munition slots have landed, below.
+    __builtin_amdgcn_s_barrier();
+    tc.write(lds_tab);
+    a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (role == 1) arow.issue(act);
+    __syncthreads();
+    if (role == 0) { quad_dynamics_wave(P, c, T, LQ, l, n, live, s, t); return; }
+    if (role != 3 && split_helper_wave<true>(s, t, T, LQ.S, l, c.substeps, nullptr, nullptr, &arow)) return;
   } else if (PAIR) {
     const bool flight_role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1;
     PairFlightIn fin;
     if (!flight_role) {   // the environment wave owns the task bookkeeping; the status word of every missile slot comes with it
-      a4 = load_controls(act, c.act_dim);
-      if (TASK == AC_TASK_SHOOT_MISSILE) shoot_raw = act[4];
+      a4 = make_float4(0.f, 0.f, 0.f, 0.f);              // (the control indices are the flight wave's; of the row this wave needs the shoot bit, late)
       s = State{}; load_task(P.F, P.I, N, nn, t);
 #pragma unroll
       for (int k = 0; k < MSLOTS; ++k) pre_st[k] = P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn];
@@ -947,6 +954,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
       pair_flight_wave<true>(P, c, T, LP, l, n, live, fin);
       return;
     }
+
   } else {
     TableCopy<64> tc;
     tc.issue(P.tab);
@@ -1013,6 +1021,10 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
       if (st != MSL_INACTIVE) { load_msl(P.MF, P.MI, N, nn, k, ms[k]); msl_was_active |= 1 << k; }
       else { ms[k] = Msl{}; ms[k].status = MSL_INACTIVE; }
     }
+    if (TASK == AC_TASK_SHOOT_MISSILE && PAIR) {   // the environment wave's shoot bit, behind every load of its own (a row in mapped host memory
+      __builtin_amdgcn_s_waitcnt(0x0F70);          // would hold them back: loads return in issue order); waited for where it is first needed
+      aword.issue(act + 4);
+    }
   }
 
   // ---- apply actions (normalize_action, singlecombat_task.py:141-153; property bounds catalog.py:189-197)
@@ -1023,7 +1035,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
     s.dr = clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);
     s.thr = clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
   }
-  if (TASK == AC_TASK_SHOOT_MISSILE) t.shoot_action = (shoot_raw != 0.0f) ? 1 : 0;  // singlecombat_with_missile_task.py:182-184
+  if (TASK == AC_TASK_SHOOT_MISSILE && !PAIR) t.shoot_action = (shoot_raw != 0.0f) ? 1 : 0;  // singlecombat_with_missile_task.py:182-184 (pair / quad forms: below, when the bit is first needed)
 
   // ---- substeps (env_base.py:139-154): every aircraft, then every missile against this substep's aircraft poses
   const MslParam MP = aim9l();
@@ -1080,12 +1092,8 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
     if (QUAD) wg_sync();                                       // B3 of the tick
   }
   const bool split_located = SPLIT && dynamics_wave_finish(s, d, L, l, last_tick, c.substeps);   // (+ the helper waves' fields)
-  if (SPLIT) {   // the commands, for the stored state (the dynamics wave itself never reads them: it did not wait for the action row)
-    s.da = clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);
-    s.de = clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
-    s.dr = clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);
-    s.thr = clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
-  }
+  // (three-wave form: the decoded commands of the stored state came with the systems wave's fields -- the dynamics wave itself never reads
+  //  the action row)
   if (PAIR) {
     if (QUAD) wg_sync();                           // (quad form: the helper waves hand their fields to the dynamics wave here)
     wg_sync();                                     // the flight wave has posted its final values and stored the flight state
@@ -1118,6 +1126,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
   }
   if (HAS_MSL) {
     bool launch;
+    if (TASK == AC_TASK_SHOOT_MISSILE && PAIR) { aword.take(); t.shoot_action = (aword.v != 0.0f) ? 1 : 0; }   // singlecombat_with_missile_task.py:182-184
     if (TASK == AC_TASK_DODGE_MISSILE) {
       // singlecombat_with_missile_task.py:108-124: rule-based launch — the enemy within max_attack_angle of the velocity vector
       // for a full lock window (1 s of env steps), inside max_attack_distance, min_attack_interval steps after the last shot.

@@ -227,17 +227,14 @@ __device__ __forceinline__ bool quad_substep_begin(Task& t, QuadLds& Q, int l, i
 }
 // The dynamics wave's whole step in the quad form (the caller returns afterwards).
 __device__ __forceinline__ void quad_dynamics_wave(const DevPtrs& P, const DevCfg& c, const f16::Tab& T, QuadLds& Q, int l, int n, bool live,
-                                                   f16::State& s, Task& t, const float4& a4) {
+                                                   f16::State& s, Task& t) {
   f16::Derived d;
   bool have_pose = false, d_stale = false;
   int last_tick = -1;
   for (int sub = 0; sub < c.substeps; ++sub)
     if (dynamics_wave_tick<true>(s, t, d, T, Q.S, l, sub, &d_stale)) { have_pose = true; last_tick = sub; }
   const bool located = dynamics_wave_finish(s, d, Q.S, l, last_tick, c.substeps);   // (+ the helper waves' fields)
-  s.da = f16::clampf(-1.0f, a4.x / 20.0f - 1.0f, 1.0f);   // the commands, for the stored state (normalize_action, singlecombat_task.py:141-153)
-  s.de = f16::clampf(-1.0f, a4.y / 20.0f - 1.0f, 1.0f);
-  s.dr = f16::clampf(-1.0f, a4.z / 20.0f - 1.0f, 1.0f);
-  s.thr = f16::clampf(0.0f, a4.w / 58.0f + 0.4f, 0.9f);
+  // (the decoded commands of the stored state came with the systems wave's fields)
   if (!located) f16::locate(s, d);
   if (!have_pose || d_stale) f16::body_frame(s, d);        // never flew, or the last piece it ran was undone: the frames of the stored pose
   Props pp;

@@ -262,18 +262,27 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     if (wave == 0) { load_flight_role<0>(P.F, P.I, P.D, N, nn, s); t.status = state_word(P.F, SW_status, N, nn); }
     else if (wave == 1) load_flight_role<1>(P.F, P.I, P.D, N, nn, s);
     else { load_flight_role<2>(P.F, P.I, P.D, N, nn, s); t.status = state_word(P.F, SW_status, N, nn); }
-    a4 = load_controls(act, c.act_dim);
   } else if (!flight_role) {
-    a4 = load_controls(act, c.act_dim);
-    if (c.act_dim == 8) b4 = load_controls(act + 4, c.act_dim);
+    // (pair / quad forms: the control indices are the flight / systems wave's; of the row this wave needs the weapon bits, after the last
+    // substep -- asked for below once its own loads have landed: a row in mapped host memory, ac_step_host, takes ~5 k cycles across PCIe
+    // and the CU returns loads in issue order ACROSS its waves, so a row asked for first holds every state load of the workgroup back)
+    if (!PAIR) {
+      a4 = load_controls(act, c.act_dim);
+      if (c.act_dim == 8) b4 = load_controls(act + 4, c.act_dim);
+    }
 #pragma unroll
     for (int k = 0; k < MS; ++k) mst[k] = P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn];
     if (PAIR) s = State{};
   }
   stage_tables<SPLIT ? 192 : (QUAD ? 256 : (PAIR ? 128 : 64))>(lds_tab, P.tab);
   AC_CLKE(0);
-  if (QUAD && wave == 0) { quad_dynamics_wave(P, c, T, LQ, lane, n, live, s, t, a4); return; }
-  if (fdm_role && split_helper_wave<true, true>(s, t, T, LQ.S, lane, c.substeps, &a4, &c)) return;
+  ActionRow arow, brow;   // quad form: the systems wave's control indices; pair / quad form: the environment wave's weapon bits
+  if (QUAD && fdm_role) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // every load the compiler knows of has landed (the state, one round trip like the tables)
+    if (wave == 1) arow.issue(act);
+  }
+  if (QUAD && wave == 0) { quad_dynamics_wave(P, c, T, LQ, lane, n, live, s, t); return; }
+  if (fdm_role && split_helper_wave<true, true>(s, t, T, LQ.S, lane, c.substeps, nullptr, &c, &arow)) return;
   // The NvN observation row (scenario2_task.py:256-316: ego 9, partners, enemies; the missile block after them is the environment
   // wave's), not clipped, written straight into this lane's row of the output staging buffer (a block's place in the row is a
   // run-time index: an LDS address, not a select chain over 63 registers). In the pair form of the NvN tasks the FLIGHT wave builds it
@@ -343,6 +352,11 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   int msl_was_active = 0;
 #pragma unroll
   for (int k = 0; k < MS; ++k) msl_was_active |= (ms[k].status != MSL_INACTIVE) << k;
+  const bool late_bits = PAIR && c.act_dim == 8;
+  if (late_bits) {                        // behind every load of this wave's own; waited for in front of the weapon rules
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    brow.issue(act + 4);
+  }
   int msl_moved = 0;   // bit k: slot k took a state transition this step (flew a substep, was launched, was reset)
 
   // ---- actions: 4 control indices + [gun, AIM-9M, AIM-120B, chaff] (scenario1_task.py:33-48: Scenario1 only refreshes the ego
@@ -358,10 +372,10 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   // MultipleCombatDodgeMissileTask (multiplecombat_with_missile_task.py:13-145): the NvN env with a rule-based launch of the base-class missile at
   // enemies[0], no gun, no chaff, the paired-enemy 21-value observation (c.legacy_obs) and four reward terms
   const bool dodge = MULTI && c.task == AC_TASK_DODGE_MISSILE;
-  if (!gun_only && !dodge && (MULTI || team == 0))
-  {
-    x.bits = (b4.x != 0.0f ? 1 : 0) | (b4.y != 0.0f ? 2 : 0) | (b4.z != 0.0f ? 4 : 0) | (b4.w != 0.0f ? 8 : 0);
-  }
+  auto decode_bits = [&](float bx, float by, float bz, float bw) {
+    if (!gun_only && !dodge && (MULTI || team == 0)) x.bits = (bx != 0.0f ? 1 : 0) | (by != 0.0f ? 2 : 0) | (bz != 0.0f ? 4 : 0) | (bw != 0.0f ? 8 : 0);
+  };
+  if (!late_bits) decode_bits(b4.x, b4.y, b4.z, b4.w);
 
   const MslParam MP = dodge ? aim9l() : aim120b();   // (MissileSimulator's own parameters, simulatior.py:421-433, for the rule-based task)
   bool have_pose = false;
@@ -550,6 +564,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   // depends on the others only through the chaff rule, which counts the dict's missiles aimed at it (so it sees the launches of the
   // agents before it, and entries those launches replaced are gone). Gun damage lands on bloods, which nobody reads until the next
   // substep. So every lane decides gun / missiles for itself at once, and the chaff count reconstructs the dict as agent `slot` saw it.
+  if (late_bits) { brow.take(); decode_bits(brow.v.x, brow.v.y, brow.v.z, brow.v.w); }
   {
     const float hv = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve + pr.vd * pr.vd);
     // farthest enemy (get_target, :139-145): poses and statuses do not change while the weapons are evaluated

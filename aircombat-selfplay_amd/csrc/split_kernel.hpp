@@ -24,7 +24,7 @@ enum { RUNF,                                                       // dynamics -
        LK_CLB, LK_CNB, LK_G7,                                       // kinematics -> dynamics: its share of the table look-ups
        MASS0 = LK_G7 + 4, MASS_N = 18,                              // systems -> dynamics: mass properties of the coming tick
        F_TEF = MASS0 + MASS_N, F_PINR, F_PINP, F_PINY, F_PIR, F_PIP, F_PIY, F_AIL, F_ELEV, F_SBDEG, F_N1, F_N2, F_N2NORM, F_FF, F_TANK0, F_TANK1,
-       F_ENG,                                                       // final hand-over of the fields the systems wave owns
+       F_ENG, F_DA, F_DE, F_DR, F_THR,                              // final hand-over of the fields the systems wave owns (the decoded commands among them)
        K_W, K_V = K_W + 3,                                          // dynamics -> kinematics after part 1: body rates, ECI velocity
        K_OUT = K_V + 3, K_OUT_N = 27,                               // kinematics -> dynamics: f16::KinOut of the coming tick
        G_Q = K_OUT + K_OUT_N,                                       // kinematics -> dynamics: quaternion of tick k in rows G_Q + 4 (k & 1) ..
@@ -87,6 +87,12 @@ struct ActionRow {
   __device__ __forceinline__ void issue(const float* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
   __device__ __forceinline__ void take() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory"); }
 };
+// the same for one word of the row (the shoot bit behind the four control indices)
+struct ActionWord {
+  float v;
+  __device__ __forceinline__ void issue(const float* p) { asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
+  __device__ __forceinline__ void take() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory"); }
+};
 __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::Tab& T, float (*M)[64], int l, int substeps, const float4* raw = nullptr,
                                              ActionRow* row = nullptr) {
   using namespace mail;
@@ -136,10 +142,17 @@ __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::
       post_mass(M, l, km);
     }
   }
+  if (substeps == 0 && (row || raw)) {                     // (no tick flown: the commands are still decoded for the stored state)
+    f32x4 v;
+    if (row) { row->take(); v = row->v; } else { v.x = raw->x; v.y = raw->y; v.z = raw->z; v.w = raw->w; }
+    s.da = f16::clampf(-1.0f, v.x / 20.0f - 1.0f, 1.0f); s.de = f16::clampf(-1.0f, v.y / 20.0f - 1.0f, 1.0f);
+    s.dr = f16::clampf(-1.0f, v.z / 20.0f - 1.0f, 1.0f); s.thr = f16::clampf(0.0f, v.w / 58.0f + 0.4f, 0.9f);
+  }
   M[F_TEF][l] = s.tef; M[F_PINR][l] = s.pin_r; M[F_PINP][l] = s.pin_p; M[F_PINY][l] = s.pin_y;
   M[F_PIR][l] = s.pi_r; M[F_PIP][l] = s.pi_p; M[F_PIY][l] = s.pi_y; M[F_AIL][l] = s.ail; M[F_ELEV][l] = s.elev; M[F_SBDEG][l] = s.sbdeg;
   M[F_N1][l] = s.n1; M[F_N2][l] = s.n2; M[F_N2NORM][l] = s.n2norm; M[F_FF][l] = s.ff; M[F_TANK0][l] = s.tank0; M[F_TANK1][l] = s.tank1;
   M[F_ENG][l] = __int_as_float(s.eng);
+  M[F_DA][l] = s.da; M[F_DE][l] = s.de; M[F_DR][l] = s.dr; M[F_THR][l] = s.thr;   // (the dynamics wave stores the flight state and may never have seen the action row)
   wg_sync();
 }
 // The kinematics wave of a SPLIT workgroup. Attitude and position are integrated explicitly from the PREVIOUS tick's rates and
@@ -328,6 +341,7 @@ __device__ __forceinline__ bool dynamics_wave_finish(f16::State& s, f16::Derived
   s.pi_r = M[F_PIR][l]; s.pi_p = M[F_PIP][l]; s.pi_y = M[F_PIY][l]; s.ail = M[F_AIL][l]; s.elev = M[F_ELEV][l]; s.sbdeg = M[F_SBDEG][l];
   s.n1 = M[F_N1][l]; s.n2 = M[F_N2][l]; s.n2norm = M[F_N2NORM][l]; s.ff = M[F_FF][l]; s.tank0 = M[F_TANK0][l]; s.tank1 = M[F_TANK1][l];
   s.eng = __float_as_int(M[F_ENG][l]);
+  s.da = M[F_DA][l]; s.de = M[F_DE][l]; s.dr = M[F_DR][l]; s.thr = M[F_THR][l];
   if (last_tick >= 1) {
     const int pb = last_tick & 1;
     s.q0 = M[G_Q + 4 * pb][l]; s.q1 = M[G_Q + 4 * pb + 1][l]; s.q2 = M[G_Q + 4 * pb + 2][l]; s.q3 = M[G_Q + 4 * pb + 3][l];

@@ -40,7 +40,45 @@ FORMS = [
 ]
 
 
-@pytest.mark.parametrize("form", FORMS, ids=[f[0].split(":")[0].split(" (")[0].replace(" ", "_").replace(",", "") for f in FORMS])
+FORM_IDS = [f[0].split(":")[0].split(" (")[0].replace(" ", "_").replace(",", "") for f in FORMS]
+
+
+@pytest.mark.parametrize("form", FORMS + [("hierarchical C2: commands from the controller kernel", "hierarchical_singlecombat", 1, {})], ids=FORM_IDS + ["C2_hierarchical"])
+def test_stored_commands_are_the_decoded_action_in_every_form(pkg, monkeypatch, form):
+    """fcs/*-cmd-norm of the stored state after a step (ac_get_state: da, de, dr, thr) = normalize_action of the control indices the step
+    was given (singlecombat_task.py:141-153), whichever wave of the form decodes the action row: in the three-wave and quad forms only the
+    systems wave ever sees the row, and the dynamics wave -- which stores the flight state -- gets the commands with the systems wave's fields."""
+    from open_loop_util import make_config, STARTS
+    name, task, per_side, pins = form
+    for k, v in pins.items():
+        monkeypatch.setenv(k, v)
+    hier = task.startswith("hierarchical")
+    cfg = pkg.default_config(task, hierarchical=True) if hier else make_config(pkg, task, per_side, STARTS[0], 6)
+    A, E = cfg.n_agents, 70
+    cls = pkg.HipShareVecEnv if A > 2 else pkg.HipVecEnv
+    env = cls(cfg, E, seed=2)
+    env.reset()
+    ix = {nm: k for k, nm in enumerate(env.lib.state_field_names()) if nm}
+    rng = np.random.default_rng(4)
+    for step in range(3):
+        if hier:
+            act = np.stack([rng.integers(0, n, size=(E, A)) for n in (3, 5, 3)], axis=-1).astype(np.float32)
+        else:
+            act = np.stack([rng.integers(0, n, size=(E, A)) for n in (41, 41, 41, 30)], axis=-1).astype(np.float32)
+            if env.act_dim > 4:
+                act = np.concatenate([act, np.zeros((E, A, env.act_dim - 4), dtype=np.float32)], axis=-1)
+        env.step(act)
+        for e in (0, 1, 33, 63, 64, 69):
+            for a in range(A):
+                low = env.get_controller_state(e, a)[1][:4] if hier else act[e, a, :4]
+                want = [np.clip(low[0] / 20.0 - 1.0, -1, 1), np.clip(low[1] / 20.0 - 1.0, -1, 1), np.clip(low[2] / 20.0 - 1.0, -1, 1), np.clip(low[3] / 58.0 + 0.4, 0, 0.9)]
+                st = env.get_state(e, a)
+                got = [st[ix["da"]], st[ix["de"]], st[ix["dr"]], st[ix["thr"]]]
+                assert np.allclose(got, want, atol=1e-6), (name, step, e, a, got, want)
+    env.close()
+
+
+@pytest.mark.parametrize("form", FORMS, ids=FORM_IDS)
 def test_straight_flight_600_steps_open_loop(pkg, oracle, monkeypatch, form):
     """Eight sets of initial conditions (15 000 - 30 000 ft, 600 - 1000 ft/s, every quadrant of heading), every aircraft holds the
     reference's straight-fly action [20, 19, 20, 0] (model/baseline.py:168; weapon bits 0) for 600 env steps = 60 s = 3600 FDM ticks,
