@@ -106,6 +106,9 @@ def test_teacher_forced_steps(pkg, oracle, task):
     env.close()
 
 
+REST_USED = {}
+
+
 @pytest.mark.parametrize("two_waves", ["0", "1"])
 def test_singlecombat_kernel_forms_teacher_forced(pkg, oracle, monkeypatch, two_waves):
     """SingleCombat has two kernel forms: one wave per 64 aircraft, and (at small batches) three waves per 64 aircraft that
@@ -142,6 +145,25 @@ def test_singlecombat_kernel_forms_teacher_forced(pkg, oracle, monkeypatch, two_
                 for f in ("rx", "ry", "rz"):                # position: fp64 ECI coordinates of ~2e7 ft
                     assert abs(got[ix[f]] - want[ix[f]]) <= 0.05, (step, e, a, f, got[ix[f]], want[ix[f]])
                 assert got[ix["eng"]] == want[ix["eng"]] and got[ix["ticks"]] == want[ix["ticks"]]
+                # ... and the REST of the record, so that every stored word is held to something: the decoded commands, the rates FGAuxiliary
+                # published, the pilot-station load factors, the Adams-Bashforth histories of both integrators (accelerations: differences of
+                # forces, so they carry the fp32 noise of the force build-up relative to the acceleration of gravity, 32 ft/s^2), the task record
+                for f in ("da", "de", "dr", "thr"):
+                    assert abs(got[ix[f]] - want[ix[f]]) <= 1e-6, (step, e, a, f, got[ix[f]], want[ix[f]])
+                # (measured: 0.1 - 0.35 of these)
+                for f, tol, floor in (("ap", 3e-6, 1.0), ("aq", 3e-6, 1.0), ("ar", 3e-6, 1.0), ("npx", 1.5e-5, 1.0), ("npy", 1.5e-5, 1.0), ("npz", 1.5e-5, 1.0),
+                                      ("hv1x", 1e-5, 32.0), ("hv1y", 1e-5, 32.0), ("hv1z", 1e-5, 32.0), ("hv2x", 1e-5, 32.0), ("hv2y", 1e-5, 32.0), ("hv2z", 1e-5, 32.0),
+                                      ("ha1x", 1.2e-5, 32.0), ("ha1y", 1.2e-5, 32.0), ("ha1z", 1.2e-5, 32.0), ("wdx", 3e-5, 1.0), ("wdy", 3e-5, 1.0), ("wdz", 3e-5, 1.0),
+                                      ("aix", 1.2e-5, 32.0), ("aiy", 1.2e-5, 32.0), ("aiz", 1.2e-5, 32.0), ("bax", 1.5e-5, 32.0), ("bay", 1.5e-5, 32.0), ("baz", 1.5e-5, 32.0)):
+                    err = abs(got[ix[f]] - want[ix[f]]) / (tol * max(floor, abs(want[ix[f]])))
+                    REST_USED[f] = max(REST_USED.get(f, 0.0), err)
+                    assert err <= 1.0, (step, e, a, f, got[ix[f]], want[ix[f]])
+                if not rinfo[e][3]:
+                    for f in ("bloods", "status", "die_flag", "cur_step"):
+                        assert got[ix[f]] == want[ix[f]], (step, e, a, f, got[ix[f]], want[ix[f]])
+                    for f, tol in (("pre_posture", 5e-3), ("pre_altitude", 1e-4), ("pre_event", 1e-6)):
+                        assert abs(got[ix[f]] - want[ix[f]]) <= tol * max(1.0, abs(want[ix[f]])), (step, e, a, f, got[ix[f]], want[ix[f]])
+    print("rest of the record, fraction of its bounds used:", {k: round(v, 2) for k, v in sorted(REST_USED.items())})
     env.close()
 
 
