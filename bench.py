@@ -182,6 +182,13 @@ def roofline(env, task, kernel_ms, hierarchical=False, controller_ms=None, step_
            "munitions_in_flight_per_aircraft": missiles}
     if traffic:
         out["traffic_over_algorithmic"] = traffic / algo
+        if hierarchical:
+            # SURVEY 8(d)'s per-unit figure has no term for the controller; what it adds per aircraft-step: the GRU state 512 B in + 512 B out,
+            # and the 544 KB weight pack that each of the 8 XCDs' L2 fetches once per launch (profiles/pmc_traffic.json)
+            n = env.num_envs * env.num_agents
+            extra = 1024.0 * n + 8 * 544.0 * 1024.0
+            out["traffic_over_algorithmic_with_controller_state"] = traffic / (algo + extra)
+            out["traffic_note"] += "; as shipped the launch includes controller8_kernel, whose GRU state (1024 B per aircraft-step) and weight pack (544 KB per XCD and launch) SURVEY 8(d)'s figure does not price"
     if step_ms is not None:
         a = algo / (step_ms * 1e-3) / 1e9
         out["step_kernel"] = {"kernel_ms": step_ms, "achieved": a, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS}

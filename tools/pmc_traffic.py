@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--task", default="singlecombat"); ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--agents", type=int, default=2)
     ap.add_argument("--kernel", default="step_kernel")
+    ap.add_argument("--hierarchical", action="store_true", help="an as-shipped run: the controller kernel's traffic is added to the step kernel's")
     ap.add_argument("--out", default=None)
     ap.add_argument("--round", type=int, default=2, help="build round the measurement belongs to (bench.py reports entries of round >= 2)")
     a = ap.parse_args()
@@ -50,7 +51,14 @@ def main():
     f = pick(fetch, a.kernel); w = pick(write, a.kernel)
     f = f[len(f) // 4:]; w = w[len(w) // 4:]                       # drop the warm-up quarter
     fetch_kb, write_kb = sum(f) / len(f), sum(w) / len(w)
-    rec = {"task": a.task, "round": a.round, "envs_per_gpu": a.envs, "aircraft": lanes, "kernel": a.kernel, "dispatches": len(f),
+    ctl = None
+    if a.hierarchical:                                             # controller8_kernel of the same steps (one launch per step, like the step kernel)
+        cf = pick(fetch, "controller8_kernel"); cw = pick(write, "controller8_kernel")
+        cf = cf[len(cf) // 4:]; cw = cw[len(cw) // 4:]
+        ctl = {"FETCH_SIZE_KB_raw": sum(cf) / len(cf), "WRITE_SIZE_KB": sum(cw) / len(cw)}
+        fetch_kb += ctl["FETCH_SIZE_KB_raw"]; write_kb += ctl["WRITE_SIZE_KB"]
+    rec = {"task": a.task, "round": a.round, "envs_per_gpu": a.envs, "aircraft": lanes, "kernel": a.kernel + (" + controller8_kernel" if a.hierarchical else ""),
+           "hierarchical": bool(a.hierarchical), "controller": ctl, "dispatches": len(f),
            "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
            "fetch_calibration": {"kernel": "state_checksum_kernel", "known_KB": STATE_READ_BYTES * lanes / 1024.0,
                                  "FETCH_SIZE_KB_raw": cal_kb, "factor": factor, "dispatches": len(cal)},
@@ -62,7 +70,8 @@ def main():
             allrec = json.load(open(a.out))
         except (OSError, ValueError):
             allrec = {"runs": []}
-        allrec["runs"] = [r for r in allrec["runs"] if not (r["task"] == a.task and r["envs_per_gpu"] == a.envs and r["aircraft"] == lanes)] + [rec]
+        allrec["runs"] = [r for r in allrec["runs"] if not (r["task"] == a.task and r["envs_per_gpu"] == a.envs and r["aircraft"] == lanes
+                                                            and bool(r.get("hierarchical", False)) == bool(a.hierarchical))] + [rec]
         json.dump(allrec, open(a.out, "w"), indent=1)
 
 
