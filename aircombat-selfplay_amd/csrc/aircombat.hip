@@ -1789,7 +1789,15 @@ static int launch_step(ac_env* h, const float* d_actions, int host_set = -1) {
     if (h->split_waves) hipLaunchKernelGGL((step_kernel_scenario<2, 1, FORM_SPLIT>), grid, dim3(192), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
     else if (pair_wpe1) hipLaunchKernelGGL((step_kernel_scenario<2, 1, FORM_PAIR>), grid, dim3(128), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
     else hipLaunchKernelGGL((step_kernel_scenario<2, 2, FORM_PAIR>), grid, dim3(128), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);
-  } else if (h->cfg.task == AC_TASK_SCENARIO1 || h->cfg.task == AC_TASK_SCENARIO_NVN || (h->cfg.task == AC_TASK_DODGE_MISSILE && h->A > 2)) {
+  } else if (h->cfg.task == AC_TASK_DODGE_MISSILE && h->A > 2) {   // multiplecombat_dodge_missile: the scenario kernel family's NvN pair form, DODGE build
+#define AC_LAUNCH_DODGE(AA)                                                                                                                                     \
+  do {                                                                                                                                                          \
+    if (pair_wpe1) hipLaunchKernelGGL((step_kernel_scenario<AA, 1, FORM_PAIR, true>), grid, dim3(128), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr); \
+    else hipLaunchKernelGGL((step_kernel_scenario<AA, 2, FORM_PAIR, true>), grid, dim3(128), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr);          \
+  } while (0)
+    if (h->A == 4) AC_LAUNCH_DODGE(4); else AC_LAUNCH_DODGE(8);
+#undef AC_LAUNCH_DODGE
+  } else if (h->cfg.task == AC_TASK_SCENARIO1 || h->cfg.task == AC_TASK_SCENARIO_NVN) {
 #define AC_LAUNCH_PAIR(AA)                                                                                                                                \
   do {                                                                                                                                                    \
     if (pair_wpe1) hipLaunchKernelGGL((step_kernel_scenario<AA, 1, FORM_PAIR>), grid, dim3(128), 0, h->stream, p, h->dc, h->d_XF, h->d_XI, nullptr, nullptr); \

@@ -198,7 +198,8 @@ __device__ __forceinline__ double pair_swap(double v) {
 }
 // (cycle stamps of the wave that runs the environment layer: wave 3 in the quad form, wave 0 otherwise)
 #define AC_CLKE(i) AC_CLKW(QUAD ? 3 : 0, i)
-template <int A, int WPE, int FORM = FORM_ONE>
+// DODGE: the rule-based MultipleCombatDodgeMissileTask on the NvN machinery (its own instantiations: the scenario builds do not carry its code).
+template <int A, int WPE, int FORM = FORM_ONE, bool DODGE = false>
 __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128 : (FORM == FORM_QUAD ? 256 : 64)), WPE) void step_kernel_scenario(DevPtrs P, DevCfg c, float* XF, int* XI, const float* tXF, const int* tXI) {
   using SD = ScenarioDims<A>;
   // forms launch_step reaches: the gun-only 1v1 tasks in the three-wave form, everything else in the pair form, the 1v1 scenario also in the quad form
@@ -371,7 +372,8 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   const bool wvr = gun_only && !maneuver;
   // MultipleCombatDodgeMissileTask (multiplecombat_with_missile_task.py:13-145): the NvN env with a rule-based launch of the base-class missile at
   // enemies[0], no gun, no chaff, the paired-enemy 21-value observation (c.legacy_obs) and four reward terms
-  const bool dodge = MULTI && c.task == AC_TASK_DODGE_MISSILE;
+  static_assert(!DODGE || (SD::MULTI && FORM == FORM_PAIR), "the rule-based NvN task runs the pair form");
+  constexpr bool dodge = DODGE;
   auto decode_bits = [&](float bx, float by, float bz, float bw) {
     if (!gun_only && !dodge && (MULTI || team == 0)) x.bits = (bx != 0.0f ? 1 : 0) | (by != 0.0f ? 2 : 0) | (bz != 0.0f ? 4 : 0) | (bw != 0.0f ? 8 : 0);
   };
