@@ -1603,7 +1603,7 @@ __device__ void initial_state(const ac_init_state_t& ic, const Tab& T, State& s,
 }
 
 template <int TASK>
-__global__ void init_kernel_1v1(InitArgs ia, DevCfg c, const float* tab, float* tF, int* tI, double* tD) {
+__global__ __launch_bounds__(64) void init_kernel_1v1(InitArgs ia, DevCfg c, const float* tab, float* tF, int* tI, double* tD) {
   using TT = TaskTraits<TASK>;
   constexpr int OBS = TT::OBS;
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
@@ -1632,7 +1632,7 @@ __global__ void init_kernel_1v1(InitArgs ia, DevCfg c, const float* tab, float* 
 }
 
 template <int A>
-__global__ void init_kernel_nvn(InitArgs ia, DevCfg c, const float* tab, float* tF, int* tI, double* tD) {
+__global__ __launch_bounds__(64) void init_kernel_nvn(InitArgs ia, DevCfg c, const float* tab, float* tF, int* tI, double* tD) {
   constexpr int OBS = 9 + 6 * (A - 1);
   __shared__ __attribute__((aligned(16))) float lds_tab[F16_PACK_LEN];
   stage_tables(lds_tab, tab);

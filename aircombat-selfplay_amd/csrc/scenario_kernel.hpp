@@ -962,7 +962,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
 
 // reset template for the scenario tasks: same initial-condition pass, scenario observation layout, potential seeds
 template <int A>
-__global__ void init_kernel_scenario(InitArgs ia, DevCfg c, const float* tab, float* tF, int* tI, double* tD) {
+__global__ __launch_bounds__(64) void init_kernel_scenario(InitArgs ia, DevCfg c, const float* tab, float* tF, int* tI, double* tD) {
   using SD = ScenarioDims<A>;
   constexpr int OBS = SD::OBS;
   constexpr int NE = SD::NE;
