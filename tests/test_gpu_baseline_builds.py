@@ -175,3 +175,12 @@ def test_hierarchical_baseline_shapes_sampled_envs_match_oracle(pkg, oracle, tas
     from test_gpu_parity import _lowlevel_controller_parity
     sample = SAMPLE_4096 if E == 4096 else None
     _lowlevel_controller_parity(pkg, oracle, task, 0, E=E, sample=sample, per_side=per_side or None, steps=60)
+
+
+def test_as_shipped_c3_batch_every_env_matches_oracle(pkg, oracle):
+    """BASELINE C3 AS SHIPPED (`scenario1` hierarchical, 4096 envs x 2 aircraft: the controller kernel on 256 workgroups in front of the quad-form
+    step kernel), EVERY env replayed on the oracle for 10 steps: 81 920 controller outputs (argmax indices, GRU state), observations,
+    rewards and dones of all 8192 aircraft -- not a sample."""
+    from test_gpu_parity import _lowlevel_controller_parity
+    _lowlevel_controller_parity(pkg, oracle, "scenario1", 0, E=4096, sample=None, steps=10)
+
