@@ -274,3 +274,20 @@ def test_controller_products_split_into_two_fp16_pieces(pkg):
     lib.dll.ac_split_f16x2(p(bad), 4, p(bh), p(bl))
     with np.errstate(invalid="ignore"):
         assert not np.isfinite(bh + bl).any()          # (1e9 is beyond fp16: it saturates to inf rather than wrap to something plausible)
+
+
+def test_multiplecombat_missile_task_names_resolve(pkg):
+    """The three MultipleCombat missile classes no env of the reference constructs (multiplecombat_with_missile_task.py:13-216) have names of
+    this package's own: the rule-based one is AC_TASK_DODGE_MISSILE with the NvN aircraft block, the shoot one MULTICOMBAT with the paired-enemy
+    observation; `hierarchical_*` sets the controller form."""
+    from aircombat_selfplay_amd.capi import AC_TASK_DODGE_MISSILE, AC_TASK_MULTICOMBAT
+    d = pkg.default_config("multiplecombat_dodge_missile")
+    assert (d.task, d.n_agents, d.n_ego, d.legacy_obs, d.hierarchical) == (AC_TASK_DODGE_MISSILE, 4, 2, 1, 0)
+    assert list(d.num_missiles)[:4] == [2, 2, 2, 2] and d.min_attack_interval == 125 and d.max_attack_distance == 14000
+    h = pkg.default_config("hierarchical_multiplecombat_dodge_missile")
+    assert (h.task, h.n_agents, h.legacy_obs, h.hierarchical) == (AC_TASK_DODGE_MISSILE, 4, 1, 1)
+    s8 = pkg.default_nvn_config(4, task="multiplecombat_shoot")
+    assert (s8.task, s8.n_agents, s8.n_ego, s8.legacy_obs, s8.hierarchical) == (AC_TASK_MULTICOMBAT, 8, 4, 1, 0)
+    with pytest.raises(NotImplementedError):
+        pkg.default_nvn_config(2, task="multiplecombat_no_such_task")
+
