@@ -176,6 +176,10 @@ _LIB = None
 
 def load_library(path=None):
     global _LIB
+    # Kernel arguments in device memory: with them in host memory every kernel's first scalar load crosses PCIe (measured on this stack:
+    # the BASELINE step kernel 16.3 -> 19.4 us with HIP_FORCE_DEV_KERNARG=0). ROCm 7 defaults to device memory; on a runtime that does not,
+    # this asks for it -- it only takes effect if no HIP call has been made in the process yet, and never overrides the caller's setting.
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     if _LIB is None or (path and _LIB.path != path):
         _LIB = Lib(path)
     return _LIB
