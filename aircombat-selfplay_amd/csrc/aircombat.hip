@@ -882,8 +882,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
   // loads behind them, and the LDS copy of the tables waits (in-order vmcnt) for the table loads alone.
   const float* act = P.actions + (size_t)nn * c.act_dim;
   float4 a4;
-  ActionRow arow;                        // three-wave / quad form: the systems wave's action row (asked for late, waited for by hand)
-  ActionWord aword;                      // pair / quad form of the shoot task: the environment wave's shoot bit, likewise
+  ActionFetch arow;                      // three-wave / quad form: the systems wave's action row (asked for late, waited for by hand)
   float shoot_raw = 0.0f;
   if (SPLIT) {
     TableCopy<192> tc;
@@ -908,7 +907,7 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
     // left anywhere behind this point (the counter counts all loads: it would wait for the row as well) -- before the one it does not
     // know of is issued
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the wave's own state, one round trip like the tables
-    if (role == 1) arow.issue(act);
+    if (role == 1) arow.issue(act, c.act_dim);
     AC_CLKW(0, 120); AC_CLKW(1, 121); AC_CLKW(2, 122);
     __syncthreads();                      // (LDS visibility; loads in flight are not waited for)
   } else if (QUAD) {
@@ -927,13 +926,12 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
     }
     // The action row like in the three-wave form above (it may cross PCIe, and loads return in issue order across the CU's waves): a bare
     // barrier once every wave has issued its state loads, the tables, every known load landed; then the systems wave alone asks for the
-    // control indices (decoded after B1 of the first tick); the environment wave asks for the shoot bit (first needed after the last substep)
-    // once its munition slots have landed, below.
+    // row (control indices decoded after B1 of the first tick; the shoot bit goes to the environment wave with the systems wave's fields).
     __builtin_amdgcn_s_barrier();
     tc.write(lds_tab);
     a4 = make_float4(0.f, 0.f, 0.f, 0.f);
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    if (role == 1) arow.issue(act);
+    if (role == 1) arow.issue(act, c.act_dim);
     __syncthreads();
     if (role == 0) { quad_dynamics_wave(P, c, T, LQ, l, n, live, s, t); return; }
     if (role != 3 && split_helper_wave<true>(s, t, T, LQ.S, l, c.substeps, nullptr, nullptr, &arow)) return;
@@ -1020,10 +1018,6 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
       const int st = (k < nslots) ? (PAIR ? pre_st[k] : P.MI[((size_t)k * NMI + MI_status) * (size_t)N + nn]) : MSL_INACTIVE;
       if (st != MSL_INACTIVE) { load_msl(P.MF, P.MI, N, nn, k, ms[k]); msl_was_active |= 1 << k; }
       else { ms[k] = Msl{}; ms[k].status = MSL_INACTIVE; }
-    }
-    if (TASK == AC_TASK_SHOOT_MISSILE && PAIR) {   // the environment wave's shoot bit, behind every load of its own (a row in mapped host memory
-      __builtin_amdgcn_s_waitcnt(0x0F70);          // would hold them back: loads return in issue order); waited for where it is first needed
-      aword.issue(act + 4);
     }
   }
 
@@ -1126,7 +1120,8 @@ __global__ __launch_bounds__(FORM == 1 ? 192 : (FORM == 2 ? 128 : (FORM == 3 ? 2
   }
   if (HAS_MSL) {
     bool launch;
-    if (TASK == AC_TASK_SHOOT_MISSILE && PAIR) { aword.take(); t.shoot_action = (aword.v != 0.0f) ? 1 : 0; }   // singlecombat_with_missile_task.py:182-184
+    // singlecombat_with_missile_task.py:182-184 (pair / quad form: the wave that flies read the action row and posted the shoot bit with its final values)
+    if (TASK == AC_TASK_SHOOT_MISSILE && PAIR) t.shoot_action = ((QUAD ? LQ.S.M[mail::F_BITS][l] : LP.FIN[pair::FIN_BITS][l]) != 0.0f) ? 1 : 0;
     if (TASK == AC_TASK_DODGE_MISSILE) {
       // singlecombat_with_missile_task.py:108-124: rule-based launch — the enemy within max_attack_angle of the velocity vector
       // for a full lock window (1 s of env steps), inside max_attack_distance, min_attack_interval steps after the last shot.

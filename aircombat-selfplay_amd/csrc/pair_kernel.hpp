@@ -19,7 +19,9 @@
 
 namespace pair {
 enum { FIN_VN, FIN_VE, FIN_VD, FIN_ALT, FIN_UB, FIN_VB, FIN_WB, FIN_VC, FIN_SPHI, FIN_CPHI, FIN_STHT, FIN_CTHT, FIN_M11, FIN_M12,
-       FIN_P, FIN_Q, FIN_R, FIN_VECI, FIN_HSL, FIN_NPX, FIN_NPY, FIN_NPZ, FIN_TICKS, NFIN };
+       FIN_P, FIN_Q, FIN_R, FIN_VECI, FIN_HSL, FIN_NPX, FIN_NPY, FIN_NPZ, FIN_TICKS,
+       FIN_BITS,   // what the action row holds behind the control indices (the shoot bit / the four weapon bits, packed): only the flight wave reads the row
+       NFIN };
 enum { RUN_FLY = 1, RUN_NEED_POSE = 2 };
 }
 struct PairLds {
@@ -40,8 +42,9 @@ __device__ __forceinline__ void ned_velocity(const f16::State& s, f16::Derived& 
 }
 
 // what the environment wave reads off the aircraft after the last tick (pair_read_final)
-__device__ __forceinline__ void pair_post_final(PairLds& L, int l, const f16::State& s, const f16::Derived& d, const Props& pp) {
+__device__ __forceinline__ void pair_post_final(PairLds& L, int l, const f16::State& s, const f16::Derived& d, const Props& pp, float bits = 0.0f) {
   using namespace pair;
+  L.FIN[FIN_BITS][l] = bits;
   L.F64[0][l] = pp.n64; L.F64[1][l] = pp.e64; L.F64[2][l] = pp.u64;
   L.FIN[FIN_VN][l] = pp.vn; L.FIN[FIN_VE][l] = pp.ve; L.FIN[FIN_VD][l] = pp.vd; L.FIN[FIN_ALT][l] = pp.alt_m;
   L.FIN[FIN_UB][l] = pp.ub; L.FIN[FIN_VB][l] = pp.vb; L.FIN[FIN_WB][l] = pp.wb; L.FIN[FIN_VC][l] = pp.vc;
@@ -56,11 +59,19 @@ __device__ __forceinline__ void pair_post_final(PairLds& L, int l, const f16::St
 // missile tasks, whose fp32 AIM-9L update leaves that wave the slack (there the flight wave is the longer of the two).
 // What the flight wave reads from HBM: the flight state, the aircraft's status (only to know whether tick 0 flies: the environment
 // wave owns the field) and its action row. Separate from the wave's body so that a kernel can issue the loads behind its table loads.
-struct PairFlightIn { f16::State s; int status0; float4 a4; };
+struct PairFlightIn { f16::State s; int status0; float4 a4; float bits; };
 __device__ __forceinline__ void pair_flight_load(const DevPtrs& P, const DevCfg& c, int nn, PairFlightIn& in) {
   load_flight(P.F, P.I, P.D, c.N, nn, in.s);
   in.status0 = state_word(P.F, SW_status, c.N, nn);
-  in.a4 = load_controls(P.actions + (size_t)nn * c.act_dim, c.act_dim);
+  const float* act = P.actions + (size_t)nn * c.act_dim;
+  in.a4 = load_controls(act, c.act_dim);
+  // the rest of the row, for the environment wave (which never reads the row itself: in a host-boundary step it lives in mapped host
+  // memory, and a PCIe read asked for early holds every later load of the workgroup back)
+  in.bits = 0.0f;
+  if (c.act_dim == 8) {
+    const float4 b = load_controls(act + 4, c.act_dim);
+    in.bits = (float)((b.x != 0.0f ? 1 : 0) | (b.y != 0.0f ? 2 : 0) | (b.z != 0.0f ? 4 : 0) | (b.w != 0.0f ? 8 : 0));
+  } else if (c.act_dim == 5) in.bits = act[4] != 0.0f ? 1.0f : 0.0f;
 }
 // `tail(pp)`: work for this wave after its final values are posted and the flight state is stored, while the environment wave runs the
 // weapon rules, rewards and terminations (the NvN scenario kernels build the observation rows here). It receives this aircraft's final
@@ -130,7 +141,7 @@ __device__ __forceinline__ void pair_flight_wave(const DevPtrs& P, const DevCfg&
 #pragma unroll
   for (int i = 0; i < 3; ++i) { d.n_eci[i] = dp.n_eci[i]; d.e_eci[i] = dp.e_eci[i]; d.d_eci[i] = dp.d_eci[i]; }
   make_props(s, d, c, pp);
-  pair_post_final(L, l, s, d, pp);
+  pair_post_final(L, l, s, d, pp, in.bits);
   if (!LATE_STORE && live) store_flight(P.F, P.I, P.D, c.N, n, s);
   AC_CLKW(1, 160);
   wg_sync();   // final values posted, flight state stored (the release half of the barrier waits for the stores: an episode reset by

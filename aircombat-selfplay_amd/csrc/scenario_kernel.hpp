@@ -264,9 +264,9 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
     else if (wave == 1) load_flight_role<1>(P.F, P.I, P.D, N, nn, s);
     else { load_flight_role<2>(P.F, P.I, P.D, N, nn, s); t.status = state_word(P.F, SW_status, N, nn); }
   } else if (!flight_role) {
-    // (pair / quad forms: the control indices are the flight / systems wave's; of the row this wave needs the weapon bits, after the last
-    // substep -- asked for below once its own loads have landed: a row in mapped host memory, ac_step_host, takes ~5 k cycles across PCIe
-    // and the CU returns loads in issue order ACROSS its waves, so a row asked for first holds every state load of the workgroup back)
+    // (pair / quad forms: only the wave that flies reads the action row -- a row in mapped host memory, ac_step_host, takes ~5 k cycles
+    // across PCIe and the CU returns loads in issue order ACROSS its waves, so a row asked for first holds every state load of the workgroup
+    // back -- and posts the weapon bits, which this wave needs after the last substep, with its final values)
     if (!PAIR) {
       a4 = load_controls(act, c.act_dim);
       if (c.act_dim == 8) b4 = load_controls(act + 4, c.act_dim);
@@ -277,10 +277,10 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   }
   stage_tables<SPLIT ? 192 : (QUAD ? 256 : (PAIR ? 128 : 64))>(lds_tab, P.tab);
   AC_CLKE(0);
-  ActionRow arow, brow;   // quad form: the systems wave's control indices; pair / quad form: the environment wave's weapon bits
+  ActionFetch arow;       // quad form: the systems wave's action row (control indices; the weapon bits go on to the environment wave through LDS)
   if (QUAD && fdm_role) {
     __builtin_amdgcn_s_waitcnt(0x0F70);   // every load the compiler knows of has landed (the state, one round trip like the tables)
-    if (wave == 1) arow.issue(act);
+    if (wave == 1) arow.issue(act, c.act_dim);
   }
   if (QUAD && wave == 0) { quad_dynamics_wave(P, c, T, LQ, lane, n, live, s, t); return; }
   if (fdm_role && split_helper_wave<true, true>(s, t, T, LQ.S, lane, c.substeps, nullptr, &c, &arow)) return;
@@ -353,11 +353,7 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   int msl_was_active = 0;
 #pragma unroll
   for (int k = 0; k < MS; ++k) msl_was_active |= (ms[k].status != MSL_INACTIVE) << k;
-  const bool late_bits = PAIR && c.act_dim == 8;
-  if (late_bits) {                        // behind every load of this wave's own; waited for in front of the weapon rules
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    brow.issue(act + 4);
-  }
+  const bool late_bits = PAIR && c.act_dim == 8;   // (the wave that flies read the row and posts the bits with its final values)
   int msl_moved = 0;   // bit k: slot k took a state transition this step (flew a substep, was launched, was reset)
 
   // ---- actions: 4 control indices + [gun, AIM-9M, AIM-120B, chaff] (scenario1_task.py:33-48: Scenario1 only refreshes the ego
@@ -566,7 +562,10 @@ __global__ __launch_bounds__(FORM == FORM_SPLIT ? 192 : (FORM == FORM_PAIR ? 128
   // depends on the others only through the chaff rule, which counts the dict's missiles aimed at it (so it sees the launches of the
   // agents before it, and entries those launches replaced are gone). Gun damage lands on bloods, which nobody reads until the next
   // substep. So every lane decides gun / missiles for itself at once, and the chaff count reconstructs the dict as agent `slot` saw it.
-  if (late_bits) { brow.take(); decode_bits(brow.v.x, brow.v.y, brow.v.z, brow.v.w); }
+  if (late_bits) {
+    const int pk = (int)(QUAD ? LQ.S.M[mail::F_BITS][lane] : LP.FIN[pair::FIN_BITS][lane]);
+    decode_bits((float)(pk & 1), (float)(pk & 2), (float)(pk & 4), (float)(pk & 8));
+  }
   {
     const float hv = sqrtf(pr.vn * pr.vn + pr.ve * pr.ve + pr.vd * pr.vd);
     // farthest enemy (get_target, :139-145): poses and statuses do not change while the weapons are evaluated

@@ -25,6 +25,7 @@ enum { RUNF,                                                       // dynamics -
        MASS0 = LK_G7 + 4, MASS_N = 18,                              // systems -> dynamics: mass properties of the coming tick
        F_TEF = MASS0 + MASS_N, F_PINR, F_PINP, F_PINY, F_PIR, F_PIP, F_PIY, F_AIL, F_ELEV, F_SBDEG, F_N1, F_N2, F_N2NORM, F_FF, F_TANK0, F_TANK1,
        F_ENG, F_DA, F_DE, F_DR, F_THR,                              // final hand-over of the fields the systems wave owns (the decoded commands among them)
+       F_BITS,                                                      // ... and, quad form, what else the action row holds: the shoot bit / the four weapon bits, packed (environment wave)
        K_W, K_V = K_W + 3,                                          // dynamics -> kinematics after part 1: body rates, ECI velocity
        K_OUT = K_V + 3, K_OUT_N = 27,                               // kinematics -> dynamics: f16::KinOut of the coming tick
        G_Q = K_OUT + K_OUT_N,                                       // kinematics -> dynamics: quaternion of tick k in rows G_Q + 4 (k & 1) ..
@@ -93,8 +94,27 @@ struct ActionWord {
   __device__ __forceinline__ void issue(const float* p) { asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
   __device__ __forceinline__ void take() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory"); }
 };
+// The whole action row as the wave that decodes it sees it: the four control indices, and behind them nothing (act_dim 4), one shoot bit
+// (5) or the four weapon bits (8). Only THIS wave reads the row; what the environment wave needs of it comes through LDS (F_BITS).
+struct ActionFetch {
+  ActionRow idx, bits;
+  ActionWord bit;
+  int extra;
+  __device__ __forceinline__ void issue(const float* act, int act_dim) {
+    extra = act_dim == 8 ? 4 : (act_dim == 5 ? 1 : 0);
+    idx.issue(act);
+    if (extra == 4) bits.issue(act + 4);
+    if (extra == 1) bit.issue(act + 4);
+  }
+  __device__ __forceinline__ void take() { idx.take(); if (extra == 4) bits.take(); if (extra == 1) bit.take(); }
+  __device__ __forceinline__ float packed() const {       // bit k set = element 4 + k of the row is non-zero
+    if (extra == 4) return (float)((bits.v.x != 0.0f ? 1 : 0) | (bits.v.y != 0.0f ? 2 : 0) | (bits.v.z != 0.0f ? 4 : 0) | (bits.v.w != 0.0f ? 8 : 0));
+    if (extra == 1) return bit.v != 0.0f ? 1.0f : 0.0f;
+    return 0.0f;
+  }
+};
 __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::Tab& T, float (*M)[64], int l, int substeps, const float4* raw = nullptr,
-                                             ActionRow* row = nullptr) {
+                                             ActionFetch* row = nullptr) {
   using namespace mail;
   f16::DynVars km{};
   f16::sys_mass(s, km);
@@ -106,10 +126,10 @@ __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::
     wg_sync();                                             // B1: this tick's attitude is known
     if (row && sub == 0) {                                 // normalize_action (singlecombat_task.py:141-153), property bounds catalog.py:189-197
       row->take();
-      s.da = f16::clampf(-1.0f, row->v.x / 20.0f - 1.0f, 1.0f);
-      s.de = f16::clampf(-1.0f, row->v.y / 20.0f - 1.0f, 1.0f);
-      s.dr = f16::clampf(-1.0f, row->v.z / 20.0f - 1.0f, 1.0f);
-      s.thr = f16::clampf(0.0f, row->v.w / 58.0f + 0.4f, 0.9f);
+      s.da = f16::clampf(-1.0f, row->idx.v.x / 20.0f - 1.0f, 1.0f);
+      s.de = f16::clampf(-1.0f, row->idx.v.y / 20.0f - 1.0f, 1.0f);
+      s.dr = f16::clampf(-1.0f, row->idx.v.z / 20.0f - 1.0f, 1.0f);
+      s.thr = f16::clampf(0.0f, row->idx.v.w / 58.0f + 0.4f, 0.9f);
     } else if (raw && sub == 0) {
       s.da = f16::clampf(-1.0f, raw->x / 20.0f - 1.0f, 1.0f);
       s.de = f16::clampf(-1.0f, raw->y / 20.0f - 1.0f, 1.0f);
@@ -144,7 +164,7 @@ __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::
   }
   if (substeps == 0 && (row || raw)) {                     // (no tick flown: the commands are still decoded for the stored state)
     f32x4 v;
-    if (row) { row->take(); v = row->v; } else { v.x = raw->x; v.y = raw->y; v.z = raw->z; v.w = raw->w; }
+    if (row) { row->take(); v = row->idx.v; } else { v.x = raw->x; v.y = raw->y; v.z = raw->z; v.w = raw->w; }
     s.da = f16::clampf(-1.0f, v.x / 20.0f - 1.0f, 1.0f); s.de = f16::clampf(-1.0f, v.y / 20.0f - 1.0f, 1.0f);
     s.dr = f16::clampf(-1.0f, v.z / 20.0f - 1.0f, 1.0f); s.thr = f16::clampf(0.0f, v.w / 58.0f + 0.4f, 0.9f);
   }
@@ -153,6 +173,7 @@ __device__ __forceinline__ void systems_wave(f16::State& s, Task& t, const f16::
   M[F_N1][l] = s.n1; M[F_N2][l] = s.n2; M[F_N2NORM][l] = s.n2norm; M[F_FF][l] = s.ff; M[F_TANK0][l] = s.tank0; M[F_TANK1][l] = s.tank1;
   M[F_ENG][l] = __int_as_float(s.eng);
   M[F_DA][l] = s.da; M[F_DE][l] = s.de; M[F_DR][l] = s.dr; M[F_THR][l] = s.thr;   // (the dynamics wave stores the flight state and may never have seen the action row)
+  M[F_BITS][l] = row ? row->packed() : 0.0f;
   wg_sync();
 }
 // The kinematics wave of a SPLIT workgroup. Attitude and position are integrated explicitly from the PREVIOUS tick's rates and
@@ -246,7 +267,7 @@ struct SplitLds {
 // wave (wave 0) gets false. Commands (s.da .. s.thr) must be decoded before the call, or handed over as the raw action row.
 template <bool QUAD = false, bool POSE = false>
 __device__ __forceinline__ bool split_helper_wave(f16::State& s, Task& t, const f16::Tab& T, SplitLds& L, int l, int substeps, const float4* raw = nullptr,
-                                                  const DevCfg* cfg = nullptr, ActionRow* row = nullptr) {
+                                                  const DevCfg* cfg = nullptr, ActionFetch* row = nullptr) {
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (role == 2) { kinematics_wave<QUAD, POSE>(s, t, T, L.M, L.MD, l, substeps, cfg); return true; }   // (a caller with work left for this wave tests the role itself)
   if (role == 1) { systems_wave(s, t, T, L.M, l, substeps, raw, row); return true; }
