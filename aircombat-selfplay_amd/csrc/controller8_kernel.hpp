@@ -291,6 +291,16 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
     for (int q = 0; q < FPT / 4; ++q)
       *reinterpret_cast<float4*>(hf + srow * RS + spart * FPT + 4 * q) = make_float4(hv[4 * q], hv[4 * q + 1], hv[4 * q + 2], hv[4 * q + 3]);
   }
+  // The GRU's weight ring (one k-step per stage: two ahead, or one). Its first stages are asked for HERE, behind layer 1: LayerNorm 1 and
+  // layer 2 (whose own weights came with the first loads) leave the L1 idle for ~3.5 k cycles. (Asked for behind layer 2, where round 4 first
+  // had them, layer 2's phase ended with 96 KB per CU queueing at the L1: 1-2.5 % slower at every size. Asked for with the kernel's first
+  // loads they queue in front of what layer 1 waits for: 2-4 % slower. With two fp16 pieces the registers would allow deeper rings --
+  // a fourth stage at 32 rows +1 to +4 %, a third stage and A operands one k-step ahead at 64 rows +1 %: depth is not what the loop waits for.)
+  constexpr int RING = MTL == 2 ? 3 : 2;
+  BS ring[RING][3];   // [stage][gate]
+#pragma unroll
+  for (int st = 0; st < RING - 1; ++st) ring_load(W, w, lane, st, ring[st]);
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   AC_CLK(202);
   layer_norm_planes<MTL>(stg, PA, prm + (C_G1 - C_B1), prm + (C_BE1 - C_B1), tid);
@@ -307,13 +317,6 @@ __global__ __launch_bounds__(512) void controller8_kernel(ctl::Args a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) stg[c_row(mt, i, lane) * RS + w * 16 + col] = fmaxf(acc[mt][i], 0.0f);
   }
-  // stages of the weight ring (one k-step each): two ahead, or one. (With two fp16 pieces the registers would allow more -- measured: a
-  // fourth stage at 32 rows +1 to +4 %, a third stage and A operands one k-step ahead at 64 rows +1 %: depth is not what the loop waits for.)
-  constexpr int RING = MTL == 2 ? 3 : 2;
-  BS ring[RING][3];   // [stage][gate]: the GRU's first k-steps, behind LayerNorm 2
-#pragma unroll
-  for (int st = 0; st < RING - 1; ++st) ring_load(W, w, lane, st, ring[st]);
-  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
   AC_CLK(204);
   layer_norm_planes<MTL>(stg, PA, prm + (C_G2 - C_B1), prm + (C_BE2 - C_B1), tid);
