@@ -15,6 +15,10 @@ pytestmark = pytest.mark.gpu
 from parity_util import TASK_FIELDS, RewardBound, assert_obs, team_max
 
 
+FLIGHT_FIELDS = ("rx", "ry", "rz", "vx", "vy", "vz", "q0", "q1", "q2", "q3", "wp", "wq", "wr", "da", "de", "dr", "thr", "tef", "ail", "elev", "sbdeg", "pi_r", "pi_p", "pi_y",
+                 "pin_r", "pin_p", "pin_y", "n1", "n2", "n2norm", "ff", "tank0", "tank1", "alpha", "mach", "qc", "vg")
+
+
 def make_cfg(pkg, task, per_side):
     if per_side == 1:
         cfg = pkg.default_config(task)
@@ -86,6 +90,19 @@ def run_sampled(pkg, oracle, task, per_side, E, sample, steps, seed=77, expect_k
         parity_util.USED[lab] = max(parity_util.USED.get(lab, 0.0), float((np.abs(rew[sample] - rrew) / rt).max()))
         if weapons:
             launched = max(launched, max(len(r.missiles()) for r in ref.envs))
+        # the stored flight record after the step (one teacher-forced step from the oracle's state): every kernel form writes it back through its own
+        # store path -- three-wave / quad hand-over, the pair form's flight wave, the one-wave forms -- and all of them must leave what the oracle holds
+        for k, e in enumerate(sample):
+            if rinfo[k][3]:
+                continue
+            for a in range(A):
+                got, want = env.get_state(e, a), ref.envs[k].export_state(a)
+                for f in FLIGHT_FIELDS:
+                    tol = (5e-4 if f == "ff" else 2e-5) * max(1.0, abs(want[ix[f]])) + 1e-6
+                    if f in ("rx", "ry", "rz"):
+                        tol = 0.05
+                    assert abs(got[ix[f]] - want[ix[f]]) <= tol, (task, step, e, a, f, got[ix[f]], want[ix[f]])
+                assert got[ix["eng"]] == want[ix["eng"]] and got[ix["ticks"]] == want[ix["ticks"]], (task, step, e, a)
     if weapons:
         assert launched >= 1, "no munition flew during the comparison"
     import parity_util
