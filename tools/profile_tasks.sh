@@ -6,7 +6,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 echo '"Task","Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"' > $out/tasks_kernel_stats.csv
 for spec in "singlecombat_shoot 1 0" "singlecombat_dodge_missile 1 0" "scenario1 1 0" "scenario_nvn 2 0" "scenario_nvn 4 0" "multiplecombat 2 0" "wvr_lowlevel 1 0" \
-            "heading 1 0" "approach 1 0" "hierarchical_singlecombat 1 1" "scenario1 1 1" "scenario_nvn 2 1" "scenario_nvn 4 1"; do
+            "heading 1 0" "approach 1 0" "multiplecombat_dodge_missile 2 0" "multiplecombat_dodge_missile 4 0" "hierarchical_singlecombat 1 1" "scenario1 1 1" "scenario_nvn 2 1" "scenario_nvn 4 1"; do
   set -- $spec; t=$1; ps=$2; hier=$3
   extra=""; tag=$t
   if [ $ps != 1 ]; then extra="--per-side $ps"; tag="${t}_${ps}v${ps}"; fi
